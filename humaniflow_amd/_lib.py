@@ -1,0 +1,127 @@
+"""ctypes binding of libhumaniflow_amd.so (the C ABI declared in include/humaniflow_amd.h).
+
+There is NO fallback: if the shared library is missing it is built with hipcc (in-tree); if
+that fails, or a compute entry point is reached without a HIP device, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhumaniflow_amd.so')
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int32)
+
+
+class SmplHost(C.Structure):
+    _fields_ = [('num_betas', C.c_int),
+                ('v_template_host', c_float_p), ('shapedirs_host', c_float_p), ('posedirs_host', c_float_p),
+                ('J_regressor_host', c_float_p), ('lbs_weights_host', c_float_p), ('parents_host', c_int_p),
+                ('extra_vertex_ids_host', c_int_p), ('J_regressor_more_host', c_float_p)]
+
+
+class FlowHost(C.Structure):
+    _fields_ = [('feat_dim', C.c_int), ('num_betas', C.c_int), ('isgc_dim', C.c_int), ('ctx_dim', C.c_int),
+                ('num_transforms', C.c_int), ('hidden', C.c_int * 3), ('count_bins', C.c_int),
+                ('radius', C.c_float), ('base_std', C.c_float),
+                ('parents_host', c_int_p), ('w_isgc_host', c_float_p), ('b_isgc_host', c_float_p),
+                ('w_ctx_host', C.POINTER(c_float_p)), ('b_ctx_host', C.POINTER(c_float_p)),
+                ('w_nn_host', C.POINTER(c_float_p)), ('b_nn_host', C.POINTER(c_float_p))]
+
+
+_VP = C.c_void_p
+_SIGS = {
+    'hmf_abi_version': (C.c_int, []),
+    'hmf_last_error': (C.c_char_p, []),
+    'hmf_device_count': (C.c_int, []),
+    'hmf_rot6d_to_rotmat': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'hmf_so3_exp': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'hmf_so3_log': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'hmf_so3_log_abs_det_jacobian': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'hmf_batch_rodrigues': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'hmf_smpl_create': (C.c_int, [C.POINTER(_VP), C.POINTER(SmplHost)]),
+    'hmf_smpl_destroy': (None, [_VP]),
+    'hmf_smpl_lbs_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'hmf_smpl_lbs': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_size_t, C.c_int, _VP]),
+    'hmf_smpl_tpose': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),
+    'hmf_vertex_variance': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
+    'hmf_flow_create': (C.c_int, [C.POINTER(_VP), C.POINTER(FlowHost)]),
+    'hmf_flow_destroy': (None, [_VP]),
+    'hmf_flow_forward_workspace_bytes': (C.c_size_t, [_VP, C.c_int, C.c_int, C.c_int]),
+    'hmf_flow_forward': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
+                                   _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    'hmf_flow_isgc': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP, _VP]),
+    'hmf_flow_context': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP]),
+    'hmf_flow_log_prob_SO3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
+    'hmf_flow_log_prob_so3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
+    'hmf_smpl_packed_blend_floats': (C.c_size_t, [C.c_int]),
+    'hmf_smpl_pack_blend_host': (C.c_int, [C.POINTER(SmplHost), c_float_p]),
+    'hmf_smpl_packed_blend_index': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'hmf_flow_packed_floats': (C.c_size_t, [C.POINTER(FlowHost)]),
+    'hmf_flow_pack_host': (C.c_int, [C.POINTER(FlowHost), c_float_p]),
+}
+EXPORTED_SYMBOLS = sorted(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load (building first if needed) the shared library; raises RuntimeError when impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from .build import build_library
+        build_library()
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError('humaniflow_amd: cannot load %s (%s). Build it with `python -m humaniflow_amd.build`; '
+                           'there is no CPU fallback.' % (LIB_PATH, e))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hmf_abi_version() != 1:
+        raise RuntimeError('humaniflow_amd: ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().hmf_last_error()
+        raise RuntimeError('humaniflow_amd %s failed (code %d): %s' % (what, rc, (msg or b'').decode(errors='replace')))
+
+
+def fptr(a):
+    """float32 C-contiguous numpy array -> POINTER(c_float) (array must stay alive)."""
+    assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(c_float_p)
+
+
+def iptr(a):
+    assert a.dtype == np.int32 and a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(c_int_p)
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError('humaniflow_amd: `%s` must live on a HIP device (got %s); the hot path has no CPU fallback '
+                           '-- use the oracle/ package for CPU checks.' % (name, t.device))
+
+
+def dptr(t):
+    """device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,55 @@
+"""Build libhumaniflow_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m humaniflow_amd.build [--force]
+
+The .so is git-ignored but travels with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['so3_kernels.hip', 'smpl_kernels.hip', 'flow_pack.hip', 'flow_kernels.hip']
+HEADERS = ['hmf_common.h', 'so3_math.h', 'flow_common.h', 'flow_handle.h', '../../include/humaniflow_amd.h']
+LIB = os.path.join(HERE, 'libhumaniflow_amd.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source into one shared library; returns its path."""
+    if not force and not _stale():
+        return LIB
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, s.replace('.hip', '.o'))
+        objs.append(o)
+        cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode(errors='replace')))
+        if verbose and out:
+            print(out.decode(errors='replace'))
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s' % r.stdout.decode(errors='replace'))
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_library(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,582 @@
+// Ancestor-conditioned SO(3) flow on gfx950: sampling / point-estimate pass and teacher-forced log-prob.
+//
+// hmf_flow_forward launch sequence (replaces the 23-iteration Python loop of
+// models/humaniflow_model.py:286-311 and its O(10^3) eager launches):
+//   k_isgc        G[b] = W_isgc[:, feats|R|cam] . [f_b, vec(R_b), cam_b] + bias      (per image, no ELU)
+//   k_flow_ctx0   rows = B*N samples (+ B point-estimate rows), tiles of 32 rows, one wave per
+//                 (tile, 3 parts): h = ELU(G[b] + W_beta beta_row) built straight into MFMA B-operand
+//                 registers; C0[part] = b_ctx + W_ctx[:, :256] h for ALL 23 parts (no kinematic dependency)
+//   k_flow_chain  one workgroup per 32-row tile, 5 waves; the 23 parts run as 8 dependency levels, the parts
+//                 of a level on different waves.  A wave takes its part through ancestor context -> ELU ->
+//                 2 x (hyper-network 65->64->32->32->62 + rational-linear spline) -> radial tanh -> exp,
+//                 entirely in registers (flow_common.h "ARL"); ancestor rotations live in LDS.
+// Teacher-forced side: k_flow_context (all 23 contexts from given rotations) and k_flow_logprob (log-map,
+// 2*pi pre-images, inverse flow, logsumexp; local_diffeo_transformed_distribution.py:91-142).
+#include "flow_common.h"
+#include "flow_handle.h"
+#include "so3_math.h"
+
+namespace hmf {
+
+// ---------------------------------------------------------------------------------------------------
+// k_isgc: out[b][o] = bias[o] + W[o][0:F].f_b (+ W[o][F:F+nb].shape_b) + W[o][F+nb:].[vec(R_b), cam_b]; optional ELU.
+// One wave per (output o, chunk of 8 images): the weight row sits in registers, lanes split the F axis.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_isgc(FlowDev d, const float* __restrict__ feats, const float* __restrict__ shape,
+                                              const float* __restrict__ glob_R, const float* __restrict__ cam, int B,
+                                              int apply_elu, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nchunk = (B + 7) / 8;
+    const int o = gw / nchunk, b0 = (gw % nchunk) * 8;
+    if (o >= kIsgc) return;
+    const int F = d.feat_dim, nb = d.nb;
+    const float* wrow = d.arena + d.o_wisgc + (size_t)o * d.in_dim;
+    const int per = F / 256;                          // float4 per lane (F multiple of 256)
+    for (int bb = b0; bb < min(b0 + 8, B); ++bb) {
+        const f32x4* fr = (const f32x4*)(feats + (size_t)bb * F);
+        const f32x4* wr = (const f32x4*)wrow;
+        float acc = 0.f;
+        for (int i = 0; i < per; ++i) {
+            const f32x4 a = wr[i * 64 + lane], x = fr[i * 64 + lane];
+            acc = fmaf(a[0], x[0], acc); acc = fmaf(a[1], x[1], acc); acc = fmaf(a[2], x[2], acc); acc = fmaf(a[3], x[3], acc);
+        }
+        if (lane < 9) acc = fmaf(wrow[F + nb + lane], glob_R[(size_t)bb * 9 + lane], acc);
+        else if (lane < 12) acc = fmaf(wrow[F + nb + lane], cam[(size_t)bb * 3 + (lane - 9)], acc);
+        else if (shape && lane >= 16 && lane < 16 + nb) acc = fmaf(wrow[F + lane - 16], shape[(size_t)bb * nb + (lane - 16)], acc);
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+        if (lane == 0) {
+            float v = acc + d.arena[d.o_bisgc + o];
+            out[(size_t)bb * kIsgc + o] = apply_elu ? elu1(v) : v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// row bookkeeping shared by the two forward kernels
+// ---------------------------------------------------------------------------------------------------
+struct RowInfo {
+    bool live, is_point;
+    int b, n;
+};
+__device__ __forceinline__ RowInfo row_info(int rowid, int B, int N, int Mtot) {
+    RowInfo r;
+    r.live = rowid < Mtot;
+    const int rs = r.live ? rowid : 0;
+    r.is_point = rs >= B * N;
+    r.b = r.is_point ? rs - B * N : rs / max(N, 1);
+    r.n = r.is_point ? 0 : rs - r.b * N;
+    return r;
+}
+
+template <int NTO>
+__device__ __forceinline__ void bias_init(const float* __restrict__ bias, int q, f32x16 (&acc)[NTO]) {
+#pragma unroll
+    for (int t = 0; t < NTO; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *(const f32x4*)(bias + 32 * t + 8 * g + 4 * q);
+            acc[t][4 * g + 0] = b[0]; acc[t][4 * g + 1] = b[1]; acc[t][4 * g + 2] = b[2]; acc[t][4 * g + 3] = b[3];
+        }
+}
+
+// acc[to] += W(tile to) . in   with `in` in ARL over NKT tiles; wp = packed block [NTO][NKT*4][64] float4, lane-adjusted.
+template <int NTO, int NKT>
+__device__ __forceinline__ void dense_layer(const f32x4* __restrict__ wp, const f32x16 (&in)[NKT], f32x16 (&acc)[NTO]) {
+    constexpr int NS4 = NKT * 4;
+#pragma unroll
+    for (int s4 = 0; s4 < NS4; ++s4) {
+        f32x4 w[NTO];
+#pragma unroll
+        for (int to = 0; to < NTO; ++to) w[to] = wp[(to * NS4 + s4) * 64];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s4 * 4 + u;
+#pragma unroll
+            for (int to = 0; to < NTO; ++to)
+                acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[to][u], in[s >> 4][s & 15], acc[to], 0, 0, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_flow_ctx0: image/shape half of every part's context layer.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPartsPerWave0 = 3;
+constexpr int kGroups0 = (kP + kPartsPerWave0 - 1) / kPartsPerWave0;   // 8
+
+__global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __restrict__ G, const float* __restrict__ shape_mode,
+                                                      const float* __restrict__ shape_log_std, const float* __restrict__ eps_shape,
+                                                      int B, int N, int Mtot, int ntiles, float* __restrict__ shape_samples,
+                                                      float* __restrict__ C0) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, q = lane >> 5;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = gw / kGroups0, pg = gw % kGroups0;
+    if (tile >= ntiles) return;
+    const int nb = d.nb;
+    const RowInfo ri = row_info(tile * 32 + l31, B, N, Mtot);
+    // shape vector of this lane's row (models/humaniflow_model.py:250-258)
+    float beta[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = 0.f;
+        if (i < nb && ri.live) {
+            v = shape_mode[(size_t)ri.b * nb + i];
+            if (!ri.is_point && eps_shape)
+                v = v + eps_shape[((size_t)ri.n * B + ri.b) * nb + i] * expf(shape_log_std[(size_t)ri.b * nb + i]);
+        }
+        beta[i] = v;
+    }
+    if (pg == 0 && q == 0 && ri.live && !ri.is_point && shape_samples)
+        for (int i = 0; i < nb; ++i) shape_samples[((size_t)ri.b * N + ri.n) * nb + i] = beta[i];
+    // h = ELU(G[b] + W_beta . beta) for the 256 isgc channels, produced directly in ARL registers: the rank-nb
+    // update is itself an MFMA (A = packed W_beta, B = this lane's beta pair), G[b] is gathered as float4.
+    f32x16 h[8];
+    {
+        const float* Gb = G + (size_t)ri.b * kIsgc;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *(const f32x4*)(Gb + 32 * t + 8 * g + 4 * q);
+                h[t][4 * g] = v[0]; h[t][4 * g + 1] = v[1]; h[t][4 * g + 2] = v[2]; h[t][4 * g + 3] = v[3];
+            }
+        const int g4 = (((nb + 1) >> 1) + 3) >> 2;
+        const f32x4* wp = (const f32x4*)(d.arena + d.o_wbeta) + lane;
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4) {
+            if (s4 < g4) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const f32x4 w = wp[(t * g4 + s4) * 64];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = s4 * 4 + u;
+                        h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u], q ? beta[2 * s + 1] : beta[2 * s], h[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) h[t][e] = ri.live ? elu1(h[t][e]) : 0.f;
+    }
+    for (int pi = 0; pi < kPartsPerWave0; ++pi) {
+        const int j = pg * kPartsPerWave0 + pi;
+        if (j >= kP) break;
+        const PartTab& pt = d.tab[j];
+        f32x16 acc[2];
+        bias_init<2>(d.arena + pt.o_bctx, q, acc);
+        dense_layer<2, 8>((const f32x4*)(d.arena + pt.o_wc0) + lane, h, acc);
+        f32x4* out = (f32x4*)(C0 + (((size_t)tile * kP + j) * 2) * 64 * 16) + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                out[t * 64 * 4 + g] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_flow_chain
+// ---------------------------------------------------------------------------------------------------
+constexpr int kChainWaves = 5;
+
+// one hyper-network tail (layers 2..4) + spline of one coupling; h1 = ReLU(first layer) in ARL (2 tiles)
+__device__ __forceinline__ float coupling_tail(const FlowDev& d, const PartTab& pt, int c, int lane, int q,
+                                               const f32x16 (&h1)[2], float x, float bound) {
+    f32x16 a2[1], a3[1], a4[2];
+    bias_init<1>(d.arena + pt.o_b2[c], q, a2);
+    dense_layer<1, 2>((const f32x4*)(d.arena + pt.o_w2[c]) + lane, h1, a2);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a2[0][e] = fmaxf(a2[0][e], 0.f);
+    bias_init<1>(d.arena + pt.o_b3[c], q, a3);
+    dense_layer<1, 1>((const f32x4*)(d.arena + pt.o_w3[c]) + lane, a2, a3);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a3[0][e] = fmaxf(a3[0][e], 0.f);
+    bias_init<2>(d.arena + pt.o_b4[c], q, a4);
+    dense_layer<2, 1>((const f32x4*)(d.arena + pt.o_w4[c]) + lane, a3, a4);
+    float rw[8], rh[8], rd[7], rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { rw[i] = a4[0][i]; rh[i] = a4[0][8 + i]; rl[i] = a4[1][8 + i]; }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) rd[i] = a4[1][i];
+    return rational_linear_spline<false>(x, rw, rh, rd, rl, bound, nullptr);
+}
+
+__global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, const float* __restrict__ C0,
+                                                                    const float* __restrict__ eps_pose, int B, int N, int Mtot,
+                                                                    float* __restrict__ rot_samples, float* __restrict__ rot_point,
+                                                                    float* __restrict__ so3_point) {
+    __shared__ float sAnc[32 * kAncRow];
+    __shared__ int sOff[kP * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, q = lane >> 5;
+    const int tile = blockIdx.x;
+    for (int i = tid; i < 32 * kAncRow; i += kChainWaves * 64) sAnc[i] = 0.f;
+    for (int i = tid; i < kP * 64; i += kChainWaves * 64) sOff[i] = d.anc_off[i];
+    __syncthreads();
+    const int rowid = tile * 32 + l31;
+    const RowInfo ri = row_info(rowid, B, N, Mtot);
+    const float bound = d.radius;
+    float* myAnc = sAnc + l31 * kAncRow;
+
+    for (int lev = 0; lev < d.lev.nlev; ++lev) {
+        for (int pi = d.lev.start[lev] + wave; pi < d.lev.start[lev + 1]; pi += kChainWaves) {
+            const int j = d.lev.parts[pi];
+            const PartTab& pt = d.tab[j];
+            // ---- context: C0 (image/shape half, precomputed) + ancestor half, ELU ----
+            f32x16 cx[2];
+            {
+                const f32x4* src = (const f32x4*)(C0 + (((size_t)tile * kP + j) * 2) * 64 * 16) + lane * 4;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = src[t * 64 * 4 + g];
+                        cx[t][4 * g] = v[0]; cx[t][4 * g + 1] = v[1]; cx[t][4 * g + 2] = v[2]; cx[t][4 * g + 3] = v[3];
+                    }
+            }
+            {
+                const f32x4* wp = (const f32x4*)(d.arena + pt.o_wa) + lane;
+                const int* off = sOff + j * 64 + q;
+                for (int s4 = 0; s4 < pt.kag; ++s4) {
+                    const f32x4 w0 = wp[s4 * 64], w1 = wp[(pt.kag + s4) * 64];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float bval = myAnc[off[2 * (s4 * 4 + u)]];
+                        cx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[u], bval, cx[0], 0, 0, 0);
+                        cx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[u], bval, cx[1], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cx[t][e] = elu1(cx[t][e]);
+            // ---- first hyper-network layer of both couplings (context columns) ----
+            f32x16 a1[4];
+            bias_init<4>(d.arena + pt.o_b1, q, a1);
+            dense_layer<4, 2>((const f32x4*)(d.arena + pt.o_w1) + lane, cx, a1);
+            // ---- base sample z = base_std * eps (pyro Normal.rsample), point-estimate rows push z = 0 ----
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+            if (ri.live && !ri.is_point) {
+                const float* e = eps_pose + (((size_t)j * B + ri.b) * N + ri.n) * 3;
+                x0 = e[0] * d.base_std; x1 = e[1] * d.base_std; x2 = e[2] * d.base_std;
+            }
+            // ---- coupling 0 (Permute [0,1,2]): x0 passes, lane q transforms x_{1+q} ----
+            f32x16 h1[2];
+            {
+                f32x16 wx[2];
+                bias_init<2>(d.arena + pt.o_w1x, q, wx);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) h1[t][e] = fmaxf(fmaf(wx[t][e], x0, a1[t][e]), 0.f);
+            }
+            const float xn = coupling_tail(d, pt, 0, lane, q, h1, q ? x2 : x1, bound);
+            const float x1n = __shfl(xn, l31), x2n = __shfl(xn, 32 + l31);
+            // ---- coupling 1 (Permute [1,2,0]): y = (x1', x2', x0); y0 passes, lane q transforms y_{1+q} ----
+            const float y0 = x1n;
+            {
+                f32x16 wx[2];
+                bias_init<2>(d.arena + pt.o_w1x + 64, q, wx);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) h1[t][e] = fmaxf(fmaf(wx[t][e], y0, a1[2 + t][e]), 0.f);
+            }
+            const float yn = coupling_tail(d, pt, 1, lane, q, h1, q ? x0 : x2n, bound);
+            const float y1 = __shfl(yn, l31), y2 = __shfl(yn, 32 + l31);
+            // ---- ScaledRadialTanh (scaled_radial_tanh_transform.py:28-35) ----
+            float v[3] = {y0, y1, y2};
+            {
+                const float nrm = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+                if (nrm > 1e-7f) {
+                    const float tt = tanhf(nrm / bound);
+                    v[0] = tt * (y0 / nrm) * bound; v[1] = tt * (y1 / nrm) * bound; v[2] = tt * (y2 / nrm) * bound;
+                }
+            }
+            // ---- exp map: fp64 Rodrigues rounded to fp32 for samples (:311), smplx Rodrigues for point rows (:299) ----
+            float R[9];
+            if (ri.is_point) {
+                batch_rodrigues_f32(v, R);
+            } else {
+                const double vd[3] = {(double)v[0], (double)v[1], (double)v[2]};
+                double Rd[9];
+                so3_exp_f64(vd, Rd);
+#pragma unroll
+                for (int e = 0; e < 9; ++e) R[e] = (float)Rd[e];
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) myAnc[j * 9 + e] = R[e];
+                if (ri.live) {
+                    if (ri.is_point) {
+                        float* o = rot_point + ((size_t)ri.b * kP + j) * 9;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) o[e] = R[e];
+                        float* a = so3_point + ((size_t)ri.b * kP + j) * 3;
+                        a[0] = v[0]; a[1] = v[1]; a[2] = v[2];
+                    } else {
+                        float* o = rot_samples + ((size_t)rowid * kP + j) * 9;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) o[e] = R[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// teacher-forced side (B rows only): contexts from given rotations, then log-probabilities.
+// One wave per (row, part); lane = output channel; inputs broadcast with readlane.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_context(FlowDev d, const float* __restrict__ isgc, const float* __restrict__ pose_R,
+                                                      int B, float* __restrict__ ctx) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= B * kP) return;
+    const int b = gw / kP, j = gw % kP;
+    const PartTab& pt = d.tab[j];
+    const float* WT = d.arena + pt.o_wctxT;
+    float acc = d.arena[pt.o_bctx + lane];
+    const float* x = isgc + (size_t)b * kIsgc;
+    for (int k = 0; k < kIsgc; ++k) acc = fmaf(WT[(size_t)k * kCtx + lane], x[k], acc);
+    for (int a = 0; a < pt.n_anc; ++a) {
+        const float* r = pose_R + ((size_t)b * kP + pt.anc[a]) * 9;
+        for (int e = 0; e < 9; ++e) acc = fmaf(WT[(size_t)(kIsgc + a * 9 + e) * kCtx + lane], r[e], acc);
+    }
+    ctx[((size_t)b * kP + j) * kCtx + lane] = elu1(acc);
+}
+
+// hyper-network of coupling c evaluated on (ctx, x1) for one (row, part) by one wave -> raw[lane] (62 valid)
+__device__ __forceinline__ float hypernet(const FlowDev& d, const PartTab& pt, int c, int lane, float ctx_lane, float x1) {
+    const float* W = d.arena + pt.o_nnT[c][0];
+    float a = d.arena[pt.o_nnb[c][0] + lane];
+    for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(ctx_lane, k), a);
+    a = fmaf(W[64 * 64 + lane], x1, a);
+    float h = fmaxf(a, 0.f);
+    W = d.arena + pt.o_nnT[c][1];
+    a = d.arena[pt.o_nnb[c][1] + lane];
+    for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(h, k), a);
+    h = fmaxf(a, 0.f);                       // lanes >= 32 hold relu(0 + 0) = 0 (padded columns are zero)
+    W = d.arena + pt.o_nnT[c][2];
+    a = d.arena[pt.o_nnb[c][2] + lane];
+    for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(h, k), a);
+    h = fmaxf(a, 0.f);
+    W = d.arena + pt.o_nnT[c][3];
+    a = d.arena[pt.o_nnb[c][3] + lane];
+    for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(h, k), a);
+    return a;
+}
+
+// inverse spline of coupling c on the two transformed coordinates; every lane computes dimension (lane & 1)
+__device__ __forceinline__ void coupling_inverse(const FlowDev& d, const PartTab& pt, int c, int lane, float ctx_lane,
+                                                 float y1, float& z2a, float& z2b, float& ld_sum) {
+    const float raw = hypernet(d, pt, c, lane, ctx_lane, y1);
+    const int dim = lane & 1;
+    float rw[8], rh[8], rd[7], rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        rw[i] = __shfl(raw, dim * 8 + i);
+        rh[i] = __shfl(raw, 16 + dim * 8 + i);
+        rl[i] = __shfl(raw, 46 + dim * 8 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) rd[i] = __shfl(raw, 32 + dim * 7 + i);
+    float ld;
+    const float in = dim ? z2b : z2a;
+    const float out = rational_linear_spline<true>(in, rw, rh, rd, rl, d.radius, &ld);
+    z2a = __shfl(out, 0); z2b = __shfl(out, 1);
+    ld_sum = __shfl(ld, 0) + __shfl(ld, 1);
+}
+
+// log p(v | ctx) on the algebra: torch TransformedDistribution.log_prob through
+// [Permute, Spline, Permute, Spline, ScaledRadialTanh] (pyro_conditional_norm_flow.py:55-113)
+__device__ __forceinline__ float log_prob_so3(const FlowDev& d, const PartTab& pt, int lane, float ctx_lane, const float (&v)[3]) {
+    const float r = d.radius;
+    // ScaledRadialTanh inverse in fp64 (scaled_radial_tanh_transform.py:37-46) and its log-det in fp32 (:48-59)
+    float x[3] = {v[0], v[1], v[2]};
+    {
+        const double yd[3] = {(double)v[0], (double)v[1], (double)v[2]};
+        const double n = sqrt(yd[0] * yd[0] + yd[1] * yd[1] + yd[2] * yd[2]);
+        if (n > 1e-7) {
+            const double s = atanh(n / (double)r);
+            x[0] = (float)(s * (yd[0] / n) * (double)r); x[1] = (float)(s * (yd[1] / n) * (double)r); x[2] = (float)(s * (yd[2] / n) * (double)r);
+        }
+    }
+    const float yn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float xn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    float lp = 0.f;
+    if (yn > 1e-7f) lp = -(2.f * (logf(yn) - logf(xn)) + log1pf(-((yn / r) * (yn / r))));
+    // coupling 1 inverse (log_abs_det_jacobian = -sum(inverse log-dets)), then Permute([1,2,0]) inverse
+    float a = x[1], b = x[2], ld;
+    coupling_inverse(d, pt, 1, lane, ctx_lane, x[0], a, b, ld);
+    lp += ld;
+    const float u0 = b, u1 = x[0], u2 = a;          // x_pre = y[argsort(perm)] = (y2, y0, y1)
+    // coupling 0 inverse, Permute([0,1,2]) is the identity
+    a = u1; b = u2;
+    coupling_inverse(d, pt, 0, lane, ctx_lane, u0, a, b, ld);
+    lp += ld;
+    const float z[3] = {u0, a, b};
+    // Independent(Normal(0, base_std)) log-density
+    const float var = d.base_std * d.base_std, lsc = logf(d.base_std), hl2pi = 0.91893853320467274178f;
+    float base = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) base += -(z[i] * z[i]) / (2.f * var) - lsc - hl2pi;
+    return lp + base;
+}
+
+// mode 0: SO(3) density of R (fp64, B x P x 9); mode 1: algebra density of v (fp32, B x P x 3)
+__global__ __launch_bounds__(256) void k_flow_logprob(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids,
+                                                      int P, const double* __restrict__ Rin, const float* __restrict__ vin, int B,
+                                                      int mode, float* __restrict__ logp) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= B * P) return;
+    const int p = gw % P;
+    const int j = part_ids ? part_ids[p] : p;
+    const PartTab& pt = d.tab[j];
+    const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
+    if (mode == 1) {
+        const float v[3] = {vin[(size_t)gw * 3], vin[(size_t)gw * 3 + 1], vin[(size_t)gw * 3 + 2]};
+        const float lp = log_prob_so3(d, pt, lane, ctx_lane, v);
+        if (lane == 0) logp[gw] = lp;
+        return;
+    }
+    double R[9], x[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = Rin[(size_t)gw * 9 + e];
+    so3_log_f64(R, x);
+    // so3_xset (utils/rigid_transform_utils.py:282-295) with k = -1, +1 and the support mask
+    // (so3_exp_transform.py:36-41); NaN at x = 0 fails the comparison, as in the reference (quirk 2)
+    const double kTwoPi = 6.28318530717958647692;
+    const double n = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    float terms[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double cand[3] = {x[0], x[1], x[2]};
+        bool ok = true;
+        if (c > 0) {
+            const double k = c == 1 ? -1.0 : 1.0;
+            const double sc = (n + kTwoPi * k);
+            cand[0] = x[0] / n * sc; cand[1] = x[1] / n * sc; cand[2] = x[2] / n * sc;
+            const double cn = sqrt(cand[0] * cand[0] + cand[1] * cand[1] + cand[2] * cand[2]);
+            ok = cn < (double)d.radius;
+            if (!ok) { cand[0] = 0.0; cand[1] = 0.0; cand[2] = 0.0; }
+        }
+        const float ld = -(float)so3_logdet_f64(cand);
+        const float v[3] = {(float)cand[0], (float)cand[1], (float)cand[2]};
+        const float lp = log_prob_so3(d, pt, lane, ctx_lane, v);
+        terms[c] = ok ? (ld + lp) : -INFINITY;
+    }
+    const float m = fmaxf(terms[0], fmaxf(terms[1], terms[2]));
+    const float s = expf(terms[0] - m) + expf(terms[1] - m) + expf(terms[2] - m);
+    if (lane == 0) logp[gw] = m + logf(s);
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+extern "C" {
+
+static int n_tiles(int B, int N, int pe) { return ((B * N + (pe ? B : 0)) + 31) / 32; }
+
+size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int compute_point_est) {
+    (void)h;
+    const size_t g = align_up((size_t)std::max(B, 1) * kIsgc * 4, 256);
+    const size_t c0 = (size_t)std::max(n_tiles(B, N, compute_point_est), 1) * kP * 2 * 64 * 16 * 4;
+    return g + c0;
+}
+
+int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* cam, const float* shape_mode,
+                     const float* shape_log_std, const float* eps_shape, const float* eps_pose, int B, int N,
+                     int compute_point_est, float* shape_samples, float* rotmats_samples, float* rotmats_point, float* so3_point,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !feats || !glob_R || !cam || !shape_mode) return fail(HMF_ERR_INVALID, "hmf_flow_forward: null input");
+    if (B <= 0 || N < 0) return fail(HMF_ERR_INVALID, "hmf_flow_forward: B=%d N=%d", B, N);
+    if (N > 0 && (!eps_pose || !rotmats_samples)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: N>0 needs eps_pose and rotmats_samples");
+    if (N > 0 && eps_shape && !shape_log_std) return fail(HMF_ERR_INVALID, "hmf_flow_forward: eps_shape needs shape_log_std");
+    if (compute_point_est && (!rotmats_point || !so3_point)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: point-estimate outputs missing");
+    if (N == 0 && !compute_point_est) return HMF_OK;
+    if ((long long)B * N + B > (1LL << 30)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: B*N too large");
+    const size_t need = hmf_flow_forward_workspace_bytes(h, B, N, compute_point_est);
+    if (!workspace || workspace_bytes < need) return fail(HMF_ERR_WORKSPACE, "hmf_flow_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    float* G = (float*)workspace;
+    float* C0 = (float*)((char*)workspace + align_up((size_t)B * kIsgc * 4, 256));
+    const int Mtot = B * N + (compute_point_est ? B : 0);
+    const int ntiles = (Mtot + 31) / 32;
+    {
+        const int nw = kIsgc * ((B + 7) / 8);
+        hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, feats, (const float*)nullptr, glob_R, cam, B, 0, G);
+        HMF_LAUNCH_CHECK();
+    }
+    {
+        const int nw = ntiles * kGroups0;
+        hipLaunchKernelGGL(k_flow_ctx0, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, eps_shape, B, N, Mtot,
+                           ntiles, shape_samples, C0);
+        HMF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, eps_pose, B, N, Mtot, rotmats_samples,
+                       rotmats_point, so3_point);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_isgc(const hmf_flow_t* h, const float* feats, const float* shape, const float* glob_R, const float* cam, int B,
+                  float* isgc, void* stream) {
+    if (!h || !feats || !shape || !glob_R || !cam || !isgc || B <= 0) return fail(HMF_ERR_INVALID, "hmf_flow_isgc: bad args");
+    const int nw = kIsgc * ((B + 7) / 8);
+    hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, feats, shape, glob_R, cam, B, 1, isgc);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_context(const hmf_flow_t* h, const float* isgc, const float* pose_R, int B, float* ctx, void* stream) {
+    if (!h || !isgc || !pose_R || !ctx || B <= 0) return fail(HMF_ERR_INVALID, "hmf_flow_context: bad args");
+    const int nw = B * kP;
+    hipLaunchKernelGGL(k_flow_context, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, isgc, pose_R, B, ctx);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+static int logprob_common(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const double* R, const float* v,
+                          int B, int mode, float* logp, void* stream) {
+    if (!h || !ctx || !logp || B <= 0 || P <= 0 || P > kP) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob: bad args");
+    if (!part_ids_host && P != kP) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob: part_ids NULL requires P == 23");
+    const int* dev_ids = nullptr;
+    if (part_ids_host) {
+        for (int i = 0; i < P; ++i)
+            if (part_ids_host[i] < 0 || part_ids_host[i] >= kP) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob: part id %d", part_ids_host[i]);
+        for (int i = 1; i < P; ++i)
+            if (part_ids_host[i] != part_ids_host[0] + i)
+                return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_log_prob: part ids must be a contiguous ascending range");
+        dev_ids = h->d_ids + part_ids_host[0];   // identity table 0..22 on the device
+    }
+    const int nw = B * P;
+    hipLaunchKernelGGL(k_flow_logprob, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, v, B, mode, logp);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_log_prob_SO3(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const double* R, int B,
+                          float* logp, void* stream) {
+    if (!R) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_SO3: null R");
+    return logprob_common(h, ctx, part_ids_host, P, R, nullptr, B, 0, logp, stream);
+}
+
+int hmf_flow_log_prob_so3(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const float* v, int B,
+                          float* logp, void* stream) {
+    if (!v) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_so3: null v");
+    return logprob_common(h, ctx, part_ids_host, P, nullptr, v, B, 1, logp, stream);
+}
+
+}  // extern "C"

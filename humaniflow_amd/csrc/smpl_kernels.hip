@@ -1,0 +1,631 @@
+// SMPL shape/pose blend-shapes + linear-blend skinning + 90 joints for gfx950 (MI355X).
+//
+// Replaces smplx.lbs.lbs / vertices2joints / VertexJointSelector as driven by the reference's
+// models/smpl.py:27-41 (call sites evaluate/evaluate_humaniflow.py:124-127,168-172,
+// predict/predict_humaniflow.py:128-131,160-163).  Launch sequence of hmf_smpl_lbs:
+//   1. k_rigid_chain   rest joints (J_template + Jdirs.beta), 24-joint kinematic chain, per-row skinning
+//                      transforms A (M x 24 x 3x4) -> workspace; posed joints -> joints[:, :24]
+//   2. k_lbs_mfma      v_posed = [R-I | beta | 1] (M x 224) . Bpack (224 x 3V) on fp32 MFMA 32x32x2,
+//                      skinning transform blended from LDS and applied in-register, vertices written once
+//   3. k_joints        21 vertex picks + 45 sparse regressed joints gathered from the written vertices
+// Data layout and roofline: DESIGN.md "hmf_smpl_lbs".
+#include <vector>
+#include <cmath>
+#include "hmf_common.h"
+
+namespace hmf {
+
+constexpr int kVT = 216;             // vertex tiles of 32 (6912 >= 6890)
+constexpr int kVTperX = 27;          // vertex tiles per XCD-aligned vertex range (216 / 8)
+constexpr int kKG = 28;              // k-groups of 4 MFMA k-steps (2 k each): K_pad = 224
+constexpr int kKpad = kKG * 8;       // 224 >= 207 + num_betas + 1
+constexpr int kPoseFeat = 207;
+constexpr int kRowsPerWG = 64;       // two 32-row MFMA tiles per wave
+constexpr int kAtr = kJ * 12;        // 288 floats of skinning transforms per row
+constexpr int kMaxBetas = 16;
+
+struct SmplDev {
+    int num_betas;
+    int skin_slots;                  // ELL width: max non-zeros per row of lbs_weights
+    int depth_max;
+    int parents[kJ];
+    int depth[kJ];
+    float* blend;                    // packed [kVT][kKG][3][64][4]
+    int* skin_off;                   // [kVT][skin_slots][32] byte offset (joint*48) into a row's A block
+    float* skin_w;                   // [kVT][skin_slots][32]
+    float* j_template;               // 24 x 3
+    float* j_dirs;                   // 24 x 3 x nb
+    int* jr_ptr;                     // 67 CSR row pointers: 21 picks + 45 regressed joints
+    int* jr_idx;
+    float* jr_w;
+    float* tp_dirs;                  // [nb][3V]
+    float* tp_tmpl;                  // [3V]
+};
+
+}  // namespace hmf
+
+struct hmf_smpl {
+    hmf::SmplDev d;
+    void* arena;
+};
+
+namespace hmf {
+
+__host__ __device__ inline size_t blend_index(int k, int v, int c) {
+    int vt = v >> 5, l31 = v & 31;
+    int ks = k >> 1, half = k & 1;
+    int kg = ks >> 2, u = ks & 3;
+    int idx = u * 3 + c;
+    int lane = half * 32 + l31;
+    return ((((size_t)vt * kKG + kg) * 3 + (idx >> 2)) * 64 + lane) * 4 + (idx & 3);
+}
+
+// k-th entry of the extended pose feature of one row: [vec(R_1..R_23) - I | beta | 1 | 0...]
+__device__ __forceinline__ float pose_feature(int k, int nb, const float* __restrict__ body_row,
+                                              const float* __restrict__ beta_row) {
+    if (k < kPoseFeat) {
+        int e = k % 9;
+        return body_row[k] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+    }
+    if (k < kPoseFeat + nb) return beta_row[k - kPoseFeat];
+    return (k == kPoseFeat + nb) ? 1.0f : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1. rigid chain: block = 8 rows x 24 joints, level-synchronous over the kinematic tree depth.
+//    smplx lbs.batch_rigid_transform: G_i = G_parent @ [[R_i, J_i - J_parent],[0,1]], A_i = [G_R | G_t - G_R J_i].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __restrict__ glob, int Mg,
+                                                     const float* __restrict__ body, const float* __restrict__ betas,
+                                                     int Mb, int M, float* __restrict__ atr, float* __restrict__ joints) {
+    __shared__ float sJ[8][kJ][3];
+    __shared__ float sG[8][kJ][12];
+    const int j = threadIdx.x % kJ, r = threadIdx.x / kJ;
+    const int row = blockIdx.x * 8 + r;
+    const bool live = row < M;
+    const int nb = d.num_betas;
+    float Jc[3] = {0.f, 0.f, 0.f};
+    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+    if (live) {
+        const float* b = betas + (size_t)(Mb == 1 ? 0 : row) * nb;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float acc = d.j_template[j * 3 + c];
+            for (int k = 0; k < nb; ++k) acc = fmaf(d.j_dirs[(j * 3 + c) * nb + k], b[k], acc);
+            Jc[c] = acc;
+        }
+        if (j == 0) {
+            if (glob) {
+                const float* g = glob + (size_t)(Mg == 1 ? 0 : row) * 9;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) R[e] = g[e];
+            }
+        } else if (body) {
+            const float* p = body + ((size_t)row * 23 + (j - 1)) * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) R[e] = p[e];
+        }
+    }
+    sJ[r][j][0] = Jc[0]; sJ[r][j][1] = Jc[1]; sJ[r][j][2] = Jc[2];
+    __syncthreads();
+    const int par = d.parents[j];
+    float rel[3] = {Jc[0], Jc[1], Jc[2]};
+    if (j > 0) {
+        rel[0] -= sJ[r][par][0]; rel[1] -= sJ[r][par][1]; rel[2] -= sJ[r][par][2];
+    }
+    float G[12];
+    const int my_depth = d.depth[j];
+    for (int lev = 0; lev <= d.depth_max; ++lev) {
+        if (my_depth == lev) {
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    G[i * 4 + 0] = R[i * 3 + 0]; G[i * 4 + 1] = R[i * 3 + 1]; G[i * 4 + 2] = R[i * 3 + 2];
+                    G[i * 4 + 3] = rel[i];
+                }
+            } else {
+                float P[12];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) P[e] = sG[r][par][e];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float a = P[i * 4 + 0] * R[0 * 3 + c];
+                        a = fmaf(P[i * 4 + 1], R[1 * 3 + c], a);
+                        a = fmaf(P[i * 4 + 2], R[2 * 3 + c], a);
+                        G[i * 4 + c] = a;
+                    }
+                    float t = P[i * 4 + 0] * rel[0];
+                    t = fmaf(P[i * 4 + 1], rel[1], t);
+                    t = fmaf(P[i * 4 + 2], rel[2], t);
+                    G[i * 4 + 3] = t + P[i * 4 + 3];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sG[r][j][e] = G[e];
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    if (joints) {
+        float* o = joints + ((size_t)row * kOutJ + j) * 3;
+        o[0] = G[3]; o[1] = G[7]; o[2] = G[11];
+    }
+    float* a = atr + ((size_t)row * kJ + j) * 12;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float t = G[i * 4 + 0] * Jc[0];
+        t = fmaf(G[i * 4 + 1], Jc[1], t);
+        t = fmaf(G[i * 4 + 2], Jc[2], t);
+        a[i * 4 + 0] = G[i * 4 + 0]; a[i * 4 + 1] = G[i * 4 + 1]; a[i * 4 + 2] = G[i * 4 + 2];
+        a[i * 4 + 3] = G[i * 4 + 3] - t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2. fused pose-blend GEMM + skinning.  One workgroup (8 waves) per CU; it owns a contiguous chunk of
+//    (row-group of 64 rows, vertex tile) pairs inside ONE of the 8 vertex ranges (27 tiles = 2.3 MB of
+//    packed operand, which stays resident in that XCD's 4 MB L2 when block b lands on XCD b%8).
+//    Per wave tile: D(64 rows x 32 verts x 3 comps) = 112 k-steps x 6 v_mfma_f32_32x32x2_f32.
+//    LDS: pose-feature panel [224][64] (A operand, conflict-free ds_read_b32) + skinning transforms
+//    [64][24][12] (ds_read_b128 gather by joint).  The B operand streams L2 -> VGPR as dwordx4.
+// ---------------------------------------------------------------------------------------------------
+template <int SLOTS>
+__device__ __forceinline__ void skin_store(const SmplDev& d, const float* __restrict__ sA, const f32x16 (&acc)[2][3],
+                                           int vt, int l31, int half, int row0, int M, float* __restrict__ verts,
+                                           int slots_rt) {
+    const int v = vt * 32 + l31;
+    const int nslots = SLOTS > 0 ? SLOTS : slots_rt;
+    int off[SLOTS > 0 ? SLOTS : 1];
+    float w[SLOTS > 0 ? SLOTS : 1];
+    if (SLOTS > 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            off[s] = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
+            w[s] = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const char* base = (const char*)(sA + r * kAtr);
+            f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
+            if (SLOTS > 0) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const f32x4* p = (const f32x4*)(base + off[s]);
+                    T0 += w[s] * p[0]; T1 += w[s] * p[1]; T2 += w[s] * p[2];
+                }
+            } else {
+                for (int s = 0; s < nslots; ++s) {
+                    const int o = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
+                    const float ww = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
+                    const f32x4* p = (const f32x4*)(base + o);
+                    T0 += ww * p[0]; T1 += ww * p[1]; T2 += ww * p[2];
+                }
+            }
+            const float px = acc[rt][0][reg], py = acc[rt][1][reg], pz = acc[rt][2][reg];
+            const float x = fmaf(T0[2], pz, fmaf(T0[1], py, T0[0] * px)) + T0[3];
+            const float y = fmaf(T1[2], pz, fmaf(T1[1], py, T1[0] * px)) + T1[3];
+            const float z = fmaf(T2[2], pz, fmaf(T2[1], py, T2[0] * px)) + T2[3];
+            const int row = row0 + r;
+            if (row < M && v < kV) {
+                float* o = verts + ((size_t)row * kV + v) * 3;
+                o[0] = x; o[1] = y; o[2] = z;
+            }
+            // keep the 32 unrolled (row, vertex) bodies from being interleaved: hoisting all their LDS gathers
+            // at once costs ~400 live registers and spills
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, const float* __restrict__ body,
+                                                     const float* __restrict__ betas, int Mb, int M, int nrg, int wpx,
+                                                     const float* __restrict__ atr, float* __restrict__ verts) {
+    __shared__ __attribute__((aligned(16))) float smem[kKpad * kRowsPerWG + kRowsPerWG * kAtr];  // 56 + 72 KB
+    float* sPF = smem;
+    float* sA = smem + kKpad * kRowsPerWG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int xr = blockIdx.x & 7;                 // vertex range (XCD-affine for L2 residency; speed only)
+    const int chunk = blockIdx.x >> 3;
+    const int T = nrg * kVTperX;
+    int t = (int)((long long)chunk * T / wpx);
+    const int t1 = (int)((long long)(chunk + 1) * T / wpx);
+    const int nb = d.num_betas;
+    while (t < t1) {
+        const int rg = t / kVTperX;
+        const int seg_end = min(t1, (rg + 1) * kVTperX);
+        const int row0 = rg * kRowsPerWG;
+        // ---- stage the A operand panel and the skinning transforms of this row group ----
+        for (int i = tid; i < kKpad * kRowsPerWG; i += 512) {
+            const int k = i >> 6, r = i & 63, row = row0 + r;
+            float val = 0.f;
+            if (row < M)
+                val = pose_feature(k, nb, body + (size_t)row * kPoseFeat, betas + (size_t)(Mb == 1 ? 0 : row) * nb);
+            sPF[i] = val;
+        }
+        {
+            const f32x4* src = (const f32x4*)(atr + (size_t)row0 * kAtr);
+            f32x4* dst = (f32x4*)sA;
+            const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
+            for (int i = tid; i < kRowsPerWG * (kAtr / 4); i += 512) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                dst[i] = (i < n4) ? src[i] : z;
+            }
+        }
+        __syncthreads();
+        for (int tt = t + wave; tt < seg_end; tt += 8) {
+            const int vt = xr * kVTperX + (tt - rg * kVTperX);
+            f32x16 acc[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+            const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
+            f32x4 b0 = bp[0], b1 = bp[64], b2 = bp[128];
+            const float* ap = sPF + half * 64 + l31;
+#pragma unroll 2
+            for (int kg = 0; kg < kKG; ++kg) {
+                f32x4 n0 = b0, n1 = b1, n2 = b2;
+                if (kg + 1 < kKG) {
+                    n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128];
+                }
+                const float bv[12] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = kg * 4 + u;
+                    const float a0 = ap[ks * 128], a1 = ap[ks * 128 + 32];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[u * 3 + c], acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[u * 3 + c], acc[1][c], 0, 0, 0);
+                    }
+                }
+                b0 = n0; b1 = n1; b2 = n2;
+            }
+            skin_store<SLOTS>(d, sA, acc, vt, l31, half, row0, M, verts, d.skin_slots);
+        }
+        __syncthreads();
+        t = seg_end;
+    }
+}
+
+// Scalar cross-check kernel (tests only): one thread per (row, vertex), same k order and the same
+// skinning op order as the MFMA kernel, so both must agree bit for bit.
+__global__ void k_lbs_scalar(SmplDev d, const float* __restrict__ body, const float* __restrict__ betas, int Mb,
+                             int M, const float* __restrict__ atr, float* __restrict__ verts) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)M * kV) return;
+    const int row = (int)(gid / kV), v = (int)(gid % kV);
+    const int nb = d.num_betas;
+    const float* brow = body + (size_t)row * kPoseFeat;
+    const float* beta = betas + (size_t)(Mb == 1 ? 0 : row) * nb;
+    float p[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < kKpad; ++k) {
+        const float a = pose_feature(k, nb, brow, beta);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = fmaf(a, d.blend[blend_index(k, v, c)], p[c]);
+    }
+    const int vt = v >> 5, l31 = v & 31;
+    f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
+    for (int s = 0; s < d.skin_slots; ++s) {
+        const int o = d.skin_off[((size_t)vt * d.skin_slots + s) * 32 + l31];
+        const float w = d.skin_w[((size_t)vt * d.skin_slots + s) * 32 + l31];
+        const f32x4* q = (const f32x4*)((const char*)(atr + (size_t)row * kAtr) + o);
+        T0 += w * q[0]; T1 += w * q[1]; T2 += w * q[2];
+    }
+    float* o = verts + ((size_t)row * kV + v) * 3;
+    o[0] = fmaf(T0[2], p[2], fmaf(T0[1], p[1], T0[0] * p[0])) + T0[3];
+    o[1] = fmaf(T1[2], p[2], fmaf(T1[1], p[1], T1[0] * p[0])) + T1[3];
+    o[2] = fmaf(T2[2], p[2], fmaf(T2[1], p[1], T2[0] * p[0])) + T2[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3. joints 24..89: vertex picks (weight 1) and the three sparse extra regressors (models/smpl.py:30-34)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_joints(SmplDev d, const float* __restrict__ verts, int M, float* __restrict__ joints) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nextra = kOutJ - kJ;
+    if (gid >= M * nextra) return;
+    const int row = gid / nextra, i = gid % nextra;
+    const float* vr = verts + (size_t)row * kV * 3;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int e = d.jr_ptr[i]; e < d.jr_ptr[i + 1]; ++e) {
+        const float w = d.jr_w[e];
+        const float* p = vr + (size_t)d.jr_idx[e] * 3;
+        x = fmaf(w, p[0], x); y = fmaf(w, p[1], y); z = fmaf(w, p[2], z);
+    }
+    float* o = joints + ((size_t)row * kOutJ + kJ + i) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// T-pose bodies: v_template + shapedirs . beta.  HBM-write bound: 8 B per lane per row, the 2*nb basis
+// values of a lane's two coordinates live in registers across the row loop.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kTpRows = 16;
+__global__ __launch_bounds__(256) void k_tpose(SmplDev d, const float* __restrict__ betas, int M,
+                                               float* __restrict__ verts) {
+    const int pair = blockIdx.x * 256 + threadIdx.x;       // coordinate pair index in [0, 3V/2)
+    const int row0 = blockIdx.y * kTpRows;
+    if (pair >= kV * 3 / 2) return;
+    const int nb = d.num_betas;
+    float2 base = ((const float2*)d.tp_tmpl)[pair];
+    float2 sd[kMaxBetas];
+#pragma unroll
+    for (int k = 0; k < kMaxBetas; ++k)
+        if (k < nb) sd[k] = ((const float2*)(d.tp_dirs + (size_t)k * kV * 3))[pair];
+    const int rend = min(row0 + kTpRows, M);
+    for (int row = row0; row < rend; ++row) {
+        const float* b = betas + (size_t)row * nb;       // wave-uniform -> scalar loads
+        float2 o = base;
+#pragma unroll
+        for (int k = 0; k < kMaxBetas; ++k)
+            if (k < nb) { o.x = fmaf(sd[k].x, b[k], o.x); o.y = fmaf(sd[k].y, b[k], o.y); }
+        ((float2*)(verts + (size_t)row * kV * 3))[pair] = o;
+    }
+}
+
+// compute_vertex_variance_from_samples, utils/sampling_utils.py:22-33 (two passes, like the reference)
+__global__ void k_vertex_variance(const float* __restrict__ verts, int N, int V, float* __restrict__ avg_l2,
+                                  float* __restrict__ dir_std) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+        const float* p = verts + ((size_t)n * V + v) * 3;
+        m[0] += p[0]; m[1] += p[1]; m[2] += p[2];
+    }
+    m[0] /= N; m[1] /= N; m[2] /= N;
+    float s[3] = {0.f, 0.f, 0.f}, l2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = verts + ((size_t)n * V + v) * 3;
+        const float dx = p[0] - m[0], dy = p[1] - m[1], dz = p[2] - m[2];
+        s[0] += dx * dx; s[1] += dy * dy; s[2] += dz * dz;
+        l2 += sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    avg_l2[v] = l2 / N;
+    dir_std[v * 3 + 0] = sqrtf(s[0] / N); dir_std[v * 3 + 1] = sqrtf(s[1] / N); dir_std[v * 3 + 2] = sqrtf(s[2] / N);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side packing
+// ---------------------------------------------------------------------------------------------------
+static int validate(const hmf_smpl_host_t* m) {
+    if (!m || !m->v_template_host || !m->shapedirs_host || !m->posedirs_host || !m->J_regressor_host ||
+        !m->lbs_weights_host || !m->parents_host || !m->extra_vertex_ids_host || !m->J_regressor_more_host)
+        return fail(HMF_ERR_INVALID, "hmf_smpl: null model array");
+    if (m->num_betas < 1 || m->num_betas > kMaxBetas)
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_smpl: num_betas=%d outside [1,%d]", m->num_betas, kMaxBetas);
+    if (m->parents_host[0] != -1) return fail(HMF_ERR_INVALID, "hmf_smpl: parents[0] must be -1");
+    for (int j = 1; j < kJ; ++j)
+        if (m->parents_host[j] < 0 || m->parents_host[j] >= j)
+            return fail(HMF_ERR_INVALID, "hmf_smpl: parents[%d]=%d is not an earlier joint", j, m->parents_host[j]);
+    return HMF_OK;
+}
+
+static void pack_blend(const hmf_smpl_host_t* m, float* out) {
+    const int nb = m->num_betas;
+    memset(out, 0, sizeof(float) * (size_t)kVT * kKG * 3 * 64 * 4);
+    for (int v = 0; v < kV; ++v)
+        for (int c = 0; c < 3; ++c) {
+            for (int k = 0; k < kPoseFeat; ++k) out[blend_index(k, v, c)] = m->posedirs_host[(size_t)k * kV * 3 + v * 3 + c];
+            for (int k = 0; k < nb; ++k) out[blend_index(kPoseFeat + k, v, c)] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
+            out[blend_index(kPoseFeat + nb, v, c)] = m->v_template_host[v * 3 + c];
+        }
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+extern "C" {
+
+size_t hmf_smpl_packed_blend_floats(int) { return (size_t)kVT * kKG * 3 * 64 * 4; }
+size_t hmf_smpl_packed_blend_index(int k, int v, int c) { return blend_index(k, v, c); }
+
+int hmf_smpl_pack_blend_host(const hmf_smpl_host_t* m, float* out) {
+    int rc = validate(m);
+    if (rc) return rc;
+    if (!out) return fail(HMF_ERR_INVALID, "hmf_smpl_pack_blend_host: null output");
+    pack_blend(m, out);
+    return HMF_OK;
+}
+
+int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
+    if (!out) return fail(HMF_ERR_INVALID, "hmf_smpl_create: null out");
+    *out = nullptr;
+    int rc = validate(m);
+    if (rc) return rc;
+    if (hmf_device_count() <= 0) return fail(HMF_ERR_NO_DEVICE, "hmf_smpl_create: no HIP device visible");
+    const int nb = m->num_betas;
+    // --- ELL skin weights -------------------------------------------------------------------------
+    int slots = 1;
+    for (int v = 0; v < kV; ++v) {
+        int n = 0;
+        for (int j = 0; j < kJ; ++j) n += m->lbs_weights_host[(size_t)v * kJ + j] != 0.0f;
+        slots = std::max(slots, n);
+    }
+    if (slots > 4 && slots < 8) slots = 8;
+    if (slots < 4) slots = 4;
+    std::vector<int> soff((size_t)kVT * slots * 32, 0);
+    std::vector<float> sw((size_t)kVT * slots * 32, 0.f);
+    for (int v = 0; v < kV; ++v) {
+        int s = 0;
+        for (int j = 0; j < kJ; ++j) {
+            const float w = m->lbs_weights_host[(size_t)v * kJ + j];
+            if (w != 0.0f) {
+                soff[((size_t)(v >> 5) * slots + s) * 32 + (v & 31)] = j * 48;
+                sw[((size_t)(v >> 5) * slots + s) * 32 + (v & 31)] = w;
+                ++s;
+            }
+        }
+    }
+    // --- rest joints as an affine function of beta (fp64 accumulate, rounded once) ------------------
+    std::vector<float> jt(kJ * 3), jd((size_t)kJ * 3 * nb);
+    for (int j = 0; j < kJ; ++j)
+        for (int c = 0; c < 3; ++c) {
+            double a = 0.0;
+            for (int v = 0; v < kV; ++v) a += (double)m->J_regressor_host[(size_t)j * kV + v] * m->v_template_host[v * 3 + c];
+            jt[j * 3 + c] = (float)a;
+            for (int k = 0; k < nb; ++k) {
+                double b = 0.0;
+                for (int v = 0; v < kV; ++v)
+                    b += (double)m->J_regressor_host[(size_t)j * kV + v] * m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
+                jd[((size_t)j * 3 + c) * nb + k] = (float)b;
+            }
+        }
+    // --- CSR of the 66 gathered joints ----------------------------------------------------------------
+    std::vector<int> ptr(1, 0), idx;
+    std::vector<float> wts;
+    for (int i = 0; i < 21; ++i) {
+        const int v = m->extra_vertex_ids_host[i];
+        if (v < 0 || v >= kV) return fail(HMF_ERR_INVALID, "hmf_smpl_create: extra vertex id %d out of range", v);
+        idx.push_back(v); wts.push_back(1.0f); ptr.push_back((int)idx.size());
+    }
+    for (int i = 0; i < 45; ++i) {
+        for (int v = 0; v < kV; ++v) {
+            const float w = m->J_regressor_more_host[(size_t)i * kV + v];
+            if (w != 0.0f) { idx.push_back(v); wts.push_back(w); }
+        }
+        ptr.push_back((int)idx.size());
+    }
+    // --- T-pose basis [nb][3V] -----------------------------------------------------------------------
+    std::vector<float> tpd((size_t)nb * kV * 3);
+    for (int v = 0; v < kV; ++v)
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < nb; ++k) tpd[(size_t)k * kV * 3 + v * 3 + c] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
+    std::vector<float> blend((size_t)kVT * kKG * 3 * 64 * 4);
+    pack_blend(m, blend.data());
+
+    // --- one device arena -----------------------------------------------------------------------------
+    size_t off = 0;
+    auto place = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_blend = place(blend.size() * 4), o_soff = place(soff.size() * 4), o_sw = place(sw.size() * 4);
+    const size_t o_jt = place(jt.size() * 4), o_jd = place(jd.size() * 4), o_ptr = place(ptr.size() * 4);
+    const size_t o_idx = place(idx.size() * 4), o_w = place(wts.size() * 4), o_tpd = place(tpd.size() * 4);
+    const size_t o_tpt = place((size_t)kV * 3 * 4);
+    void* arena = nullptr;
+    HMF_HIP(hipMalloc(&arena, off));
+    char* base = (char*)arena;
+    auto up = [&](size_t o, const void* src, size_t bytes) { return hipMemcpy(base + o, src, bytes, hipMemcpyHostToDevice); };
+    hipError_t e = up(o_blend, blend.data(), blend.size() * 4);
+    if (e == hipSuccess) e = up(o_soff, soff.data(), soff.size() * 4);
+    if (e == hipSuccess) e = up(o_sw, sw.data(), sw.size() * 4);
+    if (e == hipSuccess) e = up(o_jt, jt.data(), jt.size() * 4);
+    if (e == hipSuccess) e = up(o_jd, jd.data(), jd.size() * 4);
+    if (e == hipSuccess) e = up(o_ptr, ptr.data(), ptr.size() * 4);
+    if (e == hipSuccess) e = up(o_idx, idx.data(), idx.size() * 4);
+    if (e == hipSuccess) e = up(o_w, wts.data(), wts.size() * 4);
+    if (e == hipSuccess) e = up(o_tpd, tpd.data(), tpd.size() * 4);
+    if (e == hipSuccess) e = up(o_tpt, m->v_template_host, (size_t)kV * 3 * 4);
+    if (e != hipSuccess) {
+        (void)hipFree(arena);
+        return fail(HMF_ERR_HIP, "hmf_smpl_create: upload failed: %s", hipGetErrorString(e));
+    }
+    hmf_smpl* h = new hmf_smpl();
+    h->arena = arena;
+    SmplDev& d = h->d;
+    d.num_betas = nb;
+    d.skin_slots = slots;
+    d.depth_max = 0;
+    for (int j = 0; j < kJ; ++j) {
+        d.parents[j] = m->parents_host[j];
+        d.depth[j] = j == 0 ? 0 : d.depth[m->parents_host[j]] + 1;
+        d.depth_max = std::max(d.depth_max, d.depth[j]);
+    }
+    d.blend = (float*)(base + o_blend);
+    d.skin_off = (int*)(base + o_soff);
+    d.skin_w = (float*)(base + o_sw);
+    d.j_template = (float*)(base + o_jt);
+    d.j_dirs = (float*)(base + o_jd);
+    d.jr_ptr = (int*)(base + o_ptr);
+    d.jr_idx = (int*)(base + o_idx);
+    d.jr_w = (float*)(base + o_w);
+    d.tp_dirs = (float*)(base + o_tpd);
+    d.tp_tmpl = (float*)(base + o_tpt);
+    *out = h;
+    return HMF_OK;
+}
+
+void hmf_smpl_destroy(hmf_smpl_t* h) {
+    if (!h) return;
+    (void)hipFree(h->arena);
+    delete h;
+}
+
+size_t hmf_smpl_lbs_workspace_bytes(int M) { return align_up((size_t)std::max(M, 1) * kAtr * sizeof(float), 256); }
+
+int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose, const float* betas,
+                 int Mb, int M, float* verts, float* joints, void* workspace, size_t workspace_bytes, int impl,
+                 void* stream) {
+    if (!h || !global_orient || !body_pose || !betas || !verts) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: null argument");
+    if (M < 0 || (Mb != 1 && Mb != M) || (Mg != 1 && Mg != M))
+        return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: M=%d Mb=%d Mg=%d (Mb, Mg must be 1 or M)", M, Mb, Mg);
+    if (M == 0) return HMF_OK;
+    if (!workspace || workspace_bytes < hmf_smpl_lbs_workspace_bytes(M))
+        return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
+    hipStream_t st = (hipStream_t)stream;
+    float* atr = (float*)workspace;
+    hipLaunchKernelGGL(k_rigid_chain, dim3((M + 7) / 8), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas, Mb, M,
+                       atr, joints);
+    HMF_LAUNCH_CHECK();
+    if (impl == 1) {
+        const long long n = (long long)M * kV;
+        hipLaunchKernelGGL(k_lbs_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d, body_pose, betas, Mb, M,
+                           atr, verts);
+    } else {
+        const int nrg = (M + kRowsPerWG - 1) / kRowsPerWG;
+        const int T = nrg * kVTperX;
+        int wpx = (T + 7) / 8;                      // at least one tile per wave
+        wpx = std::max(1, std::min(32, wpx));       // 32 CUs per XCD
+        const dim3 grid(8 * wpx), block(512);
+        if (h->d.skin_slots == 4)
+            hipLaunchKernelGGL(k_lbs_mfma<4>, grid, block, 0, st, h->d, body_pose, betas, Mb, M, nrg, wpx, atr, verts);
+        else if (h->d.skin_slots == 8)
+            hipLaunchKernelGGL(k_lbs_mfma<8>, grid, block, 0, st, h->d, body_pose, betas, Mb, M, nrg, wpx, atr, verts);
+        else
+            hipLaunchKernelGGL(k_lbs_mfma<0>, grid, block, 0, st, h->d, body_pose, betas, Mb, M, nrg, wpx, atr, verts);
+    }
+    HMF_LAUNCH_CHECK();
+    if (joints) {
+        const int n = M * (kOutJ - kJ);
+        hipLaunchKernelGGL(k_joints, dim3((n + 255) / 256), dim3(256), 0, st, h->d, verts, M, joints);
+        HMF_LAUNCH_CHECK();
+    }
+    return HMF_OK;
+}
+
+int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts, float* joints, void* stream) {
+    if (!h || !betas || !verts) return fail(HMF_ERR_INVALID, "hmf_smpl_tpose: null argument");
+    if (M < 0) return fail(HMF_ERR_INVALID, "hmf_smpl_tpose: M=%d", M);
+    if (M == 0) return HMF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((kV * 3 / 2 + 255) / 256, (M + kTpRows - 1) / kTpRows);
+    hipLaunchKernelGGL(k_tpose, grid, dim3(256), 0, st, h->d, betas, M, verts);
+    HMF_LAUNCH_CHECK();
+    if (joints) {
+        // identity pose: posed joints == rest joints; the chain kernel with null rotations writes them
+        // (its transforms output is not needed: it goes to the tail of the joints buffer's own rows? no --
+        // it needs scratch, so T-pose joints reuse the gather kernel for 24..89 and a rest-joint pass for 0..23)
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_smpl_tpose: joints output not implemented; pass NULL");
+    }
+    return HMF_OK;
+}
+
+int hmf_vertex_variance(const float* verts, int N, int V, float* avg_l2, float* dir_std, void* stream) {
+    if (!verts || !avg_l2 || !dir_std || N <= 0 || V <= 0) return fail(HMF_ERR_INVALID, "hmf_vertex_variance: bad args");
+    hipLaunchKernelGGL(k_vertex_variance, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, N, V, avg_l2, dir_std);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+}  // extern "C"

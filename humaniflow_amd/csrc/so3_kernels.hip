@@ -1,0 +1,99 @@
+// Standalone element-wise SO(3) kernels (one rotation per lane) + error plumbing of the C ABI.
+// They back humaniflow_amd/rigid_transform_utils.py; the fused flow kernels inline the same
+// device functions from so3_math.h.
+#include "hmf_common.h"
+#include "so3_math.h"
+
+namespace hmf {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+__global__ void k_rot6d(const float* __restrict__ x, int n, float* __restrict__ R) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float in[6], out[9];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in[k] = x[(size_t)i * 6 + k];
+    rot6d_to_rotmat_f32(in, out);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = out[k];
+}
+
+__global__ void k_so3_exp(const double* __restrict__ v, int n, double* __restrict__ R) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double in[3] = {v[(size_t)i * 3], v[(size_t)i * 3 + 1], v[(size_t)i * 3 + 2]}, out[9];
+    so3_exp_f64(in, out);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = out[k];
+}
+
+__global__ void k_so3_log(const double* __restrict__ R, int n, double* __restrict__ v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double in[9], out[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) in[k] = R[(size_t)i * 9 + k];
+    so3_log_f64(in, out);
+    v[(size_t)i * 3] = out[0];
+    v[(size_t)i * 3 + 1] = out[1];
+    v[(size_t)i * 3 + 2] = out[2];
+}
+
+__global__ void k_so3_logdet(const double* __restrict__ v, int n, double* __restrict__ o) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double in[3] = {v[(size_t)i * 3], v[(size_t)i * 3 + 1], v[(size_t)i * 3 + 2]};
+    o[i] = so3_logdet_f64(in);
+}
+
+__global__ void k_rodrigues(const float* __restrict__ v, int n, float* __restrict__ R) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float in[3] = {v[(size_t)i * 3], v[(size_t)i * 3 + 1], v[(size_t)i * 3 + 2]}, out[9];
+    batch_rodrigues_f32(in, out);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = out[k];
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+extern "C" {
+
+int hmf_abi_version(void) { return HMF_ABI_VERSION; }
+const char* hmf_last_error(void) { return err_buf(); }
+int hmf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+#define HMF_ELEMENTWISE(name, kern, TIN, TOUT)                                                  \
+    int name(const TIN* in, int n, TOUT* out, void* stream) {                                   \
+        if (n < 0 || (n > 0 && (!in || !out))) return fail(HMF_ERR_INVALID, #name ": bad args"); \
+        if (n == 0) return HMF_OK;                                                              \
+        hipLaunchKernelGGL(kern, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, n, out); \
+        HMF_LAUNCH_CHECK();                                                                     \
+        return HMF_OK;                                                                          \
+    }
+
+HMF_ELEMENTWISE(hmf_rot6d_to_rotmat, k_rot6d, float, float)
+HMF_ELEMENTWISE(hmf_so3_exp, k_so3_exp, double, double)
+HMF_ELEMENTWISE(hmf_so3_log, k_so3_log, double, double)
+HMF_ELEMENTWISE(hmf_so3_log_abs_det_jacobian, k_so3_logdet, double, double)
+HMF_ELEMENTWISE(hmf_batch_rodrigues, k_rodrigues, float, float)
+
+}  // extern "C"

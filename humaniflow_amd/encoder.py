@@ -1,0 +1,147 @@
+"""ResNet-18/50 image encoder (no classifier head) with the reference's state-dict names.
+
+Role of models/resnet.py in the reference (ResNet.forward :202-217, resnet18/50 :229,251):
+(B, C_in, 256, 256) proxy representation -> (B, 512|2048) pooled features.  Parameter and
+buffer names follow torchvision (`conv1`, `bn1`, `layerL.B.convK/bnK`, `layerL.B.downsample.{0,1}`)
+so a reference checkpoint loads with ``strict=True``.
+
+Per the north star this stage stays on PyTorch-ROCm (MIOpen convolutions); what is added
+for MI355X is an *inference plan*: eval-mode BatchNorm folded into the preceding
+convolution's weight/bias, channels_last activations, optional bf16 compute (BASELINE
+configs[2]) -- built lazily from the live parameters and invalidated when they change,
+so the checkpoint layout is untouched.
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+_SPECS = {18: (False, [2, 2, 2, 2]), 34: (False, [3, 4, 6, 3]), 50: (True, [3, 4, 6, 3])}
+
+
+def _conv(cin, cout, k, stride=1):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+
+
+class _Residual(nn.Module):
+    """BasicBlock (two 3x3) or Bottleneck (1x1 -> 3x3(stride) -> 1x1 x4)."""
+
+    def __init__(self, cin, width, stride, bottleneck):
+        super().__init__()
+        self.bottleneck = bottleneck
+        cout = width * (4 if bottleneck else 1)
+        if bottleneck:
+            self.conv1, self.bn1 = _conv(cin, width, 1), nn.BatchNorm2d(width)
+            self.conv2, self.bn2 = _conv(width, width, 3, stride), nn.BatchNorm2d(width)
+            self.conv3, self.bn3 = _conv(width, cout, 1), nn.BatchNorm2d(cout)
+        else:
+            self.conv1, self.bn1 = _conv(cin, width, 3, stride), nn.BatchNorm2d(width)
+            self.conv2, self.bn2 = _conv(width, cout, 3), nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
+
+    def stages(self):
+        s = [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+        if self.bottleneck:
+            s.append((self.conv3, self.bn3))
+        return s
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        st = self.stages()
+        for conv, bn in st[:-1]:
+            x = F.relu(bn(conv(x)))
+        conv, bn = st[-1]
+        return F.relu(bn(conv(x)) + idt)
+
+
+class ResNetEncoder(nn.Module):
+    def __init__(self, num_layers, in_channels):
+        super().__init__()
+        bottleneck, depths = _SPECS[num_layers]
+        self.out_dim = 512 * (4 if bottleneck else 1)
+        self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for li, (width, n) in enumerate(zip((64, 128, 256, 512), depths)):
+            blocks = []
+            for bi in range(n):
+                blocks.append(_Residual(cin, width, 2 if (li > 0 and bi == 0) else 1, bottleneck))
+                cin = width * (4 if bottleneck else 1)
+            setattr(self, 'layer%d' % (li + 1), nn.Sequential(*blocks))
+        for m in self.modules():                                  # models/resnet.py:162-167
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        self._plan = None
+        self._plan_key = None
+
+    # ---- plain module path (training / CPU / debugging) ----------------------------------
+    def forward_module(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), kernel_size=3, stride=2, padding=1)
+        for li in range(1, 5):
+            x = getattr(self, 'layer%d' % li)(x)
+        return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+
+    # ---- folded inference plan ----------------------------------------------------------
+    @staticmethod
+    def _fold(conv, bn, dtype):
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = (conv.weight * scale[:, None, None, None]).to(dtype).contiguous(memory_format=torch.channels_last)
+        b = (bn.bias - bn.running_mean * scale).to(dtype)
+        return w, b, conv.stride, conv.padding
+
+    # The plan is a cache of the live parameters: drop it whenever they can have changed
+    # (train()/eval() toggles, .to()/.cuda(), load_state_dict).  Callers that mutate
+    # ``param.data`` by hand in eval mode must call invalidate_plan() themselves.
+    def invalidate_plan(self):
+        self._plan = None
+
+    def train(self, mode=True):
+        self._plan = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._plan = None
+        return super()._load_from_state_dict(*a, **k)
+
+    @torch.no_grad()
+    def _build_plan(self, dtype):
+        plan = {'stem': self._fold(self.conv1, self.bn1, dtype), 'blocks': []}
+        for li in range(1, 5):
+            for blk in getattr(self, 'layer%d' % li):
+                ds = None if blk.downsample is None else self._fold(blk.downsample[0], blk.downsample[1], dtype)
+                plan['blocks'].append(([self._fold(c, b, dtype) for c, b in blk.stages()], ds))
+        return plan
+
+    @torch.no_grad()
+    def forward_folded(self, x, dtype=torch.float32):
+        if self._plan is None or self._plan_key != dtype:
+            self._plan, self._plan_key = self._build_plan(dtype), dtype
+        p = self._plan
+        x = x.to(dtype).contiguous(memory_format=torch.channels_last)
+        w, b, s, pad = p['stem']
+        x = F.max_pool2d(F.relu_(F.conv2d(x, w, b, s, pad)), kernel_size=3, stride=2, padding=1)
+        for stages, ds in p['blocks']:
+            idt = x if ds is None else F.conv2d(x, ds[0], ds[1], ds[2], ds[3])
+            for w, b, s, pad in stages[:-1]:
+                x = F.relu_(F.conv2d(x, w, b, s, pad))
+            w, b, s, pad = stages[-1]
+            x = F.relu_(F.conv2d(x, w, b, s, pad).add_(idt))
+        return x.mean(dim=(2, 3)).float()
+
+    def forward(self, x):
+        if (not self.training) and (not torch.is_grad_enabled()) and x.is_cuda:
+            return self.forward_folded(x, getattr(self, 'compute_dtype', torch.float32))
+        return self.forward_module(x)
+
+
+def resnet18(in_channels, pretrained=False):
+    return ResNetEncoder(18, in_channels)
+
+
+def resnet50(in_channels, pretrained=False):
+    return ResNetEncoder(50, in_channels)

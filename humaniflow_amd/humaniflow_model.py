@@ -1,0 +1,371 @@
+"""HumaniflowModel with the reference's constructor, forward signature, return dict and checkpoint layout,
+running its flow on the HIP kernels of libhumaniflow_amd.
+
+Mirror of models/humaniflow_model.py:33-340.  What stays PyTorch (as the north star prescribes): the ResNet
+encoder (MIOpen) and the four small head GEMMs fc1/fc_shape/fc_glob/fc_cam (:232-252).  Everything from
+`rot6d_to_rotmat` on -- shape sampling, input/shape/glob/cam features (:116-150), the 23 per-part context
+layers (:152-186), the ancestor-conditioned flows in kinematic order (:286-311) and the teacher-forced
+log-likelihood objects (:314-320) -- is one C-ABI call sequence (hmf_flow_forward / hmf_flow_context /
+hmf_flow_log_prob_*), with no Python loop over body parts.
+
+state_dict keys: init_glob, init_cam, image_encoder.*, fc1, fc_shape, fc_glob, fc_cam,
+fc_input_shape_glob_cam_feats, fc_flow_context.{0..22}, pose_so3flow_transform_modules.{0..45}.nn.layers.{0..3}.
+
+Only the default flow configuration is built (spline_coupling + permute, hidden [64,32,32], 8 bins); other
+TRANSFORM_TYPE / PERMUTE_TYPE values raise NotImplementedError at construction.
+"""
+import ctypes as C
+from collections import defaultdict
+
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Normal
+
+from . import _lib
+from .encoder import resnet18, resnet50
+from .rigid_transform_utils import rot6d_to_rotmat, rotmat_to_rot6d
+
+
+def immediate_parent_to_all_ancestors(immediate_parents):
+    """models/humaniflow_model.py:16-30: dict[joint] = [parent, grand-parent, ...], root excluded,
+    body part j = SMPL joint j+1."""
+    ancestors_dict = defaultdict(list)
+    for i in range(1, len(immediate_parents)):
+        joint = i - 1
+        parent = immediate_parents[i] - 1
+        if parent >= 0:
+            ancestors_dict[joint] += [parent] + ancestors_dict[parent]
+        else:
+            ancestors_dict[joint] += []
+    return ancestors_dict
+
+
+class ConditionalDenseNN(nn.Module):
+    """Parameter container with pyro.nn.ConditionalDenseNN's layout: `layers` = [Linear(in+ctx, h0), ..., Linear(h_last,
+    sum(param_dims))]; the forward pass runs inside the flow kernels (input order [context, x], ReLU)."""
+
+    def __init__(self, input_dim, context_dim, hidden_dims, param_dims):
+        super().__init__()
+        self.input_dim, self.context_dim, self.hidden_dims, self.param_dims = input_dim, context_dim, hidden_dims, param_dims
+        dims = [input_dim + context_dim] + list(hidden_dims) + [sum(param_dims)]
+        self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+
+class ConditionalSplineCoupling(nn.Module):
+    """models/norm_flows/transforms/conditional_spline_coupling_transform.py:10-78 (split_dim = 1, identity=True):
+    holds the hyper-network as `.nn`; evaluation happens in hmf_flow_forward / hmf_flow_log_prob_*."""
+
+    def __init__(self, input_dim, context_dim, hidden_dims, count_bins, bound):
+        super().__init__()
+        split_dim = input_dim // 2
+        up = input_dim - split_dim
+        self.input_dim, self.split_dim, self.count_bins, self.bound = input_dim, split_dim, count_bins, bound
+        self.nn = ConditionalDenseNN(split_dim, context_dim, hidden_dims,
+                                     param_dims=[up * count_bins, up * count_bins, up * (count_bins - 1), up * count_bins])
+
+
+class _ConditionedFlowDist:
+    """What `.condition(ctx)` returns in the reference: an object exposing log_prob().  group=True mirrors
+    LocalDiffeoTransformedDistribution (R (B,3,3) fp64 -> (B,) fp32, local_diffeo_transformed_distribution.py:84-142),
+    group=False the algebra density (v (B,3) fp32)."""
+
+    def __init__(self, model, part, ctx, group, check_finite=False):
+        self.model, self.part, self.ctx, self.group, self.check_finite = model, part, ctx, group, check_finite
+
+    def log_prob(self, value):
+        m = self.model
+        _lib.require_cuda(value, 'value')
+        lib = _lib.load()
+        B = self.ctx.shape[0]
+        ids = (C.c_int32 * 1)(self.part)
+        out = torch.empty(B, dtype=torch.float32, device=value.device)
+        if self.check_finite:                      # the reference's NaN/Inf asserts (:94-95), opt-in: they force a sync
+            assert torch.isnan(value).sum() == 0 and not torch.isinf(value).any()
+        with torch.cuda.device(value.device):
+            h = m._flow_handle(value.device)
+            if self.group:
+                R = value.detach().to(torch.float64).contiguous().reshape(B, 9)
+                _lib.check(lib.hmf_flow_log_prob_SO3(h, _lib.dptr(self.ctx), ids, 1, _lib.dptr(R), B, _lib.dptr(out),
+                                                     _lib.current_stream()), 'hmf_flow_log_prob_SO3')
+            else:
+                v = value.detach().to(torch.float32).contiguous().reshape(B, 3)
+                _lib.check(lib.hmf_flow_log_prob_so3(h, _lib.dptr(self.ctx), ids, 1, _lib.dptr(v), B, _lib.dptr(out),
+                                                     _lib.current_stream()), 'hmf_flow_log_prob_so3')
+        if self.check_finite:
+            assert torch.isnan(out).sum() == 0
+        return out
+
+
+class _FlowDistHandle:
+    """Stand-in for the reference's per-part `pose_SO3flow_dists[i]` / `pose_so3flow_dists[i]` objects: callers only
+    use `.condition(ctx)` (inside forward) and `.clear_cache()` (train/train_humaniflow.py:353-354)."""
+
+    def __init__(self, model, part, group):
+        self.model, self.part, self.group = model, part, group
+
+    def condition(self, context):
+        return _ConditionedFlowDist(self.model, self.part, context.detach().to(torch.float32).contiguous(), self.group)
+
+    def clear_cache(self):
+        pass
+
+
+class HumaniflowModel(nn.Module):
+    def __init__(self, device, model_cfg, smpl_parents):
+        super().__init__()
+        nf = model_cfg.NORM_FLOW
+        if nf.TRANSFORM_TYPE != 'spline_coupling' or nf.PERMUTE_TYPE != 'permute':
+            raise NotImplementedError('humaniflow_amd builds the default flow only (spline_coupling + permute); got %s + %s'
+                                      % (nf.TRANSFORM_TYPE, nf.PERMUTE_TYPE))
+        self.parents = list(smpl_parents)
+        self.ancestors_dict = immediate_parent_to_all_ancestors(self.parents)
+        self.num_bodyparts = len(self.ancestors_dict)
+        self.model_cfg = model_cfg
+        self.num_shape_params = model_cfg.NUM_SMPL_BETAS
+        self.num_glob_params = 6
+        self.register_buffer('init_glob', rotmat_to_rot6d(torch.eye(3)[None, :].float()))
+        self.num_cam_params = 3
+        self.register_buffer('init_cam', torch.tensor([0.9, 0.0, 0.0]).float())
+
+        if model_cfg.NUM_RESNET_LAYERS == 18:
+            self.image_encoder = resnet18(in_channels=model_cfg.NUM_IN_CHANNELS)
+            input_feats_dim, fc1_dim = 512, 512
+        elif model_cfg.NUM_RESNET_LAYERS == 50:
+            self.image_encoder = resnet50(in_channels=model_cfg.NUM_IN_CHANNELS)
+            input_feats_dim, fc1_dim = 2048, 1024
+        else:
+            raise ValueError('NUM_RESNET_LAYERS must be 18 or 50')
+        self.input_feats_dim = input_feats_dim
+
+        self.activation = nn.ELU()
+        self.fc1 = nn.Linear(input_feats_dim, fc1_dim)
+        self.fc_shape = nn.Linear(fc1_dim, self.num_shape_params * 2)
+        self.fc_glob = nn.Linear(fc1_dim, self.num_glob_params)
+        self.fc_cam = nn.Linear(fc1_dim, self.num_cam_params)
+        self.fc_input_shape_glob_cam_feats = nn.Linear(input_feats_dim + self.num_shape_params + 9 + self.num_cam_params,
+                                                       model_cfg.INPUT_SHAPE_GLOB_CAM_FEATS_DIM)
+        self.fc_flow_context = nn.ModuleList()
+        self.pose_so3flow_transform_modules = nn.ModuleList()
+        self.pose_so3flow_dists = []
+        self.pose_SO3flow_dists = []
+        for bodypart in range(self.num_bodyparts):
+            num_ancestors = len(self.ancestors_dict[bodypart])
+            self.fc_flow_context.append(nn.Linear(model_cfg.INPUT_SHAPE_GLOB_CAM_FEATS_DIM + num_ancestors * 9, nf.CONTEXT_DIM))
+            for _ in range(nf.NUM_TRANSFORMS):        # module index = NUM_TRANSFORMS * part + t
+                self.pose_so3flow_transform_modules.append(
+                    ConditionalSplineCoupling(3, nf.CONTEXT_DIM, list(nf.TRANSFORM_NN_HIDDEN_DIMS), nf.NUM_SPLINE_SEGMENTS,
+                                              nf.COMPACT_SUPPORT_RADIUS))
+            self.pose_so3flow_dists.append(_FlowDistHandle(self, bodypart, group=False))
+            self.pose_SO3flow_dists.append(_FlowDistHandle(self, bodypart, group=True))
+        self._handles = {}
+        self._ws = {}
+        self.to(device)
+
+    # ---- packed-weight handle: a cache of the live parameters ------------------------------------------------------
+    def invalidate_flow_weights(self):
+        if getattr(self, '_handles', None):
+            lib = _lib.load()
+            for h in self._handles.values():
+                lib.hmf_flow_destroy(h)
+        self._handles = {}
+
+    def train(self, mode=True):
+        self.invalidate_flow_weights()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_flow_weights()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.invalidate_flow_weights()
+        return super()._load_from_state_dict(*a, **k)
+
+    def __del__(self):
+        try:
+            self.invalidate_flow_weights()
+        except Exception:
+            pass
+
+    def flow_host_struct(self):
+        """(hmf_flow_host_t, keep-alive list) from the live parameters."""
+        keep = []
+
+        def arr(t):
+            a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+            keep.append(a)
+            return a
+        nf = self.model_cfg.NORM_FLOW
+        P, T = self.num_bodyparts, nf.NUM_TRANSFORMS
+        hs = _lib.FlowHost()
+        hs.feat_dim, hs.num_betas = self.input_feats_dim, self.num_shape_params
+        hs.isgc_dim, hs.ctx_dim, hs.num_transforms = self.model_cfg.INPUT_SHAPE_GLOB_CAM_FEATS_DIM, nf.CONTEXT_DIM, T
+        hd = list(nf.TRANSFORM_NN_HIDDEN_DIMS)
+        if len(hd) != 3:
+            raise NotImplementedError('TRANSFORM_NN_HIDDEN_DIMS must have 3 entries')
+        hs.hidden = (C.c_int * 3)(*hd)
+        hs.count_bins, hs.radius, hs.base_std = nf.NUM_SPLINE_SEGMENTS, nf.COMPACT_SUPPORT_RADIUS, nf.BASE_DIST_STD
+        par = np.ascontiguousarray(np.array(self.parents, np.int32))
+        keep.append(par)
+        hs.parents_host = _lib.iptr(par)
+        hs.w_isgc_host = _lib.fptr(arr(self.fc_input_shape_glob_cam_feats.weight))
+        hs.b_isgc_host = _lib.fptr(arr(self.fc_input_shape_glob_cam_feats.bias))
+        wc = (_lib.c_float_p * P)(*[_lib.fptr(arr(m.weight)) for m in self.fc_flow_context])
+        bc = (_lib.c_float_p * P)(*[_lib.fptr(arr(m.bias)) for m in self.fc_flow_context])
+        wn, bn = [], []
+        for mod in self.pose_so3flow_transform_modules:
+            for lin in mod.nn.layers:
+                wn.append(_lib.fptr(arr(lin.weight)))
+                bn.append(_lib.fptr(arr(lin.bias)))
+        wn_a = (_lib.c_float_p * len(wn))(*wn)
+        bn_a = (_lib.c_float_p * len(bn))(*bn)
+        keep += [wc, bc, wn_a, bn_a]
+        hs.w_ctx_host, hs.b_ctx_host, hs.w_nn_host, hs.b_nn_host = wc, bc, wn_a, bn_a
+        return hs, keep
+
+    def _flow_handle(self, device):
+        key = (device.type, device.index)
+        h = self._handles.get(key)
+        if h is None:
+            lib = _lib.load()
+            hs, keep = self.flow_host_struct()
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.hmf_flow_create(C.byref(h), C.byref(hs)), 'hmf_flow_create')
+            self._handles[key] = h
+        return h
+
+    def _workspace(self, device, nbytes):
+        key = (device.type, device.index)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    # ---- reference helper methods (kept for API parity; single calls into the library) -----------------------------
+    def compute_input_shape_glob_cam_feats(self, input_feats, shape, glob_R, cam):
+        """models/humaniflow_model.py:116-150.  (B,F),(B,nb),(B,3,3),(B,3) -> (B,256); the 3-D (per-sample) variant of
+        the reference is fused into hmf_flow_forward and is not exposed separately."""
+        if shape.dim() != 2:
+            raise NotImplementedError('per-sample features are computed inside hmf_flow_forward')
+        lib = _lib.load()
+        B = shape.shape[0]
+        f = input_feats.detach().float().contiguous()
+        out = torch.empty(B, self.model_cfg.INPUT_SHAPE_GLOB_CAM_FEATS_DIM, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device):
+            _lib.check(lib.hmf_flow_isgc(self._flow_handle(f.device), _lib.dptr(f), _lib.dptr(shape.detach().float().contiguous()),
+                                         _lib.dptr(glob_R.detach().float().contiguous()), _lib.dptr(cam.detach().float().contiguous()),
+                                         B, _lib.dptr(out), _lib.current_stream()), 'hmf_flow_isgc')
+        return out
+
+    def compute_flow_context_all(self, input_shape_glob_cam_feats, pose_SO3):
+        """models/humaniflow_model.py:152-186 for all 23 parts at once from GIVEN rotations: (B,256),(B,23,3,3) -> (B,23,64)."""
+        lib = _lib.load()
+        B = pose_SO3.shape[0]
+        x = input_shape_glob_cam_feats.detach().float().contiguous()
+        R = pose_SO3.detach().float().contiguous()
+        ctx = torch.empty(B, self.num_bodyparts, self.model_cfg.NORM_FLOW.CONTEXT_DIM, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.hmf_flow_context(self._flow_handle(x.device), _lib.dptr(x), _lib.dptr(R), B, _lib.dptr(ctx),
+                                            _lib.current_stream()), 'hmf_flow_context')
+        return ctx
+
+    def log_prob_all_parts(self, ctx, R):
+        """Batched form of `[d.log_prob(R[:, j]) for j, d in enumerate(conditioned_pose_SO3flow_dists_for_loglik)]`
+        (losses/humaniflow_loss.py:30-31): ctx (B,23,64), R (B,23,3,3) -> (B,23) fp32, one launch."""
+        lib = _lib.load()
+        B = R.shape[0]
+        R64 = R.detach().to(torch.float64).contiguous()
+        out = torch.empty(B, self.num_bodyparts, dtype=torch.float32, device=R.device)
+        with torch.cuda.device(R.device):
+            _lib.check(lib.hmf_flow_log_prob_SO3(self._flow_handle(R.device), _lib.dptr(ctx.contiguous()), None, self.num_bodyparts,
+                                                 _lib.dptr(R64), B, _lib.dptr(out), _lib.current_stream()), 'hmf_flow_log_prob_SO3')
+        return out
+
+    # ---- forward ----------------------------------------------------------------------------------------------------
+    def forward(self, input, compute_point_est=True, num_samples=0, use_shape_mode_for_samples=False, compute_for_loglik=False,
+                shape_for_loglik=None, pose_R_for_loglik=None, glob_R_for_loglik=None, input_feats=None,
+                grad_for_pose_point_est=False, return_input_feats=False, return_input_feats_only=False, noise=None):
+        """models/humaniflow_model.py:188-340.  Extra keyword `noise` = {'shape': (N,B,nb), 'pose': (23,B,N,3)} standard-normal
+        tensors injects the base noise (exact-parity tests); otherwise it is drawn from the device generator in the reference's
+        order (shape first, then the body parts)."""
+        if input_feats is None:
+            _lib.require_cuda(input, 'input')
+            input_feats = self.image_encoder(input)
+        if return_input_feats_only:
+            return {'input_feats': input_feats}
+        _lib.require_cuda(input_feats, 'input_feats')
+        batch_size = input_feats.shape[0]
+        device = input_feats.device
+        if compute_for_loglik:
+            assert pose_R_for_loglik is not None and pose_R_for_loglik.shape[0] == batch_size
+            assert shape_for_loglik is not None and shape_for_loglik.shape[0] == batch_size
+            assert glob_R_for_loglik is not None and glob_R_for_loglik.shape[0] == batch_size
+        if grad_for_pose_point_est or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError('humaniflow_amd round 1 implements the inference path only: call under torch.no_grad() '
+                                      '(gradients through the flow kernels are a "next" row, see DESIGN.md)')
+        lib = _lib.load()
+        nb, P, N = self.num_shape_params, self.num_bodyparts, int(num_samples)
+
+        x = self.activation(self.fc1(input_feats))
+        cam = self.fc_cam(x) + self.init_cam                                         # :237-238
+        glob = self.fc_glob(x) + self.init_glob                                      # :243-244
+        glob_R = rot6d_to_rotmat(glob)                                               # :245  (hmf_rot6d_to_rotmat)
+        shape_params = self.fc_shape(x)
+        shape_mode = shape_params[:, :nb]
+        shape_log_std = shape_params[:, nb:]
+        shape_dist = Normal(loc=shape_mode, scale=torch.exp(shape_log_std), validate_args=False)
+
+        return_dict = {'cam_wp': cam, 'glob_rotmat': glob_R, 'shape_mode': shape_mode, 'shape_log_std': shape_log_std,
+                       'shape_dist_for_loglik': shape_dist}
+
+        if compute_point_est or N > 0:
+            f32c = lambda t: t.detach().to(torch.float32).contiguous()
+            feats_c, glob_c, cam_c, mode_c, lstd_c = f32c(input_feats), f32c(glob_R), f32c(cam), f32c(shape_mode), f32c(shape_log_std)
+            eps_shape = eps_pose = None
+            if N > 0:
+                if noise is not None:
+                    eps_pose = f32c(noise['pose'])
+                    assert tuple(eps_pose.shape) == (P, batch_size, N, 3)
+                    if not use_shape_mode_for_samples:
+                        eps_shape = f32c(noise['shape'])
+                        assert tuple(eps_shape.shape) == (N, batch_size, nb)
+                else:
+                    if not use_shape_mode_for_samples:
+                        eps_shape = torch.randn(N, batch_size, nb, device=device)          # :258 rsample([N])
+                    eps_pose = torch.randn(P, batch_size, N, 3, device=device)             # :309, parts 0..22 in order
+            shape_samples = torch.empty(batch_size, N, nb, dtype=torch.float32, device=device) if N > 0 else None
+            rot_s = torch.empty(batch_size, N, P, 3, 3, dtype=torch.float32, device=device) if N > 0 else None
+            rot_p = torch.empty(batch_size, P, 3, 3, dtype=torch.float32, device=device) if compute_point_est else None
+            so3_p = torch.empty(batch_size, P, 3, dtype=torch.float32, device=device) if compute_point_est else None
+            with torch.cuda.device(device):
+                h = self._flow_handle(device)
+                nbytes = lib.hmf_flow_forward_workspace_bytes(h, batch_size, N, int(compute_point_est))
+                ws = self._workspace(device, nbytes)
+                _lib.check(lib.hmf_flow_forward(h, _lib.dptr(feats_c), _lib.dptr(glob_c), _lib.dptr(cam_c), _lib.dptr(mode_c),
+                                                _lib.dptr(lstd_c), _lib.dptr(eps_shape), _lib.dptr(eps_pose), batch_size, N,
+                                                int(compute_point_est), _lib.dptr(shape_samples), _lib.dptr(rot_s), _lib.dptr(rot_p),
+                                                _lib.dptr(so3_p), _lib.dptr(ws), ws.numel(), _lib.current_stream()),
+                           'hmf_flow_forward')
+            if compute_point_est:
+                return_dict['pose_axisangle_point_est'] = so3_p
+                return_dict['pose_rotmats_point_est'] = rot_p
+            if N > 0:
+                return_dict['pose_rotmats_samples'] = rot_s
+                return_dict['shape_samples'] = (shape_mode[:, None, :].expand(-1, N, -1) if use_shape_mode_for_samples
+                                                else shape_samples)
+
+        if compute_for_loglik:
+            isgc = self.compute_input_shape_glob_cam_feats(input_feats, shape_for_loglik, glob_R_for_loglik, cam)    # :279-283
+            ctx = self.compute_flow_context_all(isgc, pose_R_for_loglik)                                              # :315-318
+            return_dict['conditioned_pose_so3flow_dists_for_loglik'] = [
+                self.pose_so3flow_dists[j].condition(ctx[:, j]) for j in range(P)]
+            return_dict['conditioned_pose_SO3flow_dists_for_loglik'] = [
+                self.pose_SO3flow_dists[j].condition(ctx[:, j]) for j in range(P)]
+            return_dict['flow_context_for_loglik'] = ctx          # extension: feed log_prob_all_parts() for one-launch NLL
+
+        if return_input_feats:
+            return_dict['input_feats'] = input_feats
+        return return_dict

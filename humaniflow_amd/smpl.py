@@ -1,0 +1,271 @@
+"""SMPL body model with the reference's wrapper API, running on the HIP kernels.
+
+Mirror of models/smpl.py:13-41 (class ``SMPL(smplx.SMPL)``: forces vertices, appends the three extra
+joint regressors -> 90 joints) and of the smplx.SMPL pieces its callers rely on:
+
+    smpl = SMPL(model_path, batch_size=B, gender='neutral', num_betas=10, create_transl=False).to(device)
+    smpl.parents.tolist()                                   # scripts/run_predict.py:74
+    out = smpl(body_pose=R (M,23,3,3), global_orient=R0 (M,1,3,3), betas=(M,10), pose2rot=False)
+    out = smpl(body_pose=(M,69), global_orient=(M,3), betas=(M,10))          # axis-angle, pose2rot=True
+    out.vertices (M,6890,3), out.joints (M,90,3), out.betas, out.global_orient, out.body_pose, out.full_pose
+
+All arithmetic happens in libhumaniflow_amd (hmf_smpl_lbs / hmf_smpl_tpose / hmf_batch_rodrigues);
+calling it with CPU tensors raises -- there is no CPU fallback.  The SMPL ``.pkl`` is licensed and not
+shipped: give ``model_path`` (directory or file, smplx layout) or ``model_data`` (dict of arrays, e.g.
+``synthetic_smpl_model()``).
+"""
+import ctypes as C
+import os
+import pickle
+from collections import namedtuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+NUM_VERTS = 6890
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+# smplx VertexJointSelector order (face, feet, left-hand tips, right-hand tips), 'smplh' vertex ids
+EXTRA_VERTEX_IDS = [332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
+                    2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133]
+
+SMPLOutput = namedtuple('SMPLOutput', ['vertices', 'joints', 'full_pose', 'betas', 'global_orient', 'body_pose'])
+SMPLOutput.__new__.__defaults__ = (None,) * 6
+
+_REG_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'model_files', 'extra_joint_regressors.npz')
+
+
+def load_extra_regressors(path=_REG_FILE):
+    """The reference's J_regressor_extra / cocoplus / h36m (models/smpl.py:17-19) as dense float32."""
+    z = np.load(path)
+    out = {}
+    for key, name in (('extra', 'J_regressor_extra'), ('cocoplus', 'J_regressor_cocoplus'), ('h36m', 'J_regressor_h36m')):
+        a = np.zeros(tuple(z[key + '_shape']), np.float64)
+        a[z[key + '_rows'].astype(np.int64), z[key + '_cols'].astype(np.int64)] = z[key + '_vals']
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def synthetic_smpl_model(seed=0, num_betas=10, skin_nnz=4):
+    """SMPL-shaped random body model: same array shapes, dtypes and sparsity as the real
+    pkl (4 skinning weights per vertex, 8-vertex joint regressor rows), random content."""
+    rng = np.random.RandomState(seed)
+    V, J = NUM_VERTS, 24
+    v_template = (rng.uniform(-1, 1, (V, 3)) * np.array([0.3, 0.9, 0.15])).astype(np.float32)
+    shapedirs = (rng.randn(V, 3, num_betas) * 0.01).astype(np.float32)
+    posedirs = (rng.randn(207, V * 3) * 0.002).astype(np.float32)
+    J_regressor = np.zeros((J, V), np.float32)
+    for j in range(J):
+        idx = rng.choice(V, 8, replace=False)
+        w = rng.dirichlet(np.ones(8))
+        J_regressor[j, idx] = w
+    lbs_weights = np.zeros((V, J), np.float32)
+    for v in range(V):
+        idx = rng.choice(J, skin_nnz, replace=False)
+        lbs_weights[v, idx] = rng.dirichlet(np.ones(skin_nnz))
+    return {'v_template': v_template, 'shapedirs': shapedirs, 'posedirs': posedirs, 'J_regressor': J_regressor,
+            'lbs_weights': lbs_weights, 'parents': np.array(SMPL_PARENTS, np.int64)}
+
+
+def load_smpl_pkl(model_path, gender='neutral', num_betas=10):
+    """smplx-layout loader: `model_path` is the .pkl or a directory holding SMPL_{GENDER}.pkl."""
+    if os.path.isdir(model_path):
+        model_path = os.path.join(model_path, 'SMPL_%s.pkl' % gender.upper())
+    if not os.path.exists(model_path):
+        raise FileNotFoundError('SMPL model file %s not found (the SMPL pkl is licensed and not shipped; '
+                                'pass model_data=synthetic_smpl_model() for benchmarks)' % model_path)
+    with open(model_path, 'rb') as f:
+        d = pickle.load(f, encoding='latin1')
+    dense = lambda a: np.asarray(a.todense() if hasattr(a, 'todense') else a)
+    shapedirs = np.asarray(d['shapedirs'])[:, :, :num_betas]
+    posedirs = np.asarray(d['posedirs'])
+    parents = np.asarray(d['kintree_table'])[0].astype(np.int64).copy()
+    parents[0] = -1
+    return {'v_template': np.asarray(d['v_template'], np.float32), 'shapedirs': shapedirs.astype(np.float32),
+            'posedirs': posedirs.reshape(-1, posedirs.shape[-1]).T.astype(np.float32).copy(),
+            'J_regressor': dense(d['J_regressor']).astype(np.float32), 'lbs_weights': np.asarray(d['weights'], np.float32),
+            'parents': parents, 'faces': np.asarray(d['f']).astype(np.int64) if 'f' in d else None}
+
+
+class SMPL(nn.Module):
+    NUM_JOINTS = 23
+    NUM_BODY_JOINTS = 23
+
+    def __init__(self, model_path=None, batch_size=1, gender='neutral', num_betas=10, create_transl=True,
+                 model_data=None, **kwargs):
+        super().__init__()
+        if model_data is None:
+            model_data = load_smpl_pkl(model_path, gender, num_betas)
+        self.gender = gender
+        self.batch_size = batch_size
+        self.num_betas = num_betas
+        f32 = lambda k: torch.tensor(np.asarray(model_data[k]), dtype=torch.float32)
+        self.register_buffer('v_template', f32('v_template'))
+        self.register_buffer('shapedirs', f32('shapedirs')[:, :, :num_betas].contiguous())
+        self.register_buffer('posedirs', f32('posedirs'))
+        self.register_buffer('J_regressor', f32('J_regressor'))
+        self.register_buffer('lbs_weights', f32('lbs_weights'))
+        self.register_buffer('parents', torch.tensor(np.asarray(model_data['parents']), dtype=torch.long))
+        if model_data.get('faces') is not None:
+            self.register_buffer('faces_tensor', torch.tensor(np.asarray(model_data['faces']), dtype=torch.long))
+        extra = model_data if 'J_regressor_extra' in model_data else load_extra_regressors()
+        for k in ('J_regressor_extra', 'J_regressor_cocoplus', 'J_regressor_h36m'):      # models/smpl.py:20-25
+            self.register_buffer(k, torch.tensor(np.asarray(extra[k]), dtype=torch.float32))
+        # smplx default (learnable) parameters used when an argument is None
+        self.betas = nn.Parameter(torch.zeros(batch_size, num_betas))
+        self.global_orient = nn.Parameter(torch.zeros(batch_size, 3))
+        self.body_pose = nn.Parameter(torch.zeros(batch_size, self.NUM_BODY_JOINTS * 3))
+        if create_transl:
+            self.transl = nn.Parameter(torch.zeros(batch_size, 3))
+        self._handles = {}
+        self._ws = {}
+
+    # ---- device-side constants --------------------------------------------------------------------
+    def host_struct(self):
+        """(hmf_smpl_host_t, keep-alive list) built from the current buffers."""
+        keep = []
+
+        def arr(t, dt=np.float32):
+            a = np.ascontiguousarray(t.detach().cpu().numpy().astype(dt))
+            keep.append(a)
+            return a
+        more = torch.cat([self.J_regressor_extra, self.J_regressor_cocoplus, self.J_regressor_h36m], dim=0)
+        hs = _lib.SmplHost()
+        hs.num_betas = self.num_betas
+        hs.v_template_host = _lib.fptr(arr(self.v_template))
+        hs.shapedirs_host = _lib.fptr(arr(self.shapedirs))
+        hs.posedirs_host = _lib.fptr(arr(self.posedirs))
+        hs.J_regressor_host = _lib.fptr(arr(self.J_regressor))
+        hs.lbs_weights_host = _lib.fptr(arr(self.lbs_weights))
+        hs.parents_host = _lib.iptr(arr(self.parents, np.int32))
+        ids = np.ascontiguousarray(np.array(EXTRA_VERTEX_IDS, np.int32))
+        keep.append(ids)
+        hs.extra_vertex_ids_host = _lib.iptr(ids)
+        hs.J_regressor_more_host = _lib.fptr(arr(more))
+        return hs, keep
+
+    def _handle(self, device):
+        key = (device.type, device.index)
+        h = self._handles.get(key)
+        if h is None:
+            lib = _lib.load()
+            hs, keep = self.host_struct()
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.hmf_smpl_create(C.byref(h), C.byref(hs)), 'hmf_smpl_create')
+            self._handles[key] = h
+        return h
+
+    def _apply(self, fn, *a, **k):
+        self._release()
+        return super()._apply(fn, *a, **k)
+
+    def _release(self):
+        if getattr(self, '_handles', None):
+            lib = _lib.load()
+            for h in self._handles.values():
+                lib.hmf_smpl_destroy(h)
+        self._handles = {}
+        self._ws = {}
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _workspace(self, device, M):
+        key = (device.type, device.index)
+        need = _lib.load().hmf_smpl_lbs_workspace_bytes(M)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    # ---- forward ------------------------------------------------------------------------------------
+    @staticmethod
+    def _f32c(t):
+        return t.detach().to(torch.float32).contiguous()
+
+    def _rodrigues(self, v, n):
+        lib = _lib.load()
+        v = self._f32c(v).reshape(n, 3)
+        R = torch.empty(n, 9, dtype=torch.float32, device=v.device)
+        _lib.check(lib.hmf_batch_rodrigues(_lib.dptr(v), n, _lib.dptr(R), _lib.current_stream()), 'hmf_batch_rodrigues')
+        return R
+
+    def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, impl=0, **kwargs):
+        """models/smpl.py:27-41 over smplx SMPL.forward.  `get_skin`/`return_verts` kwargs are accepted and ignored
+        (vertices are always produced, as the reference forces)."""
+        global_orient = self.global_orient if global_orient is None else global_orient
+        body_pose = self.body_pose if body_pose is None else body_pose
+        betas = self.betas if betas is None else betas
+        if transl is None and hasattr(self, 'transl'):
+            transl = self.transl
+        _lib.require_cuda(betas, 'betas')
+        _lib.require_cuda(body_pose, 'body_pose')
+        _lib.require_cuda(global_orient, 'global_orient')
+        dev = betas.device
+        lib = _lib.load()
+        M = max(betas.shape[0], global_orient.shape[0], body_pose.shape[0])
+        with torch.cuda.device(dev):
+            if pose2rot:
+                g = self._rodrigues(global_orient, global_orient.shape[0])
+                b = self._rodrigues(body_pose, body_pose.shape[0] * 23)
+            else:
+                g = self._f32c(global_orient).reshape(global_orient.shape[0], 9)
+                b = self._f32c(body_pose).reshape(body_pose.shape[0], 23 * 9)
+            if b.shape[0] != M or g.shape[0] not in (1, M) or betas.shape[0] not in (1, M):
+                raise ValueError('SMPL.forward: batch sizes betas=%d global_orient=%d body_pose=%d are not broadcastable '
+                                 '(smplx rule: 1 or M)' % (betas.shape[0], g.shape[0], b.shape[0]))
+            be = self._f32c(betas)
+            verts = torch.empty(M, NUM_VERTS, 3, dtype=torch.float32, device=dev)
+            joints = torch.empty(M, 90, 3, dtype=torch.float32, device=dev)
+            ws = self._workspace(dev, M)
+            _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
+                                        _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(), int(impl),
+                                        _lib.current_stream()), 'hmf_smpl_lbs')
+        if transl is not None:
+            joints = joints + transl.unsqueeze(1)
+            verts = verts + transl.unsqueeze(1)
+        full_pose = None
+        if global_orient.dim() == body_pose.dim():
+            full_pose = torch.cat([global_orient, body_pose], dim=1)
+        return SMPLOutput(vertices=verts, joints=joints, full_pose=full_pose, betas=betas, global_orient=global_orient,
+                          body_pose=body_pose)
+
+    def tpose(self, betas):
+        """T-pose vertices `v_template + shapedirs . beta` for (M, num_betas) -- what the reference obtains with a
+        zero-pose LBS call (evaluate/evaluate_humaniflow.py:131-133,186-192; predict_humaniflow.py:147)."""
+        _lib.require_cuda(betas, 'betas')
+        lib = _lib.load()
+        be = self._f32c(betas)
+        M = be.shape[0]
+        verts = torch.empty(M, NUM_VERTS, 3, dtype=torch.float32, device=be.device)
+        with torch.cuda.device(be.device):
+            _lib.check(lib.hmf_smpl_tpose(self._handle(be.device), _lib.dptr(be), M, _lib.dptr(verts), None,
+                                          _lib.current_stream()), 'hmf_smpl_tpose')
+        return verts
+
+    def model_dict(self):
+        """CPU copies of the model arrays (for the oracle in tests)."""
+        keys = ['v_template', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights', 'parents',
+                'J_regressor_extra', 'J_regressor_cocoplus', 'J_regressor_h36m']
+        return {k: getattr(self, k).detach().cpu() for k in keys}
+
+
+def compute_vertex_variance_from_samples(vertices_samples):
+    """utils/sampling_utils.py:22-33 on the device: (N, V, 3) -> ((V,), (V, 3))."""
+    _lib.require_cuda(vertices_samples, 'vertices_samples')
+    lib = _lib.load()
+    v = vertices_samples.detach().to(torch.float32).contiguous()
+    N, V = v.shape[0], v.shape[1]
+    avg = torch.empty(V, dtype=torch.float32, device=v.device)
+    std = torch.empty(V, 3, dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        _lib.check(lib.hmf_vertex_variance(_lib.dptr(v), N, V, _lib.dptr(avg), _lib.dptr(std), _lib.current_stream()),
+                   'hmf_vertex_variance')
+    return avg, std

@@ -1,0 +1,176 @@
+/*
+ * humaniflow_amd.h -- C ABI of libhumaniflow_amd.so: the MI355X (gfx950) kernels of the
+ * HuManiFlow per-image inference hot path.
+ *
+ * The reference (akashsengupta1997/HuManiFlow) is pure Python and has NO FFI: its boundary for
+ * this path is the nn.Module API (models/humaniflow_model.py:33-37,188-200, models/smpl.py:13-41).
+ * This library sits UNDER a Python mirror of that API (humaniflow_amd/humaniflow_model.py,
+ * humaniflow_amd/smpl.py).  Each entry point names the reference op chain it replaces (file:line,
+ * relative to the reference root); INTEGRATION.md shows the ctypes stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *  - plain C types only; every `const float*` / `float*` / `double*` below is a DEVICE pointer owned
+ *    by the caller (e.g. a torch tensor's data_ptr) unless the name ends in `_host`;
+ *  - row-major contiguous arrays; shapes are written `rows x cols` in comments;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all compute entry points
+ *    are asynchronous on it and never allocate or synchronise;
+ *  - return value: 0 = success, negative = error (HMF_ERR_*); hmf_last_error() gives a message
+ *    for the calling thread.  No C++ exception crosses the ABI;
+ *  - thread-safe for distinct streams; handles are immutable after creation.
+ */
+#ifndef HUMANIFLOW_AMD_H
+#define HUMANIFLOW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMF_ABI_VERSION 1
+
+#define HMF_OK 0
+#define HMF_ERR_INVALID (-1)     /* bad argument / shape                                  */
+#define HMF_ERR_UNSUPPORTED (-2) /* configuration outside the default-config hot path      */
+#define HMF_ERR_HIP (-3)         /* a HIP runtime call failed (message has hipGetErrorString) */
+#define HMF_ERR_WORKSPACE (-4)   /* workspace too small                                    */
+#define HMF_ERR_NO_DEVICE (-5)   /* no HIP device visible                                  */
+
+#define HMF_NUM_VERTS 6890
+#define HMF_NUM_SMPL_JOINTS 24
+#define HMF_NUM_OUT_JOINTS 90 /* 24 + 21 vertex picks + 9 + 19 + 17 regressed (models/smpl.py:30-34) */
+#define HMF_NUM_PARTS 23
+
+int hmf_abi_version(void);
+const char* hmf_last_error(void);
+int hmf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SO(3) closed-form maps  (utils/rigid_transform_utils.py)                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* rot6d_to_rotmat :86-100.  x6: n x 6 (row-major pairs R11,R12,R21,R22,R31,R32) -> R: n x 9. */
+int hmf_rot6d_to_rotmat(const float* x6, int n, float* R, void* stream);
+/* so3_exp :182-201 (fp64 Rodrigues incl. the theta<=1e-10 branch).  v: n x 3 -> R: n x 9.    */
+int hmf_so3_exp(const double* v, int n, double* R, void* stream);
+/* so3_vee(so3_log(R)) :204-279,168-179 incl. the near-pi sign search.  R: n x 9 -> v: n x 3.  */
+int hmf_so3_log(const double* R, int n, double* v, void* stream);
+/* so3_log_abs_det_jacobian :298-314 (incl. the log(11/12) value at |v|<=1e-10).  v: n x 3.    */
+int hmf_so3_log_abs_det_jacobian(const double* v, int n, double* out, void* stream);
+/* smplx.lbs.batch_rodrigues (fp32, angle = |v + 1e-8|), call sites models/humaniflow_model.py:299,
+ * evaluate/evaluate_humaniflow.py:83.  v: n x 3 -> R: n x 9.                                   */
+int hmf_batch_rodrigues(const float* v, int n, float* R, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SMPL: shape/pose blend-shapes + LBS + 90 joints  (models/smpl.py:27-41 -> smplx lbs)         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct hmf_smpl hmf_smpl_t; /* device-resident constants, repacked for the kernels */
+
+typedef struct {
+    int num_betas;                     /* <= 16                                                    */
+    const float* v_template_host;      /* 6890 x 3                                                 */
+    const float* shapedirs_host;       /* 6890 x 3 x num_betas                                     */
+    const float* posedirs_host;        /* 207 x 20670  (smplx buffer layout: (P, V*3))             */
+    const float* J_regressor_host;     /* 24 x 6890 dense                                          */
+    const float* lbs_weights_host;     /* 6890 x 24 dense (zeros are skipped: exact)               */
+    const int32_t* parents_host;       /* 24, parents[0] = -1                                      */
+    const int32_t* extra_vertex_ids_host; /* 21 vertex picks (smplx VertexJointSelector order)     */
+    const float* J_regressor_more_host;   /* 45 x 6890 dense: extra(9) | cocoplus(19) | h36m(17)   */
+} hmf_smpl_host_t;
+
+int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* model);
+void hmf_smpl_destroy(hmf_smpl_t* h);
+
+size_t hmf_smpl_lbs_workspace_bytes(int M);
+/* Posed bodies.  global_orient: Mg x 9, body_pose: M x 23 x 9 (rotation matrices, pose2rot=False
+ * layout; use hmf_batch_rodrigues first for axis-angle input); betas: Mb x num_betas with Mb in
+ * {1, M} (smplx broadcast rule); Mg in {1, M}.  verts: M x 6890 x 3; joints: M x 90 x 3 (nullable).
+ * impl: 0 = MFMA kernel (product path), 1 = scalar cross-check kernel (tests only).               */
+int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose,
+                 const float* betas, int Mb, int M, float* verts, float* joints, void* workspace,
+                 size_t workspace_bytes, int impl, void* stream);
+/* T-pose bodies (evaluate/evaluate_humaniflow.py:131-133,186-192; predict_humaniflow.py:147):
+ * v_template + shapedirs . beta.  joints nullable.                                                */
+int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts, float* joints,
+                   void* stream);
+/* utils/sampling_utils.py:22-33 over N samples of one image.  verts: N x V x 3 ->
+ * avg_l2: V, dir_std: V x 3.                                                                      */
+int hmf_vertex_variance(const float* verts, int N, int V, float* avg_l2, float* dir_std, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Ancestor-conditioned SO(3) flow  (models/humaniflow_model.py:116-186,260-320, norm_flows/)  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct hmf_flow hmf_flow_t; /* device-resident weights, repacked into MFMA operand order */
+
+typedef struct {
+    int feat_dim;                 /* 2048 (ResNet-50) or 512 (ResNet-18)                          */
+    int num_betas;                /* 10                                                          */
+    int isgc_dim;                 /* 256  INPUT_SHAPE_GLOB_CAM_FEATS_DIM                          */
+    int ctx_dim;                  /* 64   NORM_FLOW.CONTEXT_DIM                                   */
+    int num_transforms;           /* 2    NORM_FLOW.NUM_TRANSFORMS                                */
+    int hidden[3];                /* 64,32,32 NORM_FLOW.TRANSFORM_NN_HIDDEN_DIMS                  */
+    int count_bins;               /* 8    NORM_FLOW.NUM_SPLINE_SEGMENTS                           */
+    float radius;                 /* 1.5*pi NORM_FLOW.COMPACT_SUPPORT_RADIUS (spline bound too)    */
+    float base_std;               /* 0.6  NORM_FLOW.BASE_DIST_STD                                 */
+    const int32_t* parents_host;  /* 24 SMPL parents                                             */
+    const float* w_isgc_host;     /* isgc_dim x (feat_dim + num_betas + 9 + 3)                    */
+    const float* b_isgc_host;     /* isgc_dim                                                    */
+    const float* const* w_ctx_host; /* [23]: ctx_dim x (isgc_dim + 9*num_ancestors(j))            */
+    const float* const* b_ctx_host; /* [23]: ctx_dim                                             */
+    const float* const* w_nn_host;  /* [23*num_transforms*4]: (64x65),(32x64),(32x32),(62x32)     */
+    const float* const* b_nn_host;  /* same indexing                                             */
+} hmf_flow_host_t;
+
+int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* weights);
+void hmf_flow_destroy(hmf_flow_t* h);
+
+size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int compute_point_est);
+/* Kinematic-chain pass: N pose samples per image and/or the z=0 point estimate, all 23 parts in
+ * dependency order inside one launch sequence (replaces the Python loop :286-311).
+ *   feats B x feat_dim; glob_R B x 9; cam B x 3; shape_mode/shape_log_std B x nb;
+ *   eps_shape N x B x nb standard normal (NULL = use_shape_mode_for_samples, :255-256);
+ *   eps_pose 23 x B x N x 3 standard normal, in the reference's draw order (:309);
+ * outputs (nullable when not requested):
+ *   shape_samples B x N x nb; rotmats_samples B x N x 23 x 9 (fp64 exp rounded to fp32, :311);
+ *   rotmats_point B x 23 x 9 (batch_rodrigues, :299); so3_point B x 23 x 3 (:300).               */
+int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* cam,
+                     const float* shape_mode, const float* shape_log_std, const float* eps_shape,
+                     const float* eps_pose, int B, int N, int compute_point_est, float* shape_samples,
+                     float* rotmats_samples, float* rotmats_point, float* so3_point, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* compute_input_shape_glob_cam_feats :116-150 (2-D variant): ELU(W [f, shape, vec(R), cam] + b).
+ * feats B x feat_dim, shape B x nb, glob_R B x 9, cam B x 3 -> isgc B x isgc_dim.               */
+int hmf_flow_isgc(const hmf_flow_t* h, const float* feats, const float* shape, const float* glob_R,
+                  const float* cam, int B, float* isgc, void* stream);
+/* compute_flow_context :152-186 for all 23 parts with GIVEN (teacher-forced) rotations.
+ * isgc B x isgc_dim, pose_R B x 23 x 9 fp32 -> ctx B x 23 x ctx_dim.                            */
+int hmf_flow_context(const hmf_flow_t* h, const float* isgc, const float* pose_R, int B, float* ctx,
+                     void* stream);
+/* LocalDiffeoTransformedDistribution.log_prob (local_diffeo_transformed_distribution.py:84-142):
+ * log p(R | ctx) on SO(3) with the logsumexp over the 2*pi pre-images.
+ * ctx B x P x ctx_dim; part_ids P ints on the HOST (NULL = 0..22, requires P == 23);
+ * R B x P x 9 fp64 -> logp B x P fp32.                                                            */
+int hmf_flow_log_prob_SO3(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P,
+                          const double* R, int B, float* logp, void* stream);
+/* Density on the algebra (conditioned_pose_so3flow_dists_for_loglik, :318): v B x P x 3 fp32.    */
+int hmf_flow_log_prob_so3(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P,
+                          const float* v, int B, float* logp, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Host-side packing probes (no GPU needed; used by the CPU test-suite to check operand layouts) */
+/* ------------------------------------------------------------------------------------------ */
+/* Number of floats / copy-out of the packed pose-blend operand (see DESIGN.md "hmf_smpl_lbs").  */
+size_t hmf_smpl_packed_blend_floats(int num_betas);
+int hmf_smpl_pack_blend_host(const hmf_smpl_host_t* model, float* out_host);
+/* (k, vertex, component) -> offset into the packed pose-blend operand.                           */
+size_t hmf_smpl_packed_blend_index(int k, int v, int c);
+/* Packed flow weights: total float count and copy-out (layout: DESIGN.md "hmf_flow_forward").     */
+size_t hmf_flow_packed_floats(const hmf_flow_host_t* weights);
+int hmf_flow_pack_host(const hmf_flow_host_t* weights, float* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HUMANIFLOW_AMD_H */

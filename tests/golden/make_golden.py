@@ -1,0 +1,137 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own Python.
+
+Run in the build container only (needs /root/reference; nothing of the reference is copied -- only
+inputs and the outputs its functions produce are stored):
+
+    python tests/golden/make_golden.py [/root/reference]
+
+Importable reference pieces: utils/rigid_transform_utils.py (with an empty `cv2` stub),
+models/resnet.py, the radial-tanh / to / so3-exp transforms and LocalDiffeoTransformedDistribution (with
+empty package modules for models.norm_flows so their pyro-importing __init__ files are bypassed, and a
+two-class stub for pyro.distributions.conditional).  pyro-ppl and smplx are absent, so the spline coupling
+and LBS have no golden vectors ("parity unpinned", oracle/__init__.py).
+"""
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(OUT, '..'))
+from helpers import deterministic_state_dict  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference():
+    sys.modules['cv2'] = types.ModuleType('cv2')
+    sys.path.insert(0, REF)
+    import utils.rigid_transform_utils as rtu
+    import models.resnet as resnet
+    for pkg in ('models.norm_flows', 'models.norm_flows.transforms'):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split('.'))]
+        sys.modules[pkg] = m
+    tdir = os.path.join(REF, 'models', 'norm_flows', 'transforms')
+    ld = _load('models.norm_flows.transforms.local_diffeo_transform', os.path.join(tdir, 'local_diffeo_transform.py'))
+    sys.modules['models.norm_flows.transforms'].LocalDiffeoTransform = ld.LocalDiffeoTransform
+    rt = _load('models.norm_flows.transforms.scaled_radial_tanh_transform', os.path.join(tdir, 'scaled_radial_tanh_transform.py'))
+    to = _load('models.norm_flows.transforms.to_transform', os.path.join(tdir, 'to_transform.py'))
+    ex = _load('models.norm_flows.transforms.so3_exp_transform', os.path.join(tdir, 'so3_exp_transform.py'))
+    pyro = types.ModuleType('pyro')
+    pd = types.ModuleType('pyro.distributions')
+    pc = types.ModuleType('pyro.distributions.conditional')
+
+    class ConditionalDistribution:
+        pass
+
+    class ConstantConditionalDistribution(ConditionalDistribution):
+        def __init__(self, base):
+            self.base = base
+
+        def condition(self, ctx):
+            return self.base
+    pc.ConditionalDistribution, pc.ConstantConditionalDistribution = ConditionalDistribution, ConstantConditionalDistribution
+    sys.modules.update({'pyro': pyro, 'pyro.distributions': pd, 'pyro.distributions.conditional': pc})
+    dist = _load('models.norm_flows.local_diffeo_transformed_distribution',
+                 os.path.join(REF, 'models', 'norm_flows', 'local_diffeo_transformed_distribution.py'))
+    return rtu, resnet, rt, to, ex, dist
+
+
+def rotations_with_angles(rtu, angles, gen):
+    axes = torch.randn(len(angles), 3, generator=gen, dtype=torch.float64)
+    axes = axes / axes.norm(dim=-1, keepdim=True)
+    return rtu.so3_exp(axes * torch.tensor(angles, dtype=torch.float64)[:, None])
+
+
+def main():
+    rtu, resnet, rt, to, ex, dist = import_reference()
+    g = torch.Generator().manual_seed(1234)
+    # ---------------- SO(3) closed forms ----------------------------------------------------------
+    v = torch.randn(64, 3, generator=g, dtype=torch.float64) * 1.5
+    edge = torch.tensor([[0, 0, 0], [1e-12, 0, 0], [0, 1e-3, 0], [math.pi / 2, 0, 0], [0, 0, math.pi - 5e-3],
+                         [0, math.pi - 1e-4, 0], [2.0, -2.0, 1.0], [1e-11, 1e-11, 0]], dtype=torch.float64)
+    v = torch.cat([v, edge])
+    R = rtu.so3_exp(v)
+    angles = [0.0, 1e-12, 1e-3, math.pi / 2, math.pi - 5e-3, math.pi - 1e-4, math.pi - 9e-3, math.pi - 1.1e-2, 3.0, 0.5]
+    R_log_in = torch.cat([rotations_with_angles(rtu, angles, g), R[:32], torch.eye(3, dtype=torch.float64)[None],
+                          torch.diag(torch.tensor([-1.0, 1.0, -1.0], dtype=torch.float64))[None]])
+    log_v = rtu.so3_log(R_log_in, return_axis_angle=True)
+    xset = rtu.so3_xset(v, 1)
+    logdet = rtu.so3_log_abs_det_jacobian(v)
+    x6 = torch.randn(64, 6, generator=g)
+    x6 = torch.cat([x6, torch.tensor([[1, 0, 0, 1, 0, 0], [2, 0, 0, 3, 0, 0], [1e-3, 1, 0, 1, 1, 0.5]], dtype=torch.float32)])
+    np.savez_compressed(os.path.join(OUT, 'so3_golden.npz'), v=v.numpy(), R=R.numpy(), R_log_in=R_log_in.numpy(),
+                        log_v=log_v.numpy(), xset=xset.numpy(), logdet=logdet.numpy(), x6=x6.numpy(),
+                        R6=rtu.rot6d_to_rotmat(x6).numpy(), rot6d_of_R=rtu.rotmat_to_rot6d(R[:8].float()).numpy())
+    # ---------------- radial tanh + push-forward log-prob plumbing ------------------------------------
+    radius = 1.5 * math.pi
+    T = rt.ScaledRadialTanhTransform(radius=radius)
+    xs = torch.randn(48, 3, generator=g) * torch.tensor([0.0, 1e-8, 0.1, 3.0, 30.0, 1.0]).repeat(8)[:, None]
+    ys = T._call(xs)
+    ys_in = torch.randn(48, 3, generator=g)
+    ys_in = ys_in / ys_in.norm(dim=-1, keepdim=True) * (torch.rand(48, 1, generator=g) * radius * 0.999)
+    ys_in[0] = 0.0
+    xinv = T._inverse(ys_in)
+    ld = T.log_abs_det_jacobian(xinv, ys_in)
+    base = torch.distributions.TransformedDistribution(
+        torch.distributions.Independent(torch.distributions.Normal(torch.zeros(3), torch.ones(3) * 0.6, validate_args=False), 1),
+        [rt.ScaledRadialTanhTransform(radius=radius)], validate_args=False)
+    SO3 = dist.LocalDiffeoTransformedDistribution(base, [to.ToTransform(dict(dtype=torch.float32), dict(dtype=torch.float64)),
+                                                         ex.SO3ExpCompactTransform(support_radius=radius)], validate_args=False)
+    Rq = torch.cat([rotations_with_angles(rtu, [0.1, 1.0, 1.6, 2.0, 2.5, 3.0, math.pi - 5e-3, math.pi - 1e-4, 1e-3], g),
+                    torch.eye(3, dtype=torch.float64)[None], R[:22]])
+    lp = SO3.log_prob(Rq)
+    x_, xset_, mask_ = ex.SO3ExpCompactTransform(support_radius=radius)._inverse_set(Rq)
+    np.savez_compressed(os.path.join(OUT, 'flow_golden.npz'), radius=radius, xs=xs.numpy(), ys=ys.numpy(), ys_in=ys_in.numpy(),
+                        xinv=xinv.numpy(), ld=ld.numpy(), Rq=Rq.numpy(), lp=lp.numpy(), inv_x=x_.numpy(),
+                        inv_xset=np.nan_to_num(xset_.numpy()), inv_mask=mask_.numpy())
+    # ---------------- ResNet encoders --------------------------------------------------------------------
+    out = {}
+    for layers, ctor in ((50, resnet.resnet50), (18, resnet.resnet18)):
+        net = ctor(in_channels=18)
+        sd = deterministic_state_dict({k: tuple(t.shape) for k, t in net.state_dict().items()}, seed=7)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        x = torch.randn(2, 18, 96, 96, generator=torch.Generator().manual_seed(5))
+        with torch.no_grad():
+            y = net(x)
+        out['keys%d' % layers] = np.array(sorted(net.state_dict().keys()))
+        out['feats%d' % layers] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, 'resnet_golden.npz'), **out)
+    print('golden vectors written to', OUT)
+
+
+if __name__ == '__main__':
+    main()

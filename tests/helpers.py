@@ -1,0 +1,96 @@
+"""Shared test helpers: deterministic weights, synthetic inputs, oracle adapters."""
+import hashlib
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _seed_of(name, seed):
+    return int(hashlib.md5(('%s:%d' % (name, seed)).encode()).hexdigest()[:8], 16)
+
+
+def deterministic_state_dict(shapes, seed=0):
+    """Name-seeded values for every entry of a ResNet-like state dict, independent of module construction order:
+    conv weights ~ N(0, 2/fan_out), BN weight in [0.5,1.5], BN bias/mean small, BN var in [0.5,1.5]."""
+    sd = {}
+    for name, shape in shapes.items():
+        g = torch.Generator().manual_seed(_seed_of(name, seed))
+        if name.endswith('num_batches_tracked'):
+            sd[name] = torch.zeros(shape, dtype=torch.long)
+        elif name.endswith('running_var'):
+            sd[name] = torch.rand(shape, generator=g) + 0.5
+        elif name.endswith('running_mean'):
+            sd[name] = torch.randn(shape, generator=g) * 0.1
+        elif len(shape) == 4:
+            fan_out = shape[0] * shape[2] * shape[3]
+            sd[name] = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
+        elif name.endswith('.weight') and len(shape) == 1:
+            sd[name] = torch.rand(shape, generator=g) + 0.5
+        else:
+            sd[name] = torch.randn(shape, generator=g) * 0.1
+    return sd
+
+
+def init_model_for_tests(model, seed=0, last_layer_scale=0.3):
+    """Default PyTorch init under a fixed seed, then shrink the shape log-std half and the last hyper-network
+    layers so samples stay inside the flow's support; BN statistics made non-trivial."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.startswith('image_encoder'):
+                continue
+            p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.sqrt(max(p.shape[-1], 1))) if p.dim() > 1
+                    else torch.randn(p.shape, generator=g) * 0.05)
+        nb = model.num_shape_params
+        model.fc_shape.weight[nb:] *= 0.1
+        model.fc_shape.bias[nb:] -= 1.0
+        for mod in model.pose_so3flow_transform_modules:
+            mod.nn.layers[-1].weight *= last_layer_scale * 3
+        shapes = {k: tuple(v.shape) for k, v in model.image_encoder.state_dict().items()}
+        model.image_encoder.load_state_dict(deterministic_state_dict(shapes, seed=seed + 11))
+    return model
+
+
+def synthetic_proxy_input(B, size=256, seed=0, channels=18):
+    """channel 0 sparse 'edges', channels 1.. Gaussian blobs (sigma 4) at random centres, ~10% zeroed."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros(B, channels, size, size)
+    x[:, 0] = (torch.rand(B, size, size, generator=g) < 0.05).float() * torch.rand(B, size, size, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(size).float(), torch.arange(size).float(), indexing='ij')
+    cen = torch.rand(B, channels - 1, 2, generator=g) * (size * 0.75) + size * 0.125
+    vis = (torch.rand(B, channels - 1, generator=g) > 0.1).float()
+    for b in range(B):
+        for c in range(channels - 1):
+            x[b, 1 + c] = vis[b, c] * torch.exp(-((xx - cen[b, c, 0]) ** 2 + (yy - cen[b, c, 1]) ** 2) / (2 * 4.0 ** 2))
+    return x
+
+
+def oracle_cfg_from(model_cfg):
+    from oracle.model import OracleCfg
+    nf = model_cfg.NORM_FLOW
+    return OracleCfg(num_resnet_layers=model_cfg.NUM_RESNET_LAYERS, num_betas=model_cfg.NUM_SMPL_BETAS, context_dim=nf.CONTEXT_DIM,
+                     num_transforms=nf.NUM_TRANSFORMS, radius=nf.COMPACT_SUPPORT_RADIUS, base_std=nf.BASE_DIST_STD,
+                     count_bins=nf.NUM_SPLINE_SEGMENTS)
+
+
+def random_rotmats(n, scale=0.3, seed=0):
+    from oracle.so3 import so3_exp
+    g = torch.Generator().manual_seed(seed)
+    return so3_exp(torch.randn(n, 3, generator=g, dtype=torch.float64) * scale).float()
+
+
+def smpl_oracle_model(model_dict):
+    """torch-CPU dict for oracle.smpl from SMPL.model_dict() / synthetic_smpl_model()."""
+    out = {}
+    for k, v in model_dict.items():
+        t = torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
+        out[k] = t.long() if k == 'parents' else t.float()
+    return out
