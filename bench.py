@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- images.samples/sec of the HuManiFlow inference hot path on MI355X (BASELINE.json metric).
+
+One step = one batch of B synthetic 256x256 proxy inputs through
+    ResNet-50 encoder -> heads -> flow (N pose samples + point estimate) -> SMPL on the point estimate (M = B)
+    -> SMPL on the samples (M = B*N)  [--tpose adds the evaluate-flavour T-pose bodies],
+all resident in HBM; fp32 throughout (BASELINE configs[1]); outputs stay on the device.
+
+    python bench.py                     # 1 GPU, B=32, N=100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 20 --warmup 5
+
+Prints ONE JSON line (rank 0): the throughput, the roofline of the dominant hand-written kernel (k_lbs_mfma: HIP
+events on its own launch stream via hmf_profile_*), and the CPU baseline (the oracle in reference mode, a bounded
+sample, rank 0 at N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per image.sample of the SMPL stage: shape blend 0.413 + pose blend 8.557 +
+# 4-nnz skinning blend 0.66 + transform apply 0.145 MFLOP
+LBS_FLOP_PER_UNIT = 9.775e6
+FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--samples', type=int, default=100)
+    ap.add_argument('--layers', type=int, default=50)
+    ap.add_argument('--tpose', action='store_true', help='add the evaluate-flavour T-pose bodies to the step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=32, help='images of the bounded CPU-baseline sample')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark (MIOpen find mode)')
+    return ap.parse_args()
+
+
+def cpu_baseline(model_sd, cfg, smpl_model_dict, images, N, seed=0):
+    """The oracle in reference mode (Python loop over 23 parts, per-call hyper-nets, fp64 exp, smplx-style dense LBS with
+    the (M,6890,4,4) temporary) on `images` synthetic inputs x N samples, all host cores."""
+    from oracle import model as omodel
+    from oracle import smpl as osmpl
+    from humaniflow_amd.synthetic import synthetic_proxy_input
+    torch.set_num_threads(os.cpu_count())
+    ocfg = omodel.OracleCfg(num_resnet_layers=cfg.MODEL.NUM_RESNET_LAYERS, num_betas=cfg.MODEL.NUM_SMPL_BETAS)
+    x = synthetic_proxy_input(images, 256, seed=seed)
+    sm = {k: (v.long() if k == 'parents' else v.float()) for k, v in smpl_model_dict.items()}
+
+    def run():
+        out = omodel.forward(model_sd, ocfg, input=x, num_samples=N)
+        g = out['glob_rotmat']
+        osmpl.smpl_forward(sm, out['shape_mode'], out['pose_rotmats_point_est'], g[:, None], pose2rot=False)
+        osmpl.smpl_forward(sm, out['shape_samples'].reshape(-1, 10), out['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
+                           g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3), pose2rot=False)
+    run()                                           # warm-up
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return {'value': images * N / t, 'unit': 'images*samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d images x %d samples (ResNet-50 + 23-part flow loop + smplx-style LBS), median of 2 after 1 warm-up, %.2f s/iter'
+                      % (images, N, t)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (the hot path has no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)          # RCCL on ROCm
+    if args.gpus != world and rank == 0:
+        print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    import humaniflow_amd as H
+    from humaniflow_amd import _lib
+    from humaniflow_amd.synthetic import synthetic_proxy_input, init_benchmark_weights
+    lib = _lib.load()
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_RESNET_LAYERS = args.layers
+    torch.manual_seed(0)
+    model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).eval()
+    model_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(dev)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=args.batch, create_transl=False).to(dev)
+    B, N = args.batch, args.samples
+    x = synthetic_proxy_input(B, 256, seed=100 + rank).to(dev)      # each rank its own shard of the synthetic set
+    torch.manual_seed(1234 + rank)
+
+    def step():
+        with torch.no_grad():
+            pred = model(x, num_samples=N)
+            g = pred['glob_rotmat']
+            pe = smpl(body_pose=pred['pose_rotmats_point_est'], global_orient=g[:, None], betas=pred['shape_mode'], pose2rot=False)
+            sa = smpl(body_pose=pred['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
+                      global_orient=g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3),
+                      betas=pred['shape_samples'].reshape(-1, 10), pose2rot=False)
+            extra = None
+            if args.tpose:
+                extra = (smpl.tpose(pred['shape_mode']), smpl.tpose(pred['shape_samples'].reshape(-1, 10)))
+        return pred, pe, sa, extra
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync_all()
+    lib.hmf_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    # the one exchange step of the data-parallel eval path: per-rank metric sums gathered over RCCL/xGMI
+    pred, pe, sa, _ = out
+    metric_vec = torch.stack([sa.vertices.abs().mean(), sa.joints.abs().mean(), pe.vertices.abs().mean(),
+                              pred['pose_rotmats_samples'].mean()]).double()
+    if dist is not None:
+        gathered = torch.empty(world * metric_vec.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, metric_vec)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # ---- per-kernel times from the HIP events recorded on the launch stream during the timed region ----
+    ms = np.zeros(4096)
+    tag = np.zeros(4096, np.int32)
+    rows = np.zeros(4096, np.int32)
+    n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), 4096)
+    lib.hmf_profile_enable(0)
+    ms, tag, rows = ms[:n], tag[:n], rows[:n]
+    names = {1: 'k_lbs_mfma', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
+    kern = {}
+    for tg, nm in names.items():
+        for r in sorted(set(rows[tag == tg].tolist())):
+            sel = (tag == tg) & (rows == r)
+            kern['%s[M=%d]' % (nm, r)] = round(float(ms[sel].mean()) * 1e3, 2)      # us
+    lbs_sel = (tag == 1) & (rows == B * N)
+    lbs_ms = float(ms[lbs_sel].mean()) if lbs_sel.any() else float('nan')
+    achieved = LBS_FLOP_PER_UNIT * B * N / (lbs_ms * 1e-3) / 1e12
+    # ---- stage breakdown (separate untimed pass, torch events on the current stream) ----
+    def timed(fn, reps=5):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            r = fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps, r
+    with torch.no_grad():
+        enc_ms, feats = timed(lambda: model(x, return_input_feats_only=True)['input_feats'])
+        flow_ms, pred = timed(lambda: model(None, input_feats=feats, num_samples=N))
+        g = pred['glob_rotmat']
+        go = g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3).contiguous()
+        bp = pred['pose_rotmats_samples'].reshape(-1, 23, 3, 3)
+        be = pred['shape_samples'].reshape(-1, 10)
+        smpl_ms, _ = timed(lambda: smpl(body_pose=bp, global_orient=go, betas=be, pose2rot=False))
+        tp_ms, _ = timed(lambda: smpl.tpose(be))
+
+    if rank == 0:
+        value = world * B * N * args.steps / elapsed
+        res = {
+            'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': round(value, 1), 'unit': 'images*samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL '
+                                   'fp32, random-init weights, synthetic SMPL-shaped body model%s'
+                                   % (B, N, args.layers, ' + T-pose bodies' if args.tpose else ''),
+                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world,
+                       'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},
+            'roofline': {'kernel': 'k_lbs_mfma (SMPL pose-blend GEMM + skinning, M=%d rows)' % (B * N), 'bound': 'mfma',
+                         'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                         'avg_launch_us': round(lbs_ms * 1e3, 2), 'launches': int(lbs_sel.sum()),
+                         'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * B * N},
+            'stages_ms': {'encoder_resnet%d_miopen' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
+                          'smpl_samples': round(smpl_ms, 3), 'smpl_tpose': round(tp_ms, 3)},
+            'kernels_us': kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(model_sd, cfg, smpl.model_dict(), args.cpu_images, N)
+            res['speedup_vs_cpu_baseline'] = round(value / res['cpu_baseline']['value'], 1)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

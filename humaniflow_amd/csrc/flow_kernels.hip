@@ -516,17 +516,22 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
     const int ntiles = (Mtot + 31) / 32;
     {
         const int nw = kIsgc * ((B + 7) / 8);
+        ProfScope ps(7, B, st);
         hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, feats, (const float*)nullptr, glob_R, cam, B, 0, G);
         HMF_LAUNCH_CHECK();
     }
     {
         const int nw = ntiles * kGroups0;
+        ProfScope ps(5, Mtot, st);
         hipLaunchKernelGGL(k_flow_ctx0, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, eps_shape, B, N, Mtot,
                            ntiles, shape_samples, C0);
         HMF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, eps_pose, B, N, Mtot, rotmats_samples,
-                       rotmats_point, so3_point);
+    {
+        ProfScope ps(6, Mtot, st);
+        hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, eps_pose, B, N, Mtot, rotmats_samples,
+                           rotmats_point, so3_point);
+    }
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

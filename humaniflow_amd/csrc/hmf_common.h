@@ -28,6 +28,17 @@ int fail(int code, const char* fmt, ...);
                              hipGetErrorString(e_), __FILE__, __LINE__);                       \
     } while (0)
 
+// optional per-launch HIP-event timing (hmf_profile_enable / hmf_profile_collect)
+bool prof_on();
+void prof_begin(int tag, int rows, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    ProfScope(int tag, int rows, hipStream_t s) : st(s), on(prof_on()) { if (on) prof_begin(tag, rows, st); }
+    ~ProfScope() { if (on) prof_end(st); }
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

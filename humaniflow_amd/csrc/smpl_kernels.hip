@@ -374,6 +374,19 @@ __global__ __launch_bounds__(256) void k_tpose(SmplDev d, const float* __restric
     }
 }
 
+__global__ void k_rest_joints(SmplDev d, const float* __restrict__ betas, int M, float* __restrict__ joints) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= M * kJ) return;
+    const int row = gid / kJ, j = gid % kJ, nb = d.num_betas;
+    const float* b = betas + (size_t)row * nb;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = d.j_template[j * 3 + c];
+        for (int k = 0; k < nb; ++k) acc = fmaf(d.j_dirs[(j * 3 + c) * nb + k], b[k], acc);
+        joints[((size_t)row * kOutJ + j) * 3 + c] = acc;
+    }
+}
+
 // compute_vertex_variance_from_samples, utils/sampling_utils.py:22-33 (two passes, like the reference)
 __global__ void k_vertex_variance(const float* __restrict__ verts, int N, int V, float* __restrict__ avg_l2,
                                   float* __restrict__ dir_std) {
@@ -575,14 +588,18 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
     hipStream_t st = (hipStream_t)stream;
     float* atr = (float*)workspace;
-    hipLaunchKernelGGL(k_rigid_chain, dim3((M + 7) / 8), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas, Mb, M,
-                       atr, joints);
+    {
+        ProfScope ps(2, M, st);
+        hipLaunchKernelGGL(k_rigid_chain, dim3((M + 7) / 8), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas, Mb, M,
+                           atr, joints);
+    }
     HMF_LAUNCH_CHECK();
     if (impl == 1) {
         const long long n = (long long)M * kV;
         hipLaunchKernelGGL(k_lbs_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d, body_pose, betas, Mb, M,
                            atr, verts);
     } else {
+        ProfScope ps(1, M, st);
         const int nrg = (M + kRowsPerWG - 1) / kRowsPerWG;
         const int T = nrg * kVTperX;
         int wpx = (T + 7) / 8;                      // at least one tile per wave
@@ -598,6 +615,7 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
     HMF_LAUNCH_CHECK();
     if (joints) {
         const int n = M * (kOutJ - kJ);
+        ProfScope ps(3, M, st);
         hipLaunchKernelGGL(k_joints, dim3((n + 255) / 256), dim3(256), 0, st, h->d, verts, M, joints);
         HMF_LAUNCH_CHECK();
     }
@@ -610,13 +628,17 @@ int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts,
     if (M == 0) return HMF_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((kV * 3 / 2 + 255) / 256, (M + kTpRows - 1) / kTpRows);
-    hipLaunchKernelGGL(k_tpose, grid, dim3(256), 0, st, h->d, betas, M, verts);
+    {
+        ProfScope ps(4, M, st);
+        hipLaunchKernelGGL(k_tpose, grid, dim3(256), 0, st, h->d, betas, M, verts);
+    }
     HMF_LAUNCH_CHECK();
-    if (joints) {
-        // identity pose: posed joints == rest joints; the chain kernel with null rotations writes them
-        // (its transforms output is not needed: it goes to the tail of the joints buffer's own rows? no --
-        // it needs scratch, so T-pose joints reuse the gather kernel for 24..89 and a rest-joint pass for 0..23)
-        return fail(HMF_ERR_UNSUPPORTED, "hmf_smpl_tpose: joints output not implemented; pass NULL");
+    if (joints) {   // identity pose: posed joints == rest joints (0..23); 24..89 gathered from the vertices
+        hipLaunchKernelGGL(k_rest_joints, dim3((M * kJ + 255) / 256), dim3(256), 0, st, h->d, betas, M, joints);
+        HMF_LAUNCH_CHECK();
+        const int n = M * (kOutJ - kJ);
+        hipLaunchKernelGGL(k_joints, dim3((n + 255) / 256), dim3(256), 0, st, h->d, verts, M, joints);
+        HMF_LAUNCH_CHECK();
     }
     return HMF_OK;
 }

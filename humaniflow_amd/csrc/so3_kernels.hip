@@ -19,6 +19,28 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- per-launch event timing --------------------------------------------------------------------
+namespace {
+constexpr int kProfMax = 4096;
+struct ProfRec { hipEvent_t a, b; int tag, rows; };
+ProfRec g_prof[kProfMax];
+int g_prof_n = 0;
+bool g_prof_on = false;
+}  // namespace
+bool prof_on() { return g_prof_on; }
+void prof_begin(int tag, int rows, hipStream_t st) {
+    if (g_prof_n >= kProfMax) return;
+    ProfRec& r = g_prof[g_prof_n];
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    r.tag = tag; r.rows = rows;
+    (void)hipEventRecord(r.a, st);
+}
+void prof_end(hipStream_t st) {
+    if (g_prof_n >= kProfMax) return;
+    (void)hipEventRecord(g_prof[g_prof_n].b, st);
+    ++g_prof_n;
+}
+
 __global__ void k_rot6d(const float* __restrict__ x, int n, float* __restrict__ R) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -78,6 +100,25 @@ const char* hmf_last_error(void) { return err_buf(); }
 int hmf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int hmf_profile_enable(int enable) {
+    for (int i = 0; i < g_prof_n; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
+    g_prof_n = 0;
+    g_prof_on = enable != 0;
+    return HMF_OK;
+}
+
+int hmf_profile_collect(double* ms, int32_t* tag, int32_t* rows, int max) {
+    if (!ms || !tag || !rows || max < 0) return fail(HMF_ERR_INVALID, "hmf_profile_collect: bad args");
+    int n = g_prof_n < max ? g_prof_n : max;
+    for (int i = 0; i < n; ++i) {
+        HMF_HIP(hipEventSynchronize(g_prof[i].b));
+        float t = 0.f;
+        HMF_HIP(hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b));
+        ms[i] = t; tag[i] = g_prof[i].tag; rows[i] = g_prof[i].rows;
+    }
     return n;
 }
 

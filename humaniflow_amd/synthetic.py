@@ -1,0 +1,43 @@
+"""Synthetic benchmark inputs and weights: no dataset, checkpoint or SMPL pkl is available offline."""
+import math
+
+import torch
+
+
+def synthetic_proxy_input(B, size=256, channels=18, seed=0, device='cpu'):
+    """(B, 18, size, size) proxy representation: channel 0 sparse 'edges' (Bernoulli(0.05) * U(0,1)), channels 1..17
+    Gaussian joint heat-maps (sigma 4, utils/label_conversions.py:106-125) at random centres, ~10 % zeroed."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros(B, channels, size, size)
+    x[:, 0] = (torch.rand(B, size, size, generator=g) < 0.05).float() * torch.rand(B, size, size, generator=g)
+    ax = torch.arange(size).float()
+    cen = torch.rand(B, channels - 1, 2, generator=g) * (size * 0.75) + size * 0.125
+    vis = (torch.rand(B, channels - 1, generator=g) > 0.1).float()
+    gx = torch.exp(-(ax[None, None, :] - cen[..., 0:1]) ** 2 / (2 * 4.0 ** 2))        # (B, C-1, size)
+    gy = torch.exp(-(ax[None, None, :] - cen[..., 1:2]) ** 2 / (2 * 4.0 ** 2))
+    x[:, 1:] = vis[..., None, None] * gy[..., :, None] * gx[..., None, :]
+    return x.to(device)
+
+
+def init_benchmark_weights(model, seed=0):
+    """Default PyTorch init under a fixed seed, then shrink the shape log-std half and the last hyper-network layers so
+    that samples stay inside the flow's support (random init otherwise gives near-uniform splines); give BatchNorm
+    non-trivial running statistics so the encoder does real work."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.startswith('image_encoder'):
+                continue
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(p.shape[-1]))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        nb = model.num_shape_params
+        model.fc_shape.weight[nb:] *= 0.1
+        model.fc_shape.bias[nb:] -= 1.0
+        for name, b in model.image_encoder.named_buffers():
+            if name.endswith('running_var'):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+            elif name.endswith('running_mean'):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+    return model

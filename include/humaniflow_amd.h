@@ -150,13 +150,25 @@ int hmf_flow_context(const hmf_flow_t* h, const float* isgc, const float* pose_R
                      void* stream);
 /* LocalDiffeoTransformedDistribution.log_prob (local_diffeo_transformed_distribution.py:84-142):
  * log p(R | ctx) on SO(3) with the logsumexp over the 2*pi pre-images.
- * ctx B x P x ctx_dim; part_ids P ints on the HOST (NULL = 0..22, requires P == 23);
+ * ctx B x P x ctx_dim; part_ids P ints on the HOST, a contiguous ascending range of part indices
+ * (NULL = 0..22, requires P == 23);
  * R B x P x 9 fp64 -> logp B x P fp32.                                                            */
 int hmf_flow_log_prob_SO3(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P,
                           const double* R, int B, float* logp, void* stream);
 /* Density on the algebra (conditioned_pose_so3flow_dists_for_loglik, :318): v B x P x 3 fp32.    */
 int hmf_flow_log_prob_so3(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P,
                           const float* v, int B, float* logp, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */
+/* ------------------------------------------------------------------------------------------ */
+/* While enabled, every launch of the kernels tagged below is bracketed by hipEventRecord on ITS stream
+ * (no synchronisation, <= 4096 launches kept).  hmf_profile_collect synchronises the recorded events and
+ * copies out, per launch: duration in ms, kernel tag, and the launch's row count M (or B*N for flow).
+ * Tags: 1 = k_lbs_mfma, 2 = k_rigid_chain, 3 = k_joints, 4 = k_tpose, 5 = k_flow_ctx0, 6 = k_flow_chain,
+ * 7 = k_isgc.  Returns the number of launches copied (<= max), or a negative error.                */
+int hmf_profile_enable(int enable);
+int hmf_profile_collect(double* ms_host, int32_t* tag_host, int32_t* rows_host, int max);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host-side packing probes (no GPU needed; used by the CPU test-suite to check operand layouts) */

@@ -1,0 +1,195 @@
+"""NumPy emulation of the wave-level data flow of the MFMA kernels (test infrastructure).
+
+It replays, lane by lane, what k_lbs_mfma / k_flow_ctx0 / k_flow_chain do with the PACKED operand arenas
+produced by the C++ packers (hmf_smpl_pack_blend_host / hmf_flow_pack_host), using the documented
+v_mfma_f32_32x32x2_f32 operand/result lane mapping (guides/cdna_hip_programming.md section 3):
+    A operand: lane l supplies A[i = l & 31][k = l >> 5]
+    B operand: lane l supplies B[k = l >> 5][j = l & 31]
+    C/D      : lane l, register r holds D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31]
+Runs on CPU, so operand-layout mistakes are caught before any GPU time is spent.
+"""
+import numpy as np
+import torch
+
+LANES = np.arange(64)
+L31 = LANES & 31
+Q = LANES >> 5
+# D row index held by (reg, lane)
+D_ROW = (np.arange(16)[:, None] & 3) + 8 * (np.arange(16)[:, None] >> 2) + 4 * Q[None, :]     # (16, 64)
+
+PART_FIELDS = [('n_anc', 1), ('anc', 7), ('kas', 1), ('kag', 1), ('o_wc0', 1), ('o_bctx', 1), ('o_wa', 1), ('o_w1', 1),
+               ('o_b1', 1), ('o_w1x', 1), ('o_w2', 2), ('o_b2', 2), ('o_w3', 2), ('o_b3', 2), ('o_w4', 2), ('o_b4', 2),
+               ('o_wctxT', 1), ('o_nnT', 8), ('o_nnb', 8)]
+PART_INTS = sum(n for _, n in PART_FIELDS)
+
+
+def mfma(a, b, acc):
+    """acc (16, 64) += A(32x2) . B(2x32) with a, b the per-lane operand values (64,)."""
+    A = a.reshape(2, 32).T.astype(np.float32)          # [i][k]
+    Bm = b.reshape(2, 32).astype(np.float32)           # [k][j]
+    D = (A[:, 0:1] * Bm[0:1, :]).astype(np.float32)
+    D = (D + A[:, 1:2] * Bm[1:2, :]).astype(np.float32)
+    acc += D[D_ROW, L31[None, :]]
+    return acc
+
+
+def parse_flow_pack(buf):
+    """Split hmf_flow_pack_host output -> (arena float32, list of part dicts, anc_off (23,64), globals dict)."""
+    ints = buf.view(np.int32)
+    n_arena = int(ints[-1])
+    arena = buf[:n_arena]
+    tab_raw = ints[n_arena:n_arena + 23 * PART_INTS].reshape(23, PART_INTS)
+    parts = []
+    for j in range(23):
+        d, o = {}, 0
+        for name, n in PART_FIELDS:
+            v = tab_raw[j, o:o + n]
+            d[name] = int(v[0]) if n == 1 else [int(x) for x in v]
+            o += n
+        parts.append(d)
+    anc_off = ints[n_arena + 23 * PART_INTS:n_arena + 23 * PART_INTS + 23 * 64].reshape(23, 64)
+    glob = {'o_wisgc': int(ints[-4]), 'o_bisgc': int(ints[-3]), 'o_wbeta': int(ints[-2])}
+    return arena, parts, anc_off, glob
+
+
+def a_block(arena, off, ntiles, g4):
+    """View of a packed A-operand block as [tile][g4][lane][4]."""
+    return arena[off:off + ntiles * g4 * 64 * 4].reshape(ntiles, g4, 64, 4)
+
+
+def bias_init(arena, off, ntiles):
+    """acc[t][4g + r][lane] = bias[32 t + 8 g + 4 q + r]"""
+    acc = np.zeros((ntiles, 16, 64), np.float32)
+    for t in range(ntiles):
+        for g in range(4):
+            for r in range(4):
+                acc[t, 4 * g + r] = arena[off + 32 * t + 8 * g + 4 * Q + r]
+    return acc
+
+
+def dense_layer(wblk, x_in, acc):
+    """wblk [NTO][NKT*4][64][4]; x_in (NKT, 16, 64) in ARL; acc (NTO, 16, 64)."""
+    nto, ns4 = wblk.shape[0], wblk.shape[1]
+    for s4 in range(ns4):
+        for u in range(4):
+            s = s4 * 4 + u
+            for to in range(nto):
+                mfma(wblk[to, s4, :, u], x_in[s >> 4, s & 15], acc[to])
+    return acc
+
+
+def elu(x):
+    return np.where(x > 0, x, np.expm1(np.minimum(x, 0))).astype(np.float32)
+
+
+def spline_lane(a4, x, bound, inverse=False):
+    """Per-lane spline from the 32 packed parameter registers a4 (2, 16, 64) using the ORACLE's spline code:
+    slots [0,8) widths, [8,16) heights, [16,23) derivatives, [24,32) lambdas of dimension q = lane >> 5."""
+    from oracle.spline import rational_linear_spline
+    import torch.nn.functional as F
+    rw = torch.from_numpy(a4[0, 0:8].T.copy())      # (64, 8)
+    rh = torch.from_numpy(a4[0, 8:16].T.copy())
+    rd = torch.from_numpy(a4[1, 0:7].T.copy())
+    rl = torch.from_numpy(a4[1, 8:16].T.copy())
+    w, h, d, l = F.softmax(rw, -1), F.softmax(rh, -1), F.softplus(rd), torch.sigmoid(rl)
+    y, ld = rational_linear_spline(torch.from_numpy(x.astype(np.float32)), w, h, d, l, bound, inverse=inverse)
+    return y.numpy(), ld.numpy()
+
+
+def emulate_flow_tile(arena, parts, anc_off, glob, levels, nb, G, shape_mode, shape_log_std, eps_shape, eps_pose, B, N, pe,
+                      tile, radius, base_std):
+    """One 32-row tile through k_flow_ctx0 + k_flow_chain.  Returns dict rowid -> (R (23,9), v (23,3), beta (nb,))."""
+    from oracle import so3
+    Mtot = B * N + (B if pe else 0)
+    rowid = tile * 32 + L31
+    live = rowid < Mtot
+    rs = np.where(live, rowid, 0)
+    is_point = rs >= B * N
+    b = np.where(is_point, rs - B * N, rs // max(N, 1))
+    n = np.where(is_point, 0, rs - b * N)
+    # ---- k_flow_ctx0 prologue ----
+    beta = np.zeros((16, 64), np.float32)
+    for i in range(nb):
+        v = shape_mode[b, i].astype(np.float32)
+        if eps_shape is not None:
+            v = np.where(is_point, v, (v + eps_shape[n, b, i] * np.exp(shape_log_std[b, i])).astype(np.float32))
+        beta[i] = np.where(live, v, 0)
+    h = np.zeros((8, 16, 64), np.float32)
+    for t in range(8):
+        for g in range(4):
+            for r in range(4):
+                h[t, 4 * g + r] = G[b, 32 * t + 8 * g + 4 * Q + r]
+    g4 = (((nb + 1) >> 1) + 3) >> 2
+    wb = a_block(arena, glob['o_wbeta'], 8, g4)
+    for s4 in range(g4):
+        for t in range(8):
+            for u in range(4):
+                s = s4 * 4 + u
+                bop = np.where(Q == 1, beta[2 * s + 1], beta[2 * s])
+                mfma(wb[t, s4, :, u], bop, h[t])
+    h = np.where(live[None, None, :], elu(h), 0).astype(np.float32)
+    C0 = {}
+    for j in range(23):
+        pt = parts[j]
+        acc = bias_init(arena, pt['o_bctx'], 2)
+        C0[j] = dense_layer(a_block(arena, pt['o_wc0'], 2, 32), h, acc)
+    # ---- k_flow_chain ----
+    sAnc = np.zeros((32, 209), np.float32)
+    out_R = np.zeros((64, 23, 9), np.float32)
+    out_v = np.zeros((64, 23, 3), np.float32)
+    for lev in levels:
+        for j in lev:
+            pt = parts[j]
+            cx = C0[j].copy()
+            if pt['kag'] > 0:
+                wa = a_block(arena, pt['o_wa'], 2, pt['kag'])
+                for s4 in range(pt['kag']):
+                    for u in range(4):
+                        s = s4 * 4 + u
+                        off = anc_off[j, 2 * s + Q]
+                        bval = sAnc[L31, off]
+                        mfma(wa[0, s4, :, u], bval, cx[0])
+                        mfma(wa[1, s4, :, u], bval, cx[1])
+            cx = elu(cx)
+            a1 = bias_init(arena, pt['o_b1'], 4)
+            dense_layer(a_block(arena, pt['o_w1'], 4, 8), cx, a1)
+            x = np.zeros((3, 64), np.float32)
+            if N > 0:
+                e = eps_pose[j, b, n]                                   # (64, 3)
+                x = np.where((live & ~is_point)[None, :], (e * np.float32(base_std)).T, 0).astype(np.float32)
+            x0, x1, x2 = x
+
+            def tail(c, h1, xin):
+                a2 = bias_init(arena, pt['o_b2'][c], 1)
+                dense_layer(a_block(arena, pt['o_w2'][c], 1, 8), h1, a2)
+                a2 = np.maximum(a2, 0)
+                a3 = bias_init(arena, pt['o_b3'][c], 1)
+                dense_layer(a_block(arena, pt['o_w3'][c], 1, 4), a2, a3)
+                a3 = np.maximum(a3, 0)
+                a4 = bias_init(arena, pt['o_b4'][c], 2)
+                dense_layer(a_block(arena, pt['o_w4'][c], 2, 4), a3, a4)
+                y, _ = spline_lane(a4, xin, radius)
+                return y
+            wx = bias_init(arena, pt['o_w1x'], 2)
+            h1 = np.maximum(wx * x0[None, None, :] + a1[0:2], 0).astype(np.float32)
+            xn = tail(0, h1, np.where(Q == 1, x2, x1))
+            x1n, x2n = xn[L31], xn[32 + L31]
+            y0 = x1n
+            wx = bias_init(arena, pt['o_w1x'] + 64, 2)
+            h1 = np.maximum(wx * y0[None, None, :] + a1[2:4], 0).astype(np.float32)
+            yn = tail(1, h1, np.where(Q == 1, x0, x2n))
+            y1, y2 = yn[L31], yn[32 + L31]
+            yv = torch.from_numpy(np.stack([y0, y1, y2], -1).astype(np.float32))
+            from oracle.flow import radial_tanh_forward
+            v = radial_tanh_forward(yv, radius)
+            R_s = so3.so3_exp(v.double()).float().reshape(64, 9).numpy()
+            R_p = so3.batch_rodrigues(v).reshape(64, 9).numpy()
+            R = np.where(is_point[:, None], R_p, R_s)
+            sAnc[L31[:32], j * 9:(j + 1) * 9] = R[:32]
+            out_R[:, j] = R
+            out_v[:, j] = v.numpy()
+    res = {}
+    for lane in range(32):
+        if live[lane]:
+            res[int(rowid[lane])] = (out_R[lane], out_v[lane], beta[:nb, lane].copy())
+    return res

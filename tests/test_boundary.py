@@ -1,0 +1,174 @@
+"""C-ABI boundary + host logic, no GPU: the library loads, exports every declared symbol, the operand packers
+agree with a lane-level emulation of the MFMA kernels, the Python mirror keeps the reference's checkpoint layout."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import humaniflow_amd as H
+from humaniflow_amd import _lib
+from helpers import ROOT, init_model_for_tests, oracle_cfg_from
+import mfma_emulator as E
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'humaniflow_amd.h')).read()
+    declared = sorted(set(re.findall(r'\b(hmf_[a-zA-Z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), 'symbol %s declared in include/humaniflow_amd.h is not exported' % name
+    assert sorted(declared) == sorted(_lib.EXPORTED_SYMBOLS)
+    assert lib.hmf_abi_version() == 1
+
+
+def test_error_reporting_without_device(lib):
+    if lib.hmf_device_count() > 0:
+        pytest.skip('GPU present')
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model())
+    hs, keep = smpl.host_struct()
+    h = C.c_void_p()
+    rc = lib.hmf_smpl_create(C.byref(h), C.byref(hs))
+    assert rc == -5 and b'no HIP device' in lib.hmf_last_error()         # HMF_ERR_NO_DEVICE, never a silent fallback
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        smpl(betas=torch.zeros(1, 10), body_pose=torch.zeros(1, 69), global_orient=torch.zeros(1, 3))
+    model = H.HumaniflowModel(torch.device('cpu'), H.get_benchmark_cfg().MODEL, H.SMPL_PARENTS).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(torch.zeros(1, 18, 64, 64))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'humaniflow_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+    code = 'import sys; import humaniflow_amd; assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules)'
+    subprocess.check_call([sys.executable, '-c', code], cwd=ROOT)
+
+
+def test_checkpoint_layout_matches_reference_contract():
+    cfg = H.get_benchmark_cfg()
+    m = H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS)
+    sd = m.state_dict()
+    assert len(sd) == 744
+    assert tuple(sd['init_glob'].shape) == (1, 6) and torch.equal(sd['init_glob'], torch.tensor([[1., 0, 0, 1, 0, 0]]))
+    assert torch.equal(sd['init_cam'], torch.tensor([0.9, 0.0, 0.0]))
+    assert tuple(sd['image_encoder.conv1.weight'].shape) == (64, 18, 7, 7)
+    assert tuple(sd['fc_input_shape_glob_cam_feats.weight'].shape) == (256, 2048 + 10 + 9 + 3)
+    anc = H.immediate_parent_to_all_ancestors(H.SMPL_PARENTS)
+    assert anc[22] == [20, 18, 16, 13, 8, 5, 2] and anc[3] == [0] and anc[0] == []
+    for j in range(23):
+        assert tuple(sd['fc_flow_context.%d.weight' % j].shape) == (64, 256 + 9 * len(anc[j]))
+    for k in range(46):
+        shapes = [tuple(sd['pose_so3flow_transform_modules.%d.nn.layers.%d.weight' % (k, i)].shape) for i in range(4)]
+        assert shapes == [(64, 65), (32, 64), (32, 32), (62, 32)]
+    # strict round trip, as scripts/run_predict.py:75-76 does
+    m2 = H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS)
+    m2.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    cfg18 = H.get_humaniflow_cfg_defaults()
+    assert cfg18.MODEL.NUM_RESNET_LAYERS == 18
+    m18 = H.HumaniflowModel(torch.device('cpu'), cfg18.MODEL, H.SMPL_PARENTS)
+    assert tuple(m18.state_dict()['fc1.weight'].shape) == (512, 512)
+
+
+def test_config_mirror():
+    cfg = H.get_humaniflow_cfg_defaults()
+    assert cfg.MODEL.NORM_FLOW.CONTEXT_DIM == 64 and cfg.MODEL.NORM_FLOW.TRANSFORM_NN_HIDDEN_DIMS == [64, 32, 32]
+    assert abs(cfg.MODEL.NORM_FLOW.COMPACT_SUPPORT_RADIUS - 1.5 * np.pi) < 1e-12 and cfg.DATA.PROXY_REP_SIZE == 256
+    c2 = cfg.clone()
+    c2.merge_from_list(['MODEL.NUM_RESNET_LAYERS', '50', 'TRAIN.LR', '0.001'])
+    assert c2.MODEL.NUM_RESNET_LAYERS == 50 and c2.TRAIN.LR == 0.001 and cfg.MODEL.NUM_RESNET_LAYERS == 18
+    with pytest.raises(NotImplementedError):
+        c3 = cfg.clone()
+        c3.MODEL.NORM_FLOW.PERMUTE_TYPE = 'linear_plu'
+        H.HumaniflowModel(torch.device('cpu'), c3.MODEL, H.SMPL_PARENTS)
+
+
+def test_smpl_blend_operand_pack_matches_mfma_lane_semantics(lib):
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=1))
+    hs, keep = smpl.host_struct()
+    n = lib.hmf_smpl_packed_blend_floats(10)
+    packed = np.zeros(n, np.float32)
+    assert lib.hmf_smpl_pack_blend_host(C.byref(hs), _lib.fptr(packed)) == 0
+    md = smpl.model_dict()
+    V = 6890
+    Bsrc = np.zeros((224, V, 3), np.float32)
+    Bsrc[:207] = md['posedirs'].numpy().reshape(207, V, 3)
+    Bsrc[207:217] = md['shapedirs'].numpy().transpose(2, 0, 1)
+    Bsrc[217] = md['v_template'].numpy()
+    rng = np.random.RandomState(0)
+    for (k, v, c) in [(0, 0, 0), (1, 31, 2), (206, 6889, 1), (217, 100, 0), (223, 6889, 2), (55, 3333, 1)]:
+        assert packed[lib.hmf_smpl_packed_blend_index(k, v, c)] == Bsrc[k, v, c]
+    # replay the k-loop of k_lbs_mfma for two vertex tiles with the emulated MFMA
+    pf = rng.randn(32, 224).astype(np.float32)
+    blk = packed.reshape(216, 28, 3, 64, 4)
+    for vt in (0, 215, 107):
+        acc = np.zeros((3, 16, 64), np.float32)
+        for kg in range(28):
+            bv = blk[vt, kg].transpose(1, 0, 2).reshape(64, 12)          # per lane: 3 float4 = 12 values
+            for u in range(4):
+                ks = kg * 4 + u
+                a = pf[E.L31, 2 * ks + E.Q]
+                for c in range(3):
+                    E.mfma(a, bv[:, u * 3 + c], acc[c])
+        ref = np.einsum('rk,kvc->rvc', pf.astype(np.float64), np.pad(Bsrc, ((0, 0), (0, 6912 - V), (0, 0)))[:, vt * 32:(vt + 1) * 32].astype(np.float64))
+        got = np.zeros((32, 32, 3))
+        for c in range(3):
+            for reg in range(16):
+                got[E.D_ROW[reg], E.L31, c] = acc[c, reg]
+        assert np.abs(got - ref).max() < 1e-4
+
+
+def _flow_pack(model, lib):
+    hs, keep = model.flow_host_struct()
+    n = lib.hmf_flow_packed_floats(C.byref(hs))
+    assert n > 0, lib.hmf_last_error()
+    buf = np.zeros(n, np.float32)
+    assert lib.hmf_flow_pack_host(C.byref(hs), _lib.fptr(buf)) == 0
+    return buf
+
+
+@pytest.mark.parametrize('use_mode', [False, True])
+def test_flow_operand_pack_and_kernel_dataflow_match_oracle(lib, use_mode):
+    """Replays k_flow_ctx0 + k_flow_chain lane by lane on the C++-packed arena and compares with the oracle's
+    reference-mode forward (Python loop over the 23 parts) on the same weights and injected noise."""
+    from oracle import model as omodel
+    cfg = H.get_humaniflow_cfg_defaults()          # ResNet-18 features (512) keep the CPU test light
+    model = init_model_for_tests(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=3).eval()
+    arena, parts, anc_off, glob = E.parse_flow_pack(_flow_pack(model, lib))
+    B, N, nb = 2, 13, 10
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(B, 512, generator=g)
+    noise = {'shape': torch.randn(N, B, nb, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    ref = omodel.forward(sd, ocfg, input_feats=feats, num_samples=N, noise=noise, use_shape_mode_for_samples=use_mode)
+    # image part G = W[:, feats|R|cam] . [f, vec(R), cam] + b (k_isgc), fp64 here
+    W = sd['fc_input_shape_glob_cam_feats.weight'].double()
+    bias = sd['fc_input_shape_glob_cam_feats.bias'].double()
+    gc = torch.cat([ref['glob_rotmat'].reshape(B, 9), ref['cam_wp']], 1).double()
+    G = (feats.double() @ W[:, :512].T + gc @ W[:, 522:].T + bias).float().numpy()
+    assert np.array_equal(arena[glob['o_wisgc']:glob['o_wisgc'] + W.numel()].reshape(W.shape), W.float().numpy())
+    depth = [len(H.immediate_parent_to_all_ancestors(H.SMPL_PARENTS)[j]) for j in range(23)]
+    levels = [[j for j in range(23) if depth[j] == d] for d in range(max(depth) + 1)]
+    assert [len(l) for l in levels] == [3, 3, 3, 5, 3, 2, 2, 2]
+    got = {}
+    for tile in range((B * N + B + 31) // 32):
+        got.update(E.emulate_flow_tile(arena, parts, anc_off, glob, levels, nb, G, ref['shape_mode'].numpy(),
+                                       ref['shape_log_std'].numpy(), None if use_mode else noise['shape'].numpy(),
+                                       noise['pose'].numpy(), B, N, True, tile, ocfg.radius, ocfg.base_std))
+    assert sorted(got) == list(range(B * N + B))
+    Rs = ref['pose_rotmats_samples'].reshape(B * N, 23, 9).numpy()
+    err_s = max(np.abs(got[m][0] - Rs[m]).max() for m in range(B * N))
+    err_p = max(np.abs(got[B * N + b][0] - ref['pose_rotmats_point_est'][b].reshape(23, 9).numpy()).max() for b in range(B))
+    err_v = max(np.abs(got[B * N + b][1] - ref['pose_axisangle_point_est'][b].numpy()).max() for b in range(B))
+    err_b = max(np.abs(got[m][2] - ref['shape_samples'].reshape(B * N, nb)[m].numpy()).max() for m in range(B * N))
+    assert err_s < 2e-5 and err_p < 2e-5 and err_v < 2e-5 and err_b < 1e-6, (err_s, err_p, err_v, err_b)
+    # the samples must actually exercise the spline (not all identity / out of support)
+    assert np.abs(Rs - np.eye(3).reshape(9)).max() > 0.3

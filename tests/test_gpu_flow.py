@@ -1,0 +1,171 @@
+"""GPU parity: the flow (hmf_flow_forward / context / log-prob) and the whole HumaniflowModel.forward dict through the
+C ABI vs the oracle's reference-mode forward.  Tolerances (BASELINE.json north_star): rotations feed vertices that must
+hold 1e-4 -> rot-mats checked at 5e-5; log-probs within 1e-3."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import humaniflow_amd as H
+from helpers import init_model_for_tests, oracle_cfg_from, synthetic_proxy_input, random_rotmats, smpl_oracle_model
+from oracle import model as omodel
+from oracle import smpl as osmpl
+
+pytestmark = pytest.mark.gpu
+RTOL = 5e-5
+
+
+def _model(layers, seed=3):
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_RESNET_LAYERS = layers
+    m = init_model_for_tests(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=seed).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m.to('cuda:0'), sd, cfg
+
+
+def _noise(B, N, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return {'shape': torch.randn(N, B, 10, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+
+
+def _cuda(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+@pytest.mark.parametrize('layers,B,N,use_mode', [(18, 2, 13, False), (18, 3, 1, True), (50, 1, 40, False), (18, 5, 64, False)])
+def test_flow_forward_matches_oracle(layers, B, N, use_mode):
+    model, sd, cfg = _model(layers)
+    F = 512 if layers == 18 else 2048
+    feats = torch.randn(B, F, generator=torch.Generator().manual_seed(B * 7 + N)) * 0.5
+    noise = _noise(B, N, seed=N)
+    ref = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input_feats=feats, num_samples=N, noise=noise,
+                         use_shape_mode_for_samples=use_mode)
+    with torch.no_grad():
+        out = model(None, input_feats=feats.cuda(), num_samples=N, noise=_cuda(noise), use_shape_mode_for_samples=use_mode)
+    for k in ('cam_wp', 'glob_rotmat', 'shape_mode', 'shape_log_std'):
+        assert (out[k].cpu() - ref[k]).abs().max() < 1e-5, k
+    assert out['pose_rotmats_samples'].shape == (B, N, 23, 3, 3) and out['pose_rotmats_samples'].dtype == torch.float32
+    assert (out['shape_samples'].cpu() - ref['shape_samples']).abs().max() < 1e-5
+    assert (out['pose_rotmats_samples'].cpu() - ref['pose_rotmats_samples']).abs().max() < RTOL
+    assert (out['pose_rotmats_point_est'].cpu() - ref['pose_rotmats_point_est']).abs().max() < RTOL
+    assert (out['pose_axisangle_point_est'].cpu() - ref['pose_axisangle_point_est']).abs().max() < RTOL
+    assert (ref['pose_rotmats_samples'] - torch.eye(3)).abs().max() > 0.3         # flow is not degenerate
+
+
+def test_point_estimate_only_and_samples_only_paths():
+    model, sd, cfg = _model(18)
+    feats = torch.randn(4, 512, generator=torch.Generator().manual_seed(1)) * 0.5
+    ref = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input_feats=feats, num_samples=0)
+    with torch.no_grad():
+        out = model(None, input_feats=feats.cuda())
+        assert 'pose_rotmats_samples' not in out
+        assert (out['pose_rotmats_point_est'].cpu() - ref['pose_rotmats_point_est']).abs().max() < RTOL
+        noise = _noise(4, 3)
+        out2 = model(None, input_feats=feats.cuda(), compute_point_est=False, num_samples=3, noise=_cuda(noise))
+        assert 'pose_rotmats_point_est' not in out2
+        ref2 = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input_feats=feats, num_samples=3, noise=noise, compute_point_est=False)
+        assert (out2['pose_rotmats_samples'].cpu() - ref2['pose_rotmats_samples']).abs().max() < RTOL
+        only = model(torch.zeros(1, 18, 64, 64).cuda(), return_input_feats_only=True)
+        assert list(only) == ['input_feats'] and only['input_feats'].shape == (1, 512)
+
+
+def test_end_to_end_forward_dict_with_encoder_and_smpl():
+    """predict-style call on a synthetic proxy input: the six save_pred_output model keys (utils/predict_utils.py:19-24) plus
+    samples -> SMPL vertices/joints, all vs the oracle.  ResNet-50, 256x256, as BASELINE configs name."""
+    model, sd, cfg = _model(50, seed=5)
+    x = synthetic_proxy_input(2, 256, seed=0)
+    N = 6
+    noise = _noise(2, N, seed=2)
+    ref = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input=x, num_samples=N, noise=noise)
+    with torch.no_grad():
+        out = model(x.cuda(), num_samples=N, noise=_cuda(noise), return_input_feats=True)
+    scale = ref['input_feats'].abs().max().item()
+    assert (out['input_feats'].cpu() - ref['input_feats']).abs().max() < 2e-4 * max(1.0, scale)
+    # feed the ORACLE's features to isolate the flow from conv round-off, then compare the whole dict
+    with torch.no_grad():
+        out = model(None, input_feats=ref['input_feats'].cuda(), num_samples=N, noise=_cuda(noise), return_input_feats=True)
+    for k in ('pose_axisangle_point_est', 'pose_rotmats_point_est', 'shape_mode', 'glob_rotmat', 'cam_wp', 'input_feats',
+              'pose_rotmats_samples', 'shape_samples', 'shape_log_std'):
+        assert (out[k].cpu() - ref[k]).abs().max() < RTOL, k
+    assert isinstance(out['shape_dist_for_loglik'], torch.distributions.Normal)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    so = smpl(body_pose=out['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
+              global_orient=out['glob_rotmat'][:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3),
+              betas=out['shape_samples'].reshape(-1, 10), pose2rot=False)
+    v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(smpl.model_dict()), ref['shape_samples'].reshape(-1, 10),
+                                      ref['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
+                                      ref['glob_rotmat'][:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3), pose2rot=False)
+    assert (so.vertices.cpu() - v_ref).abs().max() < 1e-4 and (so.joints.cpu() - j_ref).abs().max() < 1e-4
+
+
+def test_teacher_forced_log_prob_matches_oracle():
+    model, sd, cfg = _model(18, seed=4)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B = 9
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    R_gt = random_rotmats(B * 23, 0.7, seed=1).view(B, 23, 3, 3)
+    R_gt[0, 0] = torch.eye(3)                                                   # quirk 1/2: identity target
+    from oracle.so3 import so3_exp
+    ax = torch.tensor([[0.6, 0.0, 0.8]], dtype=torch.float64)
+    R_gt[1, 1] = so3_exp(ax * (math.pi - 1e-4))[0].float()                       # near-pi branch of the log map
+    R_gt[2, 2] = so3_exp(ax * 2.0)[0].float()                                   # theta > pi/2: a second pre-image in support
+    shape_gt = torch.randn(B, 10, generator=g)
+    glob_gt = random_rotmats(B, 1.0, seed=2)
+    ref = omodel.forward(sd, ocfg, input_feats=feats, compute_for_loglik=True, shape_for_loglik=shape_gt,
+                         pose_R_for_loglik=R_gt, glob_R_for_loglik=glob_gt)
+    lp_ref = omodel.log_prob_SO3(sd, ocfg, ref['flow_context_for_loglik'], R_gt.double())
+    with torch.no_grad():
+        out = model(None, input_feats=feats.cuda(), compute_for_loglik=True, shape_for_loglik=shape_gt.cuda(),
+                    pose_R_for_loglik=R_gt.cuda(), glob_R_for_loglik=glob_gt.cuda())
+    assert (out['flow_context_for_loglik'].cpu() - ref['flow_context_for_loglik']).abs().max() < 1e-5
+    dists = out['conditioned_pose_SO3flow_dists_for_loglik']
+    assert len(dists) == 23 and len(out['conditioned_pose_so3flow_dists_for_loglik']) == 23
+    lp = torch.stack([dists[j].log_prob(R_gt[:, j].double().cuda()) for j in range(23)], dim=1).cpu()   # reference call pattern
+    assert lp.dtype == torch.float32 and torch.isfinite(lp).all()
+    assert (lp - lp_ref).abs().max() < 1e-3, (lp - lp_ref).abs().max()
+    lp_all = model.log_prob_all_parts(out['flow_context_for_loglik'], R_gt.cuda()).cpu()
+    assert torch.equal(lp_all, lp)
+    # density on the algebra (conditioned_pose_so3flow_dists_for_loglik)
+    v = torch.randn(B, 23, 3, generator=g) * 0.8
+    lp_so3_ref = omodel.log_prob_so3(sd, ocfg, ref['flow_context_for_loglik'], v)
+    lp_so3 = torch.stack([out['conditioned_pose_so3flow_dists_for_loglik'][j].log_prob(v[:, j].cuda()) for j in range(23)], 1).cpu()
+    assert (lp_so3 - lp_so3_ref).abs().max() < 1e-3
+    model.pose_SO3flow_dists[0].clear_cache()
+
+
+def test_full_size_B32_N100_properties():
+    """BASELINE configs[1] size: orthonormality, determinism, agreement of the point estimate with an N=0 call, row
+    independence (any sample row equals the same row computed in a small batch) and a slice against the oracle."""
+    model, sd, cfg = _model(50, seed=6)
+    B, N = 32, 100
+    feats = torch.randn(B, 2048, generator=torch.Generator().manual_seed(5)) * 0.3
+    noise = _noise(B, N, seed=9)
+    with torch.no_grad():
+        out = model(None, input_feats=feats.cuda(), num_samples=N, noise=_cuda(noise))
+        out_b = model(None, input_feats=feats.cuda(), num_samples=N, noise=_cuda(noise))
+        pe = model(None, input_feats=feats.cuda())
+    Rs = out['pose_rotmats_samples']
+    assert torch.equal(Rs, out_b['pose_rotmats_samples'])                       # deterministic
+    I = torch.eye(3, device='cuda')
+    assert (Rs @ Rs.transpose(-1, -2) - I).abs().max().item() < 1e-5 and (torch.linalg.det(Rs) - 1).abs().max().item() < 1e-5
+    assert torch.equal(pe['pose_rotmats_point_est'], out['pose_rotmats_point_est'])
+    sub = {'shape': noise['shape'][:7, 30:32].contiguous(), 'pose': noise['pose'][:, 30:32, :7].contiguous()}
+    with torch.no_grad():
+        small = model(None, input_feats=feats[30:32].cuda(), num_samples=7, noise=_cuda(sub))
+    assert (small['pose_rotmats_samples'] - Rs[30:32, :7]).abs().max().item() < 1e-5
+    ref = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input_feats=feats[30:32], num_samples=7, noise=sub)
+    assert (Rs[30:32, :7].cpu() - ref['pose_rotmats_samples']).abs().max() < RTOL
+    # default (device generator) path draws noise and stays in support
+    with torch.no_grad():
+        torch.manual_seed(0)
+        rnd = model(None, input_feats=feats.cuda(), num_samples=N)
+    assert torch.isfinite(rnd['pose_rotmats_samples']).all() and rnd['shape_samples'].shape == (B, N, 10)
+    assert rnd['shape_samples'].std(dim=1).mean().item() > 1e-3
+
+
+def test_grad_mode_fails_loudly():
+    model, _, _ = _model(18)
+    with pytest.raises(NotImplementedError):
+        model(None, input_feats=torch.zeros(1, 512).cuda())

@@ -1,0 +1,116 @@
+"""GPU parity: hmf_smpl_lbs / hmf_smpl_tpose / joints through the C ABI vs the oracle (smplx restatement).
+Tolerance from BASELINE.json north_star: vertices/joints within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+import humaniflow_amd as H
+from helpers import smpl_oracle_model, random_rotmats
+from oracle import smpl as osmpl
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def smpl():
+    assert torch.cuda.is_available()
+    return H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=1, create_transl=False).to('cuda:0')
+
+
+def _inputs(M, seed, scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    R = random_rotmats(M * 24, scale, seed=seed).view(M, 24, 3, 3)
+    betas = torch.randn(M, 10, generator=g) * 1.25
+    return R, betas
+
+
+@pytest.mark.parametrize('M', [1, 5, 64, 70, 257])
+@pytest.mark.parametrize('impl', [0, 1])
+def test_lbs_matches_oracle(smpl, M, impl):
+    R, betas = _inputs(M, seed=M)
+    out = smpl(body_pose=R[:, 1:].cuda(), global_orient=R[:, :1].cuda(), betas=betas.cuda(), pose2rot=False, impl=impl)
+    v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(smpl.model_dict()), betas, R[:, 1:], R[:, :1], pose2rot=False)
+    assert out.vertices.shape == (M, 6890, 3) and out.joints.shape == (M, 90, 3)
+    assert (out.vertices.cpu() - v_ref).abs().max() < TOL
+    assert (out.joints.cpu() - j_ref).abs().max() < TOL
+
+
+def test_mfma_and_scalar_kernels_agree_tightly(smpl):
+    R, betas = _inputs(130, seed=9, scale=1.0)
+    a = smpl(body_pose=R[:, 1:].cuda(), global_orient=R[:, :1].cuda(), betas=betas.cuda(), pose2rot=False, impl=0)
+    b = smpl(body_pose=R[:, 1:].cuda(), global_orient=R[:, :1].cuda(), betas=betas.cuda(), pose2rot=False, impl=1)
+    assert (a.vertices - b.vertices).abs().max().item() < 2e-6
+
+
+def test_axis_angle_path_betas_broadcast_and_large_rotations(smpl):
+    g = torch.Generator().manual_seed(4)
+    M = 33
+    aa = torch.randn(M, 72, generator=g) * 1.0
+    betas1 = torch.randn(1, 10, generator=g)
+    out = smpl(body_pose=aa[:, 3:].cuda(), global_orient=aa[:, :3].cuda(), betas=betas1.cuda())      # pose2rot=True, Mb=1
+    v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(smpl.model_dict()), betas1, aa[:, 3:], aa[:, :3], pose2rot=True)
+    assert (out.vertices.cpu() - v_ref).abs().max() < TOL and (out.joints.cpu() - j_ref).abs().max() < TOL
+
+
+def test_tpose_and_zero_pose_call(smpl):
+    g = torch.Generator().manual_seed(5)
+    betas = torch.randn(40, 10, generator=g) * 1.25
+    m = smpl_oracle_model(smpl.model_dict())
+    v_shaped = m['v_template'] + osmpl.blend_shapes(betas, m['shapedirs'])
+    assert (smpl.tpose(betas.cuda()).cpu() - v_shaped).abs().max() < 1e-5
+    # what the reference does for T-pose: zero axis-angle through the full LBS (evaluate_humaniflow.py:131-133)
+    out = smpl(body_pose=torch.zeros(40, 69).cuda(), global_orient=torch.zeros(40, 3).cuda(), betas=betas.cuda())
+    v_ref, _ = osmpl.smpl_forward(m, betas, torch.zeros(40, 69), torch.zeros(40, 3), pose2rot=True)
+    assert (out.vertices.cpu() - v_ref).abs().max() < TOL
+
+
+def test_dense_skinning_weights_path():
+    """lbs_weights with 24 non-zeros per vertex takes the generic ELL width."""
+    md = H.synthetic_smpl_model(seed=2)
+    rng = np.random.RandomState(0)
+    md['lbs_weights'] = rng.dirichlet(np.ones(24), size=6890).astype(np.float32)
+    s = H.SMPL(model_data=md, create_transl=False).to('cuda:0')
+    R, betas = _inputs(9, seed=3)
+    out = s(body_pose=R[:, 1:].cuda(), global_orient=R[:, :1].cuda(), betas=betas.cuda(), pose2rot=False)
+    v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(s.model_dict()), betas, R[:, 1:], R[:, :1], pose2rot=False)
+    assert (out.vertices.cpu() - v_ref).abs().max() < TOL and (out.joints.cpu() - j_ref).abs().max() < TOL
+
+
+def test_full_size_properties_B32_N100(smpl):
+    """BASELINE configs[1] size (M = 3200): size-independent identities instead of the (slow) oracle."""
+    M = 3200
+    g = torch.Generator().manual_seed(6)
+    betas = (torch.randn(M, 10, generator=g) * 1.25).cuda()
+    eye = torch.eye(3, device='cuda')[None, None].expand(M, 24, 3, 3).contiguous()
+    out = smpl(body_pose=eye[:, 1:], global_orient=eye[:, :1], betas=betas, pose2rot=False)
+    assert (out.vertices - smpl.tpose(betas)).abs().max().item() < 2e-5           # identity pose == shaped template
+    # rigid global rotation about the root joint
+    R0 = random_rotmats(M, 1.5, seed=7).cuda()
+    out2 = smpl(body_pose=eye[:, 1:], global_orient=R0[:, None], betas=betas, pose2rot=False)
+    J0 = out.joints[:, 0]
+    ref = torch.einsum('bij,bvj->bvi', R0, out.vertices - J0[:, None]) + J0[:, None]
+    assert (out2.vertices - ref).abs().max().item() < 5e-5
+    # random poses: MFMA kernel vs the independent scalar kernel on every row
+    R = random_rotmats(M * 24, 0.6, seed=8).view(M, 24, 3, 3).cuda()
+    a = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False, impl=0)
+    b = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False, impl=1)
+    assert (a.vertices - b.vertices).abs().max().item() < 5e-6 and (a.joints - b.joints).abs().max().item() < 5e-6
+    assert torch.isfinite(a.vertices).all()
+    # ... and a slice of rows against the oracle
+    v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(smpl.model_dict()), betas[3100:3132].cpu(), R[3100:3132, 1:].cpu(),
+                                      R[3100:3132, :1].cpu(), pose2rot=False)
+    assert (a.vertices[3100:3132].cpu() - v_ref).abs().max() < TOL and (a.joints[3100:3132].cpu() - j_ref).abs().max() < TOL
+
+
+def test_vertex_variance(smpl):
+    from oracle.smpl import vertex_variance
+    v = torch.randn(50, 6890, 3, generator=torch.Generator().manual_seed(1))
+    a, s = H.compute_vertex_variance_from_samples(v.cuda())
+    ra, rs = vertex_variance(v)
+    assert (a.cpu() - ra).abs().max() < 1e-5 and (s.cpu() - rs).abs().max() < 1e-5
+
+
+def test_empty_and_bad_shapes(smpl):
+    with pytest.raises(ValueError):
+        smpl(body_pose=torch.zeros(3, 69).cuda(), global_orient=torch.zeros(2, 3).cuda(), betas=torch.zeros(3, 10).cuda())

@@ -1,0 +1,79 @@
+"""LBS identities anchoring the restated smplx arithmetic (parity unpinned: SURVEY App. B)."""
+import numpy as np
+import torch
+
+from helpers import smpl_oracle_model, random_rotmats
+from humaniflow_amd.smpl import synthetic_smpl_model, load_extra_regressors, SMPL_PARENTS
+from oracle import smpl as osmpl
+from oracle.so3 import batch_rodrigues
+
+
+def _model():
+    m = synthetic_smpl_model(seed=0)
+    m.update(load_extra_regressors())
+    return smpl_oracle_model(m)
+
+
+def test_identity_pose_returns_shaped_template():
+    m = _model()
+    betas = torch.randn(3, 10, generator=torch.Generator().manual_seed(0))
+    eye = torch.eye(3)[None, None].expand(3, 24, 3, 3).contiguous()
+    verts, joints = osmpl.smpl_forward(m, betas, eye[:, 1:], eye[:, :1], pose2rot=False)
+    v_shaped = m['v_template'] + osmpl.blend_shapes(betas, m['shapedirs'])
+    assert (verts - v_shaped).abs().max() < 1e-5
+    assert (joints[:, :24] - osmpl.vertices2joints(m['J_regressor'], v_shaped)).abs().max() < 1e-5
+    assert joints.shape == (3, 90, 3)
+    assert torch.equal(joints[:, 24:45], verts[:, torch.tensor(osmpl.EXTRA_VERTEX_IDS)])
+
+
+def test_global_rotation_only_is_rigid_about_root():
+    m = _model()
+    betas = torch.zeros(2, 10)
+    R0 = random_rotmats(2, 1.0, seed=1)
+    eye = torch.eye(3)[None, None].expand(2, 23, 3, 3).contiguous()
+    verts, joints = osmpl.smpl_forward(m, betas, eye, R0[:, None], pose2rot=False)
+    J0 = osmpl.vertices2joints(m['J_regressor'], m['v_template'][None])[0, 0]
+    ref = torch.einsum('bij,vj->bvi', R0, m['v_template'] - J0) + J0
+    assert (verts - ref).abs().max() < 1e-5
+
+
+def test_chain_matches_naive_forward_kinematics_and_axis_angle_path():
+    m = _model()
+    g = torch.Generator().manual_seed(2)
+    aa = torch.randn(2, 72, generator=g) * 0.4
+    betas = torch.randn(2, 10, generator=g)
+    v1, j1 = osmpl.smpl_forward(m, betas, aa[:, 3:], aa[:, :3], pose2rot=True)
+    R = batch_rodrigues(aa.reshape(-1, 3)).view(2, 24, 3, 3)
+    v2, j2 = osmpl.smpl_forward(m, betas, R[:, 1:], R[:, :1], pose2rot=False)
+    assert (v1 - v2).abs().max() < 1e-6
+    # naive FK for posed joints
+    v_shaped = m['v_template'] + osmpl.blend_shapes(betas, m['shapedirs'])
+    J = osmpl.vertices2joints(m['J_regressor'], v_shaped)
+    for b in range(2):
+        Gr, Gt = [None] * 24, [None] * 24
+        for i in range(24):
+            p = SMPL_PARENTS[i]
+            if p < 0:
+                Gr[i], Gt[i] = R[b, i], J[b, i]
+            else:
+                Gr[i] = Gr[p] @ R[b, i]
+                Gt[i] = Gr[p] @ (J[b, i] - J[b, p]) + Gt[p]
+        assert (torch.stack(Gt) - j2[b, :24]).abs().max() < 1e-5
+
+
+def test_linear_in_betas_at_fixed_pose_feature():
+    m = _model()
+    eye = torch.eye(3)[None, None].expand(1, 24, 3, 3).contiguous()
+    b1 = torch.randn(1, 10, generator=torch.Generator().manual_seed(3))
+    v0, _ = osmpl.smpl_forward(m, torch.zeros(1, 10), eye[:, 1:], eye[:, :1], pose2rot=False)
+    v1, _ = osmpl.smpl_forward(m, b1, eye[:, 1:], eye[:, :1], pose2rot=False)
+    v2, _ = osmpl.smpl_forward(m, 2 * b1, eye[:, 1:], eye[:, :1], pose2rot=False)
+    assert ((v2 - v0) - 2 * (v1 - v0)).abs().max() < 1e-5
+
+
+def test_extra_regressors_are_the_reference_data():
+    r = load_extra_regressors()
+    assert r['J_regressor_extra'].shape == (9, 6890) and (r['J_regressor_extra'] != 0).sum() == 62
+    assert r['J_regressor_cocoplus'].shape == (19, 6890) and (r['J_regressor_cocoplus'] != 0).sum() == 86
+    assert r['J_regressor_h36m'].shape == (17, 6890) and (r['J_regressor_h36m'] != 0).sum() == 107
+    assert np.allclose(r['J_regressor_extra'].sum(1), 1.0, atol=2e-4)
