@@ -214,7 +214,7 @@ class SMPL(nn.Module):
         with torch.cuda.device(dev):
             if pose2rot:
                 g = self._rodrigues(global_orient, global_orient.shape[0])
-                b = self._rodrigues(body_pose, body_pose.shape[0] * 23)
+                b = self._rodrigues(body_pose, body_pose.shape[0] * 23).reshape(body_pose.shape[0], 23 * 9)
             else:
                 g = self._f32c(global_orient).reshape(global_orient.shape[0], 9)
                 b = self._f32c(body_pose).reshape(body_pose.shape[0], 23 * 9)
