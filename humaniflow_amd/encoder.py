@@ -7,9 +7,10 @@ so a reference checkpoint loads with ``strict=True``.
 
 Per the north star this stage stays on PyTorch-ROCm (MIOpen convolutions); what is added
 for MI355X is an *inference plan*: eval-mode BatchNorm folded into the preceding
-convolution's weight/bias, channels_last activations, optional bf16 compute (BASELINE
-configs[2]) -- built lazily from the live parameters and invalidated when they change,
-so the checkpoint layout is untouched.
+convolution's weight plus a per-channel bias, and one fused HIP epilogue pass per
+convolution (hmf_bias_act) instead of eager PyTorch's 2-3 elementwise passes -- built
+lazily from the live parameters and invalidated when they change, so the checkpoint
+layout is untouched.
 """
 import torch
 from torch import nn
@@ -83,11 +84,19 @@ class ResNetEncoder(nn.Module):
         return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
 
     # ---- folded inference plan ----------------------------------------------------------
-    @staticmethod
-    def _fold(conv, bn, dtype):
+    # eval-mode BatchNorm folded into the conv weight + a per-channel bias; convolutions run bias-free on MIOpen and
+    # ONE fused HIP pass (hmf_bias_act: + bias, + identity, ReLU, in place) follows each of them.  The stem's
+    # bias+ReLU commutes with max-pooling (both monotone), so it runs on the 4x smaller pooled tensor; a downsample
+    # branch's bias is added to the block's last bias so that branch needs no pass of its own.
+    layout = 'nchw'          # or 'nhwc'; see tools/encoder_probe.py for the measured MIOpen fp32 timings on MI355X
+
+    def _fmt(self):
+        return torch.channels_last if self.layout == 'nhwc' else torch.contiguous_format
+
+    def _fold(self, conv, bn):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        w = (conv.weight * scale[:, None, None, None]).to(dtype).contiguous(memory_format=torch.channels_last)
-        b = (bn.bias - bn.running_mean * scale).to(dtype)
+        w = (conv.weight * scale[:, None, None, None]).float().contiguous(memory_format=self._fmt())
+        b = (bn.bias - bn.running_mean * scale).float().contiguous()
         return w, b, conv.stride, conv.padding
 
     # The plan is a cache of the live parameters: drop it whenever they can have changed
@@ -109,33 +118,55 @@ class ResNetEncoder(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     @torch.no_grad()
-    def _build_plan(self, dtype):
-        plan = {'stem': self._fold(self.conv1, self.bn1, dtype), 'blocks': []}
+    def _build_plan(self):
+        plan = {'stem': self._fold(self.conv1, self.bn1), 'blocks': []}
         for li in range(1, 5):
             for blk in getattr(self, 'layer%d' % li):
-                ds = None if blk.downsample is None else self._fold(blk.downsample[0], blk.downsample[1], dtype)
-                plan['blocks'].append(([self._fold(c, b, dtype) for c, b in blk.stages()], ds))
+                stages = [self._fold(c, b) for c, b in blk.stages()]
+                ds = None
+                if blk.downsample is not None:
+                    ds = self._fold(blk.downsample[0], blk.downsample[1])
+                    w, b, s, p = stages[-1]
+                    stages[-1] = (w, (b + ds[1]).contiguous(), s, p)
+                plan['blocks'].append((stages, ds))
         return plan
 
+    def _epilogue(self, x, bias, residual, relu):
+        from . import _lib
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        nhwc = self.layout == 'nhwc'
+        fmt = self._fmt()
+        if not x.is_contiguous(memory_format=fmt):
+            x = x.contiguous(memory_format=fmt)
+        if residual is not None and not residual.is_contiguous(memory_format=fmt):
+            residual = residual.contiguous(memory_format=fmt)
+        _lib.check(lib.hmf_bias_act(x.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(), N, C, H * W,
+                                    int(nhwc), int(relu), _lib.current_stream()), 'hmf_bias_act')
+        return x
+
     @torch.no_grad()
-    def forward_folded(self, x, dtype=torch.float32):
-        if self._plan is None or self._plan_key != dtype:
-            self._plan, self._plan_key = self._build_plan(dtype), dtype
+    def forward_folded(self, x):
+        key = self.layout
+        if self._plan is None or self._plan_key != key:
+            self._plan, self._plan_key = self._build_plan(), key
         p = self._plan
-        x = x.to(dtype).contiguous(memory_format=torch.channels_last)
-        w, b, s, pad = p['stem']
-        x = F.max_pool2d(F.relu_(F.conv2d(x, w, b, s, pad)), kernel_size=3, stride=2, padding=1)
-        for stages, ds in p['blocks']:
-            idt = x if ds is None else F.conv2d(x, ds[0], ds[1], ds[2], ds[3])
-            for w, b, s, pad in stages[:-1]:
-                x = F.relu_(F.conv2d(x, w, b, s, pad))
-            w, b, s, pad = stages[-1]
-            x = F.relu_(F.conv2d(x, w, b, s, pad).add_(idt))
-        return x.mean(dim=(2, 3)).float()
+        with torch.cuda.device(x.device):
+            x = x.float().contiguous(memory_format=self._fmt())
+            w, b, s, pad = p['stem']
+            x = F.max_pool2d(F.conv2d(x, w, None, s, pad), kernel_size=3, stride=2, padding=1)
+            x = self._epilogue(x, b, None, True)
+            for stages, ds in p['blocks']:
+                idt = x if ds is None else F.conv2d(x, ds[0], None, ds[2], ds[3])
+                for w, b, s, pad in stages[:-1]:
+                    x = self._epilogue(F.conv2d(x, w, None, s, pad), b, None, True)
+                w, b, s, pad = stages[-1]
+                x = self._epilogue(F.conv2d(x, w, None, s, pad), b, idt, True)
+            return x.mean(dim=(2, 3))
 
     def forward(self, x):
         if (not self.training) and (not torch.is_grad_enabled()) and x.is_cuda:
-            return self.forward_folded(x, getattr(self, 'compute_dtype', torch.float32))
+            return self.forward_folded(x)
         return self.forward_module(x)
 
 

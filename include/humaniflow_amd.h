@@ -160,6 +160,14 @@ int hmf_flow_log_prob_so3(const hmf_flow_t* h, const float* ctx, const int32_t* 
                           const float* v, int B, float* logp, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Encoder glue (models/resnet.py:102-122: bn -> relu / bn -> += identity -> relu after each conv)   */
+/* ------------------------------------------------------------------------------------------ */
+/* In place, one pass: x = relu?(x + bias[channel] (+ residual)) for a conv output with eval-mode BatchNorm folded into
+ * the conv weight and `bias`.  x/residual: N x C x HW (nhwc = 0) or N x HW x C (nhwc = 1), 16-byte aligned.          */
+int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int C, int HW, int nhwc, int relu,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */
 /* ------------------------------------------------------------------------------------------ */
 /* While enabled, every launch of the kernels tagged below is bracketed by hipEventRecord on ITS stream

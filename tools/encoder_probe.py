@@ -34,5 +34,11 @@ with torch.no_grad():
         print('  module path NCHW (BN unfused): %.3f ms' % timeit(lambda: enc.forward_module(x)), flush=True)
         xcl = x.contiguous(memory_format=torch.channels_last)
         print('  module path NHWC input       : %.3f ms' % timeit(lambda: enc.forward_module(xcl)), flush=True)
-        print('  folded NHWC (product path)   : %.3f ms' % timeit(lambda: enc.forward_folded(x)), flush=True)
+        for lay in ('nchw', 'nhwc'):
+            enc.layout = lay
+            enc.invalidate_plan()
+            y = enc.forward_folded(x)
+            ref = enc.forward_module(x)
+            print('  folded %s + fused epilogue   : %.3f ms   (max rel err vs module path %.2e)'
+                  % (lay, timeit(lambda: enc.forward_folded(x)), ((y - ref).abs().max() / ref.abs().max()).item()), flush=True)
         print('  (setup+timing took %.1f s)' % (time.time() - t0), flush=True)
