@@ -130,6 +130,13 @@ def main():
         out['keys%d' % layers] = np.array(sorted(net.state_dict().keys()))
         out['feats%d' % layers] = y.numpy()
     np.savez_compressed(os.path.join(OUT, 'resnet_golden.npz'), **out)
+    # ---------------- eval metric helpers (numpy, importable as is) -----------------------------------------
+    import utils.eval_utils as eu
+    rng = np.random.RandomState(3)
+    P = rng.randn(6, 50, 3)
+    T = P @ np.linalg.qr(rng.randn(3, 3))[0] * 1.3 + rng.randn(6, 1, 3) * 0.2 + rng.randn(6, 50, 3) * 0.05
+    np.savez_compressed(os.path.join(OUT, 'metrics_golden.npz'), P=P, T=T, pa=eu.procrustes_analysis_batch(P, T),
+                        sc=eu.scale_and_translation_transform_batch(P, T))
     print('golden vectors written to', OUT)
 
 

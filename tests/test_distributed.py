@@ -1,0 +1,97 @@
+"""Host logic of the data-parallel path on CPU: metric functions vs the reference's numpy (golden), sharding, and the one
+exchange step (all-reduce of packed sums + all-gather of per-frame arrays) with gloo at world_size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import GOLDEN, ROOT
+from humaniflow_amd import evaluate as ev
+
+
+def test_metric_helpers_match_reference_numpy():
+    z = np.load(os.path.join(GOLDEN, 'metrics_golden.npz'))
+    P, T = torch.from_numpy(z['P']), torch.from_numpy(z['T'])
+    assert np.abs(ev.procrustes_analysis_batch(P, T).numpy() - z['pa']).max() < 1e-10
+    assert np.abs(ev.scale_and_translation_transform_batch(P, T).numpy() - z['sc']).max() < 1e-12
+    assert ev.ALL_JOINTS_TO_H36M_MAP == list(range(73, 90)) and len(ev.H36M_TO_J14) == 14 and len(ev.ALL_JOINTS_TO_COCO_MAP) == 17
+
+
+def test_sharding_covers_every_item_once():
+    for n, w in [(10, 1), (10, 2), (7, 4), (64, 8), (3, 8)]:
+        got = sorted(i for r in range(w) for i in ev.shard_indices(n, r, w))
+        assert got == list(range(n))
+
+
+class FakeSet:
+    """Deterministic per-index items; `batch` has the SyntheticEvalSet interface."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def batch(self, indices, device):
+        return {'index': torch.tensor(indices)}
+
+
+def _fake(batch, salt, samples):
+    outs = []
+    for i in batch['index'].tolist():
+        g = torch.Generator().manual_seed(1000 * salt + i)
+        d = {'verts3D': torch.randn(40, 3, generator=g), 'tpose_verts3D': torch.randn(40, 3, generator=g),
+             'joints3D': torch.randn(14, 3, generator=g)}
+        if samples:
+            d['verts3D_samples'] = torch.randn(5, 40, 3, generator=g)
+            d['joints3D_samples'] = torch.randn(5, 14, 3, generator=g)
+        outs.append(d)
+    return {k: torch.stack([o[k] for o in outs]) for k in outs[0]}
+
+
+def _run_eval(rank, world, n, dist_mod):
+    return ev.evaluate_humaniflow(FakeSet(n), 3, torch.device('cpu'), lambda b: _fake(b, 1, True), lambda b: _fake(b, 2, False),
+                                  dist=dist_mod, rank=rank, world_size=world)
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    metrics, frames = _run_eval(rank, world, n, dist)
+    q.put((rank, metrics, {k: v.numpy() for k, v in frames.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_eval_equals_single_process():
+    n = 11                                             # ragged: 6 + 5 items, last batches of different sizes
+    single, frames1 = _run_eval(0, 1, n, None)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, metrics, frames in res:
+        assert metrics['num_total_test_data'] == n
+        for k, v in single.items():
+            assert abs(metrics[k] - v) < 1e-9 * max(1.0, abs(v)), (k, metrics[k], v)       # sums are order-independent up to fp64
+        for k in frames1:
+            assert frames[k].shape == (n,)
+            # per-frame arrays come back rank-major (rank 0's items r, r+W, ... first)
+            order = ev.shard_indices(n, 0, 2) + ev.shard_indices(n, 1, 2)
+            ref = np.empty(n)
+            ref[:] = frames1[k].numpy()
+            assert np.allclose(frames[k], ref[order], atol=1e-6)

@@ -171,3 +171,20 @@ def test_grad_mode_fails_loudly():
     model, _, _ = _model(18)
     with pytest.raises(NotImplementedError):
         model(None, input_feats=torch.zeros(1, 512).cuda())
+
+
+def test_sharded_eval_driver_on_device():
+    """humaniflow_amd.evaluate on the GPU (world 1): predictions + targets + 3D metrics stay on the device, and the metric
+    of a model evaluated against ITS OWN point estimate is zero."""
+    from humaniflow_amd import evaluate as ev
+    model, sd, cfg = _model(18, seed=2)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    ds = ev.SyntheticEvalSet(5, size=128, seed=1)
+    dev = torch.device('cuda:0')
+    metrics, frames = ev.evaluate_humaniflow(ds, 2, dev, lambda b: ev.predict_batch(model, smpl, b, 4), lambda b: ev.target_batch(smpl, b))
+    assert metrics['num_total_test_data'] == 5 and all(np.isfinite(v) for v in metrics.values())
+    assert metrics['PVE-PA'] <= metrics['PVE-SC'] + 1e-3 <= metrics['PVE'] + 2e-3
+    assert metrics['PVE_samples_min'] > 0 and frames['PVE'].shape == (5,)
+    self_metrics, _ = ev.evaluate_humaniflow(ds, 2, dev, lambda b: ev.predict_batch(model, smpl, b, 0),
+                                             lambda b: {k: v for k, v in ev.predict_batch(model, smpl, b, 0).items()})
+    assert self_metrics['PVE'] < 1e-3 and self_metrics['MPJPE'] < 1e-3
