@@ -26,19 +26,23 @@ struct PartTab {
     int n_anc, anc[kMaxAnc];
     int kas, kag;          // ancestor k-steps ceil(9a/2) and float4 groups ceil(kas/4)
     int o_wc0, o_bctx, o_wa;
-    int o_w1, o_b1, o_w1x;
-    int o_w2[2], o_b2[2], o_w3[2], o_b3[2], o_w4[2], o_b4[2];
+    int o_w1, o_w1e;       // first hyper-net layer of both couplings [4 tiles]; extra k-step [4][64]: (x1 column | bias)
+    int o_w2[2], o_w3[2], o_w4[2];
+    int o_we[2];           // bias k-steps of layers 2,3,4a,4b of coupling c: [4][64], lane q=0 -> bias, q=1 -> 0
     int o_wctxT;           // [(256 + 9a)][64]  natural transposed, for the teacher-forced kernels
     int o_nnT[2][4];       // [K][N] transposed hyper-network layers
     int o_nnb[2][4];
 };
 constexpr int kPartTabInts = sizeof(PartTab) / sizeof(int);
 
+// Rounds of the kinematic schedule: parts of one round are mutually independent and all their ancestors belong to
+// earlier rounds; at most kChainWaves parts per round (greedy list schedule by height, flow_pack.hip).
 struct Levels {
     int nlev;
     int start[kP + 1];
     int parts[kP];
 };
+constexpr int kChainWaves = 4;   // one wave per SIMD: the full 512-VGPR budget for the prefetched weights
 
 struct FlowDev {
     int feat_dim, nb, in_dim;        // in_dim = feat_dim + nb + 12
@@ -66,6 +70,8 @@ __host__ __device__ inline int spline_orig_index(int packed_channel) {
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// sampling-path variant: hardware exp2 (v_exp_f32) instead of the correctly rounded expm1f; abs error <= 2e-7 on (-1, 0]
+__device__ __forceinline__ float elu_fast(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 __device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid1(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -145,6 +151,63 @@ __device__ __forceinline__ float rational_linear_spline(float x, const float (&r
     const bool inside = (x >= -bound) && (x <= bound);
     if (logabsdet) *logabsdet = inside ? (logf(dnum) - 2.f * logf(fabsf(den))) : 0.f;
     return inside ? out : x;
+}
+
+// Forward (sampling) direction of the same spline, arranged for latency: softmax through v_exp_f32 and one reciprocal,
+// softplus only for the two derivatives of the selected bin, sigmoid only for the selected lambda, no log-det.
+__device__ __forceinline__ float spline_forward_fast(float x, const float (&rw)[8], const float (&rh)[8], const float (&rd)[7],
+                                                     const float (&rl)[8], float bound) {
+    float w[8], h[8], cw[9], chh[9];
+    {
+        float m = rw[0], n = rh[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { m = fmaxf(m, rw[i]); n = fmaxf(n, rh[i]); }
+        float s = 0.f, t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w[i] = __expf(rw[i] - m); s += w[i]; h[i] = __expf(rh[i] - n); t += h[i]; }
+        const float is = (1.0f - 1e-3f * 8) / s, it = (1.0f - 1e-3f * 8) / t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w[i] = fmaf(w[i], is, 1e-3f); h[i] = fmaf(h[i], it, 1e-3f); }
+    }
+    {
+        float a = 0.f, b = 0.f;
+        cw[0] = -bound; chh[0] = -bound;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a += w[i]; b += h[i];
+            cw[i + 1] = fmaf(2.f * bound, a, -bound);
+            chh[i + 1] = fmaf(2.f * bound, b, -bound);
+        }
+        cw[8] = bound; chh[8] = bound;
+    }
+    int bin = -1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bin += (x >= cw[i] + 1e-6f) ? 1 : 0;
+    bin = min(max(bin, 0), 7);
+    float k_lo = cw[0], k_hi = cw[1], c_lo = chh[0], c_hi = chh[1], lam = rl[0];
+    float rd0 = 0.f, rd1 = rd[0];          // raw derivatives left/right of the bin (the end knots' are fixed, below)
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const bool sel = bin == i;
+        k_lo = sel ? cw[i] : k_lo; k_hi = sel ? cw[i + 1] : k_hi; c_lo = sel ? chh[i] : c_lo; c_hi = sel ? chh[i + 1] : c_hi;
+        lam = sel ? rl[i] : lam; rd0 = sel ? rd[i - 1] : rd0;
+        if (i < 7) rd1 = sel ? rd[i] : rd1;
+    }
+    const float in_w = k_hi - k_lo, in_h = c_hi - c_lo;
+    const float in_d = bin == 0 ? 1.0f - 1e-3f : 1e-3f + softplus1(rd0);
+    const float in_d1 = bin == 7 ? 1.0f - 1e-3f : 1e-3f + softplus1(rd1);
+    lam = (1.f - 2.f * 0.025f) * sigmoid1(lam) + 0.025f;
+    const float delta = in_h / in_w;
+    const float wb = sqrtf(in_d / in_d1);
+    const float wc = (lam * in_d + (1.f - lam) * wb * in_d1) / delta;
+    const float ya = c_lo, yb = c_hi;
+    const float yc = ((1.f - lam) * ya + lam * wb * yb) / ((1.f - lam) + lam * wb);
+    const float th = (x - k_lo) / in_w;
+    const bool lo = th <= lam;
+    const float num = lo ? (ya * (lam - th) + wc * yc * th) : (wc * yc * (1.f - th) + wb * yb * (th - lam));
+    const float den = lo ? ((lam - th) + wc * th) : (wc * (1.f - th) + wb * (th - lam));
+    const bool inside = (x >= -bound) && (x <= bound);
+    return inside ? num / den : x;
 }
 
 }  // namespace hmf

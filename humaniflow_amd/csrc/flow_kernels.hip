@@ -184,34 +184,78 @@ __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __
 // ---------------------------------------------------------------------------------------------------
 // k_flow_chain
 // ---------------------------------------------------------------------------------------------------
-constexpr int kChainWaves = 5;
+// Hyper-network tail (layers 2..4) of one coupling.  Its 20 weight float4 + 4 bias dwords are fetched by tail_fetch()
+// one stage before tail_compute() consumes them, so the L2 latency of this dependent chain of small layers hides behind
+// the previous stage's MFMAs.  Biases ride in one extra MFMA k-step per tile (A = (bias | 0), B = (1 | 0)): no bias
+// registers, accumulators start at zero.
+struct TailRegs {
+    f32x4 w2[8], w3[4], w4[2][4];
+    float we[4];
+};
 
-// one hyper-network tail (layers 2..4) + spline of one coupling; h1 = ReLU(first layer) in ARL (2 tiles)
-__device__ __forceinline__ float coupling_tail(const FlowDev& d, const PartTab& pt, int c, int lane, int q,
-                                               const f32x16 (&h1)[2], float x, float bound) {
-    f32x16 a2[1], a3[1], a4[2];
-    bias_init<1>(d.arena + pt.o_b2[c], q, a2);
-    dense_layer<1, 2>((const f32x4*)(d.arena + pt.o_w2[c]) + lane, h1, a2);
+__device__ __forceinline__ void tail_fetch(const FlowDev& d, const PartTab& pt, int c, int lane, TailRegs& t) {
+    const f32x4* p2 = (const f32x4*)(d.arena + pt.o_w2[c]) + lane;
+    const f32x4* p3 = (const f32x4*)(d.arena + pt.o_w3[c]) + lane;
+    const f32x4* p4 = (const f32x4*)(d.arena + pt.o_w4[c]) + lane;
+    const float* pe = d.arena + pt.o_we[c] + lane;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) a2[0][e] = fmaxf(a2[0][e], 0.f);
-    bias_init<1>(d.arena + pt.o_b3[c], q, a3);
-    dense_layer<1, 1>((const f32x4*)(d.arena + pt.o_w3[c]) + lane, a2, a3);
+    for (int i = 0; i < 8; ++i) t.w2[i] = p2[i * 64];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) a3[0][e] = fmaxf(a3[0][e], 0.f);
-    bias_init<2>(d.arena + pt.o_b4[c], q, a4);
-    dense_layer<2, 1>((const f32x4*)(d.arena + pt.o_w4[c]) + lane, a3, a4);
+    for (int i = 0; i < 4; ++i) t.w3[i] = p3[i * 64];
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.w4[to][i] = p4[(to * 4 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.we[i] = pe[i * 64];
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    return z;
+}
+
+__device__ __forceinline__ float tail_compute(const TailRegs& t, const f32x16 (&h1)[2], float x, float bound, float one_q0) {
+    f32x16 a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.we[0], one_q0, zero16(), 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s4 * 4 + u;
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w2[s4][u], h1[s >> 4][s & 15], a2, 0, 0, 0);
+        }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a2[e] = fmaxf(a2[e], 0.f);
+    f32x16 a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.we[1], one_q0, zero16(), 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w3[s4][u], a2[s4 * 4 + u], a3, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a3[e] = fmaxf(a3[e], 0.f);
+    f32x16 a40 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.we[2], one_q0, zero16(), 0, 0, 0);
+    f32x16 a41 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.we[3], one_q0, zero16(), 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a40 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w4[0][s4][u], a3[s4 * 4 + u], a40, 0, 0, 0);
+            a41 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w4[1][s4][u], a3[s4 * 4 + u], a41, 0, 0, 0);
+        }
     float rw[8], rh[8], rd[7], rl[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { rw[i] = a4[0][i]; rh[i] = a4[0][8 + i]; rl[i] = a4[1][8 + i]; }
+    for (int i = 0; i < 8; ++i) { rw[i] = a40[i]; rh[i] = a40[8 + i]; rl[i] = a41[8 + i]; }
 #pragma unroll
-    for (int i = 0; i < 7; ++i) rd[i] = a4[1][i];
-    return rational_linear_spline<false>(x, rw, rh, rd, rl, bound, nullptr);
+    for (int i = 0; i < 7; ++i) rd[i] = a41[i];
+    return spline_forward_fast(x, rw, rh, rd, rl, bound);
 }
 
 __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, const float* __restrict__ C0,
                                                                     const float* __restrict__ eps_pose, int B, int N, int Mtot,
                                                                     float* __restrict__ rot_samples, float* __restrict__ rot_point,
-                                                                    float* __restrict__ so3_point) {
+                                                                    float* __restrict__ so3_point, long long* __restrict__ timeline) {
     __shared__ float sAnc[32 * kAncRow];
     __shared__ int sOff[kP * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, q = lane >> 5;
@@ -222,14 +266,27 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
     const int rowid = tile * 32 + l31;
     const RowInfo ri = row_info(rowid, B, N, Mtot);
     const float bound = d.radius;
+    const float one_q0 = q == 0 ? 1.f : 0.f;
     float* myAnc = sAnc + l31 * kAncRow;
 
     for (int lev = 0; lev < d.lev.nlev; ++lev) {
-        for (int pi = d.lev.start[lev] + wave; pi < d.lev.start[lev + 1]; pi += kChainWaves) {
+        const int pi = d.lev.start[lev] + wave;
+        if (pi < d.lev.start[lev + 1]) {
             const int j = d.lev.parts[pi];
             const PartTab& pt = d.tab[j];
-            // ---- context: C0 (image/shape half, precomputed) + ancestor half, ELU ----
-            f32x16 cx[2];
+            // diagnostic timeline (hmf_debug_set_timeline): shader-clock stamps of tile 0's phases, 8 per part
+            long long* tl = (timeline && tile == 0 && lane == 0) ? timeline + j * 8 : nullptr;
+#define HMF_STAMP(i) do { if (tl) tl[i] = (long long)__builtin_readcyclecounter(); } while (0)
+            HMF_STAMP(0);
+            // ================= stage 0: issue every load the first two stages need =================
+            // ancestor entries of this lane's row (B operands of the ancestor half): 32 LDS reads up front
+            float bv[32];
+            {
+                const int* off = sOff + j * 64 + q;
+#pragma unroll
+                for (int s = 0; s < 32; ++s) bv[s] = myAnc[off[2 * s]];
+            }
+            f32x16 cx[2];                                   // context accumulators <- C0 (image/shape half, k_flow_ctx0)
             {
                 const f32x4* src = (const f32x4*)(C0 + (((size_t)tile * kP + j) * 2) * 64 * 16) + lane * 4;
 #pragma unroll
@@ -240,58 +297,100 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
                         cx[t][4 * g] = v[0]; cx[t][4 * g + 1] = v[1]; cx[t][4 * g + 2] = v[2]; cx[t][4 * g + 3] = v[3];
                     }
             }
+            const int kag = pt.kag;
+            f32x4 wa[2][8];
             {
                 const f32x4* wp = (const f32x4*)(d.arena + pt.o_wa) + lane;
-                const int* off = sOff + j * 64 + q;
-                for (int s4 = 0; s4 < pt.kag; ++s4) {
-                    const f32x4 w0 = wp[s4 * 64], w1 = wp[(pt.kag + s4) * 64];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float bval = myAnc[off[2 * (s4 * 4 + u)]];
-                        cx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[u], bval, cx[0], 0, 0, 0);
-                        cx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[u], bval, cx[1], 0, 0, 0);
-                    }
-                }
+                for (int s4 = 0; s4 < 8; ++s4)
+                    if (s4 < kag) { wa[0][s4] = wp[s4 * 64]; wa[1][s4] = wp[(kag + s4) * 64]; }
             }
+            const f32x4* w1p = (const f32x4*)(d.arena + pt.o_w1) + lane;
+            f32x4 w1a[4][4], w1b[4][4];                     // first layer of both couplings: k-step groups 0..3 / 4..7
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int to = 0; to < 4; ++to)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) cx[t][e] = elu1(cx[t][e]);
-            // ---- first hyper-network layer of both couplings (context columns) ----
-            f32x16 a1[4];
-            bias_init<4>(d.arena + pt.o_b1, q, a1);
-            dense_layer<4, 2>((const f32x4*)(d.arena + pt.o_w1) + lane, cx, a1);
-            // ---- base sample z = base_std * eps (pyro Normal.rsample), point-estimate rows push z = 0 ----
-            float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+                for (int i = 0; i < 4; ++i) w1a[to][i] = w1p[(to * 8 + i) * 64];
+            float w1e[4];
+#pragma unroll
+            for (int to = 0; to < 4; ++to) w1e[to] = d.arena[pt.o_w1e + to * 64 + lane];
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f;            // base sample z = base_std * eps; point-estimate rows push z = 0
             if (ri.live && !ri.is_point) {
                 const float* e = eps_pose + (((size_t)j * B + ri.b) * N + ri.n) * 3;
                 x0 = e[0] * d.base_std; x1 = e[1] * d.base_std; x2 = e[2] * d.base_std;
             }
-            // ---- coupling 0 (Permute [0,1,2]): x0 passes, lane q transforms x_{1+q} ----
+            TailRegs tr0, tr1;
+            tail_fetch(d, pt, 0, lane, tr0);
+            __builtin_amdgcn_sched_barrier(0);
+            HMF_STAMP(1);
+            // ================= stage 1: ancestor half of the context layer, ELU =================
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                if (s4 < kag) {                                           // wave-uniform
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s4][u], bv[s4 * 4 + u], cx[0], 0, 0, 0);
+                        cx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s4][u], bv[s4 * 4 + u], cx[1], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int to = 0; to < 4; ++to)                                  // second half of the first-layer weights
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w1b[to][i] = w1p[(to * 8 + 4 + i) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cx[t][e] = elu_fast(cx[t][e]);
+            HMF_STAMP(2);
+            // ================= stage 2: first hyper-network layer of both couplings =================
+            // extra k-step: (x1 column | bias) . (x0 | 1) for coupling 0 now; coupling 1's needs y0 and comes later
+            const float bx0 = q == 0 ? x0 : 1.f;
+            f32x16 a1[4];
+            a1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1e[0], bx0, zero16(), 0, 0, 0);
+            a1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1e[1], bx0, zero16(), 0, 0, 0);
+            a1[2] = zero16();
+            a1[3] = zero16();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int to = 0; to < 4; ++to)
+                        a1[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[to][s4][u], cx[0][s4 * 4 + u], a1[to], 0, 0, 0);
+            tail_fetch(d, pt, 1, lane, tr1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int to = 0; to < 4; ++to)
+                        a1[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[to][s4][u], cx[1][s4 * 4 + u], a1[to], 0, 0, 0);
+            HMF_STAMP(3);
+            // ================= stage 3: coupling 0 (Permute [0,1,2]): x0 passes, lane q transforms x_{1+q} =================
             f32x16 h1[2];
-            {
-                f32x16 wx[2];
-                bias_init<2>(d.arena + pt.o_w1x, q, wx);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) h1[t][e] = fmaxf(fmaf(wx[t][e], x0, a1[t][e]), 0.f);
-            }
-            const float xn = coupling_tail(d, pt, 0, lane, q, h1, q ? x2 : x1, bound);
+                for (int e = 0; e < 16; ++e) h1[t][e] = fmaxf(a1[t][e], 0.f);
+            const float xn = tail_compute(tr0, h1, q ? x2 : x1, bound, one_q0);
             const float x1n = __shfl(xn, l31), x2n = __shfl(xn, 32 + l31);
-            // ---- coupling 1 (Permute [1,2,0]): y = (x1', x2', x0); y0 passes, lane q transforms y_{1+q} ----
+            HMF_STAMP(4);
+            // ================= stage 4: coupling 1 (Permute [1,2,0]): y = (x1', x2', x0); y0 passes =================
             const float y0 = x1n;
-            {
-                f32x16 wx[2];
-                bias_init<2>(d.arena + pt.o_w1x + 64, q, wx);
+            const float by0 = q == 0 ? y0 : 1.f;
+            a1[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1e[2], by0, a1[2], 0, 0, 0);
+            a1[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1e[3], by0, a1[3], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) h1[t][e] = fmaxf(fmaf(wx[t][e], y0, a1[2 + t][e]), 0.f);
-            }
-            const float yn = coupling_tail(d, pt, 1, lane, q, h1, q ? x0 : x2n, bound);
+                for (int e = 0; e < 16; ++e) h1[t][e] = fmaxf(a1[2 + t][e], 0.f);
+            const float yn = tail_compute(tr1, h1, q ? x0 : x2n, bound, one_q0);
             const float y1 = __shfl(yn, l31), y2 = __shfl(yn, 32 + l31);
-            // ---- ScaledRadialTanh (scaled_radial_tanh_transform.py:28-35) ----
+            HMF_STAMP(5);
+            // ================= stage 5: ScaledRadialTanh (scaled_radial_tanh_transform.py:28-35) + exp map =================
             float v[3] = {y0, y1, y2};
             {
                 const float nrm = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
@@ -300,7 +399,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
                     v[0] = tt * (y0 / nrm) * bound; v[1] = tt * (y1 / nrm) * bound; v[2] = tt * (y2 / nrm) * bound;
                 }
             }
-            // ---- exp map: fp64 Rodrigues rounded to fp32 for samples (:311), smplx Rodrigues for point rows (:299) ----
+            // fp64 Rodrigues rounded to fp32 for samples (:311), smplx Rodrigues for point rows (:299)
             float R[9];
             if (ri.is_point) {
                 batch_rodrigues_f32(v, R);
@@ -311,6 +410,7 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
 #pragma unroll
                 for (int e = 0; e < 9; ++e) R[e] = (float)Rd[e];
             }
+            HMF_STAMP(6);
             if (q == 0) {
 #pragma unroll
                 for (int e = 0; e < 9; ++e) myAnc[j * 9 + e] = R[e];
@@ -328,6 +428,8 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
                     }
                 }
             }
+            HMF_STAMP(7);
+#undef HMF_STAMP
         }
         __syncthreads();
     }
@@ -485,7 +587,12 @@ __global__ __launch_bounds__(256) void k_flow_logprob(FlowDev d, const float* __
 
 using namespace hmf;
 
+static long long* g_timeline = nullptr;
+
 extern "C" {
+
+/* diagnostic (tools/flow_timeline.py): device buffer of 23 x 8 int64 shader-clock stamps written by tile 0, or NULL */
+int hmf_debug_set_timeline(void* dev_ptr) { g_timeline = (long long*)dev_ptr; return HMF_OK; }
 
 static int n_tiles(int B, int N, int pe) { return ((B * N + (pe ? B : 0)) + 31) / 32; }
 
@@ -530,7 +637,7 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
     {
         ProfScope ps(6, Mtot, st);
         hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, eps_pose, B, N, Mtot, rotmats_samples,
-                           rotmats_point, so3_point);
+                           rotmats_point, so3_point, g_timeline);
     }
     HMF_LAUNCH_CHECK();
     return HMF_OK;

@@ -114,31 +114,33 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
             const float* W = wn[(tl >> 1) * 4 + 0];   // (64 x 65), input = [context(64), x1]
             return W[(size_t)(32 * (tl & 1) + (lane & 31)) * 65 + arl_channel(s >> 4, s & 15, lane >> 5)];
         });
-        t.o_b1 = (int)P.place(128);
-        t.o_w1x = (int)P.place(128);
-        for (int c = 0; c < 2; ++c)
-            for (int n = 0; n < 64; ++n) {
-                P.buf[t.o_b1 + c * 64 + n] = bn[c * 4 + 0][n];
-                P.buf[t.o_w1x + c * 64 + n] = wn[c * 4 + 0][(size_t)n * 65 + 64];
+        // extra k-step of the first layer: A[n][k=0] = W1[n][64] (the x1 input column), A[n][k=1] = bias[n];
+        // the kernel supplies B = (q == 0 ? x1 : 1)
+        t.o_w1e = (int)P.place(4 * 64);
+        for (int tl = 0; tl < 4; ++tl)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int c = tl >> 1, n = 32 * (tl & 1) + (lane & 31);
+                P.buf[t.o_w1e + tl * 64 + lane] = (lane >> 5) == 0 ? wn[c * 4 + 0][(size_t)n * 65 + 64] : bn[c * 4 + 0][n];
             }
         for (int c = 0; c < 2; ++c) {
             const float* W2 = wn[c * 4 + 1];   // (32 x 64)
             const float* W3 = wn[c * 4 + 2];   // (32 x 32)
             const float* W4 = wn[c * 4 + 3];   // (62 x 32)
             t.o_w2[c] = (int)pack_a(P, 1, 32, [&](int, int s, int lane) { return W2[(size_t)(lane & 31) * 64 + arl_channel(s >> 4, s & 15, lane >> 5)]; });
-            t.o_b2[c] = (int)P.place(32);
-            std::copy(bn[c * 4 + 1], bn[c * 4 + 1] + 32, P.buf.begin() + t.o_b2[c]);
             t.o_w3[c] = (int)pack_a(P, 1, 16, [&](int, int s, int lane) { return W3[(size_t)(lane & 31) * 32 + arl_channel(0, s & 15, lane >> 5)]; });
-            t.o_b3[c] = (int)P.place(32);
-            std::copy(bn[c * 4 + 2], bn[c * 4 + 2] + 32, P.buf.begin() + t.o_b3[c]);
             t.o_w4[c] = (int)pack_a(P, 2, 16, [&](int tl, int s, int lane) {
                 const int o = spline_orig_index(32 * tl + (lane & 31));
                 return o < 0 ? 0.f : W4[(size_t)o * 32 + arl_channel(0, s & 15, lane >> 5)];
             });
-            t.o_b4[c] = (int)P.place(64);
-            for (int pc = 0; pc < 64; ++pc) {
-                const int o = spline_orig_index(pc);
-                P.buf[t.o_b4[c] + pc] = o < 0 ? 0.f : bn[c * 4 + 3][o];
+            // bias k-steps (B operand = (q == 0 ? 1 : 0)): rows 0,1 = layers 2,3; rows 2,3 = the two tiles of layer 4
+            t.o_we[c] = (int)P.place(4 * 64);
+            for (int lane = 0; lane < 32; ++lane) {
+                P.buf[t.o_we[c] + 0 * 64 + lane] = bn[c * 4 + 1][lane];
+                P.buf[t.o_we[c] + 1 * 64 + lane] = bn[c * 4 + 2][lane];
+                for (int tl = 0; tl < 2; ++tl) {
+                    const int o = spline_orig_index(32 * tl + lane);
+                    P.buf[t.o_we[c] + (2 + tl) * 64 + lane] = o < 0 ? 0.f : bn[c * 4 + 3][o];
+                }
             }
         }
         // natural transposed copies for the teacher-forced kernels (lane = output channel)
@@ -155,18 +157,38 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
                 std::copy(bn[c * 4 + l], bn[c * 4 + l] + Nd[l], P.buf.begin() + t.o_nnb[c][l]);
             }
     }
-    // dependency levels of the kinematic tree (parts of equal depth are independent)
+    // Rounds: greedy list schedule of the kinematic tree, <= kChainWaves independent parts per round, all ancestors in
+    // earlier rounds, longest-remaining-chain first (so leaf parts fill the idle waves of later rounds).
     Levels& L = fp.lev;
-    int maxd = 0;
-    for (int j = 0; j < kP; ++j) maxd = std::max(maxd, depth[j]);
-    L.nlev = maxd + 1;
-    int n = 0;
-    for (int d = 0; d <= maxd; ++d) {
-        L.start[d] = n;
-        for (int j = 0; j < kP; ++j)
-            if (depth[j] == d) L.parts[n++] = j;
+    int height[kP], done[kP], placed = 0;
+    for (int j = kP - 1; j >= 0; --j) {
+        height[j] = 0;
+        for (int k = j + 1; k < kP; ++k)
+            if (w->parents_host[k + 1] - 1 == j) height[j] = std::max(height[j], height[k] + 1);
+        done[j] = -1;
     }
-    for (int d = maxd + 1; d <= kP; ++d) L.start[d] = n;
+    L.nlev = 0;
+    while (placed < kP) {
+        L.start[L.nlev] = placed;
+        int chosen[kChainWaves], nc = 0;
+        for (int slot = 0; slot < kChainWaves; ++slot) {
+            int best = -1;
+            for (int j = 0; j < kP; ++j) {
+                if (done[j] >= 0) continue;
+                const int par = w->parents_host[j + 1] - 1;
+                if (par >= 0 && (done[par] < 0 || done[par] == L.nlev)) continue;       // parent not in an EARLIER round
+                bool taken = false;
+                for (int i = 0; i < nc; ++i) taken |= chosen[i] == j;
+                if (!taken && (best < 0 || height[j] > height[best])) best = j;
+            }
+            if (best < 0) break;
+            chosen[nc++] = best;
+        }
+        for (int i = 0; i < nc; ++i) { done[chosen[i]] = L.nlev; L.parts[placed++] = chosen[i]; }
+        ++L.nlev;
+    }
+    for (int d2 = L.nlev; d2 <= kP; ++d2) L.start[d2] = placed;
+    (void)depth;
     fp.arena.swap(P.buf);
     return HMF_OK;
 }
@@ -180,11 +202,11 @@ extern "C" {
 size_t hmf_flow_packed_floats(const hmf_flow_host_t* w) {
     FlowPack fp;
     if (build_flow_pack(w, fp)) return 0;
-    return fp.arena.size() + (size_t)kP * kPartTabInts + (size_t)kP * 64 + 4;
+    return fp.arena.size() + (size_t)kP * kPartTabInts + (size_t)kP * 64 + (1 + kP + 1 + kP) + 4;
 }
 
 // out = [arena floats | PartTab[23] as raw int32 bit patterns | anc_off[23][64] as raw int32 |
-//        o_wisgc, o_bisgc, o_wbeta, arena_floats as raw int32]
+//        Levels {nlev, start[24], parts[23]} | o_wisgc, o_bisgc, o_wbeta, arena_floats as raw int32]
 int hmf_flow_pack_host(const hmf_flow_host_t* w, float* out) {
     if (!out) return fail(HMF_ERR_INVALID, "hmf_flow_pack_host: null output");
     FlowPack fp;
@@ -193,8 +215,11 @@ int hmf_flow_pack_host(const hmf_flow_host_t* w, float* out) {
     memcpy(out, fp.arena.data(), fp.arena.size() * 4);
     memcpy(out + fp.arena.size(), fp.tab.data(), (size_t)kP * sizeof(PartTab));
     memcpy(out + fp.arena.size() + (size_t)kP * kPartTabInts, fp.anc_off.data(), (size_t)kP * 64 * 4);
+    float* pos = out + fp.arena.size() + (size_t)kP * kPartTabInts + (size_t)kP * 64;
+    memcpy(pos, &fp.lev, sizeof(Levels));                     // nlev, start[24], parts[23]
+    pos += sizeof(Levels) / 4;
     const int tail[4] = {fp.o_wisgc, fp.o_bisgc, fp.o_wbeta, (int)fp.arena.size()};
-    memcpy(out + fp.arena.size() + (size_t)kP * kPartTabInts + (size_t)kP * 64, tail, sizeof(tail));
+    memcpy(pos, tail, sizeof(tail));
     return HMF_OK;
 }
 

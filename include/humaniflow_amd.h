@@ -177,6 +177,9 @@ int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int 
  * 7 = k_isgc.  Returns the number of launches copied (<= max), or a negative error.                */
 int hmf_profile_enable(int enable);
 int hmf_profile_collect(double* ms_host, int32_t* tag_host, int32_t* rows_host, int max);
+/* Diagnostic: device buffer of 23 x 8 int64 that k_flow_chain's tile 0 fills with shader-clock stamps per part phase
+ * (tools/flow_timeline.py); NULL (default) disables it.                                            */
+int hmf_debug_set_timeline(void* dev_ptr);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host-side packing probes (no GPU needed; used by the CPU test-suite to check operand layouts) */

@@ -18,8 +18,8 @@ Q = LANES >> 5
 D_ROW = (np.arange(16)[:, None] & 3) + 8 * (np.arange(16)[:, None] >> 2) + 4 * Q[None, :]     # (16, 64)
 
 PART_FIELDS = [('n_anc', 1), ('anc', 7), ('kas', 1), ('kag', 1), ('o_wc0', 1), ('o_bctx', 1), ('o_wa', 1), ('o_w1', 1),
-               ('o_b1', 1), ('o_w1x', 1), ('o_w2', 2), ('o_b2', 2), ('o_w3', 2), ('o_b3', 2), ('o_w4', 2), ('o_b4', 2),
-               ('o_wctxT', 1), ('o_nnT', 8), ('o_nnb', 8)]
+               ('o_w1e', 1), ('o_w2', 2), ('o_w3', 2), ('o_w4', 2), ('o_we', 2), ('o_wctxT', 1), ('o_nnT', 8), ('o_nnb', 8)]
+LEVEL_INTS = 1 + 24 + 23
 PART_INTS = sum(n for _, n in PART_FIELDS)
 
 
@@ -48,7 +48,10 @@ def parse_flow_pack(buf):
             o += n
         parts.append(d)
     anc_off = ints[n_arena + 23 * PART_INTS:n_arena + 23 * PART_INTS + 23 * 64].reshape(23, 64)
-    glob = {'o_wisgc': int(ints[-4]), 'o_bisgc': int(ints[-3]), 'o_wbeta': int(ints[-2])}
+    lev = ints[n_arena + 23 * PART_INTS + 23 * 64:n_arena + 23 * PART_INTS + 23 * 64 + LEVEL_INTS]
+    nlev, start, order = int(lev[0]), lev[1:25], lev[25:48]
+    rounds = [[int(order[i]) for i in range(start[r], start[r + 1])] for r in range(nlev)]
+    glob = {'o_wisgc': int(ints[-4]), 'o_bisgc': int(ints[-3]), 'o_wbeta': int(ints[-2]), 'rounds': rounds}
     return arena, parts, anc_off, glob
 
 
@@ -151,32 +154,43 @@ def emulate_flow_tile(arena, parts, anc_off, glob, levels, nb, G, shape_mode, sh
                         mfma(wa[0, s4, :, u], bval, cx[0])
                         mfma(wa[1, s4, :, u], bval, cx[1])
             cx = elu(cx)
-            a1 = bias_init(arena, pt['o_b1'], 4)
-            dense_layer(a_block(arena, pt['o_w1'], 4, 8), cx, a1)
             x = np.zeros((3, 64), np.float32)
             if N > 0:
                 e = eps_pose[j, b, n]                                   # (64, 3)
                 x = np.where((live & ~is_point)[None, :], (e * np.float32(base_std)).T, 0).astype(np.float32)
             x0, x1, x2 = x
+            one_q0 = np.where(Q == 0, 1.0, 0.0).astype(np.float32)
+            w1e = arena[pt['o_w1e']:pt['o_w1e'] + 256].reshape(4, 64)
+            a1 = np.zeros((4, 16, 64), np.float32)
+            bx0 = np.where(Q == 0, x0, 1.0).astype(np.float32)
+            mfma(w1e[0], bx0, a1[0])
+            mfma(w1e[1], bx0, a1[1])
+            dense_layer(a_block(arena, pt['o_w1'], 4, 8), cx, a1)
 
             def tail(c, h1, xin):
-                a2 = bias_init(arena, pt['o_b2'][c], 1)
+                we = arena[pt['o_we'][c]:pt['o_we'][c] + 256].reshape(4, 64)
+                a2 = np.zeros((1, 16, 64), np.float32)
+                mfma(we[0], one_q0, a2[0])
                 dense_layer(a_block(arena, pt['o_w2'][c], 1, 8), h1, a2)
                 a2 = np.maximum(a2, 0)
-                a3 = bias_init(arena, pt['o_b3'][c], 1)
+                a3 = np.zeros((1, 16, 64), np.float32)
+                mfma(we[1], one_q0, a3[0])
                 dense_layer(a_block(arena, pt['o_w3'][c], 1, 4), a2, a3)
                 a3 = np.maximum(a3, 0)
-                a4 = bias_init(arena, pt['o_b4'][c], 2)
+                a4 = np.zeros((2, 16, 64), np.float32)
+                mfma(we[2], one_q0, a4[0])
+                mfma(we[3], one_q0, a4[1])
                 dense_layer(a_block(arena, pt['o_w4'][c], 2, 4), a3, a4)
                 y, _ = spline_lane(a4, xin, radius)
                 return y
-            wx = bias_init(arena, pt['o_w1x'], 2)
-            h1 = np.maximum(wx * x0[None, None, :] + a1[0:2], 0).astype(np.float32)
+            h1 = np.maximum(a1[0:2], 0).astype(np.float32)
             xn = tail(0, h1, np.where(Q == 1, x2, x1))
             x1n, x2n = xn[L31], xn[32 + L31]
             y0 = x1n
-            wx = bias_init(arena, pt['o_w1x'] + 64, 2)
-            h1 = np.maximum(wx * y0[None, None, :] + a1[2:4], 0).astype(np.float32)
+            by0 = np.where(Q == 0, y0, 1.0).astype(np.float32)
+            mfma(w1e[2], by0, a1[2])
+            mfma(w1e[3], by0, a1[3])
+            h1 = np.maximum(a1[2:4], 0).astype(np.float32)
             yn = tail(1, h1, np.where(Q == 1, x0, x2n))
             y1, y2 = yn[L31], yn[32 + L31]
             yv = torch.from_numpy(np.stack([y0, y1, y2], -1).astype(np.float32))

@@ -155,9 +155,14 @@ def test_flow_operand_pack_and_kernel_dataflow_match_oracle(lib, use_mode):
     gc = torch.cat([ref['glob_rotmat'].reshape(B, 9), ref['cam_wp']], 1).double()
     G = (feats.double() @ W[:, :512].T + gc @ W[:, 522:].T + bias).float().numpy()
     assert np.array_equal(arena[glob['o_wisgc']:glob['o_wisgc'] + W.numel()].reshape(W.shape), W.float().numpy())
-    depth = [len(H.immediate_parent_to_all_ancestors(H.SMPL_PARENTS)[j]) for j in range(23)]
-    levels = [[j for j in range(23) if depth[j] == d] for d in range(max(depth) + 1)]
-    assert [len(l) for l in levels] == [3, 3, 3, 5, 3, 2, 2, 2]
+    # the packer's round schedule: <= 4 independent parts per round, ancestors strictly earlier, 8 rounds for SMPL
+    levels = glob['rounds']
+    anc = H.immediate_parent_to_all_ancestors(H.SMPL_PARENTS)
+    seen = set()
+    for rnd in levels:
+        assert 1 <= len(rnd) <= 4 and all(set(anc[j]) <= seen for j in rnd)
+        seen |= set(rnd)
+    assert sorted(seen) == list(range(23)) and len(levels) == 8
     got = {}
     for tile in range((B * N + B + 31) // 32):
         got.update(E.emulate_flow_tile(arena, parts, anc_off, glob, levels, nb, G, ref['shape_mode'].numpy(),
