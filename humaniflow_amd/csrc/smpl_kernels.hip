@@ -77,7 +77,8 @@ __device__ __forceinline__ float pose_feature(int k, int nb, const float* __rest
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __restrict__ glob, int Mg,
                                                      const float* __restrict__ body, const float* __restrict__ betas,
-                                                     int Mb, int M, float* __restrict__ atr, float* __restrict__ joints) {
+                                                     int Mb, int M, float* __restrict__ atr, float* __restrict__ joints,
+                                                     float* __restrict__ panel) {
     __shared__ float sJ[8][kJ][3];
     __shared__ float sG[8][kJ][12];
     const int j = threadIdx.x % kJ, r = threadIdx.x / kJ;
@@ -104,6 +105,20 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
             const float* p = body + ((size_t)row * 23 + (j - 1)) * 9;
 #pragma unroll
             for (int e = 0; e < 9; ++e) R[e] = p[e];
+        }
+    }
+    // extended pose feature [vec(R_1..R_23) - I | beta | 1 | 0] of this row, written in the A-operand panel layout
+    // panel[row / 64][k][row % 64] that k_lbs_mfma stages into LDS with plain coalesced float4 copies (dead rows: zeros)
+    if (panel) {
+        float* pr = panel + (size_t)(row >> 6) * (kKpad * 64) + (row & 63);
+        if (j > 0) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e)
+                pr[((j - 1) * 9 + e) * 64] = live ? R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f) : 0.0f;
+        } else {
+            const float* b = betas + (size_t)((Mb == 1 || !live) ? 0 : row) * nb;
+            for (int k = kPoseFeat; k < kKpad; ++k)
+                pr[k * 64] = !live ? 0.0f : (k < kPoseFeat + nb ? b[k - kPoseFeat] : (k == kPoseFeat + nb ? 1.0f : 0.0f));
         }
     }
     sJ[r][j][0] = Jc[0]; sJ[r][j][1] = Jc[1]; sJ[r][j][2] = Jc[2];
@@ -163,70 +178,64 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// 2. fused pose-blend GEMM + skinning.  One workgroup (8 waves) per CU; it owns a contiguous chunk of
-//    (row-group of 64 rows, vertex tile) pairs inside ONE of the 8 vertex ranges (27 tiles = 2.3 MB of
-//    packed operand, which stays resident in that XCD's 4 MB L2 when block b lands on XCD b%8).
-//    Per wave tile: D(64 rows x 32 verts x 3 comps) = 112 k-steps x 6 v_mfma_f32_32x32x2_f32.
-//    LDS: pose-feature panel [224][64] (A operand, conflict-free ds_read_b32) + skinning transforms
-//    [64][24][12] (ds_read_b128 gather by joint).  The B operand streams L2 -> VGPR as dwordx4.
-// ---------------------------------------------------------------------------------------------------
+// Per-tile constants of the skinning epilogue of k_lbs_mfma.
+struct EpiCtx {
+    float* obase;                    // verts + ((row0 + 4*half) * V + v) * 3
+    bool ok_v, full_rows;
+    int row_lim;                     // M - row0 - 4*half
+};
+
 template <int SLOTS>
-__device__ __forceinline__ void skin_store(const SmplDev& d, const float* __restrict__ sA, const f32x16 (&acc)[2][3],
-                                           int vt, int l31, int half, int row0, int M, float* __restrict__ verts,
-                                           int slots_rt) {
-    const int v = vt * 32 + l31;
-    const int nslots = SLOTS > 0 ? SLOTS : slots_rt;
-    int off[SLOTS > 0 ? SLOTS : 1];
-    float w[SLOTS > 0 ? SLOTS : 1];
+__device__ __forceinline__ void skin_element(const SmplDev& d, const char* __restrict__ lbase, const int (&off)[SLOTS > 0 ? SLOTS : 1],
+                                             const float (&w)[SLOTS > 0 ? SLOTS : 1], int nslots, int vt, int l31,
+                                             const f32x16 (&acc)[2][3], int rt, int reg, const EpiCtx& e) {
+    const int rc = rt * 32 + (reg & 3) + 8 * (reg >> 2);
+    const char* base = lbase + rc * kAtr * 4;
+    f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
     if (SLOTS > 0) {
+        f32x4 ga[SLOTS > 0 ? SLOTS : 1][3];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            off[s] = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
-            w[s] = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
+            const f32x4* p = (const f32x4*)(base + off[s]);
+            ga[s][0] = p[0]; ga[s][1] = p[1]; ga[s][2] = p[2];
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) { T0 += w[s] * ga[s][0]; T1 += w[s] * ga[s][1]; T2 += w[s] * ga[s][2]; }
+    } else {
+        for (int s = 0; s < nslots; ++s) {
+            const int o = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
+            const float ww = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
+            const f32x4* p = (const f32x4*)(base + o);
+            T0 += ww * p[0]; T1 += ww * p[1]; T2 += ww * p[2];
         }
     }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            const char* base = (const char*)(sA + r * kAtr);
-            f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
-            if (SLOTS > 0) {
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    const f32x4* p = (const f32x4*)(base + off[s]);
-                    T0 += w[s] * p[0]; T1 += w[s] * p[1]; T2 += w[s] * p[2];
-                }
-            } else {
-                for (int s = 0; s < nslots; ++s) {
-                    const int o = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
-                    const float ww = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
-                    const f32x4* p = (const f32x4*)(base + o);
-                    T0 += ww * p[0]; T1 += ww * p[1]; T2 += ww * p[2];
-                }
-            }
-            const float px = acc[rt][0][reg], py = acc[rt][1][reg], pz = acc[rt][2][reg];
-            const float x = fmaf(T0[2], pz, fmaf(T0[1], py, T0[0] * px)) + T0[3];
-            const float y = fmaf(T1[2], pz, fmaf(T1[1], py, T1[0] * px)) + T1[3];
-            const float z = fmaf(T2[2], pz, fmaf(T2[1], py, T2[0] * px)) + T2[3];
-            const int row = row0 + r;
-            if (row < M && v < kV) {
-                float* o = verts + ((size_t)row * kV + v) * 3;
-                o[0] = x; o[1] = y; o[2] = z;
-            }
-            // keep the 32 unrolled (row, vertex) bodies from being interleaved: hoisting all their LDS gathers
-            // at once costs ~400 live registers and spills
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    const float px = acc[rt][0][reg], py = acc[rt][1][reg], pz = acc[rt][2][reg];
+    float x = fmaf(T0[2], pz, fmaf(T0[1], py, T0[0] * px)) + T0[3];
+    float y = fmaf(T1[2], pz, fmaf(T1[1], py, T1[0] * px)) + T1[3];
+    float z = fmaf(T2[2], pz, fmaf(T2[1], py, T2[0] * px)) + T2[3];
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));        // keep the body OUT of the exec-masked store block (otherwise the compiler sinks each body into its own exec-masked block and serialises 32 x 4 LDS round trips per tile)
+    if (e.ok_v && (e.full_rows || rc < e.row_lim)) {
+        float* o = e.obase + rc * (kV * 3);
+        o[0] = x; o[1] = y; o[2] = z;
     }
 }
 
-template <int SLOTS>
-__global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, const float* __restrict__ body,
-                                                     const float* __restrict__ betas, int Mb, int M, int nrg, int wpx,
-                                                     const float* __restrict__ atr, float* __restrict__ verts) {
+// ---------------------------------------------------------------------------------------------------
+// 2. fused pose-blend GEMM + skinning.  One workgroup (8 waves, 2 per SIMD) per CU; it owns a contiguous chunk of
+//    (row-group of 64 rows, vertex tile) pairs inside ONE of the 8 vertex ranges (27 tiles = 2.3 MB of packed operand,
+//    L2-resident per XCD when block b lands on XCD b%8 -- speed only).  Per wave tile: D(64 rows x 32 verts x 3 comps) =
+//    112 k-steps x 6 v_mfma_f32_32x32x2_f32.  LDS: pose-feature panel [224][64] (A operand, conflict-free ds_read_b32,
+//    pre-laid-out by k_rigid_chain so staging is a coalesced float4 copy) + skinning transforms [64][24][12]
+//    (ds_read_b128 gather by joint).  The B operand streams L2 -> VGPR as dwordx4, one k-group ahead; the next tile's
+//    first k-group and skinning slots are fetched before the current tile's epilogue.
+//    ABL != 0: ablation builds (tools/lbs_tune.py) -- 1 no epilogue, 2 no B stream, 4 no A reads.
+//    Measured on MI355X at M = 3200: bare MFMA loop 260 us, + operands 285 us, + epilogue 328 us.
+// ---------------------------------------------------------------------------------------------------
+template <int SLOTS, int ABL>
+__global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, int wpx, const float* __restrict__ panel,
+                                                   const float* __restrict__ atr, float* __restrict__ verts,
+                                                   long long* __restrict__ cycles) {
+    const long long c_start = cycles ? (long long)__builtin_readcyclecounter() : 0;
     __shared__ __attribute__((aligned(16))) float smem[kKpad * kRowsPerWG + kRowsPerWG * kAtr];  // 56 + 72 KB
     float* sPF = smem;
     float* sA = smem + kKpad * kRowsPerWG;
@@ -237,30 +246,44 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, const float* __r
     const int T = nrg * kVTperX;
     int t = (int)((long long)chunk * T / wpx);
     const int t1 = (int)((long long)(chunk + 1) * T / wpx);
-    const int nb = d.num_betas;
+    const int nslots = d.skin_slots;
     while (t < t1) {
         const int rg = t / kVTperX;
         const int seg_end = min(t1, (rg + 1) * kVTperX);
         const int row0 = rg * kRowsPerWG;
-        // ---- stage the A operand panel and the skinning transforms of this row group ----
-        for (int i = tid; i < kKpad * kRowsPerWG; i += 512) {
-            const int k = i >> 6, r = i & 63, row = row0 + r;
-            float val = 0.f;
-            if (row < M)
-                val = pose_feature(k, nb, body + (size_t)row * kPoseFeat, betas + (size_t)(Mb == 1 ? 0 : row) * nb);
-            sPF[i] = val;
-        }
         {
-            const f32x4* src = (const f32x4*)(atr + (size_t)row0 * kAtr);
-            f32x4* dst = (f32x4*)sA;
+            const f32x4* src = (const f32x4*)(panel + (size_t)rg * (kKpad * 64));
+            f32x4* dst = (f32x4*)sPF;
+#pragma unroll
+            for (int i = 0; i < kKpad * 64 / 4 / 512; ++i) dst[tid + i * 512] = src[tid + i * 512];
+            const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
+            f32x4* dst2 = (f32x4*)sA;
             const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
-            for (int i = tid; i < kRowsPerWG * (kAtr / 4); i += 512) {
+#pragma unroll
+            for (int i = 0; i < kRowsPerWG * (kAtr / 4) / 512; ++i) {
+                const int ii = tid + i * 512;
                 f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                dst[i] = (i < n4) ? src[i] : z;
+                dst2[ii] = (ii < n4) ? src2[ii] : z;
             }
         }
         __syncthreads();
-        for (int tt = t + wave; tt < seg_end; tt += 8) {
+        int tt = t + wave;
+        f32x4 b0, b1, b2;
+        int off[SLOTS > 0 ? SLOTS : 1];
+        float w[SLOTS > 0 ? SLOTS : 1];
+        if (tt < seg_end) {
+            const int vt = xr * kVTperX + (tt - rg * kVTperX);
+            const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
+            b0 = bp[0]; b1 = bp[64]; b2 = bp[128];
+            if (SLOTS > 0) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    off[s] = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
+                    w[s] = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
+                }
+            }
+        }
+        while (tt < seg_end) {
             const int vt = xr * kVTperX + (tt - rg * kVTperX);
             f32x16 acc[2][3];
 #pragma unroll
@@ -270,19 +293,18 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, const float* __r
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
             const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
-            f32x4 b0 = bp[0], b1 = bp[64], b2 = bp[128];
             const float* ap = sPF + half * 64 + l31;
 #pragma unroll 2
             for (int kg = 0; kg < kKG; ++kg) {
                 f32x4 n0 = b0, n1 = b1, n2 = b2;
-                if (kg + 1 < kKG) {
+                if (kg + 1 < kKG && !(ABL & 2)) {
                     n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128];
                 }
                 const float bv[12] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int ks = kg * 4 + u;
-                    const float a0 = ap[ks * 128], a1 = ap[ks * 128 + 32];
+                    const float a0 = (ABL & 4) ? b0[u] : ap[ks * 128], a1 = (ABL & 4) ? b1[u] : ap[ks * 128 + 32];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[u * 3 + c], acc[0][c], 0, 0, 0);
@@ -291,11 +313,48 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, const float* __r
                 }
                 b0 = n0; b1 = n1; b2 = n2;
             }
-            skin_store<SLOTS>(d, sA, acc, vt, l31, half, row0, M, verts, d.skin_slots);
+            // next tile's first operand group + skinning slots: in flight during this tile's epilogue
+            const int ntt = tt + 8;
+            int noff[SLOTS > 0 ? SLOTS : 1];
+            float nw[SLOTS > 0 ? SLOTS : 1];
+            if (ntt < seg_end) {
+                const int nvt = xr * kVTperX + (ntt - rg * kVTperX);
+                const f32x4* nbp = (const f32x4*)(d.blend + (size_t)nvt * kKG * 3 * 64 * 4) + lane;
+                b0 = nbp[0]; b1 = nbp[64]; b2 = nbp[128];
+                if (SLOTS > 0) {
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        noff[s] = d.skin_off[((size_t)nvt * nslots + s) * 32 + l31];
+                        nw[s] = d.skin_w[((size_t)nvt * nslots + s) * 32 + l31];
+                    }
+                }
+            }
+            if (ABL & 1) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) asm volatile("" ::"v"(acc[a][c]));
+            } else {
+                EpiCtx e;
+                const int v = vt * 32 + l31;
+                e.ok_v = v < kV;
+                e.full_rows = row0 + kRowsPerWG <= M;
+                e.row_lim = M - row0 - 4 * half;
+                e.obase = verts + ((size_t)(row0 + 4 * half) * kV + v) * 3;
+                const char* lbase = (const char*)(sA + 4 * half * kAtr);
+#pragma unroll
+                for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el & 15, e);
+            }
+            if (SLOTS > 0) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) { off[s] = noff[s]; w[s] = nw[s]; }
+            }
+            tt = ntt;
         }
         __syncthreads();
         t = seg_end;
     }
+    if (cycles && threadIdx.x == 0) cycles[blockIdx.x] = (long long)__builtin_readcyclecounter() - c_start;
 }
 
 // Scalar cross-check kernel (tests only): one thread per (row, vertex), same k order and the same
@@ -440,7 +499,12 @@ static void pack_blend(const hmf_smpl_host_t* m, float* out) {
 
 using namespace hmf;
 
+static long long* g_lbs_cycles = nullptr;
+
 extern "C" {
+
+/* diagnostic (tools/lbs_tune.py): device buffer of >= 256 int64; every k_lbs_mfma block stores its shader-clock span */
+int hmf_debug_set_lbs_cycles(void* dev_ptr) { g_lbs_cycles = (long long*)dev_ptr; return HMF_OK; }
 
 size_t hmf_smpl_packed_blend_floats(int) { return (size_t)kVT * kKG * 3 * 64 * 4; }
 size_t hmf_smpl_packed_blend_index(int k, int v, int c) { return blend_index(k, v, c); }
@@ -575,7 +639,9 @@ void hmf_smpl_destroy(hmf_smpl_t* h) {
     delete h;
 }
 
-size_t hmf_smpl_lbs_workspace_bytes(int M) { return align_up((size_t)std::max(M, 1) * kAtr * sizeof(float), 256); }
+static size_t ws_atr_bytes(int M) { return align_up((size_t)std::max(M, 1) * kAtr * sizeof(float), 256); }
+static size_t ws_panel_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kKpad * 64 * sizeof(float); }
+size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M); }
 
 int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose, const float* betas,
                  int Mb, int M, float* verts, float* joints, void* workspace, size_t workspace_bytes, int impl,
@@ -588,13 +654,15 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
     hipStream_t st = (hipStream_t)stream;
     float* atr = (float*)workspace;
+    float* panel = (float*)((char*)workspace + ws_atr_bytes(M));
+    const int nrg_all = (M + kRowsPerWG - 1) / kRowsPerWG;
     {
-        ProfScope ps(2, M, st);
-        hipLaunchKernelGGL(k_rigid_chain, dim3((M + 7) / 8), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas, Mb, M,
-                           atr, joints);
+        ProfScope ps(2, M, st);      // grid padded to whole row groups: dead rows zero their slice of the panel
+        hipLaunchKernelGGL(k_rigid_chain, dim3(nrg_all * (kRowsPerWG / 8)), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas,
+                           Mb, M, atr, joints, panel);
     }
     HMF_LAUNCH_CHECK();
-    if (impl == 1) {
+    if ((impl & 15) == 1) {
         const long long n = (long long)M * kV;
         hipLaunchKernelGGL(k_lbs_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d, body_pose, betas, Mb, M,
                            atr, verts);
@@ -605,12 +673,20 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         int wpx = (T + 7) / 8;                      // at least one tile per wave
         wpx = std::max(1, std::min(32, wpx));       // 32 CUs per XCD
         const dim3 grid(8 * wpx), block(512);
-        if (h->d.skin_slots == 4)
-            hipLaunchKernelGGL(k_lbs_mfma<4>, grid, block, 0, st, h->d, body_pose, betas, Mb, M, nrg, wpx, atr, verts);
-        else if (h->d.skin_slots == 8)
-            hipLaunchKernelGGL(k_lbs_mfma<8>, grid, block, 0, st, h->d, body_pose, betas, Mb, M, nrg, wpx, atr, verts);
-        else
-            hipLaunchKernelGGL(k_lbs_mfma<0>, grid, block, 0, st, h->d, body_pose, betas, Mb, M, nrg, wpx, atr, verts);
+#define HMF_LBS(S, ABL) hipLaunchKernelGGL((k_lbs_mfma<S, ABL>), grid, block, 0, st, h->d, M, nrg, wpx, panel, atr, verts, g_lbs_cycles)
+        if (h->d.skin_slots == 4) {
+            switch (impl >> 4) {          // impl = 16 * ABL: ablation variants for tools/lbs_tune.py; 0 = product kernel
+                case 1: HMF_LBS(4, 1); break;        // no skinning epilogue
+                case 3: HMF_LBS(4, 3); break;        // ... and no B-operand stream
+                case 7: HMF_LBS(4, 7); break;        // ... and no A-operand LDS reads: bare MFMA loop
+                default: HMF_LBS(4, 0); break;
+            }
+        } else if (h->d.skin_slots == 8) {
+            HMF_LBS(8, 0);
+        } else {
+            HMF_LBS(0, 0);
+        }
+#undef HMF_LBS
     }
     HMF_LAUNCH_CHECK();
     if (joints) {

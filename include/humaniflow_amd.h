@@ -180,6 +180,9 @@ int hmf_profile_collect(double* ms_host, int32_t* tag_host, int32_t* rows_host, 
 /* Diagnostic: device buffer of 23 x 8 int64 that k_flow_chain's tile 0 fills with shader-clock stamps per part phase
  * (tools/flow_timeline.py); NULL (default) disables it.                                            */
 int hmf_debug_set_timeline(void* dev_ptr);
+/* Diagnostic: device buffer of >= 256 int64; every k_lbs_mfma block stores its shader-clock span (effective clock =
+ * span / event time, tools/lbs_tune.py); NULL disables it.                                          */
+int hmf_debug_set_lbs_cycles(void* dev_ptr);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host-side packing probes (no GPU needed; used by the CPU test-suite to check operand layouts) */
