@@ -214,6 +214,17 @@ def main():
         smpl_ms, _ = timed(lambda: smpl(body_pose=bp, global_orient=go, betas=be, pose2rot=False))
         tp_ms, _ = timed(lambda: smpl.tpose(be))
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; they come from the two separate
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command summarised in profiles/r01_pmc.json
+    # (tools/pmc_summary.py: FETCH_SIZE doubled per the gfx950 note of the MI355X guide, WRITE_SIZE calibrated on k_tpose).
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+        cand = [v for k, v in pmc.items() if 'k_lbs_mfma' in k]
+        if cand and B * N == 3200:
+            traffic = max(c['hbm_bytes_per_launch'] for c in cand)
+    except Exception:
+        pass
     if rank == 0:
         value = world * B * N * args.steps / elapsed
         res = {
@@ -227,7 +238,8 @@ def main():
                        'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},
             'roofline': {'kernel': 'k_lbs_mfma (SMPL pose-blend GEMM + skinning, M=%d rows)' % (B * N), 'bound': 'mfma',
                          'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_note': 'HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/r01_pmc.json); algorithmic: 264.6 MB vertex write + 25 MB reads',
                          'avg_launch_us': round(lbs_ms * 1e3, 2), 'launches': int(lbs_sel.sum()),
                          'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * B * N},
             'stages_ms': {'encoder_resnet%d_miopen' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
