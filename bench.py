@@ -44,7 +44,8 @@ def parse():
     ap.add_argument('--tpose', action='store_true', help='add the evaluate-flavour T-pose bodies to the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=32, help='images of the bounded CPU-baseline sample')
-    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark (MIOpen find mode)')
+    ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps are round-robined over (batches are independent: the '
+                    'low-occupancy flow kernels of step i overlap the encoder convolutions of step i+1)')
     return ap.parse_args()
 
 
@@ -116,7 +117,6 @@ def main():
         dist.init_process_group('nccl', device_id=dev)          # RCCL on ROCm
     if args.gpus != world and rank == 0:
         print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     import humaniflow_amd as H
     from humaniflow_amd import _lib
@@ -153,8 +153,22 @@ def main():
             torch.cuda.synchronize()
 
     log('model + SMPL on device; warm-up (%d steps; the first one includes MIOpen kernel selection)' % args.warmup)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+
+    def run_steps(n):
+        out = None
+        cur = torch.cuda.current_stream()
+        for s_ in streams:
+            s_.wait_stream(cur)
+        for i in range(n):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                out = step()
+        for s_ in streams:
+            cur.wait_stream(s_)
+        return out
+
     for i in range(args.warmup):
-        out = step()
+        out = run_steps(1)
         if i == 0:
             torch.cuda.synchronize()
             log('first step done')
@@ -162,8 +176,7 @@ def main():
     log('timing %d steps' % args.steps)
     lib.hmf_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     # the one exchange step of the data-parallel eval path: per-rank metric sums gathered over RCCL/xGMI
     pred, pe, sa, _ = out
     metric_vec = torch.stack([sa.vertices.abs().mean(), sa.joints.abs().mean(), pe.vertices.abs().mean(),
@@ -213,6 +226,15 @@ def main():
         be = pred['shape_samples'].reshape(-1, 10)
         smpl_ms, _ = timed(lambda: smpl(body_pose=bp, global_orient=go, betas=be, pose2rot=False))
         tp_ms, _ = timed(lambda: smpl.tpose(be))
+        # the dominant kernel once more, alone on the device (no other stream active): what the kernel itself achieves
+        lib.hmf_profile_enable(1)
+        for _ in range(5):
+            smpl(body_pose=bp, global_orient=go, betas=be, pose2rot=False)
+        ms2 = np.zeros(64); tag2 = np.zeros(64, np.int32); rows2 = np.zeros(64, np.int32)
+        n2 = lib.hmf_profile_collect(ms2.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag2), _lib.iptr(rows2), 64)
+        lib.hmf_profile_enable(0)
+        iso = [ms2[i] for i in range(n2) if tag2[i] == 1 and rows2[i] == B * N]
+        lbs_iso_ms = float(np.mean(iso)) if iso else float('nan')
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; they come from the two separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command summarised in profiles/r01_pmc.json
@@ -234,13 +256,17 @@ def main():
             'config': {'workload': 'configs[1]: B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL '
                                    'fp32, random-init weights, synthetic SMPL-shaped body model%s'
                                    % (B, N, args.layers, ' + T-pose bodies' if args.tpose else ''),
-                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world,
+                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'streams_per_gpu': len(streams),
                        'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},
             'roofline': {'kernel': 'k_lbs_mfma (SMPL pose-blend GEMM + skinning, M=%d rows)' % (B * N), 'bound': 'mfma',
                          'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': 'HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/r01_pmc.json); algorithmic: 264.6 MB vertex write + 25 MB reads',
                          'avg_launch_us': round(lbs_ms * 1e3, 2), 'launches': int(lbs_sel.sum()),
+                         'note': 'timed-region launches share the GPU with the other stream(s) (encoder convolutions of the next batch)',
+                         'isolated': {'avg_launch_us': round(lbs_iso_ms * 1e3, 2),
+                                      'achieved': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12, 2),
+                                      'frac': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                          'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * B * N},
             'stages_ms': {'encoder_resnet%d_miopen' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
                           'smpl_samples': round(smpl_ms, 3), 'smpl_tpose': round(tp_ms, 3)},

@@ -237,7 +237,8 @@ class HumaniflowModel(nn.Module):
         return h
 
     def _workspace(self, device, nbytes):
-        key = (device.type, device.index)
+        # one scratch buffer per (device, stream): steps issued on different streams may be in flight together
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

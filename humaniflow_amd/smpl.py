@@ -177,7 +177,8 @@ class SMPL(nn.Module):
             pass
 
     def _workspace(self, device, M):
-        key = (device.type, device.index)
+        # one scratch buffer per (device, stream): calls issued on different streams may be in flight together
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         need = _lib.load().hmf_smpl_lbs_workspace_bytes(M)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
