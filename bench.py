@@ -177,6 +177,7 @@ def main():
     lib.hmf_profile_enable(1)
     t0 = time.perf_counter()
     out = run_steps(args.steps)
+    host_issue = time.perf_counter() - t0          # host time to ISSUE the steps (no sync yet): CPU-bound if ~ elapsed
     # the one exchange step of the data-parallel eval path: per-rank metric sums gathered over RCCL/xGMI
     pred, pe, sa, _ = out
     metric_vec = torch.stack([sa.vertices.abs().mean(), sa.joints.abs().mean(), pe.vertices.abs().mean(),
@@ -268,6 +269,7 @@ def main():
                                       'achieved': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12, 2),
                                       'frac': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                          'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * B * N},
+            'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 3),
             'stages_ms': {'encoder_resnet%d_miopen' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
                           'smpl_samples': round(smpl_ms, 3), 'smpl_tpose': round(tp_ms, 3)},
             'kernels_us': kern,

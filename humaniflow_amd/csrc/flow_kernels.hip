@@ -100,6 +100,35 @@ __device__ __forceinline__ void dense_layer(const f32x4* __restrict__ wp, const 
     }
 }
 
+// Same contraction with the weight stream software-pipelined DEPTH float4 groups ahead (the plain version above issues
+// each group's loads right before its MFMAs and eats an L2 round trip per group).
+template <int NTO, int NKT, int DEPTH>
+__device__ __forceinline__ void dense_layer_pf(const f32x4* __restrict__ wp, const f32x16 (&in)[NKT], f32x16 (&acc)[NTO]) {
+    constexpr int NS4 = NKT * 4;
+    f32x4 w[DEPTH][NTO];
+#pragma unroll
+    for (int d0 = 0; d0 < DEPTH; ++d0)
+#pragma unroll
+        for (int to = 0; to < NTO; ++to) w[d0][to] = wp[(to * NS4 + d0) * 64];
+#pragma unroll
+    for (int s4 = 0; s4 < NS4; ++s4) {
+        f32x4 cur[NTO];
+#pragma unroll
+        for (int to = 0; to < NTO; ++to) cur[to] = w[s4 % DEPTH][to];
+        if (s4 + DEPTH < NS4) {
+#pragma unroll
+            for (int to = 0; to < NTO; ++to) w[s4 % DEPTH][to] = wp[(to * NS4 + s4 + DEPTH) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s4 * 4 + u;
+#pragma unroll
+            for (int to = 0; to < NTO; ++to)
+                acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[to][u], in[s >> 4][s & 15], acc[to], 0, 0, 0);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_flow_ctx0: image/shape half of every part's context layer.
 // ---------------------------------------------------------------------------------------------------
@@ -161,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) h[t][e] = ri.live ? elu1(h[t][e]) : 0.f;
+            for (int e = 0; e < 16; ++e) h[t][e] = ri.live ? elu_fast(h[t][e]) : 0.f;
     }
     for (int pi = 0; pi < kPartsPerWave0; ++pi) {
         const int j = pg * kPartsPerWave0 + pi;
@@ -169,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __
         const PartTab& pt = d.tab[j];
         f32x16 acc[2];
         bias_init<2>(d.arena + pt.o_bctx, q, acc);
-        dense_layer<2, 8>((const f32x4*)(d.arena + pt.o_wc0) + lane, h, acc);
+        dense_layer_pf<2, 8, 6>((const f32x4*)(d.arena + pt.o_wc0) + lane, h, acc);
         f32x4* out = (f32x4*)(C0 + (((size_t)tile * kP + j) * 2) * 64 * 16) + lane * 4;
 #pragma unroll
         for (int t = 0; t < 2; ++t)

@@ -188,3 +188,30 @@ def test_sharded_eval_driver_on_device():
     self_metrics, _ = ev.evaluate_humaniflow(ds, 2, dev, lambda b: ev.predict_batch(model, smpl, b, 0),
                                              lambda b: {k: v for k, v in ev.predict_batch(model, smpl, b, 0).items()})
     assert self_metrics['PVE'] < 1e-3 and self_metrics['MPJPE'] < 1e-3
+
+
+def test_predict_driver_plumbing_config0(tmp_path):
+    """BASELINE configs[0] counterpart: 4 images, N=10, neutral body model, no render: the six save_pred_output keys with the
+    reference's names/shapes, checked against the oracle on the same injected noise."""
+    from humaniflow_amd.predict import predict_humaniflow
+    model, sd, cfg = _model(18, seed=7)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    x = synthetic_proxy_input(4, 128, seed=3)
+    N = 10
+    noise = {'shape': torch.randn(N, 4, 10), 'pose': torch.randn(23, 4, N, 3, generator=torch.Generator().manual_seed(1))}
+    names = ['%04d.png' % (i + 1) for i in range(4)]
+    res = predict_humaniflow(model, smpl, x.cuda(), names, save_dir=str(tmp_path), num_pred_samples=N, noise=_cuda(noise))
+    ref = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input=x, num_samples=N, noise=noise, use_shape_mode_for_samples=True)
+    shapes = {'pose_axisangle_point_est': (23, 3), 'pose_rotmats_point_est': (23, 3, 3), 'shape_mode': (10,), 'glob_rotmat': (3, 3),
+              'cam_wp': (3,), 'input_feats': (512,)}
+    for i, name in enumerate(names):
+        z = np.load(str(tmp_path / (name[:-4] + '_pred.npz')))
+        for k, shp in shapes.items():
+            assert z[k].shape == shp, k
+        assert res[i]['vertices_samples'].shape == (N, 6890, 3) and res[i]['per_vertex_avg_dist_from_mean'].shape == (6890,)
+        assert (res[i]['pred']['shape_samples'] - res[i]['pred']['shape_mode'][:, None]).abs().max().item() == 0     # shape mode used
+    # parity on the oracle's own features (isolates conv round-off), all four images in one call
+    with torch.no_grad():
+        out = model(None, input_feats=ref['input_feats'].cuda(), num_samples=N, noise=_cuda(noise), use_shape_mode_for_samples=True)
+    for k in ('pose_axisangle_point_est', 'pose_rotmats_point_est', 'shape_mode', 'glob_rotmat', 'cam_wp', 'pose_rotmats_samples'):
+        assert (out[k].cpu() - ref[k]).abs().max() < 1e-4 * max(1.0, ref[k].abs().max().item()), k
