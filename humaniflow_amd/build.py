@@ -14,7 +14,11 @@ SOURCES = ['so3_kernels.hip', 'smpl_kernels.hip', 'flow_pack.hip', 'flow_kernels
 HEADERS = ['hmf_common.h', 'so3_math.h', 'flow_common.h', 'flow_handle.h', '../../include/humaniflow_amd.h']
 LIB = os.path.join(HERE, 'libhumaniflow_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+# -packed-fp32-ops: no v_pk_{fma,mul,add}_f32.  Packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X guide, price
+# list): the skinning epilogue of k_lbs_mfma was emitted as ~24 v_pk_fma_f32 per (row, vertex) and did not overlap the
+# partner wave's MFMAs at all (tools/lbs_tune.py).
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
+         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
 def _stale():

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
     int t = (int)((long long)chunk * T / wpx);
     const int t1 = (int)((long long)(chunk + 1) * T / wpx);
     const int nslots = d.skin_slots;
+    const int ks_valid = (kPoseFeat + d.num_betas + 2) / 2;      // k-steps that carry data; the zero padding up to 112 is skipped
     while (t < t1) {
         const int rg = t / kVTperX;
         const int seg_end = min(t1, (rg + 1) * kVTperX);
@@ -294,24 +295,38 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
                     for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
             const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
             const float* ap = sPF + half * 64 + l31;
+            // A operands (LDS) of k-group 0; inside the loop both operand streams run one k-group ahead of the MFMAs, so a
+            // wave never waits on the LDS queue behind its neighbours' epilogue gathers
+            float a0[4], a1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0[u] = ap[u * 128]; a1[u] = ap[u * 128 + 32]; }
 #pragma unroll 2
             for (int kg = 0; kg < kKG; ++kg) {
                 f32x4 n0 = b0, n1 = b1, n2 = b2;
+                float m0[4], m1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { m0[u] = a0[u]; m1[u] = a1[u]; }
                 if (kg + 1 < kKG && !(ABL & 2)) {
                     n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128];
+                }
+                if (kg + 1 < kKG && !(ABL & 4)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { m0[u] = ap[((kg + 1) * 4 + u) * 128]; m1[u] = ap[((kg + 1) * 4 + u) * 128 + 32]; }
                 }
                 const float bv[12] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int ks = kg * 4 + u;
-                    const float a0 = (ABL & 4) ? b0[u] : ap[ks * 128], a1 = (ABL & 4) ? b1[u] : ap[ks * 128 + 32];
+                    if (ks >= ks_valid) continue;                                   // wave-uniform
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[u * 3 + c], acc[0][c], 0, 0, 0);
-                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[u * 3 + c], acc[1][c], 0, 0, 0);
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], bv[u * 3 + c], acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], bv[u * 3 + c], acc[1][c], 0, 0, 0);
                     }
                 }
                 b0 = n0; b1 = n1; b2 = n2;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a0[u] = m0[u]; a1[u] = m1[u]; }
             }
             // next tile's first operand group + skinning slots: in flight during this tile's epilogue
             const int ntt = tt + 8;

@@ -35,7 +35,9 @@ def enable_tuned_miopen_db():
     os.makedirs(dst, exist_ok=True)
     for f in os.listdir(src):
         if f.endswith('.txt') and not os.path.exists(os.path.join(dst, f)):
-            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+            tmp = os.path.join(dst, '.%s.%d.tmp' % (f, os.getpid()))          # atomic: 8 ranks of one node start together
+            shutil.copy(os.path.join(src, f), tmp)
+            os.replace(tmp, os.path.join(dst, f))
     os.environ['MIOPEN_USER_DB_PATH'] = dst
     return dst
 

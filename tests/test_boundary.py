@@ -177,3 +177,14 @@ def test_flow_operand_pack_and_kernel_dataflow_match_oracle(lib, use_mode):
     assert err_s < 2e-5 and err_p < 2e-5 and err_v < 2e-5 and err_b < 1e-6, (err_s, err_p, err_v, err_b)
     # the samples must actually exercise the spline (not all identity / out of support)
     assert np.abs(Rs - np.eye(3).reshape(9)).max() > 0.3
+
+
+def test_tuned_miopen_db_is_installed_for_the_encoder(tmp_path, monkeypatch):
+    from humaniflow_amd import encoder
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+    monkeypatch.setattr(encoder.tempfile, 'gettempdir', lambda: str(tmp_path))
+    dst = encoder.enable_tuned_miopen_db()
+    assert dst and os.environ['MIOPEN_USER_DB_PATH'] == dst
+    files = sorted(os.listdir(dst))
+    assert any(f.endswith('.ufdb.txt') for f in files) and any(f.endswith('.udb.txt') for f in files)
+    assert encoder.enable_tuned_miopen_db() == dst                         # idempotent; respects a user-provided path
