@@ -57,6 +57,8 @@ _SIGS = {
     'hmf_flow_context': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_SO3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_so3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
+    'hmf_proxy_rep': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
+                                _VP, _VP, _VP, _VP, _VP]),
     'hmf_bias_act': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     'hmf_profile_enable': (C.c_int, [C.c_int]),
     'hmf_profile_collect': (C.c_int, [c_double_p, c_int_p, c_int_p, C.c_int]),

@@ -160,6 +160,18 @@ int hmf_flow_log_prob_so3(const hmf_flow_t* h, const float* ctx, const int32_t* 
                           const float* v, int B, float* logp, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Proxy-representation front end: models/canny_edge_detector.py:104-166 +          */
+/* utils/label_conversions.py:106-125, as composed at predict/predict_humaniflow.py:101-109         */
+/* ------------------------------------------------------------------------------------------ */
+/* img B x 3 x S x S; joints2D B x J x 2 (column, row) and visib B x J (both nullable) ->
+ * proxy B x (1 + J) x S x S: channel 0 = thresholded (thin) edges, channels 1.. = Gaussian heat-maps (* visib).
+ * Optional extra outputs (B x 1 x S x S, nullable): grad_magnitude, grad_orientation (degrees, binned to 45), thin_edges.
+ * Only edge_gaussian_size == 5 is built (the default EDGE_GAUSSIAN_SIZE).                                                  */
+int hmf_proxy_rep(const float* img, const float* joints2D, const float* visib, int B, int S, int num_joints,
+                  int edge_nms, float edge_threshold, float edge_gaussian_std, int edge_gaussian_size, float heatmap_std,
+                  float* proxy, float* grad_magnitude, float* grad_orientation, float* thin_edges, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Encoder glue (models/resnet.py:102-122: bn -> relu / bn -> += identity -> relu after each conv)   */
 /* ------------------------------------------------------------------------------------------ */
 /* In place, one pass: x = relu?(x + bias[channel] (+ residual)) for a conv output with eval-mode BatchNorm folded into

@@ -137,6 +137,24 @@ def main():
     T = P @ np.linalg.qr(rng.randn(3, 3))[0] * 1.3 + rng.randn(6, 1, 3) * 0.2 + rng.randn(6, 50, 3) * 0.05
     np.savez_compressed(os.path.join(OUT, 'metrics_golden.npz'), P=P, T=T, pa=eu.procrustes_analysis_batch(P, T),
                         sc=eu.scale_and_translation_transform_batch(P, T))
+    # ---------------- proxy-representation front end (Canny + heat-maps; both importable as they are) ----------
+    import models.canny_edge_detector as ced
+    import utils.label_conversions as lc
+    gp = torch.Generator().manual_seed(11)
+    base = torch.rand(2, 3, 12, 12, generator=gp)
+    img = torch.nn.functional.interpolate(base, size=(48, 48), mode='bilinear', align_corners=False)      # smooth blobs with real edges
+    img[:, :, 10:30, 14:20] += 0.8                                                                         # a hard-edged rectangle
+    img = img.contiguous()
+    outs = {}
+    for nms, thr in ((True, 0.0), (True, 0.2), (False, 0.1)):
+        det = ced.CannyEdgeDetector(non_max_suppression=nms, gaussian_filter_std=1.0, gaussian_filter_size=5, threshold=thr)
+        with torch.no_grad():
+            o = det(img)
+        for k, v in o.items():
+            outs['canny_%d_%g_%s' % (int(nms), thr, k)] = v.numpy()
+    j2d = torch.rand(2, 17, 2, generator=gp) * 60 - 6
+    hm = lc.convert_2Djoints_to_gaussian_heatmaps_torch(j2d, 48, std=4.0)
+    np.savez_compressed(os.path.join(OUT, 'proxy_golden.npz'), img=img.numpy(), joints2D=j2d.numpy(), heatmaps=hm.numpy(), **outs)
     print('golden vectors written to', OUT)
 
 
