@@ -661,10 +661,10 @@ size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_b
 int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose, const float* betas,
                  int Mb, int M, float* verts, float* joints, void* workspace, size_t workspace_bytes, int impl,
                  void* stream) {
+    if (M == 0) return HMF_OK;                                       // empty batch: nothing to do, pointers may be null
     if (!h || !global_orient || !body_pose || !betas || !verts) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: null argument");
     if (M < 0 || (Mb != 1 && Mb != M) || (Mg != 1 && Mg != M))
         return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: M=%d Mb=%d Mg=%d (Mb, Mg must be 1 or M)", M, Mb, Mg);
-    if (M == 0) return HMF_OK;
     if (!workspace || workspace_bytes < hmf_smpl_lbs_workspace_bytes(M))
         return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
     hipStream_t st = (hipStream_t)stream;
@@ -714,9 +714,9 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
 }
 
 int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts, float* joints, void* stream) {
+    if (M == 0) return HMF_OK;
     if (!h || !betas || !verts) return fail(HMF_ERR_INVALID, "hmf_smpl_tpose: null argument");
     if (M < 0) return fail(HMF_ERR_INVALID, "hmf_smpl_tpose: M=%d", M);
-    if (M == 0) return HMF_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((kV * 3 / 2 + 255) / 256, (M + kTpRows - 1) / kTpRows);
     {

@@ -225,6 +225,9 @@ class SMPL(nn.Module):
             be = self._f32c(betas)
             verts = torch.empty(M, NUM_VERTS, 3, dtype=torch.float32, device=dev)
             joints = torch.empty(M, 90, 3, dtype=torch.float32, device=dev)
+            if M == 0:
+                return SMPLOutput(vertices=verts, joints=joints, full_pose=None, betas=betas, global_orient=global_orient,
+                                  body_pose=body_pose)
             ws = self._workspace(dev, M)
             _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
                                         _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(), int(impl),

@@ -215,3 +215,43 @@ def test_predict_driver_plumbing_config0(tmp_path):
         out = model(None, input_feats=ref['input_feats'].cuda(), num_samples=N, noise=_cuda(noise), use_shape_mode_for_samples=True)
     for k in ('pose_axisangle_point_est', 'pose_rotmats_point_est', 'shape_mode', 'glob_rotmat', 'cam_wp', 'pose_rotmats_samples'):
         assert (out[k].cpu() - ref[k]).abs().max() < 1e-4 * max(1.0, ref[k].abs().max().item()), k
+
+
+def test_non_default_beta_count_and_single_row():
+    """NUM_SMPL_BETAS other than 10 changes the isgc layer width and the rank-nb MFMA update; B = N = 1 is one live row in a tile."""
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_SMPL_BETAS = 13
+    m = init_model_for_tests(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=8).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to('cuda:0')
+    for B, N in ((1, 1), (2, 33)):
+        g = torch.Generator().manual_seed(B + N)
+        feats = torch.randn(B, 512, generator=g) * 0.5
+        noise = {'shape': torch.randn(N, B, 13, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+        ref = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input_feats=feats, num_samples=N, noise=noise)
+        with torch.no_grad():
+            out = m(None, input_feats=feats.cuda(), num_samples=N, noise=_cuda(noise))
+        assert out['shape_samples'].shape == (B, N, 13)
+        assert (out['shape_samples'].cpu() - ref['shape_samples']).abs().max() < 1e-5
+        assert (out['pose_rotmats_samples'].cpu() - ref['pose_rotmats_samples']).abs().max() < RTOL
+        assert (out['pose_rotmats_point_est'].cpu() - ref['pose_rotmats_point_est']).abs().max() < RTOL
+
+
+def test_log_prob_at_training_batch_size_72():
+    """TRAIN.BATCH_SIZE = 72 (configs/humaniflow_config.py:40): all 23 x 72 log-densities in one launch, finite, and
+    consistent with sampling: samples drawn from the flow score higher on average under their own context than under a permuted one."""
+    model, sd, cfg = _model(18, seed=9)
+    B = 72
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    with torch.no_grad():
+        s = model(None, input_feats=feats.cuda(), num_samples=1, noise=_cuda(_noise(B, 1, seed=4)))
+        R = s['pose_rotmats_samples'][:, 0]                                           # (B,23,3,3) one sample per image
+        out = model(None, input_feats=feats.cuda(), compute_for_loglik=True, shape_for_loglik=s['shape_samples'][:, 0],
+                    pose_R_for_loglik=R, glob_R_for_loglik=s['glob_rotmat'], compute_point_est=False)
+        lp = model.log_prob_all_parts(out['flow_context_for_loglik'], R)
+        lp_perm = model.log_prob_all_parts(out['flow_context_for_loglik'].roll(1, 0), R)
+    assert lp.shape == (B, 23) and torch.isfinite(lp).all() and torch.isfinite(lp_perm).all()
+    assert lp.mean().item() > lp_perm.mean().item()
+    ref = omodel.log_prob_SO3(sd, oracle_cfg_from(cfg.MODEL), out['flow_context_for_loglik'][:5].cpu(), R[:5].cpu().double())
+    assert (lp[:5].cpu() - ref).abs().max() < 1e-3

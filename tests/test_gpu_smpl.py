@@ -114,3 +114,32 @@ def test_vertex_variance(smpl):
 def test_empty_and_bad_shapes(smpl):
     with pytest.raises(ValueError):
         smpl(body_pose=torch.zeros(3, 69).cuda(), global_orient=torch.zeros(2, 3).cuda(), betas=torch.zeros(3, 10).cuda())
+
+
+def test_empty_batch_and_other_beta_counts():
+    s = H.SMPL(model_data=H.synthetic_smpl_model(seed=3, num_betas=16), num_betas=16, create_transl=False).to('cuda:0')
+    out = s(body_pose=torch.zeros(0, 23, 3, 3).cuda(), global_orient=torch.zeros(0, 1, 3, 3).cuda(), betas=torch.zeros(0, 16).cuda(),
+            pose2rot=False)
+    assert out.vertices.shape == (0, 6890, 3) and out.joints.shape == (0, 90, 3)
+    for nb in (16, 3):
+        s = H.SMPL(model_data=H.synthetic_smpl_model(seed=nb, num_betas=nb), num_betas=nb, create_transl=False).to('cuda:0')
+        g = torch.Generator().manual_seed(nb)
+        R = random_rotmats(37 * 24, 0.5, seed=nb).view(37, 24, 3, 3)
+        betas = torch.randn(37, nb, generator=g)
+        out = s(body_pose=R[:, 1:].cuda(), global_orient=R[:, :1].cuda(), betas=betas.cuda(), pose2rot=False)
+        v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(s.model_dict()), betas, R[:, 1:], R[:, :1], pose2rot=False)
+        assert (out.vertices.cpu() - v_ref).abs().max() < TOL and (out.joints.cpu() - j_ref).abs().max() < TOL
+        assert (s.tpose(betas.cuda()).cpu() - (s.model_dict()['v_template'] + osmpl.blend_shapes(betas, s.model_dict()['shapedirs']))).abs().max() < 1e-5
+
+
+def test_config3_size_B64_N100_properties(smpl):
+    """BASELINE configs[2] size (M = 6400 rows, 530 MB of vertices): identity-pose and MFMA-vs-scalar agreement."""
+    M = 6400
+    g = torch.Generator().manual_seed(16)
+    betas = (torch.randn(M, 10, generator=g) * 1.25).cuda()
+    R = random_rotmats(M * 24, 0.6, seed=17).view(M, 24, 3, 3).cuda()
+    a = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False, impl=0)
+    assert torch.isfinite(a.vertices).all()
+    sel = torch.tensor([0, 63, 64, 3199, 3200, 6336, 6399])
+    b = smpl(body_pose=R[sel, 1:], global_orient=R[sel, :1], betas=betas[sel], pose2rot=False, impl=1)
+    assert (a.vertices[sel] - b.vertices).abs().max().item() < 5e-6 and (a.joints[sel] - b.joints).abs().max().item() < 5e-6
