@@ -18,7 +18,10 @@ H36M_TO_J17 = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10, 0, 7, 9]
 H36M_TO_J14 = H36M_TO_J17[:14]
 
 METRICS = ['PVE', 'PVE-SC', 'PVE-PA', 'PVE-T', 'PVE-T-SC', 'MPJPE', 'MPJPE-SC', 'MPJPE-PA',
-           'PVE_samples_min', 'PVE-SC_samples_min', 'MPJPE_samples_min']
+           'PVE_samples_min', 'PVE-SC_samples_min', 'PVE-PA_samples_min', 'PVE-T_samples_min', 'PVE-T-SC_samples_min',
+           'MPJPE_samples_min', 'MPJPE-SC_samples_min', 'MPJPE-PA_samples_min',
+           'joints2D-L2E', 'joints2Dsamples-L2E', 'verts3D_sample_diversity', 'joints3D_sample_diversity']
+# not built: silhouette IOUs (need the pytorch3d renderer) and the input_joints2D / (in)visible-joint variants (need HRNet heat-maps)
 
 
 def procrustes_analysis_batch(S1, S2):
@@ -49,43 +52,111 @@ def scale_and_translation_transform_batch(P, T):
     return P_trans / P_scale * T_scale + T_mean
 
 
+def orthographic_project_torch(points3D, cam_params):
+    """utils/cam_utils.py:9-17: s * (xy + t)."""
+    return cam_params[:, None, [0]] * (points3D[:, :, :2] + cam_params[:, None, 1:])
+
+
+def undo_keypoint_normalisation(normalised_keypoints, img_wh):
+    """utils/joints2d_utils.py:5-10."""
+    return (normalised_keypoints + 1) * (img_wh / 2.0)
+
+
+def flip_about_x(points):
+    """aa_rotate_translate_points_pytorch3d(points, axes=[1,0,0], angles=pi, translations=0) (utils/rigid_transform_utils.py:67-83,
+    call sites evaluate_humaniflow.py:141-143,197-203): a 180-degree rotation about x, i.e. (x, -y, -z)."""
+    return points * points.new_tensor([1.0, -1.0, -1.0])
+
+
+def _pa_many(P, T):
+    sh = P.shape
+    return procrustes_analysis_batch(P.reshape(-1, *sh[-2:]), T.expand_as(P).reshape(-1, *sh[-2:])).reshape(sh)
+
+
 class EvalMetricsTracker:
-    """Running sums of metrics/eval_metrics_tracker.py:95-433 for the 3D metrics of the path, kept on the device in fp64."""
+    """Running sums of metrics/eval_metrics_tracker.py:95-433 for the metrics the path can feed, kept on the device in fp64.
+    Final metrics are ratios of sums (:437-494), in the reference's units (metres / pixels)."""
+
+    COUNTS = ['num_total_test_data', 'num_vis_joints2D', 'num_vis_joints2Dsamples']
 
     def __init__(self, device, metrics=METRICS):
         self.metrics = list(metrics)
-        self.sums = torch.zeros(len(self.metrics) + 1, dtype=torch.float64, device=device)      # [..., num_total_test_data]
+        self.slots = self.metrics + self.COUNTS
+        self.sums = torch.zeros(len(self.slots), dtype=torch.float64, device=device)
         self.per_frame = {m: [] for m in self.metrics}
 
-    def _add(self, name, err):               # err (B, P) per-point L2 errors
+    def _acc(self, name, value):
+        self.sums[self.slots.index(name)] += value
+
+    def _add(self, name, err, frame=None):               # err (B, ...) per-point errors
         if name in self.metrics:
-            self.sums[self.metrics.index(name)] += err.double().sum()
-            self.per_frame[name].append(err.mean(dim=-1))
+            self._acc(name, err.double().sum())
+            self.per_frame[name].append(err.flatten(1).mean(dim=-1) if frame is None else frame)
 
     def update_per_batch(self, pred, target):
-        """pred: verts3D (B,V,3), tpose_verts3D, joints3D (B,14,3), optional verts3D_samples (B,N,V,3), joints3D_samples (B,N,14,3);
-        target: verts3D, tpose_verts3D, joints3D."""
-        B = pred['verts3D'].shape[0]
-        self.sums[-1] += B
+        """pred: verts3D (B,V,3), tpose_verts3D, joints3D (B,14,3) [+ joints2D (B,17,2)] and optionally verts3D_samples (B,N,V,3),
+        tpose_verts3D_samples, joints3D_samples (B,N,14,3), joints2Dsamples (B,N,17,2), joints3D_coco_samples (B,N,17,3);
+        target: verts3D, tpose_verts3D, joints3D [+ joints2D, joints2D_vis]."""
+        B, self.num_verts = pred['verts3D'].shape[:2]
+        self._acc('num_total_test_data', B)
         nrm = lambda a, b: torch.linalg.norm(a - b, dim=-1)
-        self._add('PVE', nrm(pred['verts3D'], target['verts3D']))
-        self._add('PVE-SC', nrm(scale_and_translation_transform_batch(pred['verts3D'], target['verts3D']), target['verts3D']))
-        self._add('PVE-PA', nrm(procrustes_analysis_batch(pred['verts3D'], target['verts3D']), target['verts3D']))
-        self._add('PVE-T', nrm(pred['tpose_verts3D'], target['tpose_verts3D']))
-        self._add('PVE-T-SC', nrm(scale_and_translation_transform_batch(pred['tpose_verts3D'], target['tpose_verts3D']),
-                                  target['tpose_verts3D']))
-        self._add('MPJPE', nrm(pred['joints3D'], target['joints3D']))
-        self._add('MPJPE-SC', nrm(scale_and_translation_transform_batch(pred['joints3D'], target['joints3D']), target['joints3D']))
-        self._add('MPJPE-PA', nrm(procrustes_analysis_batch(pred['joints3D'], target['joints3D']), target['joints3D']))
+        sc = scale_and_translation_transform_batch
+        tv, tt, tj = target['verts3D'], target['tpose_verts3D'], target['joints3D']
+        self._add('PVE', nrm(pred['verts3D'], tv))
+        self._add('PVE-SC', nrm(sc(pred['verts3D'], tv), tv))
+        self._add('PVE-PA', nrm(procrustes_analysis_batch(pred['verts3D'], tv), tv))
+        self._add('PVE-T', nrm(pred['tpose_verts3D'], tt))
+        self._add('PVE-T-SC', nrm(sc(pred['tpose_verts3D'], tt), tt))
+        self._add('MPJPE', nrm(pred['joints3D'], tj))
+        self._add('MPJPE-SC', nrm(sc(pred['joints3D'], tj), tj))
+        self._add('MPJPE-PA', nrm(procrustes_analysis_batch(pred['joints3D'], tj), tj))
+        ar = torch.arange(B, device=self.sums.device)
+
+        def sample_min(name, e):                         # e (B, N, P): error of the sample with the smallest mean error
+            self._add(name, e[ar, e.mean(-1).argmin(-1)])
         if 'verts3D_samples' in pred:
-            ar = torch.arange(B, device=self.sums.device)
-            tv = target['verts3D'][:, None]
-            e = nrm(pred['verts3D_samples'], tv)                                                     # (B, N, V)
-            self._add('PVE_samples_min', e[ar, e.mean(-1).argmin(-1)])
-            e = nrm(scale_and_translation_transform_batch(pred['verts3D_samples'], tv.expand_as(pred['verts3D_samples'])), tv)
-            self._add('PVE-SC_samples_min', e[ar, e.mean(-1).argmin(-1)])
-            e = nrm(pred['joints3D_samples'], target['joints3D'][:, None])
-            self._add('MPJPE_samples_min', e[ar, e.mean(-1).argmin(-1)])
+            vs, js = pred['verts3D_samples'], pred['joints3D_samples']
+            sample_min('PVE_samples_min', nrm(vs, tv[:, None]))
+            sample_min('PVE-SC_samples_min', nrm(sc(vs, tv[:, None].expand_as(vs)), tv[:, None]))
+            if 'PVE-PA_samples_min' in self.metrics:
+                sample_min('PVE-PA_samples_min', nrm(_pa_many(vs, tv[:, None]), tv[:, None]))
+            if 'tpose_verts3D_samples' in pred:
+                ts = pred['tpose_verts3D_samples']
+                sample_min('PVE-T_samples_min', nrm(ts, tt[:, None]))
+                sample_min('PVE-T-SC_samples_min', nrm(sc(ts, tt[:, None].expand_as(ts)), tt[:, None]))
+            sample_min('MPJPE_samples_min', nrm(js, tj[:, None]))
+            sample_min('MPJPE-SC_samples_min', nrm(sc(js, tj[:, None].expand_as(js)), tj[:, None]))
+            sample_min('MPJPE-PA_samples_min', nrm(_pa_many(js, tj[:, None]), tj[:, None]))
+            d = torch.linalg.norm(vs - vs.mean(dim=1, keepdim=True), dim=-1)                      # (B, N, V)
+            self._add('verts3D_sample_diversity', d, d.mean(dim=(1, 2)))
+            self.num_samples = vs.shape[1]
+        if 'joints3D_coco_samples' in pred:
+            jc = pred['joints3D_coco_samples']
+            d = torch.linalg.norm(jc - jc.mean(dim=1, keepdim=True), dim=-1)
+            self._add('joints3D_sample_diversity', d, d.mean(dim=(1, 2)))
+        if 'joints2D' in pred and 'joints2D' in target and 'joints2D-L2E' in self.metrics:
+            e = nrm(pred['joints2D'], target['joints2D'])                                         # (B, 17)
+            if 'joints2D_vis' in target:
+                vis = target['joints2D_vis'].to(e.dtype)
+                e = e * vis
+                self._acc('num_vis_joints2D', vis.double().sum())
+                frame = e.sum(-1) / vis.sum(-1)
+            else:
+                self._acc('num_vis_joints2D', e.numel())
+                frame = e.mean(-1)
+            self._add('joints2D-L2E', e, frame)
+        if 'joints2Dsamples' in pred and 'joints2D' in target and 'joints2Dsamples-L2E' in self.metrics:
+            ps = pred['joints2Dsamples']
+            e = nrm(ps, target['joints2D'][:, None])                                              # (B, N, 17)
+            if 'joints2D_vis' in target:
+                vis = target['joints2D_vis'].to(e.dtype)
+                e = e * vis[:, None]
+                self._acc('num_vis_joints2Dsamples', vis.double().sum() * ps.shape[1])
+                frame = e.sum(dim=(1, 2)) / (vis.sum(-1) * ps.shape[1])
+            else:
+                self._acc('num_vis_joints2Dsamples', e.numel())
+                frame = e.mean(dim=(1, 2))
+            self._add('joints2Dsamples-L2E', e, frame)
 
     def reduce(self, dist=None):
         """The ONE exchange step: all-reduce(SUM) of the packed sums; all-gather of per-frame arrays (padded to equal length)."""
@@ -94,11 +165,13 @@ class EvalMetricsTracker:
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM)
             W = dist.get_world_size()
-            n_local = torch.tensor([len(next(iter(frames.values())))], device=sums.device)
+            n_local = torch.tensor([max(len(v) for v in frames.values())], device=sums.device)
             counts = [torch.zeros_like(n_local) for _ in range(W)]
             dist.all_gather(counts, n_local)
             nmax = int(max(c.item() for c in counts))
             for m in list(frames):
+                if len(frames[m]) == 0:
+                    continue
                 pad = torch.zeros(nmax, dtype=frames[m].dtype, device=sums.device)
                 pad[:len(frames[m])] = frames[m]
                 got = [torch.zeros_like(pad) for _ in range(W)]
@@ -106,14 +179,27 @@ class EvalMetricsTracker:
                 frames[m] = torch.cat([g[:int(c.item())] for g, c in zip(got, counts)])
         return sums, frames
 
-    def compute_final_metrics(self, dist=None, num_verts=6890, num_joints=14):
-        """metrics/eval_metrics_tracker.py:437-494: ratios of sums, in millimetres."""
+    def compute_final_metrics(self, dist=None, num_verts=None, num_joints=14, num_samples=None):
+        """metrics/eval_metrics_tracker.py:437-494: ratios of sums, in the reference's units (metres, pixels)."""
         sums, frames = self.reduce(dist)
-        n = sums[-1].item()
+        get = lambda k: sums[self.slots.index(k)].item()
+        n = get('num_total_test_data')
+        ns = num_samples if num_samples is not None else getattr(self, 'num_samples', 1)
+        num_verts = num_verts if num_verts is not None else getattr(self, 'num_verts', 6890)      # 6890 for every SMPL model
         out = {}
-        for i, m in enumerate(self.metrics):
-            pts = num_joints if m.startswith('MPJPE') else num_verts
-            out[m] = sums[i].item() / (n * pts) * 1000.0
+        for m in self.metrics:
+            if not frames[m].numel():
+                continue
+            if m == 'joints2D-L2E':
+                out[m] = get(m) / get('num_vis_joints2D')
+            elif m == 'joints2Dsamples-L2E':
+                out[m] = get(m) / get('num_vis_joints2Dsamples')
+            elif m == 'verts3D_sample_diversity':
+                out[m] = get(m) / (n * ns * num_verts)
+            elif m == 'joints3D_sample_diversity':
+                out[m] = get(m) / (n * ns * 17)
+            else:
+                out[m] = get(m) / (n * (num_joints if m.startswith('MPJPE') else num_verts))
         out['num_total_test_data'] = int(n)
         return out, frames
 
@@ -134,14 +220,16 @@ class SyntheticEvalSet:
 
     def batch(self, indices, device):
         from .synthetic import synthetic_proxy_input
-        xs, poses, shapes = [], [], []
+        xs, poses, shapes, j2d, vis = [], [], [], [], []
         for i in indices:
             g = torch.Generator().manual_seed(self.seed * 1000003 + i)
             xs.append(synthetic_proxy_input(1, self.size, seed=self.seed * 1000003 + i))
             poses.append(torch.randn(72, generator=g) * 0.3)
             shapes.append(torch.randn(10, generator=g) * 1.25)
+            j2d.append(torch.rand(17, 2, generator=g) * self.size)
+            vis.append(torch.rand(17, generator=g) > 0.2)
         return {'input': torch.cat(xs).to(device), 'pose': torch.stack(poses).to(device), 'shape': torch.stack(shapes).to(device),
-                'index': torch.tensor(indices)}
+                'joints2D': torch.stack(j2d).to(device), 'joints2D_visib': torch.stack(vis).to(device), 'index': torch.tensor(indices)}
 
 
 @torch.no_grad()
@@ -151,8 +239,10 @@ def predict_batch(model, smpl, batch, num_samples, noise=None):
     pred = model(batch['input'], num_samples=N, noise=noise)
     g = pred['glob_rotmat']
     pe = smpl(body_pose=pred['pose_rotmats_point_est'], global_orient=g[:, None], betas=pred['shape_mode'], pose2rot=False)
+    img_wh = batch['input'].shape[-1]
+    proj = lambda j3d, cam: undo_keypoint_normalisation(orthographic_project_torch(flip_about_x(j3d), cam), img_wh)     # :138-143
     out = {'verts3D': pe.vertices, 'joints3D': pe.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14],
-           'tpose_verts3D': smpl.tpose(pred['shape_mode'])}
+           'tpose_verts3D': smpl.tpose(pred['shape_mode']), 'joints2D': proj(pe.joints[:, ALL_JOINTS_TO_COCO_MAP], pred['cam_wp'])}
     if N > 0:
         B = g.shape[0]
         sa = smpl(body_pose=pred['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
@@ -160,6 +250,10 @@ def predict_batch(model, smpl, batch, num_samples, noise=None):
                   betas=pred['shape_samples'].reshape(-1, pred['shape_samples'].shape[-1]), pose2rot=False)
         out['verts3D_samples'] = sa.vertices.reshape(B, N, -1, 3)
         out['joints3D_samples'] = sa.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14].reshape(B, N, 14, 3)
+        out['joints3D_coco_samples'] = sa.joints[:, ALL_JOINTS_TO_COCO_MAP].reshape(B, N, 17, 3)                            # :180-183
+        out['tpose_verts3D_samples'] = smpl.tpose(pred['shape_samples'].reshape(B * N, -1)).reshape(B, N, -1, 3)             # :186-192
+        cam_s = pred['cam_wp'][:, None].expand(-1, N, -1).reshape(B * N, 3)
+        out['joints2Dsamples'] = proj(sa.joints[:, ALL_JOINTS_TO_COCO_MAP], cam_s).reshape(B, N, 17, 2)                      # :197-206
     return out
 
 
@@ -167,8 +261,13 @@ def predict_batch(model, smpl, batch, num_samples, noise=None):
 def target_batch(smpl, batch):
     """evaluate/evaluate_humaniflow.py:83-110 (single body model: the synthetic set has no gender split)."""
     t = smpl(body_pose=batch['pose'][:, 3:], global_orient=batch['pose'][:, :3], betas=batch['shape'])
-    return {'verts3D': t.vertices, 'joints3D': t.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14],
-            'tpose_verts3D': smpl.tpose(batch['shape'])}
+    out = {'verts3D': t.vertices, 'joints3D': t.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14],
+           'tpose_verts3D': smpl.tpose(batch['shape'])}
+    if 'joints2D' in batch:
+        out['joints2D'] = batch['joints2D']
+        if 'joints2D_visib' in batch:
+            out['joints2D_vis'] = batch['joints2D_visib']
+    return out
 
 
 def evaluate_humaniflow(dataset, batch_size, device, predict_fn, target_fn, dist=None, rank=0, world_size=1):

@@ -135,8 +135,49 @@ def main():
     rng = np.random.RandomState(3)
     P = rng.randn(6, 50, 3)
     T = P @ np.linalg.qr(rng.randn(3, 3))[0] * 1.3 + rng.randn(6, 1, 3) * 0.2 + rng.randn(6, 50, 3) * 0.05
+    # the reference's EvalMetricsTracker itself on two seeded batches (hard-codes 6890 vertices / 14 joints / 17 COCO joints)
+    import io, contextlib
+    import metrics.eval_metrics_tracker as emt
+    names = ['PVE', 'PVE-SC', 'PVE-PA', 'PVE-T', 'PVE-T-SC', 'MPJPE', 'MPJPE-SC', 'MPJPE-PA', 'PVE_samples_min', 'PVE-SC_samples_min',
+             'PVE-PA_samples_min', 'PVE-T_samples_min', 'PVE-T-SC_samples_min', 'MPJPE_samples_min', 'MPJPE-SC_samples_min',
+             'MPJPE-PA_samples_min', 'joints2D-L2E', 'joints2Dsamples-L2E', 'verts3D_sample_diversity', 'joints3D_sample_diversity']
+    NS = 3
+    batches = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        trk = emt.EvalMetricsTracker(names, num_samples_for_prob_metrics=NS)
+        trk.initialise_metric_sums()
+        trk.initialise_per_frame_metric_lists()
+        for bsz in (2, 1):
+            tv = rng.randn(bsz, 431, 3) * 0.3
+            pred = {'verts3D': tv + rng.randn(bsz, 431, 3) * 0.02, 'tpose_verts3D': rng.randn(bsz, 431, 3) * 0.3,
+                    'joints3D': rng.randn(bsz, 14, 3) * 0.3, 'joints2D': rng.rand(bsz, 17, 2) * 256,
+                    'verts3D_samples': tv[:, None] + rng.randn(bsz, NS, 431, 3) * 0.03, 'tpose_verts3D_samples': rng.randn(bsz, NS, 431, 3) * 0.3,
+                    'joints3D_samples': rng.randn(bsz, NS, 14, 3) * 0.3, 'joints2Dsamples': rng.rand(bsz, NS, 17, 2) * 256,
+                    'joints3D_coco_samples': rng.randn(bsz, NS, 17, 3) * 0.3}
+            targ = {'verts3D': tv, 'tpose_verts3D': pred['tpose_verts3D'] + rng.randn(bsz, 431, 3) * 0.01, 'joints3D': pred['joints3D'] + rng.randn(bsz, 14, 3) * 0.02,
+                    'joints2D': pred['joints2D'] + rng.randn(bsz, 17, 2) * 3, 'joints2D_vis': (rng.rand(bsz, 17) > 0.3)}
+            pred = {k: v.astype(np.float32).astype(np.float64) for k, v in pred.items()}       # the fixture stores fp32
+            targ = {k: (v.astype(np.float32).astype(np.float64) if v.dtype != bool else v) for k, v in targ.items()}
+            trk.update_per_batch(pred, targ, bsz)
+            batches.append((pred, targ))
+        trk.compute_final_metrics()          # returns nothing (prints); the golden holds the tracker's own running sums
+        printed = None
+    tr = {}
+    for bi, (pred, targ) in enumerate(batches):
+        for k, v in pred.items():
+            tr['b%d_pred_%s' % (bi, k)] = v.astype(np.float32)
+        for k, v in targ.items():
+            tr['b%d_targ_%s' % (bi, k)] = v.astype(np.float32) if v.dtype != bool else v
+    tr['final_names'] = np.array(names)
+    tr['sum_values'] = np.array([float(trk.metric_sums[k]) for k in names])
+    tr['num_total_test_data'] = np.array(trk.num_total_test_data)
+    tr['num_vis_joints2D'] = np.array(float(trk.metric_sums['num_vis_joints2D']))
+    tr['num_vis_joints2Dsamples'] = np.array(float(trk.metric_sums['num_vis_joints2Dsamples']))
+    for k in names:
+        tr['frames_' + k] = np.concatenate(trk.per_frame_metrics[k])
+    np.savez_compressed(os.path.join(OUT, 'tracker_golden.npz'), **tr)
     np.savez_compressed(os.path.join(OUT, 'metrics_golden.npz'), P=P, T=T, pa=eu.procrustes_analysis_batch(P, T),
-                        sc=eu.scale_and_translation_transform_batch(P, T))
+                        sc=eu.scale_and_translation_transform_batch(P, T), cam_pts=rng.randn(4, 17, 3), cam=rng.randn(4, 3))
     # ---------------- proxy-representation front end (Canny + heat-maps; both importable as they are) ----------
     import models.canny_edge_detector as ced
     import utils.label_conversions as lc

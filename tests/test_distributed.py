@@ -21,6 +21,46 @@ def test_metric_helpers_match_reference_numpy():
     assert ev.ALL_JOINTS_TO_H36M_MAP == list(range(73, 90)) and len(ev.H36M_TO_J14) == 14 and len(ev.ALL_JOINTS_TO_COCO_MAP) == 17
 
 
+def test_projection_helpers():
+    z = np.load(os.path.join(GOLDEN, 'metrics_golden.npz'))
+    pts, cam = torch.from_numpy(z['cam_pts']), torch.from_numpy(z['cam'])
+    p2 = ev.orthographic_project_torch(pts, cam)
+    assert torch.allclose(p2, cam[:, None, :1] * (pts[..., :2] + cam[:, None, 1:]))
+    assert torch.allclose(ev.undo_keypoint_normalisation(torch.tensor([-1.0, 0.0, 1.0]), 256), torch.tensor([0.0, 128.0, 256.0]))
+    # 180 degrees about x is (x, -y, -z): the axis-angle rotation the reference applies before projecting
+    from oracle import so3
+    R = so3.so3_exp(torch.tensor([[np.pi, 0.0, 0.0]], dtype=torch.float64))[0]
+    assert torch.allclose(ev.flip_about_x(pts), pts @ R.T, atol=1e-12)
+
+
+def test_tracker_matches_reference_tracker_sums():
+    """The reference's own EvalMetricsTracker (numpy) was run on two seeded batches (tests/golden/make_golden.py); the torch tracker
+    must reproduce every running sum, every per-frame array and therefore every final ratio."""
+    z = np.load(os.path.join(GOLDEN, 'tracker_golden.npz'))
+    names = [str(k) for k in z['final_names']]
+    trk = ev.EvalMetricsTracker(torch.device('cpu'), names)
+    for bi in range(2):
+        pred = {k[len('b%d_pred_' % bi):]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith('b%d_pred_' % bi)}
+        targ = {k[len('b%d_targ_' % bi):]: torch.from_numpy(z[k]) for k in z.files if k.startswith('b%d_targ_' % bi)}
+        targ = {k: (v.double() if v.dtype != torch.bool else v) for k, v in targ.items()}
+        trk.update_per_batch(pred, targ)
+    sums, frames = trk.reduce()
+    for i, k in enumerate(names):
+        assert abs(sums[i].item() - z['sum_values'][i]) < 1e-7 * max(1.0, abs(z['sum_values'][i])), (k, sums[i].item(), z['sum_values'][i])
+        assert np.allclose(frames[k].numpy(), z['frames_' + k], rtol=1e-7, atol=1e-9), k
+    assert sums[trk.slots.index('num_vis_joints2D')].item() == z['num_vis_joints2D']
+    assert sums[trk.slots.index('num_vis_joints2Dsamples')].item() == z['num_vis_joints2Dsamples']
+    final, _ = trk.compute_final_metrics(num_verts=6890)
+    n = int(z['num_total_test_data'])
+    assert final['num_total_test_data'] == n
+    ref = dict(zip(names, z['sum_values']))
+    assert abs(final['PVE'] - ref['PVE'] / (n * 6890)) < 1e-12 and abs(final['MPJPE-PA_samples_min'] - ref['MPJPE-PA_samples_min'] / (n * 14)) < 1e-12
+    assert abs(final['joints2D-L2E'] - ref['joints2D-L2E'] / z['num_vis_joints2D']) < 1e-9
+    assert abs(final['joints2Dsamples-L2E'] - ref['joints2Dsamples-L2E'] / z['num_vis_joints2Dsamples']) < 1e-9
+    assert abs(final['verts3D_sample_diversity'] - ref['verts3D_sample_diversity'] / (n * 3 * 6890)) < 1e-12
+    assert abs(final['joints3D_sample_diversity'] - ref['joints3D_sample_diversity'] / (n * 3 * 17)) < 1e-12
+
+
 def test_sharding_covers_every_item_once():
     for n, w in [(10, 1), (10, 2), (7, 4), (64, 8), (3, 8)]:
         got = sorted(i for r in range(w) for i in ev.shard_indices(n, r, w))
@@ -45,10 +85,15 @@ def _fake(batch, salt, samples):
     for i in batch['index'].tolist():
         g = torch.Generator().manual_seed(1000 * salt + i)
         d = {'verts3D': torch.randn(40, 3, generator=g), 'tpose_verts3D': torch.randn(40, 3, generator=g),
-             'joints3D': torch.randn(14, 3, generator=g)}
+             'joints3D': torch.randn(14, 3, generator=g), 'joints2D': torch.rand(17, 2, generator=g) * 256}
         if samples:
             d['verts3D_samples'] = torch.randn(5, 40, 3, generator=g)
+            d['tpose_verts3D_samples'] = torch.randn(5, 40, 3, generator=g)
             d['joints3D_samples'] = torch.randn(5, 14, 3, generator=g)
+            d['joints3D_coco_samples'] = torch.randn(5, 17, 3, generator=g)
+            d['joints2Dsamples'] = torch.rand(5, 17, 2, generator=g) * 256
+        else:
+            d['joints2D_vis'] = torch.rand(17, generator=g) > 0.3
         outs.append(d)
     return {k: torch.stack([o[k] for o in outs]) for k in outs[0]}
 
