@@ -1,0 +1,208 @@
+// Implicit-GEMM NHWC fp32 convolution with the folded-BatchNorm epilogue fused in, for the ResNet encoder (row a1).
+//
+//   Y[m][n] = relu?( sum_{kh,kw,c} X[b][oh*s+kh-p][ow*s+kw-p][c] * Wt[n][kh][kw][c]  + bias[n] (+ R[m][n]) ),   m = (b, oh, ow)
+//
+// i.e. the GEMM  (M = B*OH*OW) x (K = KS*KS*Cin) x (N = Cout)  whose A operand is gathered from the NHWC activation tensor on the
+// fly (zero rows where the tap falls into the padding) and whose B operand is the weight tensor in channels_last memory order
+// [Cout][KS][KS][Cin] (what torch's `.contiguous(memory_format=channels_last)` of a (Cout,Cin,KS,KS) weight already is).
+//
+// Tiling for CDNA4: a work-group of 4 waves (2x2) owns a BM x BN output tile; every wave owns (BM/2) x (BN/2) = TM x TN MFMA tiles of
+// v_mfma_f32_32x32x2_f32 (64-lane waves: pixels are the A rows, output channels the B columns, so lane l ends up holding channel
+// n0 + (l & 31) of 16 pixels per tile -> 128-byte coalesced row stores in NHWC).  K is walked in chunks of 32 channels of one filter
+// tap: the chunk's A (BM x 32) and B (BN x 32) panels are fetched global -> registers one chunk ahead (16 B per lane, 128 B runs),
+// written to a double-buffered LDS panel with a 36-float row stride (conflict-free for the 16-byte row-major writes AND for the
+// operand reads), and read back as ONE ds_read_b128 per lane per MFMA tile per 8 k (the k order inside a chunk is free as long as
+// A and B agree: lane (i, q) takes k = 8g + 4q + u for the u-th of four MFMAs).  One barrier per chunk.  The epilogue adds the
+// per-channel bias (the folded BN shift), the residual branch and the ReLU in registers: the activation tensor is written exactly
+// once and never re-read by an elementwise pass.
+//
+// Block -> tile map is XCD-aware: consecutive work-group ids round-robin over the 8 XCDs, so the ids of one XCD are remapped to a
+// CONTIGUOUS run of (m-tile, n-tile) pairs with n fastest: the N/BN blocks that share an activation panel run on the same L2.
+#include "hmf_common.h"
+
+namespace hmf {
+
+struct ConvArgs {
+    const float* x;      // [B][H][W][Cin]
+    const float* w;      // [Cout][KS][KS][Cin]
+    const float* bias;   // [Cout] or null
+    const float* res;    // [M][Cout] or null
+    float* y;            // [M][Cout]
+    int B, H, W, Cin, OH, OW, Cout, stride, pad, relu, M;
+};
+
+constexpr int kConvKC = 32;             // channels per k-chunk
+constexpr int kConvS = kConvKC + 4;     // LDS row stride in floats
+
+template <int BM, int BN, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_igemm(const ConvArgs a) {
+    constexpr int KC = kConvKC, S = kConvS;
+    constexpr int TM = BM / 64, TN = BN / 64;      // MFMA tiles per wave
+    constexpr int RA = BM / 32, RB = BN / 32;      // panel rows fetched per thread
+    __shared__ float sA[2][BM * S];
+    __shared__ float sB[2][BN * S];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lq = lane >> 5;
+
+    // ---- XCD-aware tile assignment ----
+    const int NT = a.Cout / BN, MT = (a.M + BM - 1) / BM, T = MT * NT;
+    int L = blockIdx.x;
+    if ((T & 7) == 0) L = (blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    const int m0 = (L / NT) * BM, n0 = (L % NT) * BN;
+
+    // ---- per-thread fetch coordinates ----
+    const int col4 = (tid & 7) * 4, rbase = tid >> 3;
+    int offA[RA], ih0[RA], iw0[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + rbase + 32 * i;
+        if (m < a.M) {
+            const int b = m / (a.OH * a.OW), r = m - b * a.OH * a.OW;
+            const int oh = r / a.OW, ow = r - oh * a.OW;
+            ih0[i] = oh * a.stride - a.pad;
+            iw0[i] = ow * a.stride - a.pad;
+            offA[i] = ((b * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin + col4;
+        } else {
+            ih0[i] = -(1 << 20);
+            iw0[i] = 0;
+            offA[i] = 0;
+        }
+    }
+    int offB[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) offB[i] = (n0 + rbase + 32 * i) * (KS * KS * a.Cin) + col4;
+
+    f32x4 pa[RA], pb[RB];
+    int kh = 0, kw = 0, c0 = 0;
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const bool ok = (KS == 1) ? (ih0[i] >= 0) : ((unsigned)(ih0[i] + kh) < (unsigned)a.H && (unsigned)(iw0[i] + kw) < (unsigned)a.W);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4*)(a.x + offA[i] + (kh * a.W + kw) * a.Cin + c0);
+            pa[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) pb[i] = *(const f32x4*)(a.w + offB[i] + (kh * KS + kw) * a.Cin + c0);
+        c0 += KC;
+        if (c0 == a.Cin) {
+            c0 = 0;
+            if (++kw == KS) { kw = 0; ++kh; }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *(f32x4*)&sA[buf][(rbase + 32 * i) * S + col4] = pa[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *(f32x4*)&sB[buf][(rbase + 32 * i) * S + col4] = pb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = KS * KS * (a.Cin / KC);
+    fetch();
+    stash(0);
+    __syncthreads();
+    const int rowA = (wm * (BM / 2) + li) * S + lq * 4, rowB = (wn * (BN / 2) + li) * S + lq * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch();
+#pragma unroll
+        for (int g = 0; g < KC / 8; ++g) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)&sA[buf][rowA + i * 32 * S + g * 8];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)&sB[buf][rowB + j * 32 * S + g * 8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][u], fb[j][u], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, + residual, ReLU, 128-byte row stores ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + li;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (a.res) v += a.res[(long long)m * a.Cout + n];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.y[(long long)m * a.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int KS>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+    const int T = ((a.M + BM - 1) / BM) * (a.Cout / BN);
+    ProfScope ps(8, a.M, st);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS>), dim3(T), dim3(256), 0, st, a);
+    return 0;
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+// tile: 0 = auto, else BM*1000 + BN (128128, 128064, 64128, 64064)
+extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int H, int W,
+                               int Cin, int Cout, int ks, int stride, int relu, int tile, void* stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: bad args");
+    if (ks != 1 && ks != 3) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: kernel size %d (1 and 3 are built)", ks);
+    if (stride != 1 && stride != 2) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: stride %d", stride);
+    if (Cin % kConvKC != 0 || Cout % 64 != 0) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: Cin=%d must be a multiple of 32 and Cout=%d of 64", Cin, Cout);
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: x and w must be 16-byte aligned");
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.pad = ks / 2; a.relu = relu;
+    a.OH = (H + 2 * a.pad - ks) / stride + 1;
+    a.OW = (W + 2 * a.pad - ks) / stride + 1;
+    const long long M = (long long)B * a.OH * a.OW;
+    if (M * (long long)Cout >= (1LL << 31) || (long long)B * H * W * Cin >= (1LL << 31))
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: tensor exceeds 2^31 elements");
+    a.M = (int)M;
+    if (tile == 0) {
+        // enough work-groups for two per CU (512 slots) with the largest tile that still gives them
+        const long long t128 = ((M + 127) / 128) * (Cout / 128);
+        if (Cout % 128 == 0 && t128 >= 512) tile = 128128;
+        else if (((M + 127) / 128) * (Cout / 64) >= 512) tile = 128064;
+        else tile = 64064;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define CONV_CASE(BM, BN)                                                    \
+    if (ks == 1) launch_conv<BM, BN, 1>(a, st); else launch_conv<BM, BN, 3>(a, st); \
+    break;
+    switch (tile) {
+        case 128128: if (Cout % 128) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: tile 128x128 needs Cout %% 128 == 0"); CONV_CASE(128, 128)
+        case 128064: CONV_CASE(128, 64)
+        case 64128: if (Cout % 128) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: tile 64x128 needs Cout %% 128 == 0"); CONV_CASE(64, 128)
+        case 64064: CONV_CASE(64, 64)
+        default: return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: unknown tile %d", tile);
+    }
+#undef CONV_CASE
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}

@@ -179,6 +179,15 @@ int hmf_proxy_rep(const float* img, const float* joints2D, const float* visib, i
 int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int C, int HW, int nhwc, int relu,
                  void* stream);
 
+/* Fused convolution of the encoder (models/resnet.py:24-31 conv3x3/conv1x1 + :72-76,111-127 BatchNorm/ReLU/residual of
+ * BasicBlock/Bottleneck.forward, with eval-mode BN folded into w and bias): NHWC fp32 implicit GEMM on the fp32 MFMA,
+ *   y = relu?(conv(x, w, stride, padding = ks/2) + bias (+ residual)).
+ * x (B,H,W,Cin), w (Cout,ks,ks,Cin) [= a channels_last (Cout,Cin,ks,ks) tensor], bias (Cout) or NULL, residual/y (B,OH,OW,Cout);
+ * ks in {1,3}, stride in {1,2}, Cin % 32 == 0, Cout % 64 == 0.  tile: 0 = pick by work-group count, else BM*1000+BN in
+ * {128128, 128064, 64128, 64064}.  Profiler tag 8. */
+int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int H, int W,
+                    int Cin, int Cout, int ks, int stride, int relu, int tile, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun) from the repo root: regenerates every file under profiles/ that bench.py's numbers are
+# checked against.  Usage: tools/profile_round.sh r01     -> writes gpurun_out/profiles/r01_*; copy those into profiles/.
+# Counter passes are separate runs with --kernel-trace only (no sys/hip/hsa traces), one counter per pass.
+set -u
+R=${1:-r01}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/profiles
+mkdir -p "$OUT"
+STEPS=20; WARM=6
+BENCH="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline"
+python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.log"
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH > "$OUT/${R}_bench_under_rocprof.json" 2>/tmp/kt.log
+DB=$(find /tmp/prof_kt -name '*.db' | head -1)
+python tools/rocpd_stats.py "$DB" 48 --steps $STEPS > "$OUT/${R}_kernel_stats.md"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $BENCH >/dev/null 2>/tmp/f.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $BENCH >/dev/null 2>/tmp/w.log
+python tools/pmc_summary.py "$(find /tmp/prof_f -name '*.db' | head -1)" "$(find /tmp/prof_w -name '*.db' | head -1)" > "$OUT/${R}_pmc.json"
+ls -la "$OUT"

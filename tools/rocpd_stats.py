@@ -1,19 +1,52 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace into the per-kernel stats table committed under profiles/.
 
-    python tools/rocpd_stats.py gpurun_out/prof_r01/r01_results.db > profiles/r01_kernel_stats.md
+    python tools/rocpd_stats.py <results.db> [rows] [--steps K]
+
+--steps K restricts the table to the bench's TIMED region: one hmf::k_isgc is launched per step, so the window opens at the end of
+the k_isgc that precedes the last K of them (= the last warm-up step's; with 2 streams the first timed step's encoder may already
+be running, i.e. the window holds K steps' worth of every kernel, shifted by at most one encoder) and closes at the last dispatch.
+MIOpen's find-time kernels (naive reference convolutions, candidates that lost) therefore stay out of the table.
 """
 import sqlite3
 import sys
 
-con = sqlite3.connect(sys.argv[1])
+args = sys.argv[1:]
+steps = None
+if '--steps' in args:
+    i = args.index('--steps')
+    steps = int(args[i + 1])
+    del args[i:i + 2]
+con = sqlite3.connect(args[0])
+where, note = '', 'whole process'
+if steps:
+    marks = con.execute("select end from kernels where name like '%hmf::k_isgc%' order by start").fetchall()
+    if len(marks) > steps:
+        t0 = marks[len(marks) - steps - 1][0]
+        where = ' where start >= %d' % t0
+        note = 'timed region: the last %d steps (window opens at the end of the last warm-up step\'s k_isgc)' % steps
 rows = con.execute("select name || case when name like '%hmf::%' then ' [grid ' || grid_x || ']' else '' end as nm, count(*), sum(duration), "
                    "avg(duration), min(duration), max(duration), max(vgpr_count), max(accum_vgpr_count), max(lds_size), max(scratch_size), "
-                   "max(grid_x), max(workgroup_x) from kernels group by nm order by sum(duration) desc").fetchall()
+                   "max(grid_x), max(workgroup_x) from kernels" + where + " group by nm order by sum(duration) desc").fetchall()
 total = sum(r[2] for r in rows)
+span = con.execute("select max(end) - min(start) from kernels" + where).fetchone()[0]
+print('scope: %s\n' % note)
 print('| kernel | calls | total ms | avg us | min us | max us | % | vgpr | agpr | lds B | scratch B | grid | wg |')
 print('|---|---|---|---|---|---|---|---|---|---|---|---|---|')
-for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
+for r in rows[:int(args[1]) if len(args) > 1 else 40]:
     name = r[0] if len(r[0]) < 110 else r[0][:70] + '...' + r[0][-36:]
     print('| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.1f | %d | %d | %d | %d | %d | %d |'
           % (name, r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total, r[6], r[7], r[8], r[9], r[10], r[11]))
-print('\ntotal kernel time: %.3f ms over %d dispatches' % (total / 1e6, sum(r[1] for r in rows)))
+print('\ntotal kernel time: %.3f ms over %d dispatches; wall span of the window %.3f ms' % (total / 1e6, sum(r[1] for r in rows), span / 1e6))
+if steps:
+    print('per step: %.3f ms of kernel time, %.3f ms of wall span' % (total / 1e6 / steps, span / 1e6 / steps))
+    groups = [('encoder convolutions (MIOpen: igemm / ck)', "(name like 'igemm%' or name like '%ck%tensor_operation%' or name like '%conv%')"),
+              ('encoder epilogues (hmf::k_bias_act)', "name like '%k_bias_act%'"),
+              ('flow (hmf::k_isgc, k_flow_*)', "(name like '%hmf::k_isgc%' or name like '%hmf::k_flow%')"),
+              ('SMPL (hmf::k_lbs_mfma, k_rigid_chain, k_joints, k_tpose)', "(name like '%hmf::k_lbs%' or name like '%hmf::k_rigid%' or name like '%hmf::k_joints%' or name like '%hmf::k_tpose%')")]
+    print('\n| stage | ms / step | % of kernel time |\n|---|---|---|')
+    acc = 0
+    for label, cond in groups:
+        v = con.execute("select coalesce(sum(duration), 0) from kernels" + where + " and " + cond).fetchone()[0]
+        acc += v
+        print('| %s | %.3f | %.1f |' % (label, v / 1e6 / steps, 100.0 * v / total))
+    print('| everything else (torch glue: max-pool, heads GEMMs, copies, RNG) | %.3f | %.1f |' % ((total - acc) / 1e6 / steps, 100.0 * (total - acc) / total))
