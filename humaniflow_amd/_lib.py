@@ -60,7 +60,11 @@ _SIGS = {
     'hmf_proxy_rep': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                 _VP, _VP, _VP, _VP, _VP]),
     'hmf_bias_act': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
-    'hmf_conv2d_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 10 + [_VP]),
+    'hmf_stem_packed_floats': (C.c_longlong, []),
+    'hmf_stem_pack_host': (C.c_int, [_VP, _VP]),
+    'hmf_stem_conv': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
+    'hmf_maxpool3x3s2_nhwc': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP]),
+    'hmf_conv2d_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
     'hmf_profile_enable': (C.c_int, [C.c_int]),
     'hmf_profile_collect': (C.c_int, [c_double_p, c_int_p, c_int_p, C.c_int]),
     'hmf_debug_set_timeline': (C.c_int, [_VP]),

@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int m0 = (L / NT) * BM, n0 = (L % NT) * BN;
 
     // ---- per-thread fetch coordinates ----
+    // Activation rows are fetched with raw buffer loads: a tap that falls into the zero padding (or a row beyond M) gets an
+    // out-of-range byte offset and the hardware returns zeros -- no branch, no select, loads of one chunk all in flight together.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.H * a.W * a.Cin * 4, 0x00020000);
+    constexpr int kOOB = (int)0x80000000;
     const int col4 = (tid & 7) * 4, rbase = tid >> 3;
     int offA[RA], ih0[RA], iw0[RA];
 #pragma unroll
@@ -63,29 +67,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             const int oh = r / a.OW, ow = r - oh * a.OW;
             ih0[i] = oh * a.stride - a.pad;
             iw0[i] = ow * a.stride - a.pad;
-            offA[i] = ((b * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin + col4;
+            offA[i] = (((b * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin + col4) * 4;
         } else {
             ih0[i] = -(1 << 20);
-            iw0[i] = 0;
-            offA[i] = 0;
+            iw0[i] = -(1 << 20);
+            offA[i] = kOOB;
         }
     }
-    int offB[RB];
+    const float* pB[RB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) offB[i] = (n0 + rbase + 32 * i) * (KS * KS * a.Cin) + col4;
+    for (int i = 0; i < RB; ++i) pB[i] = a.w + (long long)(n0 + rbase + 32 * i) * (KS * KS * a.Cin) + col4;
 
     f32x4 pa[RA], pb[RB];
     int kh = 0, kw = 0, c0 = 0;
     auto fetch = [&]() {
+        const int tapoff = ((kh * a.W + kw) * a.Cin + c0) * 4;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const bool ok = (KS == 1) ? (ih0[i] >= 0) : ((unsigned)(ih0[i] + kh) < (unsigned)a.H && (unsigned)(iw0[i] + kw) < (unsigned)a.W);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4*)(a.x + offA[i] + (kh * a.W + kw) * a.Cin + c0);
-            pa[i] = v;
+            int off = offA[i] + tapoff;
+            if (KS != 1) off = (((unsigned)(ih0[i] + kh) < (unsigned)a.H) & ((unsigned)(iw0[i] + kw) < (unsigned)a.W)) ? off : kOOB;
+            pa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
+        const int woff = (kh * KS + kw) * a.Cin + c0;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) pb[i] = *(const f32x4*)(a.w + offB[i] + (kh * KS + kw) * a.Cin + c0);
+        for (int i = 0; i < RB; ++i) pb[i] = *(const f32x4*)(pB[i] + woff);
         c0 += KC;
         if (c0 == a.Cin) {
             c0 = 0;
@@ -112,44 +117,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     stash(0);
     __syncthreads();
     const int rowA = (wm * (BM / 2) + li) * S + lq * 4, rowB = (wn * (BN / 2) + li) * S + lq * 4;
+    constexpr int G = KC / 8;
+    f32x4 fa[2][TM], fb[2][TN];
+    auto frag = [&](int buf, int g, int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *(const f32x4*)&sA[buf][rowA + i * 32 * S + g * 8];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *(const f32x4*)&sB[buf][rowB + j * 32 * S + g * 8];
+    };
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) fetch();
+        frag(buf, 0, 0);
 #pragma unroll
-        for (int g = 0; g < KC / 8; ++g) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)&sA[buf][rowA + i * 32 * S + g * 8];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)&sB[buf][rowB + j * 32 * S + g * 8];
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) frag(buf, g + 1, (g + 1) & 1);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][u], fb[j][u], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][u], fb[g & 1][j][u], acc[i][j], 0, 0, 0);
         }
         if (c + 1 < nchunks) stash(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: + bias, + residual, ReLU, 128-byte row stores ----
+    // ---- epilogue: + bias, + residual, ReLU, 128-byte row stores.  All residual loads of a tile column are issued before use. ----
+    const bool full = (m0 + BM <= a.M);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + li;
         const float bv = a.bias ? a.bias[n] : 0.f;
+        float rv[TM][16];
+        if (a.res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(mb + (r & 3) + 8 * (r >> 2), a.M - 1);
+                    rv[i][r] = a.res[(long long)m * a.Cout + n];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[i][r] = 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < a.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (a.res) v += a.res[(long long)m * a.Cout + n];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.y[(long long)m * a.Cout + n] = v;
-                }
+                float v = acc[i][j][r] + bv + rv[i][r];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (full || m < a.M) a.y[(long long)m * a.Cout + n] = v;
             }
         }
     }
@@ -181,15 +207,13 @@ extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias
     a.OH = (H + 2 * a.pad - ks) / stride + 1;
     a.OW = (W + 2 * a.pad - ks) / stride + 1;
     const long long M = (long long)B * a.OH * a.OW;
-    if (M * (long long)Cout >= (1LL << 31) || (long long)B * H * W * Cin >= (1LL << 31))
-        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: tensor exceeds 2^31 elements");
+    if (M * (long long)Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29))
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
     a.M = (int)M;
     if (tile == 0) {
-        // enough work-groups for two per CU (512 slots) with the largest tile that still gives them
-        const long long t128 = ((M + 127) / 128) * (Cout / 128);
-        if (Cout % 128 == 0 && t128 >= 512) tile = 128128;
-        else if (((M + 127) / 128) * (Cout / 64) >= 512) tile = 128064;
-        else tile = 64064;
+        // measured on MI355X (tools/conv_probe.py, B=32): the 64x64 tile (36 KB LDS -> 4 work-groups = 16 waves per CU) wins or ties on
+        // every ResNet layer; 64x128 is ahead by 2-3 % on the 3x3 layers with Cout >= 128 and many rows.
+        tile = (ks == 3 && Cout % 128 == 0 && M >= 32768) ? 64128 : 64064;
     }
     hipStream_t st = (hipStream_t)stream;
 #define CONV_CASE(BM, BN)                                                    \

@@ -1,0 +1,187 @@
+// Stem of the ResNet encoder (models/resnet.py:141-143,203-205: conv 7x7 / stride 2 / pad 3, 18 -> 64 channels, BatchNorm, ReLU) as ONE
+// kernel that reads the proxy representation in the layout the reference hands over (NCHW fp32) and writes the NHWC activation
+// map the residual stages consume: no NCHW->NHWC conversion pass, no separate bias/ReLU pass.
+//
+// GEMM view: M = B*OH*OW output pixels, N = 64 channels, K = 18*7*7 = 882.  A work-group (4 waves) owns an 8 x 16 tile of output
+// pixels.  It first copies the (2*8+5) x (2*16+5) x 18 input patch the tile needs into LDS (56 KB; zero where the patch leaves the
+// image, so the padding costs nothing later) and then runs 441 MFMA k-steps with NO further barrier: k-step s = (cp, kh, kw) covers the
+// channel pair (2cp, 2cp+1), so the A operand of lane (pixel i, q) is the LDS word  base_i + q*plane + const(s)  -- one ds_read_b32
+// with an immediate offset per k-step -- and the B operand (folded weights, host-packed as [s/4][n-tile][lane][s%4]) streams from
+// L2 as 16-byte loads issued a group ahead.  Each wave holds 32 pixels x 64 channels (2 MFMA tiles): lane l ends with channel
+// (l & 31) + 32t of 16 pixels, adds the folded-BN bias, applies the ReLU and stores 128-byte channel runs.  Two work-groups fit a CU
+// (2 x 56 KB LDS), so one loads its patch while the other computes.
+#include "hmf_common.h"
+
+namespace hmf {
+
+constexpr int kStemC = 18, kStemK = 7, kStemN = 64;
+constexpr int kStemTH = 8, kStemTW = 16;                                  // output tile
+constexpr int kStemPH = 2 * kStemTH + 5, kStemPW = 2 * kStemTW + 5;       // 21 x 37 input patch (odd row stride: conflict-free)
+constexpr int kStemPlane = kStemPH * kStemPW;                             // 777 floats per channel
+constexpr int kStemSteps = (kStemC / 2) * kStemK * kStemK;                // 441 k-steps
+constexpr int kStemGroups = (kStemSteps + 3) / 4;                         // 111 groups of 4
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_conv(
+    const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
+    int OH, int OW, int tiles_w, int tiles_hw) {
+    __shared__ float patch[kStemC * kStemPlane + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lq = lane >> 5;
+    const int b = blockIdx.x / tiles_hw, trem = blockIdx.x - b * tiles_hw;
+    const int oh0 = (trem / tiles_w) * kStemTH, ow0 = (trem % tiles_w) * kStemTW;
+    const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+
+    // ---- input patch -> LDS (NCHW source: 37-float runs per (channel, row)).  Raw buffer loads: an element outside the image gets an
+    // out-of-range offset and comes back as zero, so all 55 loads of a thread are in flight together (no branch, no select). ----
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * kStemC * H * W), 0, kStemC * H * W * 4, 0x00020000);
+    constexpr int kPatch = kStemC * kStemPlane, kIter = (kPatch + 255) / 256;
+    float pv[kIter];
+#pragma unroll
+    for (int k = 0; k < kIter; ++k) {
+        const int e = tid + 256 * k;
+        const int cr = e / kStemPW, col = e - cr * kStemPW;
+        const int c = cr / kStemPH, r = cr - c * kStemPH;
+        const int ih = ih0 + r, iw = iw0 + col;
+        const bool ok = (e < kPatch) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+        pv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? ((c * H + ih) * W + iw) * 4 : (int)0x80000000, 0, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < kIter - 1; ++k) patch[tid + 256 * k] = pv[k];
+    if (tid + 256 * (kIter - 1) < kPatch + 8) patch[tid + 256 * (kIter - 1)] = pv[kIter - 1];
+    __syncthreads();
+
+    // ---- 441 k-steps ----
+    const int py = 2 * wave + (li >> 4), px = li & 15;
+    const float* pa = patch + (2 * py) * kStemPW + 2 * px + lq * kStemPlane;
+    const f32x4* pw = wp + lane;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // software pipeline: weights kPF groups (= 8*kPF MFMAs) ahead in a register ring, LDS operands one group ahead; the
+    // sched_barriers pin the issue points (left alone, the compiler sinks every load next to its use and exposes the latency)
+    constexpr int kPF = 4, kRing = kPF + 1;
+    f32x4 bw[kRing][2];
+    float av[2][4];
+    auto ldsA = [&](int g, int slot) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = 4 * g + u < kStemSteps ? 4 * g + u : kStemSteps - 1;
+            const int cp = s / 49, kk = s - cp * 49, kh = kk / 7, kw = kk - kh * 7;
+            av[slot][u] = pa[cp * 2 * kStemPlane + kh * kStemPW + kw];
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < kPF; ++g) {
+        bw[g][0] = pw[g * 128];
+        bw[g][1] = pw[g * 128 + 64];
+    }
+    ldsA(0, 0);
+#pragma clang loop unroll(full)
+    for (int g = 0; g < kStemGroups; ++g) {
+        if (g + kPF < kStemGroups) {
+            bw[(g + kPF) % kRing][0] = pw[(g + kPF) * 128];
+            bw[(g + kPF) % kRing][1] = pw[(g + kPF) * 128 + 64];
+        }
+        if (g + 1 < kStemGroups) ldsA(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][u], bw[g % kRing][0][u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][u], bw[g % kRing][1][u], acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: + bias, ReLU, NHWC stores (lane = channel, 128-byte runs) ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * t + li;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lq;
+            const int oh = oh0 + 2 * wave + (i >> 4), ow = ow0 + (i & 15);
+            if (oh < OH && ow < OW) y[(((long long)b * OH + oh) * OW + ow) * kStemN + n] = fmaxf(acc[t][r] + bv, 0.f);
+        }
+    }
+}
+
+// max-pool 3x3 / stride 2 / pad 1 over an NHWC map (models/resnet.py:144,206): one float4 of channels per thread
+__global__ __launch_bounds__(256) void k_maxpool_nhwc(const f32x4* __restrict__ x, f32x4* __restrict__ y, int B, int H, int W, int C4, int OH,
+                                                      int OW) {
+    const long long n = (long long)B * OH * OW * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        long long p = e / C4;
+        const int ow = (int)(p % OW);
+        p /= OW;
+        const int oh = (int)(p % OH), b = (int)(p / OH);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh) {
+            const int ih = 2 * oh + dh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+                const int iw = 2 * ow + dw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const f32x4 v = x[(((long long)b * H + ih) * W + iw) * C4 + c];
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        y[e] = m;
+    }
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+extern "C" long long hmf_stem_packed_floats(void) { return (long long)kStemGroups * 2 * 64 * 4; }
+
+extern "C" int hmf_stem_pack_host(const float* w /*64x18x7x7*/, float* packed) {
+    if (!w || !packed) return fail(HMF_ERR_INVALID, "hmf_stem_pack_host: null pointer");
+    for (int g = 0; g < kStemGroups; ++g)
+        for (int t = 0; t < 2; ++t)
+            for (int l = 0; l < 64; ++l)
+                for (int u = 0; u < 4; ++u) {
+                    const int s = 4 * g + u, n = 32 * t + (l & 31), q = l >> 5;
+                    float v = 0.f;
+                    if (s < kStemSteps) {
+                        const int cp = s / 49, kk = s - cp * 49;
+                        v = w[(n * kStemC + 2 * cp + q) * 49 + kk];
+                    }
+                    packed[((g * 2 + t) * 64 + l) * 4 + u] = v;
+                }
+    return HMF_OK;
+}
+
+extern "C" int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, void* stream) {
+    if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_stem_conv: bad args");
+    if (C != kStemC) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv: %d input channels (the 18-channel proxy representation is built)", C);
+    if ((uintptr_t)w_packed & 15) return fail(HMF_ERR_INVALID, "hmf_stem_conv: packed weights must be 16-byte aligned");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int th = (OH + kStemTH - 1) / kStemTH, tw = (OW + kStemTW - 1) / kStemTW;
+    const long long blocks = (long long)B * th * tw;
+    if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv: too many tiles");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(9, B, st);
+    hipLaunchKernelGGL(k_stem_conv, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+extern "C" int hmf_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(HMF_ERR_INVALID, "hmf_maxpool3x3s2_nhwc: bad args");
+    if (C % 4 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return fail(HMF_ERR_UNSUPPORTED, "hmf_maxpool3x3s2_nhwc: C %% 4 != 0 or unaligned");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long n = (long long)B * OH * OW * (C / 4);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_maxpool_nhwc, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, (f32x4*)y, B, H, W, C / 4, OH, OW);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}

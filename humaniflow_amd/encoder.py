@@ -5,12 +5,12 @@ Role of models/resnet.py in the reference (ResNet.forward :202-217, resnet18/50 
 buffer names follow torchvision (`conv1`, `bn1`, `layerL.B.convK/bnK`, `layerL.B.downsample.{0,1}`)
 so a reference checkpoint loads with ``strict=True``.
 
-Per the north star this stage stays on PyTorch-ROCm (MIOpen convolutions); what is added
-for MI355X is an *inference plan*: eval-mode BatchNorm folded into the preceding
-convolution's weight plus a per-channel bias, and one fused HIP epilogue pass per
-convolution (hmf_bias_act) instead of eager PyTorch's 2-3 elementwise passes -- built
-lazily from the live parameters and invalidated when they change, so the checkpoint
-layout is untouched.
+On the GPU the eval-mode forward runs an *inference plan*: eval-mode BatchNorm folded into the
+preceding convolution's weight plus a per-channel bias, activations kept NHWC, and every 1x1 / 3x3
+convolution executed by the library's fused implicit-GEMM kernel (hmf_conv2d_nhwc: fp32 MFMA, bias +
+residual + ReLU in the epilogue, one launch and one HBM write per convolution).  The plan is built lazily
+from the live parameters and invalidated when they change, so the checkpoint layout is untouched.
+Only the 7x7 stem convolution and the max-pool still go through MIOpen / ATen.
 """
 import os
 import shutil
@@ -113,6 +113,7 @@ class ResNetEncoder(nn.Module):
     # ONE fused HIP pass (hmf_bias_act: + bias, + identity, ReLU, in place) follows each of them.  The stem's
     # bias+ReLU commutes with max-pooling (both monotone), so it runs on the 4x smaller pooled tensor; a downsample
     # branch's bias is added to the block's last bias so that branch needs no pass of its own.
+    conv_impl = 'hip'        # 'hip': hmf_conv2d_nhwc for the residual stages; 'miopen': MIOpen + hmf_bias_act (tools/encoder_probe.py A/B)
     layout = 'nhwc'          # with the tuned find-db: nhwc 4.45 ms vs nchw 4.97 ms (B=32, ResNet-50; tools/encoder_find.py)
 
     def _fmt(self):
@@ -145,6 +146,13 @@ class ResNetEncoder(nn.Module):
     @torch.no_grad()
     def _build_plan(self):
         plan = {'stem': self._fold(self.conv1, self.bn1), 'blocks': []}
+        if self.conv1.weight.is_cuda and self.conv1.in_channels == 18:
+            from . import _lib
+            lib = _lib.load()
+            w = plan['stem'][0].detach().cpu().contiguous()                      # (64,18,7,7) row-major, BN scale folded in
+            packed = torch.empty(int(lib.hmf_stem_packed_floats()), dtype=torch.float32)
+            _lib.check(lib.hmf_stem_pack_host(w.data_ptr(), packed.data_ptr()), 'hmf_stem_pack_host')
+            plan['stem_packed'] = packed.to(self.conv1.weight.device)
         for li in range(1, 5):
             for blk in getattr(self, 'layer%d' % li):
                 stages = [self._fold(c, b) for c, b in blk.stages()]
@@ -155,6 +163,34 @@ class ResNetEncoder(nn.Module):
                     stages[-1] = (w, (b + ds[1]).contiguous(), s, p)
                 plan['blocks'].append((stages, ds))
         return plan
+
+    def _conv_hip(self, x, w, bias, stride, residual, relu):
+        """y = relu?(conv(x, w) + bias + residual) in one launch; x / residual / y are channels_last (B,C,H,W) tensors."""
+        from . import _lib
+        lib = _lib.load()
+        B, Cin, H, W = x.shape
+        Cout, _, ks, _ = w.shape
+        pad = ks // 2
+        OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _lib.check(lib.hmf_conv2d_nhwc(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                       None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
+                                       int(relu), 0, _lib.current_stream()), 'hmf_conv2d_nhwc')
+        return y
+
+    def _stem_hip(self, x, w_packed, bias):
+        """NCHW proxy input -> conv7x7/2 + bias + ReLU (NHWC) -> max-pool 3x3/2: two launches, no layout-conversion pass."""
+        from . import _lib
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+        st = _lib.current_stream()
+        y = torch.empty((B, 64, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _lib.check(lib.hmf_stem_conv(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W, st), 'hmf_stem_conv')
+        z = torch.empty((B, 64, PH, PW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
+        return z
 
     def _epilogue(self, x, bias, residual, relu):
         from . import _lib
@@ -179,11 +215,23 @@ class ResNetEncoder(nn.Module):
             self._plan, self._plan_key = self._build_plan(), key
         p = self._plan
         with torch.cuda.device(x.device):
-            x = x.float().contiguous(memory_format=self._fmt())
-            w, b, s, pad = p['stem']
-            x = F.max_pool2d(F.conv2d(x, w, None, s, pad), kernel_size=3, stride=2, padding=1)
-            x = self._epilogue(x, b, None, True)
-            for stages, ds in p['blocks']:
+            hip = self.layout == 'nhwc' and self.conv_impl == 'hip'
+            if hip and 'stem_packed' in p:
+                x = self._stem_hip(x.float().contiguous(), p['stem_packed'], p['stem'][1])
+            else:
+                x = x.float().contiguous(memory_format=self._fmt())
+                w, b, s, pad = p['stem']
+                x = F.max_pool2d(F.conv2d(x, w, None, s, pad), kernel_size=3, stride=2, padding=1)
+                x = self._epilogue(x, b, None, True)
+            if hip:
+                for stages, ds in p['blocks']:
+                    idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
+                    for w, b, s, pad in stages[:-1]:
+                        x = self._conv_hip(x, w, b, s[0], None, True)
+                    w, b, s, pad = stages[-1]
+                    x = self._conv_hip(x, w, b, s[0], idt, True)
+                return x.mean(dim=(2, 3))
+            for stages, ds in p['blocks']:                      # MIOpen convolutions + one fused epilogue pass each (A/B reference)
                 idt = x if ds is None else F.conv2d(x, ds[0], None, ds[2], ds[3])
                 for w, b, s, pad in stages[:-1]:
                     x = self._epilogue(F.conv2d(x, w, None, s, pad), b, None, True)

@@ -188,6 +188,16 @@ int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int 
 int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int H, int W,
                     int Cin, int Cout, int ks, int stride, int relu, int tile, void* stream);
 
+/* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
+ * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.
+ * w_packed: hmf_stem_pack_host(w (64,18,7,7) row-major [already multiplied by the BN scale], packed[hmf_stem_packed_floats()])
+ * uploaded to the device; bias (64) = folded BN shift or NULL.  Profiler tag 9.
+ * hmf_maxpool3x3s2_nhwc: the 3x3 / stride 2 / pad 1 max-pool that follows, NHWC (B,H,W,C) -> (B,(H-1)/2+1,(W-1)/2+1,C), C % 4 == 0. */
+long long hmf_stem_packed_floats(void);
+int hmf_stem_pack_host(const float* w, float* packed);
+int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, void* stream);
+int hmf_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */
 /* ------------------------------------------------------------------------------------------ */

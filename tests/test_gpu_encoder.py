@@ -57,3 +57,53 @@ def test_conv_rejects_unsupported_shapes():
         cin, cout, ks, s = args
         rc = lib.hmf_conv2d_nhwc(x.data_ptr(), x.data_ptr(), None, None, x.data_ptr(), 1, 8, 8, cin, cout, ks, s, 1, 0, None)
         assert rc < 0 and lib.hmf_last_error()
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 48, 80), (3, 30, 22)])
+def test_stem_conv_and_maxpool_match_float64_reference(B, H, W):
+    """hmf_stem_conv (NCHW in, NHWC out, bias + ReLU fused) and hmf_maxpool3x3s2_nhwc vs float64 torch; odd sizes exercise partial tiles
+    and the zero-padded patch borders."""
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 18, H, W, generator=g)
+    w = torch.randn(64, 18, 7, 7, generator=g) / 30.0
+    bias = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), 2, 3))
+    refp = F.max_pool2d(ref, 3, 2, 1)
+    packed = torch.empty(int(lib.hmf_stem_packed_floats()))
+    _lib.check(lib.hmf_stem_pack_host(w.contiguous().data_ptr(), packed.data_ptr()), 'pack')
+    xd, pd, bd = x.cuda(), packed.cuda(), bias.cuda()
+    OH, OW = ref.shape[2:]
+    y = torch.full((B, 64, OH, OW), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    st = _lib.current_stream()
+    _lib.check(lib.hmf_stem_conv(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, 18, H, W, st), 'hmf_stem_conv')
+    z = torch.full(tuple(refp.shape), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
+    torch.cuda.synchronize()
+    assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert (z.cpu().double() - refp).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(z, F.max_pool2d(y, 3, 2, 1))              # the pool itself is exact
+
+
+def test_folded_encoder_matches_module_path():
+    """The whole inference plan (stem + fused residual stages, ResNet-50 and ResNet-18) vs the plain nn.Module path on the same weights."""
+    import humaniflow_amd as H
+    from humaniflow_amd.encoder import ResNetEncoder
+    from humaniflow_amd.synthetic import synthetic_proxy_input
+    for layers in (18, 50):
+        torch.manual_seed(layers)
+        enc = ResNetEncoder(layers, 18)
+        for m in enc.modules():                       # non-trivial running statistics so the BN fold is exercised
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.1)
+        enc = enc.eval().cuda()
+        x = synthetic_proxy_input(2, 128, seed=layers).cuda()
+        with torch.no_grad():
+            got = enc(x)
+            ref = enc.forward_module(x.double()) if False else enc.double().forward_module(x.double())
+        assert got.shape == (2, enc.out_dim)
+        assert (got.double() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
