@@ -64,6 +64,9 @@ _SIGS = {
     'hmf_stem_pack_host': (C.c_int, [_VP, _VP]),
     'hmf_stem_conv': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
     'hmf_maxpool3x3s2_nhwc': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP]),
+    'hmf_conv_patch_packed_floats': (C.c_longlong, [C.c_int] * 3),
+    'hmf_conv_patch_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 4),
+    'hmf_conv_patch': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
     'hmf_conv2d_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
     'hmf_profile_enable': (C.c_int, [C.c_int]),
     'hmf_profile_collect': (C.c_int, [c_double_p, c_int_p, c_int_p, C.c_int]),

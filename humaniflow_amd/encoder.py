@@ -162,7 +162,33 @@ class ResNetEncoder(nn.Module):
                     w, b, s, p = stages[-1]
                     stages[-1] = (w, (b + ds[1]).contiguous(), s, p)
                 plan['blocks'].append((stages, ds))
+        plan['packed'] = {}
+        if self.conv1.weight.is_cuda:
+            for stages, ds in plan['blocks']:
+                for w, b, s, p in stages:
+                    cfg = self._patch_cfg(w)
+                    if cfg:
+                        pk = self._pack_patch(w, cfg)
+                        plan['packed'][id(w)] = (cfg, pk)              # the packing depends only on the slab size (64 for every 3x3 cfg)
         return plan
+
+    @staticmethod
+    def _patch_cfg(w):
+        """Kernel choice per layer, measured on MI355X (tools/conv_probe.py): 3x3 layers run patch-resident (8x16-pixel x 32-channel
+        tiles for the 64-channel layers, 8x8 x 64 otherwise); 1x1 layers stay on the implicit-GEMM kernel (equal or faster there)."""
+        cout, cin, ks, _ = w.shape
+        if ks != 3 or cin % 64 or cout % 64:
+            return 0
+        return 16410 if cin == 64 else 8210
+
+    def _pack_patch(self, w, cfg):
+        from . import _lib
+        lib = _lib.load()
+        cout, cin, ks, _ = w.shape
+        wh = w.detach().permute(0, 2, 3, 1).contiguous().cpu()               # (Cout, ks, ks, Cin)
+        packed = torch.empty(int(lib.hmf_conv_patch_packed_floats(cin, cout, ks)), dtype=torch.float32)
+        _lib.check(lib.hmf_conv_patch_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout, ks, cfg), 'hmf_conv_patch_pack_host')
+        return packed.to(w.device)
 
     def _conv_hip(self, x, w, bias, stride, residual, relu):
         """y = relu?(conv(x, w) + bias + residual) in one launch; x / residual / y are channels_last (B,C,H,W) tensors."""
@@ -173,6 +199,13 @@ class ResNetEncoder(nn.Module):
         pad = ks // 2
         OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        pk = self._plan['packed'].get(id(w)) if self._plan is not None else None
+        if pk is not None:
+            cfg = 8210 if stride == 2 else pk[0]                            # the stride-2 3x3 variant is built for the 8x8 tile
+            _lib.check(lib.hmf_conv_patch(x.data_ptr(), pk[1].data_ptr(), None if bias is None else bias.data_ptr(),
+                                          None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
+                                          int(relu), cfg, _lib.current_stream()), 'hmf_conv_patch')
+            return y
         _lib.check(lib.hmf_conv2d_nhwc(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                                        None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
                                        int(relu), 0, _lib.current_stream()), 'hmf_conv2d_nhwc')

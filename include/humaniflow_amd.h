@@ -188,6 +188,17 @@ int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int 
 int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int H, int W,
                     int Cin, int Cout, int ks, int stride, int relu, int tile, void* stream);
 
+/* Patch-resident variant of hmf_conv2d_nhwc for stride-1 3x3 and 1x1 (stride 1 or 2) layers: the input patch of a pixel tile lives in
+ * LDS for a whole slab of input channels and the weights stream from L2 in MFMA lane order (no barrier inside a slab).
+ * w_packed = hmf_conv_patch_pack_host(w (Cout,ks,ks,Cin) channels_last, ..., cfg) uploaded to the device
+ * (hmf_conv_patch_packed_floats floats).  cfg = TW*1000 + PG*100 + TN*10 + (SC==128): 16420/16421 = 8x16-pixel tile x 64 channels,
+ * 16410/16411 = 8x16 x 32 channels, 8210/8211 = 8x8 x 64 channels; SC = input channels per slab (64, or 128 for 1x1 only);
+ * Cin % SC == 0, Cout % (channels per tile) == 0.  Same epilogue and profiler tag (8) as hmf_conv2d_nhwc. */
+long long hmf_conv_patch_packed_floats(int Cin, int Cout, int ks);
+int hmf_conv_patch_pack_host(const float* w, float* packed, int Cin, int Cout, int ks, int cfg);
+int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                   int Cin, int Cout, int ks, int stride, int relu, int cfg, void* stream);
+
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
  * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.
  * w_packed: hmf_stem_pack_host(w (64,18,7,7) row-major [already multiplied by the BN scale], packed[hmf_stem_packed_floats()])

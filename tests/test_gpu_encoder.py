@@ -49,6 +49,49 @@ def test_conv_ragged_rows_and_flags():
     _case(2, 8, 8, 2048, 512, 1, 1, res=False, relu=True, tile=0, seed=5)           # deepest K of the 1x1 layers
 
 
+def _patch_case(B, H, W, cin, cout, ks, stride, res, relu, cfg, seed=0):
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride, ks // 2)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    wh = w.permute(0, 2, 3, 1).contiguous()
+    packed = torch.empty(int(lib.hmf_conv_patch_packed_floats(cin, cout, ks)))
+    _lib.check(lib.hmf_conv_patch_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout, ks, cfg), 'pack')
+    xd, pd, bd = x.cuda().contiguous(memory_format=torch.channels_last), packed.cuda(), bias.cuda()
+    rd = r.cuda().contiguous(memory_format=torch.channels_last) if res else None
+    y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.hmf_conv_patch(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
+                                  B, H, W, cin, cout, ks, stride, int(relu), cfg, _lib.current_stream()), 'hmf_conv_patch')
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, ks, stride, res, relu, cfg, err)
+
+
+@pytest.mark.parametrize('cfg', [16420, 16410, 8210])
+def test_patch_conv3x3_matches_float64_reference(cfg):
+    _patch_case(2, 16, 16, 128, 128, 3, 1, True, True, cfg)                 # two channel slabs, whole tiles
+    _patch_case(1, 11, 19, 64, 64, 3, 1, False, False, cfg, seed=1)         # ragged tiles: masked stores, zero-filled patch borders
+
+
+@pytest.mark.parametrize('cfg', [16420, 16421, 16410, 16411, 8210, 8211])
+def test_patch_conv1x1_matches_float64_reference(cfg):
+    _patch_case(2, 16, 16, 256, 128, 1, 1, True, True, cfg)
+    _patch_case(2, 14, 10, 128, 64, 1, 2, False, True, cfg, seed=2)         # strided 1x1 (downsample branch), ragged
+
+
+def test_patch_conv3x3_stride2():
+    _patch_case(2, 16, 16, 128, 64, 3, 2, False, True, 8210)
+    _patch_case(1, 13, 9, 64, 128, 3, 2, True, False, 8210, seed=3)
+
+
 def test_conv_rejects_unsupported_shapes():
     from humaniflow_amd import _lib
     lib = _lib.load()

@@ -67,7 +67,7 @@ for name, hw, cin, cout, ks, s, res in shapes():
     t_mi = timeit(miopen)
     y = torch.empty_like(ref)
     best, line = None, ''
-    for tile in (128128, 128064, 64128, 64064):
+    for tile in (64128, 64064):
         if tile % 1000 == 128 and cout % 128:
             continue
         fn = lambda: _lib.check(lib.hmf_conv2d_nhwc(x.data_ptr(), w.data_ptr(), bias.data_ptr(), None if r is None else r.data_ptr(), y.data_ptr(),
@@ -80,6 +80,27 @@ for name, hw, cin, cout, ks, s, res in shapes():
             line += '(ERR %.2e)' % err
         if best is None or t < best[0]:
             best = (t, tile)
+    if True:
+        wh = w.permute(0, 2, 3, 1).contiguous().cpu()                     # (Cout, ks, ks, Cin) row-major
+        for cfg in (16420, 16421, 16410, 16411, 8210, 8211):
+            sc = 128 if cfg % 10 else 64
+            bn = (4 // ((cfg // 100) % 10)) * ((cfg // 10) % 10) * 32
+            if (ks == 3 and s == 2 and cfg != 8210) or cin % sc or cout % bn or (ks == 3 and cfg % 10) or (cfg // 1000 == 8 and oh % 8) or (cfg // 1000 == 16 and oh % 16 and oh > 8):
+                continue
+            packed = torch.empty(cout * ks * ks * cin)
+            _lib.check(lib.hmf_conv_patch_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout, ks, cfg), 'pack')
+            pd = packed.to(dev)
+            fn = lambda: _lib.check(lib.hmf_conv_patch(x.data_ptr(), pd.data_ptr(), bias.data_ptr(), None if r is None else r.data_ptr(), y.data_ptr(),
+                                                       B, hw, hw, cin, cout, ks, s, 1, cfg, st), 'conv_patch')
+            y.fill_(float('nan'))
+            fn()
+            err = (y - ref).abs().max().item()
+            t = timeit(fn)
+            line += ' p%5d:%7.1f' % (cfg, t)
+            if not err < 1e-3:
+                line += '(ERR %.2e)' % err
+            elif best is None or t < best[0]:
+                best = (t, cfg)
     fl = 2.0 * B * oh * oh * cout * cin * ks * ks
     print('%-9s hw%3d %4d->%4d k%d s%d  miopen %7.1f us (%5.1f TF)  ours best %7.1f us (%5.1f TF) tile %6d |%s' %
           (name, hw, cin, cout, ks, s, t_mi, fl / t_mi / 1e6, best[0], fl / best[0] / 1e6, best[1], line), flush=True)
