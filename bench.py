@@ -33,6 +33,26 @@ LBS_FLOP_PER_UNIT = 9.775e6
 FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
+def encoder_conv_flops(enc, B, size):
+    """Algorithmic FLOPs (2*M*N*K, no padding taps removed) of every convolution of the encoder in launch order."""
+    flops, kind = [2.0 * B * (size // 2) ** 2 * 64 * enc.conv1.in_channels * 49], ['7x7/2']
+    hw = size // 4
+    for li in range(1, 5):
+        for blk in getattr(enc, 'layer%d' % li):
+            seq = ([blk.downsample[0]] if blk.downsample is not None else []) + [c for c, _ in blk.stages()]
+            cur = hw
+            for ci, c in enumerate(seq):
+                is_ds = blk.downsample is not None and ci == 0
+                inhw = hw if is_ds else cur
+                oh = inhw // c.stride[0]
+                flops.append(2.0 * B * oh * oh * c.out_channels * c.in_channels * c.kernel_size[0] ** 2)
+                kind.append('%dx%d' % (c.kernel_size[0], c.kernel_size[0]))
+                if not is_ds:
+                    cur = oh
+            hw = cur
+    return flops, kind
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -44,7 +64,9 @@ def parse():
     ap.add_argument('--tpose', action='store_true', help='add the evaluate-flavour T-pose bodies to the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=32, help='images of the bounded CPU-baseline sample')
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps are round-robined over (batches are independent: the '
+    ap.add_argument('--no-chain-encoders', dest='chain_encoders', action='store_false',
+                    help='let the encoders of consecutive steps overlap each other on the streams')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams the steps are round-robined over (batches are independent: the '
                     'low-occupancy flow kernels of step i overlap the encoder convolutions of step i+1)')
     return ap.parse_args()
 
@@ -133,9 +155,19 @@ def main():
     x = synthetic_proxy_input(B, 256, seed=100 + rank).to(dev)      # each rank its own shard of the synthetic set
     torch.manual_seed(1234 + rank)
 
+    enc_done = [None]
+
     def step():
         with torch.no_grad():
-            pred = model(x, num_samples=N)
+            # the encoders of consecutive steps (on different streams) are chained through an event: what overlaps the convolutions
+            # of batch i+1 is the low-occupancy flow + SMPL tail of batch i, not another encoder competing for the same CUs
+            if args.chain_encoders and enc_done[0] is not None:
+                torch.cuda.current_stream().wait_event(enc_done[0])
+            feats = model(x, return_input_feats_only=True)['input_feats']
+            if args.chain_encoders:
+                enc_done[0] = torch.cuda.Event()
+                enc_done[0].record()
+            pred = model(None, input_feats=feats, num_samples=N)
             g = pred['glob_rotmat']
             pe = smpl(body_pose=pred['pose_rotmats_point_est'], global_orient=g[:, None], betas=pred['shape_mode'], pose2rot=False)
             sa = smpl(body_pose=pred['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
@@ -193,10 +225,10 @@ def main():
         elapsed = float(t.item())
     log('timed region done: %.3f ms/step' % (elapsed / args.steps * 1e3))
     # ---- per-kernel times from the HIP events recorded on the launch stream during the timed region ----
-    ms = np.zeros(4096)
-    tag = np.zeros(4096, np.int32)
-    rows = np.zeros(4096, np.int32)
-    n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), 4096)
+    ms = np.zeros(16384)
+    tag = np.zeros(16384, np.int32)
+    rows = np.zeros(16384, np.int32)
+    n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), 16384)
     lib.hmf_profile_enable(0)
     ms, tag, rows = ms[:n], tag[:n], rows[:n]
     names = {1: 'k_lbs_mfma', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
@@ -205,6 +237,25 @@ def main():
         for r in sorted(set(rows[tag == tg].tolist())):
             sel = (tag == tg) & (rows == r)
             kern['%s[M=%d]' % (nm, r)] = round(float(ms[sel].mean()) * 1e3, 2)      # us
+    # encoder convolutions: one record per launch in plan order (stem, then per block [downsample,] conv1..convK)
+    conv_flops, conv_kind = encoder_conv_flops(model.image_encoder, B, x.shape[-1])
+    csel = (tag >= 8) & (tag <= 10)
+    conv = None
+    if csel.sum() == args.steps * len(conv_flops):
+        cms = ms[csel].reshape(args.steps, len(conv_flops)).mean(0)                  # ms per launch, per layer
+        ctag = tag[csel].reshape(args.steps, len(conv_flops))[0]
+        fam = {}
+        for f, k, t, tg in zip(conv_flops, conv_kind, cms, ctag):
+            name = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (%s)' % k, 8: 'k_conv_igemm (%s)' % k}[int(tg)]
+            d = fam.setdefault(name, {'launches_per_step': 0, 'us_per_step': 0.0, 'flop': 0.0})
+            d['launches_per_step'] += 1
+            d['us_per_step'] += t * 1e3
+            d['flop'] += f
+        for d in fam.values():
+            d['tflops'] = round(d['flop'] / (d['us_per_step'] * 1e-6) / 1e12, 2)
+            d['us_per_step'] = round(d['us_per_step'], 1)
+            d['gflop_per_step'] = round(d.pop('flop') / 1e9, 2)
+        conv = fam
     lbs_sel = (tag == 1) & (rows == B * N)
     lbs_ms = float(ms[lbs_sel].mean()) if lbs_sel.any() else float('nan')
     achieved = LBS_FLOP_PER_UNIT * B * N / (lbs_ms * 1e-3) / 1e12
@@ -248,6 +299,14 @@ def main():
             traffic = max(c['hbm_bytes_per_launch'] for c in cand)
     except Exception:
         pass
+    conv_traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+        cand = [v for k, v in pmc.items() if 'k_conv_patch<3' in k]
+        if cand and B == 32:
+            conv_traffic = int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
+    except Exception:
+        pass
     if rank == 0:
         value = world * B * N * args.steps / elapsed
         res = {
@@ -259,7 +318,8 @@ def main():
                                    % (B, N, args.layers, ' + T-pose bodies' if args.tpose else ''),
                        'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'streams_per_gpu': len(streams),
                        'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},
-            'roofline': {'kernel': 'k_lbs_mfma (SMPL pose-blend GEMM + skinning, M=%d rows)' % (B * N), 'bound': 'mfma',
+            'roofline': None,
+            'roofline_lbs': {'kernel': 'k_lbs_mfma (SMPL pose-blend GEMM + skinning, M=%d rows)' % (B * N), 'bound': 'mfma',
                          'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': 'HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/r01_pmc.json); algorithmic: 264.6 MB vertex write + 25 MB reads',
@@ -270,10 +330,24 @@ def main():
                                       'frac': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                          'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * B * N},
             'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 3),
-            'stages_ms': {'encoder_resnet%d_miopen' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
+            'conv_kernels': conv,
+            'stages_ms': {'encoder_resnet%d' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
                           'smpl_samples': round(smpl_ms, 3), 'smpl_tpose': round(tp_ms, 3)},
             'kernels_us': kern,
         }
+        # the dominant kernel of the step: the patch-resident 3x3 convolution (16 launches per step for ResNet-50)
+        dom = None if conv is None else conv.get('k_conv_patch (3x3)')
+        if dom:
+            per_launch_flop = dom['gflop_per_step'] * 1e9 / dom['launches_per_step']
+            res['roofline'] = {'kernel': 'k_conv_patch (3x3 convolutions of the encoder, %d launches/step, largest share of the step)' % dom['launches_per_step'],
+                               'bound': 'mfma', 'achieved': dom['tflops'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': conv_traffic,
+                               'traffic_note': 'mean HBM bytes/launch over the 3x3 launches from separate rocprofv3 --pmc passes (profiles/r01_pmc.json)',
+                               'avg_launch_us': round(dom['us_per_step'] / dom['launches_per_step'], 2),
+                               'launches': dom['launches_per_step'] * args.steps, 'algorithmic_flop_per_launch': per_launch_flop,
+                               'note': 'HIP events on the launch stream inside the timed region; with 2 streams the launches share the GPU with the flow/SMPL kernels of the previous batch'}
+        else:
+            res['roofline'] = res['roofline_lbs']
         if world == 1 and not args.no_cpu_baseline:
             log('stage breakdown done; timing the CPU baseline (oracle, %d images x %d samples)' % (args.cpu_images, N))
             res['cpu_baseline'] = cpu_baseline(model_sd, cfg, smpl.model_dict(), args.cpu_images, N)

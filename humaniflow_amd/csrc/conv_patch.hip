@@ -38,8 +38,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr int NG = SC / 8;                      // k-groups per tap per slab
     constexpr int NV = PH * PW * (SC / 4);          // float4 per slab patch
     constexpr int NIT = (NV + 255) / 256;
-    constexpr int kRing = 8, kPF = 6;              // ring size divides every GPS (8, 16, 72): slot = group % kRing stays in phase over slabs
-    __shared__ float patch[PH * PW * CS];
+    // LDS row pitch (floats): ds_read_b128 is served in four 16-lane groups ({0-3,12-15,20-27}, ...) over 64 banks, so the 16-byte slots
+    // of a group must be distinct mod 16.  Pixel stride CS = 17 slots; a 16-wide tile needs the row pitch = 0 (mod 16 slots), an 8-wide
+    // tile = 8 (mod 16 slots); the stride-2 variant cannot be made conflict-free with 16-byte reads (2-way) and keeps the dense pitch.
+    constexpr int kDense = PW * CS;
+    constexpr int RPF = ST == 2 ? kDense : (TW == 16 ? (kDense + 63) / 64 * 64 : ((kDense - 32 + 63) / 64 * 64 + 32));
+    // weight ring: slot = group % kRing must stay in phase over slabs -> kRing divides GPS (8, 16 or 72 groups per slab)
+    constexpr int kRing = 8, kPF = kRing - 2;
+    __shared__ float patch[PH * RPF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int ih = KS == 1 ? (oh0 + r) * a.stride : oh0 * ST + r - 1, iw = KS == 1 ? (ow0 + col) * a.stride : ow0 * ST + col - 1;
         const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
         goff[k] = ok ? (((b * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
-        loff[k] = p * CS + 4 * c4;
+        loff[k] = r * RPF + col * CS + 4 * c4;
     }
     const int nslab = a.Cin / SC;
     constexpr int GPS = KS * KS * NG;               // groups per slab
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((long long)((nt * CG + cg) * TN + t) * nslab * GPS) * 64 + lane;
 
     const int prow = pg * RPG + li / TW, pcol = li % TW;
-    const float* pa = patch + (prow * ST * PW + pcol * ST) * CS + 4 * lq;
+    const float* pa = patch + prow * ST * RPF + pcol * ST * CS + 4 * lq;
 
     f32x16 acc[TN];
 #pragma unroll
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
             if (gi + 1 < GPS) {
                 const int tap = (gi + 1) / NG, g = (gi + 1) - tap * NG;
-                fa[(gi + 1) & 1] = *(const f32x4*)(pa + ((tap / KS) * PW + (tap % KS)) * CS + 8 * g);
+                fa[(gi + 1) & 1] = *(const f32x4*)(pa + (tap / KS) * RPF + (tap % KS) * CS + 8 * g);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -183,7 +189,7 @@ static void launch_patch(PatchArgs a, hipStream_t st) {
     a.tiles_hw = a.tiles_w * ((a.OH + TH - 1) / TH);
     a.n_tiles = a.Cout / BN;
     const long long blocks = (long long)a.B * a.tiles_hw * a.n_tiles;
-    ProfScope ps(8, a.B * a.OH * a.OW, st);
+    ProfScope ps(10, a.B * a.OH * a.OW, st);
     hipLaunchKernelGGL((k_conv_patch<KS, TW, PG, TN, SC, ST>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 

@@ -1,0 +1,207 @@
+// Evaluation epilogue on the device: the point-set error metrics of metrics/eval_metrics_tracker.py:95-280 and the
+// sample-diversity reductions :398-410, fused so that the (B,N,6890,3) sample tensors are read from HBM once instead of being copied
+// to the host (the reference's 0.53 GB/batch D2H, evaluate_humaniflow.py:227-252) or swept by ~40 elementwise passes.
+//
+// k_pointset_errors: one work-group per (prediction, target) pair of npts 3-D points.
+//   pass 1: 17 running sums (sum P, sum T, sum |P|^2, sum |T|^2, sum P T^T) in fp64 -> means, variances, cross-covariance K
+//   thread 0: scale+translation correction (utils/eval_utils.py:107-125) and the similarity Procrustes alignment (:62-104):
+//             R = V Z U^T from the SVD of K, here via the Jacobi eigen-decomposition of K^T K (fp64), scale = tr(R K) / var(P)
+//   pass 2 (second read of P comes from L2): mean |P - T|, mean |sc(P) - T|, mean |pa(P) - T|
+// k_sample_diversity: mean distance of every sample point from the per-point mean over the N samples of its image.
+// HBM-bound by construction: 12 B per point read once (+ one L2 re-read).
+#include "hmf_common.h"
+
+namespace hmf {
+
+__device__ inline double block_sum(double v, double* red) {
+    // 256 threads: wave shuffle then 4-way LDS combine
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// eigen-decomposition of a symmetric 3x3 (cyclic Jacobi, fp64): A = V diag(w) V^T, columns of V = eigenvectors
+__device__ inline void jacobi3(double A[3][3], double V[3][3], double w[3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+}
+
+struct Align {          // y = sc_a * (x - mu_p) + mu_t   |   y = pa_s * R x + pa_t
+    float mu_p[3], mu_t[3], sc_a, R[9], pa_s, pa_t[3];
+};
+
+__global__ __launch_bounds__(256) void k_pointset_errors(const float* __restrict__ P, const float* __restrict__ T, int npts, int group,
+                                                         int want_pa, float* __restrict__ out) {
+    __shared__ double red[4];
+    __shared__ Align al;
+    const int pair = blockIdx.x;
+    const float* p = P + (size_t)pair * npts * 3;
+    const float* t = T + (size_t)(pair / group) * npts * 3;
+    double s[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) s[i] = 0.0;
+    for (int i = threadIdx.x; i < npts; i += 256) {
+        const float px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+        const float tx = t[3 * i], ty = t[3 * i + 1], tz = t[3 * i + 2];
+        s[0] += px; s[1] += py; s[2] += pz;
+        s[3] += tx; s[4] += ty; s[5] += tz;
+        s[6] += (double)px * px + (double)py * py + (double)pz * pz;
+        s[7] += (double)tx * tx + (double)ty * ty + (double)tz * tz;
+        s[8] += (double)px * tx;  s[9] += (double)px * ty;  s[10] += (double)px * tz;
+        s[11] += (double)py * tx; s[12] += (double)py * ty; s[13] += (double)py * tz;
+        s[14] += (double)pz * tx; s[15] += (double)pz * ty; s[16] += (double)pz * tz;
+    }
+#pragma unroll
+    for (int i = 0; i < 17; ++i) s[i] = block_sum(s[i], red);
+    if (threadIdx.x == 0) {
+        const double n = npts;
+        double mp[3] = {s[0] / n, s[1] / n, s[2] / n}, mt[3] = {s[3] / n, s[4] / n, s[5] / n};
+        const double varp = s[6] - n * (mp[0] * mp[0] + mp[1] * mp[1] + mp[2] * mp[2]);
+        const double vart = s[7] - n * (mt[0] * mt[0] + mt[1] * mt[1] + mt[2] * mt[2]);
+        for (int i = 0; i < 3; ++i) { al.mu_p[i] = (float)mp[i]; al.mu_t[i] = (float)mt[i]; }
+        al.sc_a = (float)(sqrt(vart / n) / sqrt(varp / n));
+        if (want_pa) {
+            double K[3][3];                                   // K = X1 X2^T (source x target), utils/eval_utils.py:80
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) K[i][j] = s[8 + 3 * i + j] - n * mp[i] * mt[j];
+            double KtK[3][3], V[3][3], w[3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) KtK[i][j] = K[0][i] * K[0][j] + K[1][i] * K[1][j] + K[2][i] * K[2][j];
+            jacobi3(KtK, V, w);
+            int o[3] = {0, 1, 2};                              // descending eigenvalues
+            if (w[o[0]] < w[o[1]]) { int x = o[0]; o[0] = o[1]; o[1] = x; }
+            if (w[o[1]] < w[o[2]]) { int x = o[1]; o[1] = o[2]; o[2] = x; }
+            if (w[o[0]] < w[o[1]]) { int x = o[0]; o[0] = o[1]; o[1] = x; }
+            double v[3][3], u[3][3];                           // v[k] = k-th right singular vector, u[k] = K v[k] / sigma_k
+            for (int k = 0; k < 3; ++k)
+                for (int i = 0; i < 3; ++i) v[k][i] = V[i][o[k]];
+            for (int k = 0; k < 2; ++k) {
+                for (int i = 0; i < 3; ++i) u[k][i] = K[i][0] * v[k][0] + K[i][1] * v[k][1] + K[i][2] * v[k][2];
+                if (k == 1) {
+                    const double d = u[1][0] * u[0][0] + u[1][1] * u[0][1] + u[1][2] * u[0][2];
+                    for (int i = 0; i < 3; ++i) u[1][i] -= d * u[0][i];
+                }
+                const double nn = sqrt(u[k][0] * u[k][0] + u[k][1] * u[k][1] + u[k][2] * u[k][2]);
+                for (int i = 0; i < 3; ++i) u[k][i] /= (nn > 0 ? nn : 1.0);
+            }
+            u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+            u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+            u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+            const double detV = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
+                                v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+            double R[3][3];                                    // R = V Z U^T: Z33 u3_true = det(V) (u1 x u2)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) R[i][j] = v[0][i] * u[0][j] + v[1][i] * u[1][j] + (detV < 0 ? -1.0 : 1.0) * v[2][i] * u[2][j];
+            double tr = 0.0;
+            for (int i = 0; i < 3; ++i) tr += R[i][0] * K[0][i] + R[i][1] * K[1][i] + R[i][2] * K[2][i];
+            const double sc = tr / varp;
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) al.R[3 * i + j] = (float)R[i][j];
+                al.pa_t[i] = (float)(mt[i] - sc * (R[i][0] * mp[0] + R[i][1] * mp[1] + R[i][2] * mp[2]));
+            }
+            al.pa_s = (float)sc;
+        }
+    }
+    __syncthreads();
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+    for (int i = threadIdx.x; i < npts; i += 256) {
+        const float px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+        const float tx = t[3 * i], ty = t[3 * i + 1], tz = t[3 * i + 2];
+        float dx = px - tx, dy = py - ty, dz = pz - tz;
+        e0 += sqrtf(dx * dx + dy * dy + dz * dz);
+        dx = (px - al.mu_p[0]) * al.sc_a + al.mu_t[0] - tx;
+        dy = (py - al.mu_p[1]) * al.sc_a + al.mu_t[1] - ty;
+        dz = (pz - al.mu_p[2]) * al.sc_a + al.mu_t[2] - tz;
+        e1 += sqrtf(dx * dx + dy * dy + dz * dz);
+        if (want_pa) {
+            dx = al.pa_s * (al.R[0] * px + al.R[1] * py + al.R[2] * pz) + al.pa_t[0] - tx;
+            dy = al.pa_s * (al.R[3] * px + al.R[4] * py + al.R[5] * pz) + al.pa_t[1] - ty;
+            dz = al.pa_s * (al.R[6] * px + al.R[7] * py + al.R[8] * pz) + al.pa_t[2] - tz;
+            e2 += sqrtf(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    e0 = block_sum(e0, red);
+    e1 = block_sum(e1, red);
+    e2 = block_sum(e2, red);
+    if (threadIdx.x == 0) {
+        out[3 * pair + 0] = (float)(e0 / npts);
+        out[3 * pair + 1] = (float)(e1 / npts);
+        out[3 * pair + 2] = want_pa ? (float)(e2 / npts) : 0.f;
+    }
+}
+
+// S: (B, N, npts, 3); partial: (B, chunks) sums over n and the chunk's points of |S - mean_n S|
+__global__ __launch_bounds__(256) void k_sample_diversity(const float* __restrict__ S, int N, int npts, int chunks, float* __restrict__ partial) {
+    __shared__ double red[4];
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int i = ch * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (i < npts) {
+        const float* s = S + ((size_t)b * N * npts + i) * 3;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* q = s + (size_t)n * npts * 3;
+            m0 += q[0]; m1 += q[1]; m2 += q[2];
+        }
+        m0 /= N; m1 /= N; m2 /= N;
+        float l2 = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* q = s + (size_t)n * npts * 3;
+            const float dx = q[0] - m0, dy = q[1] - m1, dz = q[2] - m2;
+            l2 += sqrtf(dx * dx + dy * dy + dz * dz);
+        }
+        acc = l2;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (float)acc;
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+extern "C" int hmf_pointset_errors(const float* P, const float* T, int npairs, int group, int npts, int want_pa, float* out, void* stream) {
+    if (npairs == 0) return HMF_OK;
+    if (!P || !T || !out || npairs < 0 || group < 1 || npts < 1) return fail(HMF_ERR_INVALID, "hmf_pointset_errors: bad args");
+    hipLaunchKernelGGL(k_pointset_errors, dim3(npairs), dim3(256), 0, (hipStream_t)stream, P, T, npts, group, want_pa, out);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+extern "C" int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial, void* stream) {
+    if (B == 0) return HMF_OK;
+    if (!S || !partial || B < 0 || N < 1 || npts < 1) return fail(HMF_ERR_INVALID, "hmf_sample_diversity: bad args");
+    const int chunks = (npts + 255) / 256;
+    hipLaunchKernelGGL(k_sample_diversity, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, S, N, npts, chunks, partial);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}

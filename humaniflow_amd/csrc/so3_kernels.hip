@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- per-launch event timing --------------------------------------------------------------------
 namespace {
-constexpr int kProfMax = 4096;
+constexpr int kProfMax = 16384;
 struct ProfRec { hipEvent_t a, b; int tag, rows; };
 ProfRec g_prof[kProfMax];
 int g_prof_n = 0;

@@ -94,6 +94,77 @@ class EvalMetricsTracker:
             self.per_frame[name].append(err.flatten(1).mean(dim=-1) if frame is None else frame)
 
     def update_per_batch(self, pred, target):
+        """Device tensors go through the fused HIP epilogue (hmf_pointset_errors / hmf_sample_diversity); host tensors (the reference's
+        own numpy setting, used by the CPU tests of the exchange step) through the op-for-op torch restatement below."""
+        if pred['verts3D'].is_cuda:
+            return self._update_hip(pred, target)
+        return self._update_torch(pred, target)
+
+    def _pointset(self, P, T, want_pa):
+        """P (..., npts, 3) vs T (Bt, npts, 3) with P's leading dims = (Bt,) or (Bt, N): -> (..., 3) mean errors [plain, SC, PA]."""
+        from . import _lib
+        lib = _lib.load()
+        lead, npts = P.shape[:-2], P.shape[-2]
+        npairs = 1
+        for d in lead:
+            npairs *= d
+        Pc, Tc = P.float().contiguous(), T.float().contiguous()
+        out = torch.empty(npairs, 3, device=P.device, dtype=torch.float32)
+        _lib.check(lib.hmf_pointset_errors(Pc.data_ptr(), Tc.data_ptr(), npairs, npairs // Tc.shape[0], npts, int(want_pa), out.data_ptr(),
+                                           _lib.current_stream()), 'hmf_pointset_errors')
+        return out.reshape(*lead, 3)
+
+    def _diversity(self, S):
+        from . import _lib
+        lib = _lib.load()
+        B, N, npts = S.shape[:3]
+        Sc = S.float().contiguous()
+        part = torch.empty(B, (npts + 255) // 256, device=S.device, dtype=torch.float32)
+        _lib.check(lib.hmf_sample_diversity(Sc.data_ptr(), B, N, npts, part.data_ptr(), _lib.current_stream()), 'hmf_sample_diversity')
+        return part.double().sum(dim=1)                                   # (B,) sum over n, p of the distances
+
+    def _addf(self, name, frame, npts):
+        """frame (B,) per-frame MEAN error over npts points: running sum += sum_b frame * npts."""
+        if name in self.metrics:
+            self._acc(name, frame.double().sum() * npts)
+            self.per_frame[name].append(frame)
+
+    def _update_hip(self, pred, target):
+        B, self.num_verts = pred['verts3D'].shape[:2]
+        self._acc('num_total_test_data', B)
+        tv, tt, tj = target['verts3D'], target['tpose_verts3D'], target['joints3D']
+        V, J = tv.shape[1], tj.shape[1]
+        need_pa = any(m in self.metrics for m in ('PVE-PA', 'PVE-PA_samples_min'))
+        e = self._pointset(pred['verts3D'], tv, need_pa)
+        self._addf('PVE', e[:, 0], V); self._addf('PVE-SC', e[:, 1], V); self._addf('PVE-PA', e[:, 2], V)
+        e = self._pointset(pred['tpose_verts3D'], tt, False)
+        self._addf('PVE-T', e[:, 0], V); self._addf('PVE-T-SC', e[:, 1], V)
+        e = self._pointset(pred['joints3D'], tj, True)
+        self._addf('MPJPE', e[:, 0], J); self._addf('MPJPE-SC', e[:, 1], J); self._addf('MPJPE-PA', e[:, 2], J)
+        if 'verts3D_samples' in pred:
+            vs, js = pred['verts3D_samples'], pred['joints3D_samples']
+            self.num_samples = vs.shape[1]
+            e = self._pointset(vs, tv, need_pa).min(dim=1).values            # per metric: the sample with the smallest mean error
+            self._addf('PVE_samples_min', e[:, 0], V); self._addf('PVE-SC_samples_min', e[:, 1], V)
+            self._addf('PVE-PA_samples_min', e[:, 2], V)
+            if 'tpose_verts3D_samples' in pred:
+                e = self._pointset(pred['tpose_verts3D_samples'], tt, False).min(dim=1).values
+                self._addf('PVE-T_samples_min', e[:, 0], V); self._addf('PVE-T-SC_samples_min', e[:, 1], V)
+            e = self._pointset(js, tj, True).min(dim=1).values
+            self._addf('MPJPE_samples_min', e[:, 0], J); self._addf('MPJPE-SC_samples_min', e[:, 1], J)
+            self._addf('MPJPE-PA_samples_min', e[:, 2], J)
+            if 'verts3D_sample_diversity' in self.metrics:
+                d = self._diversity(vs)
+                self._acc('verts3D_sample_diversity', d.sum())
+                self.per_frame['verts3D_sample_diversity'].append((d / (vs.shape[1] * V)).float())
+        if 'joints3D_coco_samples' in pred and 'joints3D_sample_diversity' in self.metrics:
+            jc = pred['joints3D_coco_samples']
+            d = self._diversity(jc)
+            self._acc('joints3D_sample_diversity', d.sum())
+            self.per_frame['joints3D_sample_diversity'].append((d / (jc.shape[1] * jc.shape[2])).float())
+        self._update_2d(pred, target)
+
+    def _update_torch(self, pred, target):
         """pred: verts3D (B,V,3), tpose_verts3D, joints3D (B,14,3) [+ joints2D (B,17,2)] and optionally verts3D_samples (B,N,V,3),
         tpose_verts3D_samples, joints3D_samples (B,N,14,3), joints2Dsamples (B,N,17,2), joints3D_coco_samples (B,N,17,3);
         target: verts3D, tpose_verts3D, joints3D [+ joints2D, joints2D_vis]."""
@@ -134,6 +205,11 @@ class EvalMetricsTracker:
             jc = pred['joints3D_coco_samples']
             d = torch.linalg.norm(jc - jc.mean(dim=1, keepdim=True), dim=-1)
             self._add('joints3D_sample_diversity', d, d.mean(dim=(1, 2)))
+        self._update_2d(pred, target)
+
+    def _update_2d(self, pred, target):
+        """joints2D-L2E / joints2Dsamples-L2E (eval_metrics_tracker.py:284-359): 17 points per body -- a handful of small device ops."""
+        nrm = lambda a, b: torch.linalg.norm(a - b, dim=-1)
         if 'joints2D' in pred and 'joints2D' in target and 'joints2D-L2E' in self.metrics:
             e = nrm(pred['joints2D'], target['joints2D'])                                         # (B, 17)
             if 'joints2D_vis' in target:

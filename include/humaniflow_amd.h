@@ -193,7 +193,7 @@ int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const flo
  * w_packed = hmf_conv_patch_pack_host(w (Cout,ks,ks,Cin) channels_last, ..., cfg) uploaded to the device
  * (hmf_conv_patch_packed_floats floats).  cfg = TW*1000 + PG*100 + TN*10 + (SC==128): 16420/16421 = 8x16-pixel tile x 64 channels,
  * 16410/16411 = 8x16 x 32 channels, 8210/8211 = 8x8 x 64 channels; SC = input channels per slab (64, or 128 for 1x1 only);
- * Cin % SC == 0, Cout % (channels per tile) == 0.  Same epilogue and profiler tag (8) as hmf_conv2d_nhwc. */
+ * Cin % SC == 0, Cout % (channels per tile) == 0.  Same epilogue as hmf_conv2d_nhwc; profiler tag 10. */
 long long hmf_conv_patch_packed_floats(int Cin, int Cout, int ks);
 int hmf_conv_patch_pack_host(const float* w, float* packed, int Cin, int Cout, int ks, int cfg);
 int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
@@ -210,13 +210,25 @@ int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, floa
 int hmf_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Evaluation epilogue (metrics/eval_metrics_tracker.py:95-280,398-410; utils/eval_utils.py)     */
+/* ------------------------------------------------------------------------------------------ */
+/* Point-set error metrics of npairs (prediction, target) pairs of npts 3-D points.  P: (npairs, npts, 3); T: (npairs/group, npts, 3),
+ * pair p is scored against target p / group (group = N for the N samples of an image, 1 for point estimates).
+ * out: (npairs, 3) = mean |P-T| (PVE / MPJPE), mean |sc(P)-T| with scale_and_translation_transform_batch (eval_utils.py:107-125),
+ * mean |pa(P)-T| with procrustes_analysis_batch (:62-104; 0 when want_pa = 0).  All on the device, fp64 statistics. */
+int hmf_pointset_errors(const float* P, const float* T, int npairs, int group, int npts, int want_pa, float* out, void* stream);
+/* Sample diversity (eval_metrics_tracker.py:398-410): S (B, N, npts, 3) -> partial (B, ceil(npts/256)) partial sums over n and points
+ * of |S - mean_n S|; the caller adds the chunks (deterministic) and divides by N * npts. */
+int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */
 /* ------------------------------------------------------------------------------------------ */
 /* While enabled, every launch of the kernels tagged below is bracketed by hipEventRecord on ITS stream
- * (no synchronisation, <= 4096 launches kept).  hmf_profile_collect synchronises the recorded events and
+ * (no synchronisation, <= 16384 launches kept).  hmf_profile_collect synchronises the recorded events and
  * copies out, per launch: duration in ms, kernel tag, and the launch's row count M (or B*N for flow).
  * Tags: 1 = k_lbs_mfma, 2 = k_rigid_chain, 3 = k_joints, 4 = k_tpose, 5 = k_flow_ctx0, 6 = k_flow_chain,
- * 7 = k_isgc.  Returns the number of launches copied (<= max), or a negative error.                */
+ * 7 = k_isgc, 8 = k_conv_igemm, 9 = k_stem_conv, 10 = k_conv_patch (rows = output pixels B*OH*OW; stem: B).  Returns the number of launches copied (<= max), or a negative error.                */
 int hmf_profile_enable(int enable);
 int hmf_profile_collect(double* ms_host, int32_t* tag_host, int32_t* rows_host, int max);
 /* Diagnostic: device buffer of 23 x 8 int64 that k_flow_chain's tile 0 fills with shader-clock stamps per part phase
