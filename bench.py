@@ -64,8 +64,9 @@ def parse():
     ap.add_argument('--tpose', action='store_true', help='add the evaluate-flavour T-pose bodies to the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=32, help='images of the bounded CPU-baseline sample')
-    ap.add_argument('--no-chain-encoders', dest='chain_encoders', action='store_false',
-                    help='let the encoders of consecutive steps overlap each other on the streams')
+    ap.add_argument('--chain-encoders', action='store_true',
+                    help='serialise the encoders of consecutive steps with an event (cleaner per-kernel timings, ~10 %% less throughput): '
+                         'by default batches on different streams overlap freely')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the steps are round-robined over (batches are independent: the '
                     'low-occupancy flow kernels of step i overlap the encoder convolutions of step i+1)')
     return ap.parse_args()
@@ -239,11 +240,13 @@ def main():
             kern['%s[M=%d]' % (nm, r)] = round(float(ms[sel].mean()) * 1e3, 2)      # us
     # encoder convolutions: one record per launch in plan order (stem, then per block [downsample,] conv1..convK)
     conv_flops, conv_kind = encoder_conv_flops(model.image_encoder, B, x.shape[-1])
-    csel = (tag >= 8) & (tag <= 10)
-    conv = None
-    if csel.sum() == args.steps * len(conv_flops):
-        cms = ms[csel].reshape(args.steps, len(conv_flops)).mean(0)                  # ms per launch, per layer
-        ctag = tag[csel].reshape(args.steps, len(conv_flops))[0]
+
+    def conv_families(ms_, tag_, reps):
+        csel = (tag_ >= 8) & (tag_ <= 10)
+        if csel.sum() != reps * len(conv_flops):
+            return None
+        cms = ms_[csel].reshape(reps, len(conv_flops)).mean(0)                      # ms per launch, per layer
+        ctag = tag_[csel].reshape(reps, len(conv_flops))[0]
         fam = {}
         for f, k, t, tg in zip(conv_flops, conv_kind, cms, ctag):
             name = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (%s)' % k, 8: 'k_conv_igemm (%s)' % k}[int(tg)]
@@ -255,7 +258,8 @@ def main():
             d['tflops'] = round(d['flop'] / (d['us_per_step'] * 1e-6) / 1e12, 2)
             d['us_per_step'] = round(d['us_per_step'], 1)
             d['gflop_per_step'] = round(d.pop('flop') / 1e9, 2)
-        conv = fam
+        return fam
+    conv = conv_families(ms, tag, args.steps)
     lbs_sel = (tag == 1) & (rows == B * N)
     lbs_ms = float(ms[lbs_sel].mean()) if lbs_sel.any() else float('nan')
     achieved = LBS_FLOP_PER_UNIT * B * N / (lbs_ms * 1e-3) / 1e12
@@ -271,6 +275,14 @@ def main():
         return a.elapsed_time(b) / reps, r
     with torch.no_grad():
         enc_ms, feats = timed(lambda: model(x, return_input_feats_only=True)['input_feats'])
+        # the convolution kernels once more with nothing else on the device: what each family achieves by itself
+        lib.hmf_profile_enable(1)
+        for _ in range(5):
+            model(x, return_input_feats_only=True)
+        ms3 = np.zeros(1024); tag3 = np.zeros(1024, np.int32); rows3 = np.zeros(1024, np.int32)
+        n3 = lib.hmf_profile_collect(ms3.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag3), _lib.iptr(rows3), 1024)
+        lib.hmf_profile_enable(0)
+        conv_iso = conv_families(ms3[:n3], tag3[:n3], 5)
         flow_ms, pred = timed(lambda: model(None, input_feats=feats, num_samples=N))
         g = pred['glob_rotmat']
         go = g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3).contiguous()
@@ -330,7 +342,7 @@ def main():
                                       'frac': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                          'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * B * N},
             'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 3),
-            'conv_kernels': conv,
+            'conv_kernels': conv, 'conv_kernels_isolated': conv_iso,
             'stages_ms': {'encoder_resnet%d' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
                           'smpl_samples': round(smpl_ms, 3), 'smpl_tpose': round(tp_ms, 3)},
             'kernels_us': kern,
@@ -345,7 +357,14 @@ def main():
                                'traffic_note': 'mean HBM bytes/launch over the 3x3 launches from separate rocprofv3 --pmc passes (profiles/r01_pmc.json)',
                                'avg_launch_us': round(dom['us_per_step'] / dom['launches_per_step'], 2),
                                'launches': dom['launches_per_step'] * args.steps, 'algorithmic_flop_per_launch': per_launch_flop,
-                               'note': 'HIP events on the launch stream inside the timed region; with 2 streams the launches share the GPU with the flow/SMPL kernels of the previous batch'}
+                               'isolated': None if not conv_iso else {
+                                   'avg_launch_us': round(conv_iso['k_conv_patch (3x3)']['us_per_step'] / dom['launches_per_step'], 2),
+                                   'achieved': conv_iso['k_conv_patch (3x3)']['tflops'],
+                                   'frac': round(conv_iso['k_conv_patch (3x3)']['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)},
+                               'step_aggregate': {'what': 'algorithmic FLOPs of all MFMA kernels of a step (encoder convolutions + SMPL blend GEMMs) / step time',
+                                                  'achieved': round((sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)) / (elapsed / args.steps) / 1e12, 2),
+                                                  'frac': round((sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)) / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+                               'note': 'HIP events on the launch stream inside the timed region; with %d streams the launches share the CUs with the kernels of the other in-flight batches, which stretches every launch: `isolated` is the same kernel family with one stream' % len(streams)}
         else:
             res['roofline'] = res['roofline_lbs']
         if world == 1 and not args.no_cpu_baseline:

@@ -15,5 +15,7 @@ DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 python tools/rocpd_stats.py "$DB" 48 --steps $STEPS > "$OUT/${R}_kernel_stats.md"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $BENCH >/dev/null 2>/tmp/f.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $BENCH >/dev/null 2>/tmp/w.log
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_m -o m -- $BENCH --streams 1 >/dev/null 2>/tmp/m.log
+python tools/pmc_mfma.py "$(find /tmp/prof_m -name '*.db' | head -1)" > "$OUT/${R}_mfma_busy.txt"
 python tools/pmc_summary.py "$(find /tmp/prof_f -name '*.db' | head -1)" "$(find /tmp/prof_w -name '*.db' | head -1)" > "$OUT/${R}_pmc.json"
 ls -la "$OUT"

@@ -39,8 +39,8 @@ for r in rows[:int(args[1]) if len(args) > 1 else 40]:
 print('\ntotal kernel time: %.3f ms over %d dispatches; wall span of the window %.3f ms' % (total / 1e6, sum(r[1] for r in rows), span / 1e6))
 if steps:
     print('per step: %.3f ms of kernel time, %.3f ms of wall span' % (total / 1e6 / steps, span / 1e6 / steps))
-    groups = [('encoder convolutions (MIOpen: igemm / ck)', "(name like 'igemm%' or name like '%ck%tensor_operation%' or name like '%conv%')"),
-              ('encoder epilogues (hmf::k_bias_act)', "name like '%k_bias_act%'"),
+    groups = [('encoder convolutions (hmf::k_stem_conv, k_conv_patch, k_conv_igemm)', "(name like '%hmf::k_stem_conv%' or name like '%hmf::k_conv_%')"),
+              ('encoder max-pool (hmf::k_maxpool_nhwc)', "name like '%k_maxpool_nhwc%'"),
               ('flow (hmf::k_isgc, k_flow_*)', "(name like '%hmf::k_isgc%' or name like '%hmf::k_flow%')"),
               ('SMPL (hmf::k_lbs_mfma, k_rigid_chain, k_joints, k_tpose)', "(name like '%hmf::k_lbs%' or name like '%hmf::k_rigid%' or name like '%hmf::k_joints%' or name like '%hmf::k_tpose%')")]
     print('\n| stage | ms / step | % of kernel time |\n|---|---|---|')
@@ -49,4 +49,4 @@ if steps:
         v = con.execute("select coalesce(sum(duration), 0) from kernels" + where + " and " + cond).fetchone()[0]
         acc += v
         print('| %s | %.3f | %.1f |' % (label, v / 1e6 / steps, 100.0 * v / total))
-    print('| everything else (torch glue: max-pool, heads GEMMs, copies, RNG) | %.3f | %.1f |' % ((total - acc) / 1e6 / steps, 100.0 * (total - acc) / total))
+    print('| everything else (torch glue: feature mean, heads GEMMs, copies, RNG) | %.3f | %.1f |' % ((total - acc) / 1e6 / steps, 100.0 * (total - acc) / total))
