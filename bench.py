@@ -242,14 +242,14 @@ def main():
     conv_flops, conv_kind = encoder_conv_flops(model.image_encoder, B, x.shape[-1])
 
     def conv_families(ms_, tag_, reps):
-        csel = (tag_ >= 8) & (tag_ <= 10)
+        csel = (tag_ >= 8) & (tag_ <= 11)
         if csel.sum() != reps * len(conv_flops):
             return None
         cms = ms_[csel].reshape(reps, len(conv_flops)).mean(0)                      # ms per launch, per layer
         ctag = tag_[csel].reshape(reps, len(conv_flops))[0]
         fam = {}
         for f, k, t, tg in zip(conv_flops, conv_kind, cms, ctag):
-            name = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (%s)' % k, 8: 'k_conv_igemm (%s)' % k}[int(tg)]
+            name = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (%s)' % k, 8: 'k_conv_igemm (%s)' % k, 11: 'k_conv_winograd (%s)' % k}[int(tg)]
             d = fam.setdefault(name, {'launches_per_step': 0, 'us_per_step': 0.0, 'flop': 0.0})
             d['launches_per_step'] += 1
             d['us_per_step'] += t * 1e3
@@ -311,14 +311,17 @@ def main():
             traffic = max(c['hbm_bytes_per_launch'] for c in cand)
     except Exception:
         pass
-    conv_traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-        cand = [v for k, v in pmc.items() if 'k_conv_patch<3' in k]
-        if cand and B == 32:
-            conv_traffic = int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
-    except Exception:
-        pass
+    def conv_traffic(family):
+        key = {'k_conv_igemm (1x1)': 'k_conv_igemm', 'k_conv_patch (3x3)': 'k_conv_patch<3', 'k_conv_winograd (3x3)': 'k_conv_winograd',
+               'k_stem_conv (7x7/2)': 'k_stem_conv'}.get(family)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+            cand = [v for k, v in pmc.items() if key and key in k]
+            if cand and B == 32:
+                return int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
+        except Exception:
+            pass
+        return None
     if rank == 0:
         value = world * B * N * args.steps / elapsed
         res = {
@@ -347,21 +350,21 @@ def main():
                           'smpl_samples': round(smpl_ms, 3), 'smpl_tpose': round(tp_ms, 3)},
             'kernels_us': kern,
         }
-        # the dominant kernel of the step: the patch-resident 3x3 convolution (16 launches per step for ResNet-50)
-        dom = None if conv is None else conv.get('k_conv_patch (3x3)')
-        if dom:
+        # the dominant kernel of the step = the kernel family with the largest share of the step's kernel time
+        dom_name = None if conv is None else max(conv, key=lambda k: conv[k]['us_per_step'])
+        if dom_name:
+            dom = conv[dom_name]
+            iso = conv_iso.get(dom_name) if conv_iso else None
             per_launch_flop = dom['gflop_per_step'] * 1e9 / dom['launches_per_step']
-            res['roofline'] = {'kernel': 'k_conv_patch (3x3 convolutions of the encoder, %d launches/step, largest share of the step)' % dom['launches_per_step'],
+            res['roofline'] = {'kernel': '%s convolutions of the encoder: %d launches/step, largest share of the step' % (dom_name, dom['launches_per_step']),
                                'bound': 'mfma', 'achieved': dom['tflops'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': conv_traffic,
-                               'traffic_note': 'mean HBM bytes/launch over the 3x3 launches from separate rocprofv3 --pmc passes (profiles/r01_pmc.json)',
+                               'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': conv_traffic(dom_name),
+                               'traffic_note': 'mean HBM bytes/launch over these launches from separate rocprofv3 --pmc passes (profiles/r01_pmc.json)',
                                'avg_launch_us': round(dom['us_per_step'] / dom['launches_per_step'], 2),
                                'launches': dom['launches_per_step'] * args.steps, 'algorithmic_flop_per_launch': per_launch_flop,
-                               'isolated': None if not conv_iso else {
-                                   'avg_launch_us': round(conv_iso['k_conv_patch (3x3)']['us_per_step'] / dom['launches_per_step'], 2),
-                                   'achieved': conv_iso['k_conv_patch (3x3)']['tflops'],
-                                   'frac': round(conv_iso['k_conv_patch (3x3)']['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)},
-                               'step_aggregate': {'what': 'algorithmic FLOPs of all MFMA kernels of a step (encoder convolutions + SMPL blend GEMMs) / step time',
+                               'isolated': None if not iso else {'avg_launch_us': round(iso['us_per_step'] / iso['launches_per_step'], 2),
+                                                                 'achieved': iso['tflops'], 'frac': round(iso['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)},
+                               'step_aggregate': {'what': 'algorithmic FLOPs (2MNK of every convolution + SMPL blend GEMMs) of a step / step time',
                                                   'achieved': round((sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)) / (elapsed / args.steps) / 1e12, 2),
                                                   'frac': round((sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)) / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                                'note': 'HIP events on the launch stream inside the timed region; with %d streams the launches share the CUs with the kernels of the other in-flight batches, which stretches every launch: `isolated` is the same kernel family with one stream' % len(streams)}

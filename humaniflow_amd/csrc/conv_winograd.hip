@@ -1,0 +1,223 @@
+// Winograd F(2x2, 3x3) NHWC fp32 convolution for the encoder's stride-1 3x3 layers (row a1): 2.25x fewer MFMA k-steps than the direct
+// form for the same result (Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A, Lavin & Gray 2016), fused with the folded-BN epilogue.
+//
+// Work decomposition (one work-group = 4 waves):
+//   * an 8 x 16 tile of output pixels of one image = 32 Winograd tiles (4 x 8 of 2x2 pixels) x 32 output channels;
+//   * K is walked in slabs of 64 input channels; per slab the 10 x 18 x 64 input patch is copied once into LDS (raw buffer loads, zeros in the padding);
+//   * wave w owns the four transform positions (xi = w, nu = 0..3).  The input transform is done in registers on the fly: lane (tile i, q)
+//     reads the 2 x 4 patch pixels its row xi needs (8 ds_read_b128 at immediate offsets), forms t[b] = +-d[a1][b] +- d[a2][b] and
+//     V[nu] = t0-t2, t1+t2, t2-t1, t1-t3 -- 4 MFMA A operands (4 k-steps each) for 32 VALU instructions, no transformed copy in LDS;
+//   * the transformed weights U = G g G^T are computed at plan time and packed in MFMA B-operand lane order per (n-tile, wave, slab, k-group, nu):
+//     they stream L2 -> VGPR one k-group ahead and never touch LDS;
+//   * 16 accumulators (positions) x 32 tiles x 32 channels live in the 4 waves (4 x 16 registers each).  After the last slab they are
+//     exchanged through LDS (two halves of 16 tiles, reusing the patch buffer) and every thread applies the output transform to
+//     (tile, channel) pairs: + bias, + residual, ReLU, NHWC stores with lane = channel (128-byte runs).
+#include "hmf_common.h"
+
+namespace hmf {
+
+struct WinoArgs {
+    const float* x;       // [B][H][W][Cin]
+    const f32x4* wp;      // packed transformed weights
+    const float* bias;
+    const float* res;
+    float* y;             // [B][H][W][Cout]
+    int B, H, W, Cin, Cout, relu, tiles_w, tiles_hw, n_tiles;
+};
+
+constexpr int kWTH = 8, kWTW = 16, kWSC = 64;
+constexpr int kWPH = kWTH + 2, kWPW = kWTW + 2;
+constexpr int kWCS = kWSC + 4;                       // LDS pixel stride (floats)
+constexpr int kWRP = kWPW * kWCS;                    // LDS row pitch
+constexpr int kWNG = kWSC / 8;                       // k-groups per slab
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_winograd(const WinoArgs a) {
+    constexpr int NV = kWPH * kWPW * (kWSC / 4), NIT = (NV + 255) / 256;
+    __shared__ float lds[kWPH * kWRP];               // patch (49 KB); reused for the accumulator exchange (2 x 32 KB halves)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lq = lane >> 5;
+
+    const int T = gridDim.x;
+    int L = blockIdx.x;
+    if ((T & 7) == 0) L = (blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    const int nt = L % a.n_tiles, pt = L / a.n_tiles;
+    const int b = pt / a.tiles_hw, trem = pt - b * a.tiles_hw;
+    const int oh0 = (trem / a.tiles_w) * kWTH, ow0 = (trem % a.tiles_w) * kWTW;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.H * a.W * a.Cin * 4, 0x00020000);
+    constexpr int kOOB = (int)0x80000000;
+    int goff[NIT], loff[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int e = tid + 256 * k;
+        const int p = e / (kWSC / 4), c4 = e - p * (kWSC / 4);
+        const int r = p / kWPW, col = p - r * kWPW;
+        const int ih = oh0 + r - 1, iw = ow0 + col - 1;
+        const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        goff[k] = ok ? (((b * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
+        loff[k] = r * kWRP + col * kWCS + 4 * c4;
+    }
+    const int nslab = a.Cin / kWSC;
+    // weight stream of this wave: [n-tile][wave xi][slab][g][nu][lane][4]
+    const f32x4* pw = a.wp + ((long long)(nt * 4 + wave) * nslab * kWNG * 4) * 64 + lane;
+
+    // row transform of this wave: t[b] = s1 * d[a1][b] + s2 * d[a2][b]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
+    const int a1 = wave == 0 ? 0 : 1, a2 = wave == 3 ? 3 : 2;
+    const float s1 = wave == 2 ? -1.f : 1.f, s2 = (wave == 0 || wave == 3) ? -1.f : 1.f;
+    const int ti = li >> 3, tj = li & 7;
+    const float* pbase = lds + (2 * ti) * kWRP + (2 * tj) * kWCS + 4 * lq;
+    const float* p1 = pbase + a1 * kWRP;
+    const float* p2 = pbase + a2 * kWRP;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    f32x4 bw[2][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bw[0][n] = pw[n * 64];
+
+    for (int s = 0; s < nslab; ++s) {
+        f32x4 pv[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int off = goff[k] == kOOB ? kOOB : goff[k] + s * kWSC * 4;
+            pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (NV % 256 == 0 || k < NIT - 1 || tid + 256 * k < NV) *(f32x4*)&lds[loff[k]] = pv[k];
+        __syncthreads();
+
+        const bool last = (s + 1 == nslab);
+#pragma clang loop unroll(full)
+        for (int g = 0; g < kWNG; ++g) {
+            if (!(last && g + 1 == kWNG)) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bw[(g + 1) & 1][n] = pw[((g + 1) * 4 + n) * 64];
+            }
+            f32x4 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 d1 = *(const f32x4*)(p1 + c * kWCS + 8 * g);
+                const f32x4 d2 = *(const f32x4*)(p2 + c * kWCS + 8 * g);
+                t[c] = s1 * d1 + s2 * d2;
+            }
+            f32x4 v[4];
+            v[0] = t[0] - t[2];
+            v[1] = t[1] + t[2];
+            v[2] = t[2] - t[1];
+            v[3] = t[1] - t[3];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[n][u], bw[g & 1][n][u], acc[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pw += kWNG * 4 * 64;
+    }
+
+    // ---- output transform: exchange the 16 position accumulators through LDS, 16 tiles at a time ----
+    // M[pos][tile16][ch32]: pos = 4 * wave + nu; accumulator register r of lane (j = li, q) holds tile (r & 3) + 8 (r >> 2) + 4 q, channel j
+    const int ch = tid & 31;
+    const int n_out = nt * 32 + ch;
+    const float bv = a.bias ? a.bias[n_out] : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = 8 * h + rr;                                  // registers with (r >> 2) in {2h, 2h+1}: tiles 16h .. 16h+15
+                const int tl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lq;      // tile within the half
+                lds[((4 * wave + n) * 16 + tl) * 32 + li] = acc[n][r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int tl = (tid >> 5) + 8 * k, tile = 16 * h + tl;
+            float m[4][4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) m[xi][nu] = lds[((4 * xi + nu) * 16 + tl) * 32 + ch];
+            float s0[4], s1v[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                s0[nu] = m[0][nu] + m[1][nu] + m[2][nu];
+                s1v[nu] = m[1][nu] - m[2][nu] - m[3][nu];
+            }
+            const float yv[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1v[0] + s1v[1] + s1v[2], s1v[1] - s1v[2] - s1v[3]}};
+            const int oh = oh0 + 2 * (tile >> 3), ow = ow0 + 2 * (tile & 7);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    if (oh + dy < a.H && ow + dx < a.W) {
+                        const long long o = (((long long)b * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
+                        float v = yv[dy][dx] + bv;
+                        if (a.res) v += a.res[o];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        a.y[o] = v;
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+// w_packed: [Cout/32][4 xi][Cin/64][8 g][4 nu][64 lanes = q*32 + j][4 u] = U[32 t + j][slab*64 + 8 g + 4 q + u][xi][nu],  U = G g G^T
+extern "C" int hmf_conv_winograd_pack_host(const float* w /*[Cout][3][3][Cin]*/, float* packed, int Cin, int Cout) {
+    if (!w || !packed) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_pack_host: null pointer");
+    if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd_pack_host: Cin=%d %% 64 or Cout=%d %% 32", Cin, Cout);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nslab = Cin / kWSC;
+    long long o = 0;
+    for (int t = 0; t < Cout / 32; ++t)
+        for (int xi = 0; xi < 4; ++xi)
+            for (int s = 0; s < nslab; ++s)
+                for (int g = 0; g < kWNG; ++g)
+                    for (int nu = 0; nu < 4; ++nu)
+                        for (int l = 0; l < 64; ++l)
+                            for (int u = 0; u < 4; ++u) {
+                                const int n = 32 * t + (l & 31), c = s * kWSC + 8 * g + 4 * (l >> 5) + u;
+                                double acc = 0.0;
+                                for (int p = 0; p < 3; ++p)
+                                    for (int q = 0; q < 3; ++q) acc += G[xi][p] * G[nu][q] * (double)w[(((long long)n * 3 + p) * 3 + q) * Cin + c];
+                                packed[o++] = (float)acc;
+                            }
+    return HMF_OK;
+}
+
+extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }
+
+extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                                 int Cin, int Cout, int relu, void* stream) {
+    if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: bad args");
+    if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: Cin=%d must be a multiple of 64 and Cout=%d of 32", Cin, Cout);
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: x and w_packed must be 16-byte aligned");
+    if ((long long)B * H * W * Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29))
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
+    WinoArgs a;
+    a.x = x; a.wp = (const f32x4*)w_packed; a.bias = bias; a.res = residual; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+    a.tiles_w = (W + kWTW - 1) / kWTW;
+    a.tiles_hw = a.tiles_w * ((H + kWTH - 1) / kWTH);
+    a.n_tiles = Cout / 32;
+    const long long blocks = (long long)B * a.tiles_hw * a.n_tiles;
+    if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: too many tiles");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(11, B * H * W, st);
+    hipLaunchKernelGGL(k_conv_winograd, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}

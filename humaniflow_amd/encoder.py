@@ -162,11 +162,15 @@ class ResNetEncoder(nn.Module):
                     w, b, s, p = stages[-1]
                     stages[-1] = (w, (b + ds[1]).contiguous(), s, p)
                 plan['blocks'].append((stages, ds))
-        plan['packed'] = {}
+        plan['packed'], plan['wino'] = {}, {}
         if self.conv1.weight.is_cuda:
             for stages, ds in plan['blocks']:
                 for w, b, s, p in stages:
                     cfg = self._patch_cfg(w)
+                    if cfg and s[0] == 1 and w.shape[1] <= 256:
+                        # stride-1 3x3 layers on maps >= 16 pixels wide (layer1-3 at 256x256 input) run as Winograd F(2x2,3x3); the patch
+                        # kernel stays packed too for narrower maps (chosen per call from the activation width)
+                        plan['wino'][id(w)] = self._pack_winograd(w)
                     if cfg:
                         pk = self._pack_patch(w, cfg)
                         plan['packed'][id(w)] = (cfg, pk)              # the packing depends only on the slab size (64 for every 3x3 cfg)
@@ -190,6 +194,15 @@ class ResNetEncoder(nn.Module):
         _lib.check(lib.hmf_conv_patch_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout, ks, cfg), 'hmf_conv_patch_pack_host')
         return packed.to(w.device)
 
+    def _pack_winograd(self, w):
+        from . import _lib
+        lib = _lib.load()
+        cout, cin = w.shape[:2]
+        wh = w.detach().permute(0, 2, 3, 1).contiguous().cpu()
+        packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(cin, cout)), dtype=torch.float32)
+        _lib.check(lib.hmf_conv_winograd_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout), 'hmf_conv_winograd_pack_host')
+        return packed.to(w.device)
+
     def _conv_hip(self, x, w, bias, stride, residual, relu):
         """y = relu?(conv(x, w) + bias + residual) in one launch; x / residual / y are channels_last (B,C,H,W) tensors."""
         from . import _lib
@@ -199,6 +212,12 @@ class ResNetEncoder(nn.Module):
         pad = ks // 2
         OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        wk = self._plan['wino'].get(id(w)) if self._plan is not None else None
+        if wk is not None and stride == 1 and W >= 16:
+            _lib.check(lib.hmf_conv_winograd(x.data_ptr(), wk.data_ptr(), None if bias is None else bias.data_ptr(),
+                                             None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout,
+                                             int(relu), _lib.current_stream()), 'hmf_conv_winograd')
+            return y
         pk = self._plan['packed'].get(id(w)) if self._plan is not None else None
         if pk is not None:
             cfg = 8210 if stride == 2 else pk[0]                            # the stride-2 3x3 variant is built for the 8x8 tile

@@ -199,6 +199,15 @@ int hmf_conv_patch_pack_host(const float* w, float* packed, int Cin, int Cout, i
 int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                    int Cin, int Cout, int ks, int stride, int relu, int cfg, void* stream);
 
+/* Winograd F(2x2,3x3) variant for stride-1 3x3 layers (same result as hmf_conv2d_nhwc with ks = 3, 2.25x fewer MFMA k-steps): 8x16-pixel
+ * tiles x 32 channels, input transform in registers, output transform through LDS, same fused epilogue.  w_packed =
+ * hmf_conv_winograd_pack_host(w (Cout,3,3,Cin) channels_last, ...) [the transformed weights G g G^T in MFMA lane order,
+ * hmf_conv_winograd_packed_floats = 16*Cout*Cin floats] uploaded to the device.  Cin % 64 == 0, Cout % 32 == 0.  Profiler tag 11. */
+long long hmf_conv_winograd_packed_floats(int Cin, int Cout);
+int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout);
+int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                      int Cin, int Cout, int relu, void* stream);
+
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
  * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.
  * w_packed: hmf_stem_pack_host(w (64,18,7,7) row-major [already multiplied by the BN scale], packed[hmf_stem_packed_floats()])
@@ -228,7 +237,7 @@ int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial,
  * (no synchronisation, <= 16384 launches kept).  hmf_profile_collect synchronises the recorded events and
  * copies out, per launch: duration in ms, kernel tag, and the launch's row count M (or B*N for flow).
  * Tags: 1 = k_lbs_mfma, 2 = k_rigid_chain, 3 = k_joints, 4 = k_tpose, 5 = k_flow_ctx0, 6 = k_flow_chain,
- * 7 = k_isgc, 8 = k_conv_igemm, 9 = k_stem_conv, 10 = k_conv_patch (rows = output pixels B*OH*OW; stem: B).  Returns the number of launches copied (<= max), or a negative error.                */
+ * 7 = k_isgc, 8 = k_conv_igemm, 9 = k_stem_conv, 10 = k_conv_patch, 11 = k_conv_winograd (rows = output pixels B*OH*OW; stem: B).  Returns the number of launches copied (<= max), or a negative error.                */
 int hmf_profile_enable(int enable);
 int hmf_profile_collect(double* ms_host, int32_t* tag_host, int32_t* rows_host, int max);
 /* Diagnostic: device buffer of 23 x 8 int64 that k_flow_chain's tile 0 fills with shader-clock stamps per part phase

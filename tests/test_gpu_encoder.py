@@ -92,6 +92,39 @@ def test_patch_conv3x3_stride2():
     _patch_case(1, 13, 9, 64, 128, 3, 2, True, False, 8210, seed=3)
 
 
+def _wino_case(B, H, W, cin, cout, res, relu, seed=0):
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), 1, 1)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    wh = w.permute(0, 2, 3, 1).contiguous()
+    packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(cin, cout)))
+    _lib.check(lib.hmf_conv_winograd_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout), 'pack')
+    xd, pd, bd = x.cuda().contiguous(memory_format=torch.channels_last), packed.cuda(), bias.cuda()
+    rd = r.cuda().contiguous(memory_format=torch.channels_last) if res else None
+    y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.hmf_conv_winograd(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
+                                     B, H, W, cin, cout, int(relu), _lib.current_stream()), 'hmf_conv_winograd')
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, res, relu, err)      # Winograd: a few more roundings than direct
+
+
+def test_winograd_conv3x3_matches_float64_reference():
+    _wino_case(2, 16, 16, 128, 64, True, True)                  # two slabs, two channel tiles, whole pixel tiles
+    _wino_case(1, 8, 32, 64, 32, False, False, seed=1)          # one tile row, two tile columns
+    _wino_case(2, 11, 19, 64, 96, True, True, seed=2)           # ragged: odd sizes, masked stores, zero padding inside tiles
+    _wino_case(1, 32, 32, 256, 256, False, True, seed=3)        # l3-like depth
+
+
 def test_conv_rejects_unsupported_shapes():
     from humaniflow_amd import _lib
     lib = _lib.load()

@@ -101,8 +101,24 @@ for name, hw, cin, cout, ks, s, res in shapes():
                 line += '(ERR %.2e)' % err
             elif best is None or t < best[0]:
                 best = (t, cfg)
+    if ks == 3 and s == 1 and cin % 64 == 0 and hw >= 16:
+        wh = w.permute(0, 2, 3, 1).contiguous().cpu()
+        packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(cin, cout)))
+        _lib.check(lib.hmf_conv_winograd_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout), 'wpack')
+        pd = packed.to(dev)
+        fn = lambda: _lib.check(lib.hmf_conv_winograd(x.data_ptr(), pd.data_ptr(), bias.data_ptr(), None if r is None else r.data_ptr(), y.data_ptr(),
+                                                      B, hw, hw, cin, cout, 1, st), 'wino')
+        y.fill_(float('nan'))
+        fn()
+        err = (y - ref).abs().max().item()
+        t = timeit(fn)
+        line += ' wino:%7.1f' % t
+        if not err < 1e-3:
+            line += '(ERR %.2e)' % err
+        elif t < best[0]:
+            best = (t, 'wino')
     fl = 2.0 * B * oh * oh * cout * cin * ks * ks
-    print('%-9s hw%3d %4d->%4d k%d s%d  miopen %7.1f us (%5.1f TF)  ours best %7.1f us (%5.1f TF) tile %6d |%s' %
+    print('%-9s hw%3d %4d->%4d k%d s%d  miopen %7.1f us (%5.1f TF)  ours best %7.1f us (%5.1f TF) tile %6s |%s' %
           (name, hw, cin, cout, ks, s, t_mi, fl / t_mi / 1e6, best[0], fl / best[0] / 1e6, best[1], line), flush=True)
     seen[key] = (t_mi, best[0])
     tot_mi += t_mi
