@@ -31,6 +31,7 @@ constexpr int kWCS = kWSC + 4;                       // LDS pixel stride (floats
 constexpr int kWRP = kWPW * kWCS;                    // LDS row pitch
 constexpr int kWNG = kWSC / 8;                       // k-groups per slab
 
+template <int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_winograd(const WinoArgs a) {
     constexpr int NV = kWPH * kWPW * (kWSC / 4), NIT = (NV + 255) / 256;
     __shared__ float lds[kWPH * kWRP];               // patch (49 KB); reused for the accumulator exchange (2 x 32 KB halves)
@@ -59,7 +60,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     const int nslab = a.Cin / kWSC;
     // weight stream of this wave: [n-tile][wave xi][slab][g][nu][lane][4]
-    const f32x4* pw = a.wp + ((long long)(nt * 4 + wave) * nslab * kWNG * 4) * 64 + lane;
+    const f32x4* pw[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((long long)((nt * TN + t) * 4 + wave) * nslab * kWNG * 4) * 64 + lane;
 
     // row transform of this wave: t[b] = s1 * d[a1][b] + s2 * d[a2][b]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
     const int a1 = wave == 0 ? 0 : 1, a2 = wave == 3 ? 3 : 2;
@@ -69,15 +72,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const float* p1 = pbase + a1 * kWRP;
     const float* p2 = pbase + a2 * kWRP;
 
-    f32x16 acc[4];
+    f32x16 acc[TN][4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][n][r] = 0.f;
 
-    f32x4 bw[2][4];
+    f32x4 bw[2][TN][4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) bw[0][n] = pw[n * 64];
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bw[0][t][n] = pw[t][n * 64];
 
     for (int s = 0; s < nslab; ++s) {
         f32x4 pv[NIT];
@@ -98,7 +105,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int g = 0; g < kWNG; ++g) {
             if (!(last && g + 1 == kWNG)) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) bw[(g + 1) & 1][n] = pw[((g + 1) * 4 + n) * 64];
+                for (int t = 0; t < TN; ++t)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bw[(g + 1) & 1][t][n] = pw[t][((g + 1) * 4 + n) * 64];
             }
             f32x4 t[4];
 #pragma unroll
@@ -116,57 +125,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[n][u], bw[g & 1][n][u], acc[n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[n][u], bw[g & 1][t][n][u], acc[t][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        pw += kWNG * 4 * 64;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) pw[t] += kWNG * 4 * 64;
     }
 
     // ---- output transform: exchange the 16 position accumulators through LDS, 16 tiles at a time ----
     // M[pos][tile16][ch32]: pos = 4 * wave + nu; accumulator register r of lane (j = li, q) holds tile (r & 3) + 8 (r >> 2) + 4 q, channel j
     const int ch = tid & 31;
-    const int n_out = nt * 32 + ch;
-    const float bv = a.bias ? a.bias[n_out] : 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
+    for (int t = 0; t < TN; ++t) {
+        const int n_out = (nt * TN + t) * 32 + ch;
+        const float bv = a.bias ? a.bias[n_out] : 0.f;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = 8 * h + rr;                                  // registers with (r >> 2) in {2h, 2h+1}: tiles 16h .. 16h+15
-                const int tl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lq;      // tile within the half
-                lds[((4 * wave + n) * 16 + tl) * 32 + li] = acc[n][r];
-            }
-        __syncthreads();
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int tl = (tid >> 5) + 8 * k, tile = 16 * h + tl;
-            float m[4][4];
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) m[xi][nu] = lds[((4 * xi + nu) * 16 + tl) * 32 + ch];
-            float s0[4], s1v[4];
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                s0[nu] = m[0][nu] + m[1][nu] + m[2][nu];
-                s1v[nu] = m[1][nu] - m[2][nu] - m[3][nu];
-            }
-            const float yv[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1v[0] + s1v[1] + s1v[2], s1v[1] - s1v[2] - s1v[3]}};
-            const int oh = oh0 + 2 * (tile >> 3), ow = ow0 + 2 * (tile & 7);
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    if (oh + dy < a.H && ow + dx < a.W) {
-                        const long long o = (((long long)b * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
-                        float v = yv[dy][dx] + bv;
-                        if (a.res) v += a.res[o];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        a.y[o] = v;
-                    }
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * h + rr;                                  // registers with (r >> 2) in {2h, 2h+1}: tiles 16h .. 16h+15
+                    const int tl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lq;      // tile within the half
+                    lds[((4 * wave + n) * 16 + tl) * 32 + li] = acc[t][n][r];
                 }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int tl = (tid >> 5) + 8 * k, tile = 16 * h + tl;
+                float m[4][4];
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu) m[xi][nu] = lds[((4 * xi + nu) * 16 + tl) * 32 + ch];
+                float s0[4], s1v[4];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    s0[nu] = m[0][nu] + m[1][nu] + m[2][nu];
+                    s1v[nu] = m[1][nu] - m[2][nu] - m[3][nu];
+                }
+                const float yv[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1v[0] + s1v[1] + s1v[2], s1v[1] - s1v[2] - s1v[3]}};
+                const int oh = oh0 + 2 * (tile >> 3), ow = ow0 + 2 * (tile & 7);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        if (oh + dy < a.H && ow + dx < a.W) {
+                            const long long o = (((long long)b * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
+                            float v = yv[dy][dx] + bv;
+                            if (a.res) v += a.res[o];
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            a.y[o] = v;
+                        }
+                    }
+            }
         }
     }
 }
@@ -201,9 +216,10 @@ extern "C" int hmf_conv_winograd_pack_host(const float* w /*[Cout][3][3][Cin]*/,
 extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }
 
 extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
-                                 int Cin, int Cout, int relu, void* stream) {
+                                 int Cin, int Cout, int relu, int tile_channels, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: bad args");
     if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: Cin=%d must be a multiple of 64 and Cout=%d of 32", Cin, Cout);
+    if (tile_channels != 0 && tile_channels != 32 && tile_channels != 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: tile_channels in {0,32,64}");
     if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: x and w_packed must be 16-byte aligned");
     if ((long long)B * H * W * Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29))
         return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
@@ -212,12 +228,17 @@ extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const fl
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.tiles_w = (W + kWTW - 1) / kWTW;
     a.tiles_hw = a.tiles_w * ((H + kWTH - 1) / kWTH);
-    a.n_tiles = Cout / 32;
+    // two n-tiles (64 channels) per work-group halve the patch loads and input transforms per MFMA but need all 256 VGPRs; measured on
+    // MI355X (tools/conv_probe.py) it only wins on the 128-channel layers (57 vs 62 us) and loses elsewhere: auto = 32 channels
+    const int tn = tile_channels == 64 ? 2 : 1;
+    if (tn == 2 && Cout % 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: 64-channel tiles need Cout %% 64 == 0");
+    a.n_tiles = Cout / (32 * tn);
     const long long blocks = (long long)B * a.tiles_hw * a.n_tiles;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, B * H * W, st);
-    hipLaunchKernelGGL(k_conv_winograd, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (tn == 2) hipLaunchKernelGGL(k_conv_winograd<2>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_conv_winograd<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

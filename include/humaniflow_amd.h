@@ -206,7 +206,7 @@ int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, con
 long long hmf_conv_winograd_packed_floats(int Cin, int Cout);
 int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout);
 int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
-                      int Cin, int Cout, int relu, void* stream);
+                      int Cin, int Cout, int relu, int tile_channels /* 0 = auto, 32 or 64 output channels per work-group */, void* stream);
 
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
  * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.

@@ -92,7 +92,7 @@ def test_patch_conv3x3_stride2():
     _patch_case(1, 13, 9, 64, 128, 3, 2, True, False, 8210, seed=3)
 
 
-def _wino_case(B, H, W, cin, cout, res, relu, seed=0):
+def _wino_case(B, H, W, cin, cout, res, relu, seed=0, tc=0):
     from humaniflow_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(seed)
@@ -112,7 +112,7 @@ def _wino_case(B, H, W, cin, cout, res, relu, seed=0):
     rd = r.cuda().contiguous(memory_format=torch.channels_last) if res else None
     y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
     _lib.check(lib.hmf_conv_winograd(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
-                                     B, H, W, cin, cout, int(relu), _lib.current_stream()), 'hmf_conv_winograd')
+                                     B, H, W, cin, cout, int(relu), tc, _lib.current_stream()), 'hmf_conv_winograd')
     torch.cuda.synchronize()
     err = (y.cpu().double() - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, res, relu, err)      # Winograd: a few more roundings than direct
@@ -123,6 +123,9 @@ def test_winograd_conv3x3_matches_float64_reference():
     _wino_case(1, 8, 32, 64, 32, False, False, seed=1)          # one tile row, two tile columns
     _wino_case(2, 11, 19, 64, 96, True, True, seed=2)           # ragged: odd sizes, masked stores, zero padding inside tiles
     _wino_case(1, 32, 32, 256, 256, False, True, seed=3)        # l3-like depth
+    _wino_case(2, 16, 16, 128, 64, True, True, seed=4, tc=64)   # 64-channel work-group tiles
+    _wino_case(2, 11, 19, 64, 128, True, False, seed=5, tc=64)
+    _wino_case(2, 11, 19, 64, 128, True, False, seed=5, tc=32)
 
 
 def test_conv_rejects_unsupported_shapes():

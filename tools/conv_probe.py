@@ -106,17 +106,20 @@ for name, hw, cin, cout, ks, s, res in shapes():
         packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(cin, cout)))
         _lib.check(lib.hmf_conv_winograd_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout), 'wpack')
         pd = packed.to(dev)
-        fn = lambda: _lib.check(lib.hmf_conv_winograd(x.data_ptr(), pd.data_ptr(), bias.data_ptr(), None if r is None else r.data_ptr(), y.data_ptr(),
-                                                      B, hw, hw, cin, cout, 1, st), 'wino')
-        y.fill_(float('nan'))
-        fn()
-        err = (y - ref).abs().max().item()
-        t = timeit(fn)
-        line += ' wino:%7.1f' % t
-        if not err < 1e-3:
-            line += '(ERR %.2e)' % err
-        elif t < best[0]:
-            best = (t, 'wino')
+        for tc in (32, 64):
+            if cout % tc:
+                continue
+            fn = lambda: _lib.check(lib.hmf_conv_winograd(x.data_ptr(), pd.data_ptr(), bias.data_ptr(), None if r is None else r.data_ptr(), y.data_ptr(),
+                                                          B, hw, hw, cin, cout, 1, tc, st), 'wino')
+            y.fill_(float('nan'))
+            fn()
+            err = (y - ref).abs().max().item()
+            t = timeit(fn)
+            line += ' wino%d:%7.1f' % (tc, t)
+            if not err < 1e-3:
+                line += '(ERR %.2e)' % err
+            elif t < best[0]:
+                best = (t, 'wino%d' % tc)
     fl = 2.0 * B * oh * oh * cout * cin * ks * ks
     print('%-9s hw%3d %4d->%4d k%d s%d  miopen %7.1f us (%5.1f TF)  ours best %7.1f us (%5.1f TF) tile %6s |%s' %
           (name, hw, cin, cout, ks, s, t_mi, fl / t_mi / 1e6, best[0], fl / best[0] / 1e6, best[1], line), flush=True)
