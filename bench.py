@@ -64,6 +64,9 @@ def parse():
     ap.add_argument('--tpose', action='store_true', help='add the evaluate-flavour T-pose bodies to the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=32, help='images of the bounded CPU-baseline sample')
+    ap.add_argument('--blend-dtype', choices=['fp32', 'bf16'], default='fp32',
+                    help="'bf16': BASELINE configs[2] (use with --batch 64): SMPL blend-shape GEMM operands in bf16, fp32 accumulate -- a parity-test "
+                         'configuration, not the headline line')
     ap.add_argument('--chain-encoders', action='store_true',
                     help='serialise the encoders of consecutive steps with an event (cleaner per-kernel timings, ~10 %% less throughput): '
                          'by default batches on different streams overlap freely')
@@ -151,7 +154,7 @@ def main():
     model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).eval()
     model_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
-    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=args.batch, create_transl=False).to(dev)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=args.batch, create_transl=False, blend_dtype=args.blend_dtype).to(dev)
     B, N = args.batch, args.samples
     x = synthetic_proxy_input(B, 256, seed=100 + rank).to(dev)      # each rank its own shard of the synthetic set
     torch.manual_seed(1234 + rank)
@@ -232,7 +235,7 @@ def main():
     n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), 16384)
     lib.hmf_profile_enable(0)
     ms, tag, rows = ms[:n], tag[:n], rows[:n]
-    names = {1: 'k_lbs_mfma', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
+    names = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
     kern = {}
     for tg, nm in names.items():
         for r in sorted(set(rows[tag == tg].tolist())):
@@ -327,10 +330,12 @@ def main():
         res = {
             'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': round(value, 1), 'unit': 'images*samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL '
-                                   'fp32, random-init weights, synthetic SMPL-shaped body model%s'
-                                   % (B, N, args.layers, ' + T-pose bodies' if args.tpose else ''),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.blend_dtype == 'fp32' else 'bf16 blend-shape GEMM operands (f32 accumulate), f32 elsewhere', 'data': 'synthetic',
+            'config': {'workload': ('configs[1]' if args.blend_dtype == 'fp32' else 'configs[2]') + ': B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL '
+                                   '%s, random-init weights, synthetic SMPL-shaped body model%s'
+                                   % (B, N, args.layers, 'fp32' if args.blend_dtype == 'fp32' else 'fp32 with bf16 blend-shape GEMM operands',
+                                      ' + T-pose bodies' if args.tpose else ''),
                        'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'streams_per_gpu': len(streams),
                        'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},
             'roofline': None,

@@ -40,6 +40,7 @@ struct SmplDev {
     float* jr_w;
     float* tp_dirs;                  // [nb][3V]
     float* tp_tmpl;                  // [3V]
+    unsigned short* blend16;         // bf16 operand of the configs[2] variant: [kVT][kKG16][3][64 lanes][8]
 };
 
 }  // namespace hmf
@@ -60,6 +61,21 @@ __host__ __device__ inline size_t blend_index(int k, int v, int c) {
     return ((((size_t)vt * kKG + kg) * 3 + (idx >> 2)) * 64 + lane) * 4 + (idx & 3);
 }
 
+// ---- bf16 variant (BASELINE configs[2]: "bf16 MFMA blendshape GEMMs"): v_mfma_f32_32x32x16_bf16, fp32 accumulate ----
+// K order as the fp32 operand (207 pose-feature rows | num_betas shape rows), no template row: v_template is added in fp32 after the GEMM
+// (a bf16 template would cost 2^-9 of ~1 m).  Lane (j = l & 31, q = l >> 5) of k-group kg holds k = 16 kg + 8 q + e, e = 0..7, for A and B alike.
+constexpr int kKG16 = kKpad / 16;                 // 14 MFMA k-groups
+constexpr int kP16Stride = kKpad + 8;             // bf16 row stride of the row-major pose-feature panel (464 B = 29 16-byte slots: conflict-free b128 reads)
+__host__ __device__ inline unsigned short f32_to_bf16(float x) {
+    unsigned int u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);              // round to nearest even
+    return (unsigned short)(u >> 16);
+}
+__host__ __device__ inline size_t blend16_index(int k, int v, int c) {
+    return ((((size_t)(v >> 5) * kKG16 + (k >> 4)) * 3 + c) * 64 + (((k >> 3) & 1) * 32 + (v & 31))) * 8 + (k & 7);
+}
+
 // k-th entry of the extended pose feature of one row: [vec(R_1..R_23) - I | beta | 1 | 0...]
 __device__ __forceinline__ float pose_feature(int k, int nb, const float* __restrict__ body_row,
                                               const float* __restrict__ beta_row) {
@@ -78,7 +94,7 @@ __device__ __forceinline__ float pose_feature(int k, int nb, const float* __rest
 __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __restrict__ glob, int Mg,
                                                      const float* __restrict__ body, const float* __restrict__ betas,
                                                      int Mb, int M, float* __restrict__ atr, float* __restrict__ joints,
-                                                     float* __restrict__ panel) {
+                                                     float* __restrict__ panel, unsigned short* __restrict__ panel16) {
     __shared__ float sJ[8][kJ][3];
     __shared__ float sG[8][kJ][12];
     const int j = threadIdx.x % kJ, r = threadIdx.x / kJ;
@@ -119,6 +135,16 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
             const float* b = betas + (size_t)((Mb == 1 || !live) ? 0 : row) * nb;
             for (int k = kPoseFeat; k < kKpad; ++k)
                 pr[k * 64] = !live ? 0.0f : (k < kPoseFeat + nb ? b[k - kPoseFeat] : (k == kPoseFeat + nb ? 1.0f : 0.0f));
+        }
+    }
+    if (panel16) {                                  // row-major bf16 copy of the same features (no constant-1 column)
+        unsigned short* pr = panel16 + (size_t)row * kP16Stride;
+        if (j > 0) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) pr[(j - 1) * 9 + e] = live ? f32_to_bf16(R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f)) : 0;
+        } else {
+            const float* b = betas + (size_t)((Mb == 1 || !live) ? 0 : row) * nb;
+            for (int k = kPoseFeat; k < kP16Stride; ++k) pr[k] = (live && k < kPoseFeat + nb) ? f32_to_bf16(b[k - kPoseFeat]) : 0;
         }
     }
     sJ[r][j][0] = Jc[0]; sJ[r][j][1] = Jc[1]; sJ[r][j][2] = Jc[2];
@@ -484,6 +510,109 @@ __global__ void k_vertex_variance(const float* __restrict__ verts, int N, int V,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 2b. bf16 variant of the fused pose-blend GEMM + skinning (impl = 2): same tiling, operands in bf16 on
+//     v_mfma_f32_32x32x16_bf16 (14 k-groups x 6 MFMAs per wave tile instead of 112 x 6), fp32 accumulate, fp32 template add and fp32
+//     skinning.  With 1/16 of the MFMA time the kernel is bound by the skinning epilogue (LDS gathers + VALU) and the 82,680 B/row store.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int SLOTS>
+__global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
+                                                     const float* __restrict__ atr, float* __restrict__ verts) {
+    __shared__ __attribute__((aligned(16))) float smem[kRowsPerWG * kP16Stride / 2 + kRowsPerWG * kAtr];   // 29 + 72 KB
+    const unsigned short* sP = (const unsigned short*)smem;
+    float* sA = smem + kRowsPerWG * kP16Stride / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int xr = blockIdx.x & 7;
+    const int chunk = blockIdx.x >> 3;
+    const int T = nrg * kVTperX;
+    int t = (int)((long long)chunk * T / wpx);
+    const int t1 = (int)((long long)(chunk + 1) * T / wpx);
+    const int nslots = d.skin_slots;
+    while (t < t1) {
+        const int rg = t / kVTperX;
+        const int seg_end = min(t1, (rg + 1) * kVTperX);
+        const int row0 = rg * kRowsPerWG;
+        {
+            const f32x4* src = (const f32x4*)(panel16 + (size_t)row0 * kP16Stride);
+            f32x4* dst = (f32x4*)smem;
+            constexpr int n16 = kRowsPerWG * kP16Stride * 2 / 16;
+            for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+            const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
+            f32x4* dst2 = (f32x4*)sA;
+            const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
+#pragma unroll
+            for (int i = 0; i < kRowsPerWG * (kAtr / 4) / 512; ++i) {
+                const int ii = tid + i * 512;
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                dst2[ii] = (ii < n4) ? src2[ii] : z;
+            }
+        }
+        __syncthreads();
+        for (int tt = t + wave; tt < seg_end; tt += 8) {
+            const int vt = xr * kVTperX + (tt - rg * kVTperX);
+            int off[SLOTS > 0 ? SLOTS : 1];
+            float w[SLOTS > 0 ? SLOTS : 1];
+            if (SLOTS > 0) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    off[s] = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
+                    w[s] = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
+                }
+            }
+            const int v = vt * 32 + l31;
+            float tm[3] = {0.f, 0.f, 0.f};
+            if (v < kV) { tm[0] = d.tp_tmpl[v * 3]; tm[1] = d.tp_tmpl[v * 3 + 1]; tm[2] = d.tp_tmpl[v * 3 + 2]; }
+            f32x16 acc[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+            const f32x4* bp = (const f32x4*)(d.blend16 + (size_t)vt * kKG16 * 3 * 64 * 8) + lane;
+            const unsigned short* ap = sP + l31 * kP16Stride + half * 8;
+            f32x4 b0 = bp[0], b1 = bp[64], b2 = bp[128];
+            f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 32 * kP16Stride);
+#pragma unroll
+            for (int kg = 0; kg < kKG16; ++kg) {
+                f32x4 n0 = b0, n1 = b1, n2 = b2, m0 = a0, m1 = a1;
+                if (kg + 1 < kKG16) {
+                    n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128];
+                    m0 = *(const f32x4*)(ap + (kg + 1) * 16);
+                    m1 = *(const f32x4*)(ap + 32 * kP16Stride + (kg + 1) * 16);
+                }
+                const bf16x8 A0 = __builtin_bit_cast(bf16x8, a0), A1 = __builtin_bit_cast(bf16x8, a1);
+                const bf16x8 B[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[c], acc[0][c], 0, 0, 0);
+                    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[c], acc[1][c], 0, 0, 0);
+                }
+                b0 = n0; b1 = n1; b2 = n2; a0 = m0; a1 = m1;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][c][e] += tm[c];
+            EpiCtx e;
+            e.ok_v = v < kV;
+            e.full_rows = row0 + kRowsPerWG <= M;
+            e.row_lim = M - row0 - 4 * half;
+            e.obase = verts + ((size_t)(row0 + 4 * half) * kV + v) * 3;
+            const char* lbase = (const char*)(sA + 4 * half * kAtr);
+#pragma unroll
+            for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el & 15, e);
+        }
+        __syncthreads();
+        t = seg_end;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side packing
 // ---------------------------------------------------------------------------------------------------
 static int validate(const hmf_smpl_host_t* m) {
@@ -507,6 +636,16 @@ static void pack_blend(const hmf_smpl_host_t* m, float* out) {
             for (int k = 0; k < kPoseFeat; ++k) out[blend_index(k, v, c)] = m->posedirs_host[(size_t)k * kV * 3 + v * 3 + c];
             for (int k = 0; k < nb; ++k) out[blend_index(kPoseFeat + k, v, c)] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
             out[blend_index(kPoseFeat + nb, v, c)] = m->v_template_host[v * 3 + c];
+        }
+}
+
+static void pack_blend16(const hmf_smpl_host_t* m, unsigned short* out) {
+    const int nb = m->num_betas;
+    memset(out, 0, sizeof(unsigned short) * (size_t)kVT * kKG16 * 3 * 64 * 8);
+    for (int v = 0; v < kV; ++v)
+        for (int c = 0; c < 3; ++c) {
+            for (int k = 0; k < kPoseFeat; ++k) out[blend16_index(k, v, c)] = f32_to_bf16(m->posedirs_host[(size_t)k * kV * 3 + v * 3 + c]);
+            for (int k = 0; k < nb; ++k) out[blend16_index(kPoseFeat + k, v, c)] = f32_to_bf16(m->shapedirs_host[((size_t)v * 3 + c) * nb + k]);
         }
 }
 
@@ -597,6 +736,8 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
             for (int k = 0; k < nb; ++k) tpd[(size_t)k * kV * 3 + v * 3 + c] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
     std::vector<float> blend((size_t)kVT * kKG * 3 * 64 * 4);
     pack_blend(m, blend.data());
+    std::vector<unsigned short> blend16((size_t)kVT * kKG16 * 3 * 64 * 8);
+    pack_blend16(m, blend16.data());
 
     // --- one device arena -----------------------------------------------------------------------------
     size_t off = 0;
@@ -604,7 +745,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     const size_t o_blend = place(blend.size() * 4), o_soff = place(soff.size() * 4), o_sw = place(sw.size() * 4);
     const size_t o_jt = place(jt.size() * 4), o_jd = place(jd.size() * 4), o_ptr = place(ptr.size() * 4);
     const size_t o_idx = place(idx.size() * 4), o_w = place(wts.size() * 4), o_tpd = place(tpd.size() * 4);
-    const size_t o_tpt = place((size_t)kV * 3 * 4);
+    const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2);
     void* arena = nullptr;
     HMF_HIP(hipMalloc(&arena, off));
     char* base = (char*)arena;
@@ -619,6 +760,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     if (e == hipSuccess) e = up(o_w, wts.data(), wts.size() * 4);
     if (e == hipSuccess) e = up(o_tpd, tpd.data(), tpd.size() * 4);
     if (e == hipSuccess) e = up(o_tpt, m->v_template_host, (size_t)kV * 3 * 4);
+    if (e == hipSuccess) e = up(o_b16, blend16.data(), blend16.size() * 2);
     if (e != hipSuccess) {
         (void)hipFree(arena);
         return fail(HMF_ERR_HIP, "hmf_smpl_create: upload failed: %s", hipGetErrorString(e));
@@ -644,6 +786,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     d.jr_w = (float*)(base + o_w);
     d.tp_dirs = (float*)(base + o_tpd);
     d.tp_tmpl = (float*)(base + o_tpt);
+    d.blend16 = (unsigned short*)(base + o_b16);
     *out = h;
     return HMF_OK;
 }
@@ -656,7 +799,8 @@ void hmf_smpl_destroy(hmf_smpl_t* h) {
 
 static size_t ws_atr_bytes(int M) { return align_up((size_t)std::max(M, 1) * kAtr * sizeof(float), 256); }
 static size_t ws_panel_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kKpad * 64 * sizeof(float); }
-size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M); }
+static size_t ws_panel16_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kRowsPerWG * kP16Stride * 2; }
+size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + ws_panel16_bytes(M); }
 
 int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose, const float* betas,
                  int Mb, int M, float* verts, float* joints, void* workspace, size_t workspace_bytes, int impl,
@@ -670,17 +814,28 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
     hipStream_t st = (hipStream_t)stream;
     float* atr = (float*)workspace;
     float* panel = (float*)((char*)workspace + ws_atr_bytes(M));
+    unsigned short* panel16 = (unsigned short*)((char*)workspace + ws_atr_bytes(M) + ws_panel_bytes(M));
+    const bool bf16 = (impl & 15) == 2;
     const int nrg_all = (M + kRowsPerWG - 1) / kRowsPerWG;
     {
         ProfScope ps(2, M, st);      // grid padded to whole row groups: dead rows zero their slice of the panel
         hipLaunchKernelGGL(k_rigid_chain, dim3(nrg_all * (kRowsPerWG / 8)), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas,
-                           Mb, M, atr, joints, panel);
+                           Mb, M, atr, joints, bf16 ? (float*)nullptr : panel, bf16 ? panel16 : (unsigned short*)nullptr);
     }
     HMF_LAUNCH_CHECK();
     if ((impl & 15) == 1) {
         const long long n = (long long)M * kV;
         hipLaunchKernelGGL(k_lbs_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d, body_pose, betas, Mb, M,
                            atr, verts);
+    } else if (bf16) {
+        ProfScope ps(12, M, st);
+        const int nrg = (M + kRowsPerWG - 1) / kRowsPerWG;
+        const int T = nrg * kVTperX;
+        const int wpx = std::max(1, std::min(32, (T + 7) / 8));
+        const dim3 grid(8 * wpx), block(512);
+        if (h->d.skin_slots == 4) hipLaunchKernelGGL((k_lbs_mfma16<4>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, atr, verts);
+        else if (h->d.skin_slots == 8) hipLaunchKernelGGL((k_lbs_mfma16<8>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, atr, verts);
+        else hipLaunchKernelGGL((k_lbs_mfma16<0>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, atr, verts);
     } else {
         ProfScope ps(1, M, st);
         const int nrg = (M + kRowsPerWG - 1) / kRowsPerWG;

@@ -94,8 +94,11 @@ class SMPL(nn.Module):
     NUM_BODY_JOINTS = 23
 
     def __init__(self, model_path=None, batch_size=1, gender='neutral', num_betas=10, create_transl=True,
-                 model_data=None, **kwargs):
+                 model_data=None, blend_dtype='fp32', **kwargs):
         super().__init__()
+        if blend_dtype not in ('fp32', 'bf16'):
+            raise ValueError("blend_dtype must be 'fp32' or 'bf16' (BASELINE configs[2]: bf16 MFMA blend-shape GEMMs, fp32 accumulate)")
+        self.blend_dtype = blend_dtype
         if model_data is None:
             model_data = load_smpl_pkl(model_path, gender, num_betas)
         self.gender = gender
@@ -198,7 +201,7 @@ class SMPL(nn.Module):
         _lib.check(lib.hmf_batch_rodrigues(_lib.dptr(v), n, _lib.dptr(R), _lib.current_stream()), 'hmf_batch_rodrigues')
         return R
 
-    def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, impl=0, **kwargs):
+    def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, impl=None, **kwargs):
         """models/smpl.py:27-41 over smplx SMPL.forward.  `get_skin`/`return_verts` kwargs are accepted and ignored
         (vertices are always produced, as the reference forces)."""
         global_orient = self.global_orient if global_orient is None else global_orient
@@ -230,7 +233,8 @@ class SMPL(nn.Module):
                                   body_pose=body_pose)
             ws = self._workspace(dev, M)
             _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
-                                        _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(), int(impl),
+                                        _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(),
+                                        int((2 if self.blend_dtype == 'bf16' else 0) if impl is None else impl),
                                         _lib.current_stream()), 'hmf_smpl_lbs')
         if transl is not None:
             joints = joints + transl.unsqueeze(1)

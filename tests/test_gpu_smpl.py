@@ -143,3 +143,29 @@ def test_config3_size_B64_N100_properties(smpl):
     sel = torch.tensor([0, 63, 64, 3199, 3200, 6336, 6399])
     b = smpl(body_pose=R[sel, 1:], global_orient=R[sel, :1], betas=betas[sel], pose2rot=False, impl=1)
     assert (a.vertices[sel] - b.vertices).abs().max().item() < 5e-6 and (a.joints[sel] - b.joints).abs().max().item() < 5e-6
+
+
+def test_bf16_blend_variant_configs2():
+    """BASELINE configs[2]: blend-shape GEMM operands in bf16 (MFMA 32x32x16), fp32 accumulate / template / skinning.  Tolerance 1.5e-3 m
+    against the fp32 oracle (bf16 operands carry 2^-9 relative error on ~1e-2 m blend-shape offsets); the fp32 path's 1e-4 does not apply.
+    Zero pose & zero shape reproduce the template to fp32 rounding (the bf16 GEMM contributes exact zeros); ragged M."""
+    data = H.synthetic_smpl_model(seed=0)
+    smpl = H.SMPL(model_data=data, create_transl=False, blend_dtype='bf16').to('cuda:0')
+    ref = H.SMPL(model_data=data, create_transl=False).to('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    for M in (1, 70, 64 * 3):
+        pose = (torch.randn(M, 72, generator=g) * 0.4).cuda()
+        betas = (torch.randn(M, 10, generator=g) * 1.25).cuda()
+        a = smpl(body_pose=pose[:, 3:], global_orient=pose[:, :3], betas=betas)
+        b = ref(body_pose=pose[:, 3:], global_orient=pose[:, :3], betas=betas)
+        assert (a.vertices - b.vertices).abs().max().item() < 1.5e-3
+        assert (a.joints - b.joints).abs().max().item() < 1.5e-3
+        assert (a.vertices - b.vertices).abs().max().item() > 0            # it really is the other kernel
+    z = smpl(body_pose=torch.zeros(2, 69).cuda(), global_orient=torch.zeros(2, 3).cuda(), betas=torch.zeros(2, 10).cuda())
+    assert (z.vertices - smpl.v_template[None]).abs().max().item() < 1e-6     # zero features: only the fp32 skinning of the fp32 template is left
+    # oracle comparison (the reference CPU path) at the bf16 tolerance
+    pose = torch.randn(5, 72, generator=g) * 0.4
+    betas = torch.randn(5, 10, generator=g)
+    v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(smpl.model_dict()), betas, pose[:, 3:], pose[:, :3], pose2rot=True)
+    a = smpl(body_pose=pose[:, 3:].cuda(), global_orient=pose[:, :3].cuda(), betas=betas.cuda())
+    assert (a.vertices.cpu() - v_ref).abs().max().item() < 1.5e-3 and (a.joints.cpu() - j_ref).abs().max().item() < 1.5e-3
