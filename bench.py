@@ -39,13 +39,18 @@ def encoder_conv_flops(enc, B, size):
     hw = size // 4
     for li in range(1, 5):
         for blk in getattr(enc, 'layer%d' % li):
-            seq = ([blk.downsample[0]] if blk.downsample is not None else []) + [c for c, _ in blk.stages()]
+            stages = [c for c, _ in blk.stages()]
+            fused = blk.downsample is not None and enc.fuse_downsample and stages[-1].kernel_size[0] == 1     # conv3 + downsample: one launch
+            seq = ([blk.downsample[0]] if (blk.downsample is not None and not fused) else []) + stages
             cur = hw
             for ci, c in enumerate(seq):
-                is_ds = blk.downsample is not None and ci == 0
+                is_ds = blk.downsample is not None and not fused and ci == 0
                 inhw = hw if is_ds else cur
                 oh = inhw // c.stride[0]
-                flops.append(2.0 * B * oh * oh * c.out_channels * c.in_channels * c.kernel_size[0] ** 2)
+                f = 2.0 * B * oh * oh * c.out_channels * c.in_channels * c.kernel_size[0] ** 2
+                if fused and c is stages[-1]:
+                    f += 2.0 * B * oh * oh * c.out_channels * blk.downsample[0].in_channels
+                flops.append(f)
                 kind.append('%dx%d' % (c.kernel_size[0], c.kernel_size[0]))
                 if not is_ds:
                     cur = oh

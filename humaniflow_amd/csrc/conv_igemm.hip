@@ -29,12 +29,16 @@ struct ConvArgs {
     const float* res;    // [M][Cout] or null
     float* y;            // [M][Cout]
     int B, H, W, Cin, OH, OW, Cout, stride, pad, relu, M;
+    // DUAL (1x1 only): a second input concatenated along K -- y = relu(x . W[:, :Cin] + x2(strided) . W[:, Cin:] + bias): a bottleneck's last
+    // 1x1 convolution and its downsample branch (models/resnet.py:111-127) as ONE GEMM, so the identity tensor is never written or re-read
+    const float* x2;     // [B][H2][W2][Cin2]
+    int H2, W2, Cin2, stride2;
 };
 
 constexpr int kConvKC = 32;             // channels per k-chunk
 constexpr int kConvS = kConvKC + 4;     // LDS row stride in floats
 
-template <int BM, int BN, int KS>
+template <int BM, int BN, int KS, bool DUAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_igemm(const ConvArgs a) {
     constexpr int KC = kConvKC, S = kConvS;
     constexpr int TM = BM / 64, TN = BN / 64;      // MFMA tiles per wave
@@ -74,25 +78,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             offA[i] = kOOB;
         }
     }
+    const int Ktot = KS * KS * a.Cin + (DUAL ? a.Cin2 : 0);
     const float* pB[RB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) pB[i] = a.w + (long long)(n0 + rbase + 32 * i) * (KS * KS * a.Cin) + col4;
+    for (int i = 0; i < RB; ++i) pB[i] = a.w + (long long)(n0 + rbase + 32 * i) * Ktot + col4;
+    __amdgpu_buffer_rsrc_t rx2 = rx;
+    int offA2[RA];
+    if (DUAL) {
+        rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.B * a.H2 * a.W2 * a.Cin2 * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + rbase + 32 * i;
+            offA2[i] = kOOB;
+            if (m < a.M) {
+                const int b = m / (a.OH * a.OW), r = m - b * a.OH * a.OW;
+                const int oh = r / a.OW, ow = r - oh * a.OW;
+                offA2[i] = (((b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.Cin2 + col4) * 4;
+            }
+        }
+    }
 
     f32x4 pa[RA], pb[RB];
     int kh = 0, kw = 0, c0 = 0;
     auto fetch = [&]() {
         const int tapoff = ((kh * a.W + kw) * a.Cin + c0) * 4;
+        const bool second = DUAL && c0 >= a.Cin;               // block-uniform: the K range of the second input
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int off = offA[i] + tapoff;
             if (KS != 1) off = (((unsigned)(ih0[i] + kh) < (unsigned)a.H) & ((unsigned)(iw0[i] + kw) < (unsigned)a.W)) ? off : kOOB;
-            pa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            if (DUAL && second) pa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, offA2[i] + (c0 - a.Cin) * 4, 0, 0));
+            else pa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
         const int woff = (kh * KS + kw) * a.Cin + c0;
 #pragma unroll
         for (int i = 0; i < RB; ++i) pb[i] = *(const f32x4*)(pB[i] + woff);
         c0 += KC;
-        if (c0 == a.Cin) {
+        if (!DUAL && c0 == a.Cin) {
             c0 = 0;
             if (++kw == KS) { kw = 0; ++kh; }
         }
@@ -112,7 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = KS * KS * (a.Cin / KC);
+    const int nchunks = KS * KS * (a.Cin / KC) + (DUAL ? a.Cin2 / KC : 0);
     fetch();
     stash(0);
     __syncthreads();
@@ -181,11 +203,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 }
 
-template <int BM, int BN, int KS>
+template <int BM, int BN, int KS, bool DUAL = false>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int T = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     ProfScope ps(8, a.M, st);
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS>), dim3(T), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, DUAL>), dim3(T), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -202,6 +224,7 @@ extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias
     if (Cin % kConvKC != 0 || Cout % 64 != 0) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: Cin=%d must be a multiple of 32 and Cout=%d of 64", Cin, Cout);
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: x and w must be 16-byte aligned");
     ConvArgs a;
+    a.x2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
     a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.pad = ks / 2; a.relu = relu;
     a.OH = (H + 2 * a.pad - ks) / stride + 1;
@@ -227,6 +250,27 @@ extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias
         default: return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: unknown tile %d", tile);
     }
 #undef CONV_CASE
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+// y = relu?(x . W[:, :Cin] + x2[:, ::stride2, ::stride2, :] . W[:, Cin:] + bias): two 1x1 convolutions that share their output, as one GEMM over the
+// concatenated K.  x (B,OH,OW,Cin); x2 (B,H2,W2,Cin2) with OH = (H2-1)/stride2+1; w (Cout, Cin+Cin2) row-major.
+extern "C" int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const float* bias, float* y, int B, int OH, int OW, int Cin,
+                                     int H2, int W2, int Cin2, int stride2, int Cout, int relu, void* stream) {
+    if (!x || !x2 || !w || !y || B <= 0 || OH <= 0 || OW <= 0) return fail(HMF_ERR_INVALID, "hmf_conv1x1_dual_nhwc: bad args");
+    if (stride2 != 1 && stride2 != 2) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv1x1_dual_nhwc: stride %d", stride2);
+    if ((H2 - 1) / stride2 + 1 != OH || (W2 - 1) / stride2 + 1 != OW) return fail(HMF_ERR_INVALID, "hmf_conv1x1_dual_nhwc: x2 %dx%d / %d does not give %dx%d", H2, W2, stride2, OH, OW);
+    if (Cin % kConvKC || Cin2 % kConvKC || Cout % 64) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv1x1_dual_nhwc: Cin=%d, Cin2=%d must be multiples of 32 and Cout=%d of 64", Cin, Cin2, Cout);
+    if (((uintptr_t)x & 15) || ((uintptr_t)x2 & 15) || ((uintptr_t)w & 15)) return fail(HMF_ERR_INVALID, "hmf_conv1x1_dual_nhwc: x, x2 and w must be 16-byte aligned");
+    const long long M = (long long)B * OH * OW;
+    if (M * Cout >= (1LL << 29) || M * Cin >= (1LL << 29) || (long long)B * H2 * W2 * Cin2 >= (1LL << 29))
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv1x1_dual_nhwc: tensor exceeds 2^29 elements");
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = nullptr; a.y = y;
+    a.B = B; a.H = OH; a.W = OW; a.Cin = Cin; a.Cout = Cout; a.stride = 1; a.pad = 0; a.relu = relu; a.OH = OH; a.OW = OW; a.M = (int)M;
+    a.x2 = x2; a.H2 = H2; a.W2 = W2; a.Cin2 = Cin2; a.stride2 = stride2;
+    launch_conv<64, 64, 1, true>(a, (hipStream_t)stream);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -113,6 +113,7 @@ class ResNetEncoder(nn.Module):
     # ONE fused HIP pass (hmf_bias_act: + bias, + identity, ReLU, in place) follows each of them.  The stem's
     # bias+ReLU commutes with max-pooling (both monotone), so it runs on the 4x smaller pooled tensor; a downsample
     # branch's bias is added to the block's last bias so that branch needs no pass of its own.
+    fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_dual_nhwc)
     conv_impl = 'hip'        # 'hip': hmf_conv2d_nhwc for the residual stages; 'miopen': MIOpen + hmf_bias_act (tools/encoder_probe.py A/B)
     layout = 'nhwc'          # with the tuned find-db: nhwc 4.45 ms vs nchw 4.97 ms (B=32, ResNet-50; tools/encoder_find.py)
 
@@ -161,10 +162,16 @@ class ResNetEncoder(nn.Module):
                     ds = self._fold(blk.downsample[0], blk.downsample[1])
                     w, b, s, p = stages[-1]
                     stages[-1] = (w, (b + ds[1]).contiguous(), s, p)
-                plan['blocks'].append((stages, ds))
+                dual = None
+                if ds is not None and self.fuse_downsample and stages[-1][0].shape[2] == 1:
+                    # last 1x1 conv + downsample branch as one GEMM over the concatenated K: W = [W_conv3 | W_downsample]
+                    w3, wd = stages[-1][0], ds[0]
+                    wcat = torch.cat([w3.reshape(w3.shape[0], -1), wd.reshape(wd.shape[0], -1)], dim=1).contiguous()
+                    dual = (wcat, stages[-1][1], ds[2][0])
+                plan['blocks'].append((stages, ds, dual))
         plan['packed'], plan['wino'] = {}, {}
         if self.conv1.weight.is_cuda:
-            for stages, ds in plan['blocks']:
+            for stages, ds, dual in plan['blocks']:
                 for w, b, s, p in stages:
                     cfg = self._patch_cfg(w)
                     if cfg and s[0] == 1 and w.shape[1] <= 256:
@@ -193,6 +200,18 @@ class ResNetEncoder(nn.Module):
         packed = torch.empty(int(lib.hmf_conv_patch_packed_floats(cin, cout, ks)), dtype=torch.float32)
         _lib.check(lib.hmf_conv_patch_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout, ks, cfg), 'hmf_conv_patch_pack_host')
         return packed.to(w.device)
+
+    def _conv_dual(self, h, x, wcat, bias, stride):
+        """relu(conv1x1(h) + conv1x1(x, stride) + bias) in one launch (bias = both folded-BN shifts)."""
+        from . import _lib
+        lib = _lib.load()
+        B, Cin, OH, OW = h.shape
+        _, Cin2, H2, W2 = x.shape
+        Cout = wcat.shape[0]
+        y = torch.empty((B, Cout, OH, OW), device=h.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _lib.check(lib.hmf_conv1x1_dual_nhwc(h.data_ptr(), x.data_ptr(), wcat.data_ptr(), bias.data_ptr(), y.data_ptr(), B, OH, OW, Cin,
+                                             H2, W2, Cin2, stride, Cout, 1, _lib.current_stream()), 'hmf_conv1x1_dual_nhwc')
+        return y
 
     def _pack_winograd(self, w):
         from . import _lib
@@ -276,14 +295,20 @@ class ResNetEncoder(nn.Module):
                 x = F.max_pool2d(F.conv2d(x, w, None, s, pad), kernel_size=3, stride=2, padding=1)
                 x = self._epilogue(x, b, None, True)
             if hip:
-                for stages, ds in p['blocks']:
+                for stages, ds, dual in p['blocks']:
+                    if dual is not None:
+                        h = x
+                        for w, b, s, pad in stages[:-1]:
+                            h = self._conv_hip(h, w, b, s[0], None, True)
+                        x = self._conv_dual(h, x, dual[0], dual[1], dual[2])
+                        continue
                     idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
                     for w, b, s, pad in stages[:-1]:
                         x = self._conv_hip(x, w, b, s[0], None, True)
                     w, b, s, pad = stages[-1]
                     x = self._conv_hip(x, w, b, s[0], idt, True)
                 return x.mean(dim=(2, 3))
-            for stages, ds in p['blocks']:                      # MIOpen convolutions + one fused epilogue pass each (A/B reference)
+            for stages, ds, dual in p['blocks']:                      # MIOpen convolutions + one fused epilogue pass each (A/B reference)
                 idt = x if ds is None else F.conv2d(x, ds[0], None, ds[2], ds[3])
                 for w, b, s, pad in stages[:-1]:
                     x = self._epilogue(F.conv2d(x, w, None, s, pad), b, None, True)

@@ -190,6 +190,12 @@ int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int 
 int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int H, int W,
                     int Cin, int Cout, int ks, int stride, int relu, int tile, void* stream);
 
+/* Last 1x1 convolution of a bottleneck + its downsample branch (models/resnet.py:111-127 with self.downsample) as ONE GEMM over the
+ * concatenated K: y = relu?(x . W[:, :Cin] + x2[:, ::stride2, ::stride2, :] . W[:, Cin:] + bias).  x (B,OH,OW,Cin), x2 (B,H2,W2,Cin2),
+ * w (Cout, Cin+Cin2) row-major, OH = (H2-1)/stride2+1; Cin, Cin2 % 32 == 0, Cout % 64 == 0.  Profiler tag 8. */
+int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const float* bias, float* y, int B, int OH, int OW, int Cin,
+                          int H2, int W2, int Cin2, int stride2, int Cout, int relu, void* stream);
+
 /* Patch-resident variant of hmf_conv2d_nhwc for stride-1 3x3 and 1x1 (stride 1 or 2) layers: the input patch of a pixel tile lives in
  * LDS for a whole slab of input channels and the weights stream from L2 in MFMA lane order (no barrier inside a slab).
  * w_packed = hmf_conv_patch_pack_host(w (Cout,ks,ks,Cin) channels_last, ..., cfg) uploaded to the device

@@ -128,6 +128,26 @@ def test_winograd_conv3x3_matches_float64_reference():
     _wino_case(2, 11, 19, 64, 128, True, False, seed=5, tc=32)
 
 
+def test_dual_1x1_matches_float64_reference():
+    """conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_dual_nhwc), strides 1 and 2, ragged M."""
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for B, OH, OW, cin, cin2, cout, s2 in [(2, 8, 8, 64, 128, 256, 2), (1, 7, 5, 32, 64, 64, 1), (2, 6, 6, 128, 256, 128, 2)]:
+        H2, W2 = (OH - 1) * s2 + 1 + (s2 - 1), (OW - 1) * s2 + 1 + (s2 - 1)
+        h, x = torch.randn(B, cin, OH, OW, generator=g), torch.randn(B, cin2, H2, W2, generator=g)
+        w3, wd = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, torch.randn(cout, cin2, 1, 1, generator=g) / cin2 ** 0.5
+        bias = torch.randn(cout, generator=g)
+        ref = (F.conv2d(h.double(), w3.double()) + F.conv2d(x.double(), wd.double(), None, s2) + bias.double()[None, :, None, None]).clamp_min(0)
+        wcat = torch.cat([w3.reshape(cout, cin), wd.reshape(cout, cin2)], 1).contiguous().cuda()
+        hd, xd = h.cuda().contiguous(memory_format=torch.channels_last), x.cuda().contiguous(memory_format=torch.channels_last)
+        y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+        _lib.check(lib.hmf_conv1x1_dual_nhwc(hd.data_ptr(), xd.data_ptr(), wcat.data_ptr(), bias.cuda().data_ptr(), y.data_ptr(), B, OH, OW, cin,
+                                             H2, W2, cin2, s2, cout, 1, _lib.current_stream()), 'dual')
+        torch.cuda.synchronize()
+        assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_rejects_unsupported_shapes():
     from humaniflow_amd import _lib
     lib = _lib.load()

@@ -33,22 +33,11 @@ n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), 
 lib.hmf_profile_enable(0)
 per = n // reps
 us = ms[:n].reshape(reps, per).mean(0) * 1e3
-# launch order: stem, then per block [downsample], conv1.., last
-names, flops = ['stem 7x7/2 18->64'], [2.0 * B * 128 * 128 * 64 * 18 * 49]
-hw = 64
-p = enc._plan
-for bi, (stages, ds) in enumerate(p['blocks']):
-    seq = ([('ds', ds)] if ds is not None else []) + [('c%d' % (i + 1), s) for i, s in enumerate(stages)]
-    cur = hw
-    for nm, (w, bias, s, pad) in seq:
-        cout, cin, ks, _ = w.shape
-        inhw = hw if nm == 'ds' else cur
-        oh = inhw // s[0]
-        names.append('b%02d.%s %dx%d/%d %d->%d @%d' % (bi, nm, ks, ks, s[0], cin, cout, inhw))
-        flops.append(2.0 * B * oh * oh * cout * cin * ks * ks)
-        if nm != 'ds':
-            cur = oh
-    hw = cur
+# launch order and FLOPs: bench.encoder_conv_flops (stem, then per block [downsample,] conv1.., last [+ fused downsample])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from bench import encoder_conv_flops
+flops, kinds = encoder_conv_flops(enc, B, 256)
+names = ['%02d %s' % (i, k) for i, k in enumerate(kinds)]
 assert len(names) == per, (len(names), per)
 for nm, t, f in zip(names, us, flops):
     print('%-34s %8.1f us  %6.1f TFLOP/s' % (nm, t, f / t / 1e6))
