@@ -26,15 +26,17 @@ struct WinoArgs {
 };
 
 constexpr int kWTH = 8, kWTW = 16, kWSC = 64;
-constexpr int kWPH = kWTH + 2, kWPW = kWTW + 2;
+constexpr int kWPH = kWTH + 2;
 constexpr int kWCS = kWSC + 4;                       // LDS pixel stride (floats)
-constexpr int kWRP = kWPW * kWCS;                    // LDS row pitch
 constexpr int kWNG = kWSC / 8;                       // k-groups per slab
+// NIMG = 1: the 8 x 16 tile lies in one image (patch 10 x 18).  NIMG = 2: maps at most 8 pixels wide (layer4 at 256x256 input) -- the tile
+// is 8 x 8 pixels of TWO consecutive images side by side (patch 10 x (10 + 10)), so the MFMA still sees 32 Winograd tiles.
 
-template <int TN>
+template <int TN, int NIMG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_winograd(const WinoArgs a) {
+    constexpr int kWPW = NIMG == 1 ? kWTW + 2 : 20, kWRP = kWPW * kWCS;
     constexpr int NV = kWPH * kWPW * (kWSC / 4), NIT = (NV + 255) / 256;
-    __shared__ float lds[kWPH * kWRP];               // patch (49 KB); reused for the accumulator exchange (2 x 32 KB halves)
+    __shared__ float lds[kWPH * kWRP];               // patch (49 / 54 KB); reused for the accumulator exchange (2 x 32 KB halves)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
 
@@ -42,8 +44,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     int L = blockIdx.x;
     if ((T & 7) == 0) L = (blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
     const int nt = L % a.n_tiles, pt = L / a.n_tiles;
-    const int b = pt / a.tiles_hw, trem = pt - b * a.tiles_hw;
-    const int oh0 = (trem / a.tiles_w) * kWTH, ow0 = (trem % a.tiles_w) * kWTW;
+    const int b = (pt / a.tiles_hw) * NIMG, trem = pt - (pt / a.tiles_hw) * a.tiles_hw;
+    const int oh0 = (trem / a.tiles_w) * kWTH, ow0 = NIMG == 1 ? (trem % a.tiles_w) * kWTW : 0;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.H * a.W * a.Cin * 4, 0x00020000);
     constexpr int kOOB = (int)0x80000000;
@@ -53,9 +55,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int e = tid + 256 * k;
         const int p = e / (kWSC / 4), c4 = e - p * (kWSC / 4);
         const int r = p / kWPW, col = p - r * kWPW;
-        const int ih = oh0 + r - 1, iw = ow0 + col - 1;
-        const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-        goff[k] = ok ? (((b * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
+        const int img = NIMG == 1 ? 0 : col / 10;
+        const int ih = oh0 + r - 1, iw = NIMG == 1 ? ow0 + col - 1 : col - img * 10 - 1;
+        const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (b + img < a.B);
+        goff[k] = ok ? ((((b + img) * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
         loff[k] = r * kWRP + col * kWCS + 4 * c4;
     }
     const int nslab = a.Cin / kWSC;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int a1 = wave == 0 ? 0 : 1, a2 = wave == 3 ? 3 : 2;
     const float s1 = wave == 2 ? -1.f : 1.f, s2 = (wave == 0 || wave == 3) ? -1.f : 1.f;
     const int ti = li >> 3, tj = li & 7;
-    const float* pbase = lds + (2 * ti) * kWRP + (2 * tj) * kWCS + 4 * lq;
+    const float* pbase = lds + (2 * ti) * kWRP + (NIMG == 1 ? 2 * tj : (tj >> 2) * 10 + 2 * (tj & 3)) * kWCS + 4 * lq;
     const float* p1 = pbase + a1 * kWRP;
     const float* p2 = pbase + a2 * kWRP;
 
@@ -168,13 +171,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     s1v[nu] = m[1][nu] - m[2][nu] - m[3][nu];
                 }
                 const float yv[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1v[0] + s1v[1] + s1v[2], s1v[1] - s1v[2] - s1v[3]}};
-                const int oh = oh0 + 2 * (tile >> 3), ow = ow0 + 2 * (tile & 7);
+                const int oh = oh0 + 2 * (tile >> 3), ow = NIMG == 1 ? ow0 + 2 * (tile & 7) : 2 * (tile & 3);
+                const int bi = b + (NIMG == 1 ? 0 : (tile >> 2) & 1);
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        if (oh + dy < a.H && ow + dx < a.W) {
-                            const long long o = (((long long)b * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
+                        if (oh + dy < a.H && ow + dx < a.W && bi < a.B) {
+                            const long long o = (((long long)bi * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
                             float v = yv[dy][dx] + bv;
                             if (a.res) v += a.res[o];
                             if (a.relu) v = fmaxf(v, 0.f);
@@ -226,19 +230,25 @@ extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const fl
     WinoArgs a;
     a.x = x; a.wp = (const f32x4*)w_packed; a.bias = bias; a.res = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
-    a.tiles_w = (W + kWTW - 1) / kWTW;
+    const bool pair = W <= 8;                        // narrow maps: two images per work-group tile
+    a.tiles_w = pair ? 1 : (W + kWTW - 1) / kWTW;
     a.tiles_hw = a.tiles_w * ((H + kWTH - 1) / kWTH);
     // two n-tiles (64 channels) per work-group halve the patch loads and input transforms per MFMA but need all 256 VGPRs; measured on
     // MI355X (tools/conv_probe.py) it only wins on the 128-channel layers (57 vs 62 us) and loses elsewhere: auto = 32 channels
     const int tn = tile_channels == 64 ? 2 : 1;
     if (tn == 2 && Cout % 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: 64-channel tiles need Cout %% 64 == 0");
     a.n_tiles = Cout / (32 * tn);
-    const long long blocks = (long long)B * a.tiles_hw * a.n_tiles;
+    const long long blocks = (long long)(pair ? (B + 1) / 2 : B) * a.tiles_hw * a.n_tiles;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, B * H * W, st);
-    if (tn == 2) hipLaunchKernelGGL(k_conv_winograd<2>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_conv_winograd<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (pair) {
+        if (tn == 2) hipLaunchKernelGGL((k_conv_winograd<2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_winograd<1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        if (tn == 2) hipLaunchKernelGGL((k_conv_winograd<2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_winograd<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

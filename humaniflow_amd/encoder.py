@@ -174,9 +174,9 @@ class ResNetEncoder(nn.Module):
             for stages, ds, dual in plan['blocks']:
                 for w, b, s, p in stages:
                     cfg = self._patch_cfg(w)
-                    if cfg and s[0] == 1 and w.shape[1] <= 256:
-                        # stride-1 3x3 layers on maps >= 16 pixels wide (layer1-3 at 256x256 input) run as Winograd F(2x2,3x3); the patch
-                        # kernel stays packed too for narrower maps (chosen per call from the activation width)
+                    if cfg and s[0] == 1:
+                        # stride-1 3x3 layers run as Winograd F(2x2,3x3) on maps >= 16 pixels wide (8x16-pixel tiles) and on 8-pixel maps (two
+                        # images per tile); the patch kernel stays packed too for other widths (chosen per call from the activation width)
                         plan['wino'][id(w)] = self._pack_winograd(w)
                     if cfg:
                         pk = self._pack_patch(w, cfg)
@@ -232,7 +232,7 @@ class ResNetEncoder(nn.Module):
         OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         wk = self._plan['wino'].get(id(w)) if self._plan is not None else None
-        if wk is not None and stride == 1 and W >= 16:
+        if wk is not None and stride == 1 and (W >= 16 or W == 8):
             _lib.check(lib.hmf_conv_winograd(x.data_ptr(), wk.data_ptr(), None if bias is None else bias.data_ptr(),
                                              None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout,
                                              int(relu), 0, _lib.current_stream()), 'hmf_conv_winograd')

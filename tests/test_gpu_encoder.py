@@ -124,6 +124,9 @@ def test_winograd_conv3x3_matches_float64_reference():
     _wino_case(2, 11, 19, 64, 96, True, True, seed=2)           # ragged: odd sizes, masked stores, zero padding inside tiles
     _wino_case(1, 32, 32, 256, 256, False, True, seed=3)        # l3-like depth
     _wino_case(2, 16, 16, 128, 64, True, True, seed=4, tc=64)   # 64-channel work-group tiles
+    _wino_case(4, 8, 8, 128, 64, True, True, seed=6)            # 8-pixel maps: two images per tile
+    _wino_case(3, 8, 8, 64, 32, False, False, seed=7)           # ... odd batch: the last tile holds one image
+    _wino_case(2, 5, 7, 64, 32, True, True, seed=8)             # ... ragged narrow map
     _wino_case(2, 11, 19, 64, 128, True, False, seed=5, tc=64)
     _wino_case(2, 11, 19, 64, 128, True, False, seed=5, tc=32)
 

@@ -101,7 +101,7 @@ for name, hw, cin, cout, ks, s, res in shapes():
                 line += '(ERR %.2e)' % err
             elif best is None or t < best[0]:
                 best = (t, cfg)
-    if ks == 3 and s == 1 and cin % 64 == 0 and hw >= 16:
+    if ks == 3 and s == 1 and cin % 64 == 0 and (hw >= 16 or hw == 8):
         wh = w.permute(0, 2, 3, 1).contiguous().cpu()
         packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(cin, cout)))
         _lib.check(lib.hmf_conv_winograd_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout), 'wpack')
