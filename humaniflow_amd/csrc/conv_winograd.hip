@@ -34,7 +34,11 @@ constexpr int kWNG = kWSC / 8;                       // k-groups per slab
 
 template <int TN, int NIMG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_winograd(const WinoArgs a) {
-    constexpr int kWPW = NIMG == 1 ? kWTW + 2 : 20, kWRP = kWPW * kWCS;
+    // LDS image of the patch.  NIMG = 1: columns de-interleaved by parity (pixel (r, c) at slot (c & 1) * 9 + (c >> 1) of row r): the four patch
+    // columns 2 tj + {0,1,2,3} of tile tj are then slots {tj, 9 + tj, tj + 1, 9 + tj + 1}, i.e. consecutive lanes read consecutive pixels (17 x 16 B
+    // apart), and with a row pitch of 4 (mod 8) slots the four 16-lane groups of ds_read_b128 each cover 16 distinct bank slots: conflict-free.
+    constexpr int kWPW = NIMG == 1 ? kWTW + 2 : 20, kWRP = NIMG == 1 ? (kWPW * kWCS + 8) : kWPW * kWCS;
+    static_assert(NIMG != 1 || (kWRP / 4) % 8 == 4, "row pitch must be 4 (mod 8) 16-byte slots");
     constexpr int NV = kWPH * kWPW * (kWSC / 4), NIT = (NV + 255) / 256;
     __shared__ float lds[kWPH * kWRP];               // patch (49 / 54 KB); reused for the accumulator exchange (2 x 32 KB halves)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int ih = oh0 + r - 1, iw = NIMG == 1 ? ow0 + col - 1 : col - img * 10 - 1;
         const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (b + img < a.B);
         goff[k] = ok ? ((((b + img) * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
-        loff[k] = r * kWRP + col * kWCS + 4 * c4;
+        loff[k] = r * kWRP + (NIMG == 1 ? (col & 1) * 9 + (col >> 1) : col) * kWCS + 4 * c4;
     }
     const int nslab = a.Cin / kWSC;
     // weight stream of this wave: [n-tile][wave xi][slab][g][nu][lane][4]
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int a1 = wave == 0 ? 0 : 1, a2 = wave == 3 ? 3 : 2;
     const float s1 = wave == 2 ? -1.f : 1.f, s2 = (wave == 0 || wave == 3) ? -1.f : 1.f;
     const int ti = li >> 3, tj = li & 7;
-    const float* pbase = lds + (2 * ti) * kWRP + (NIMG == 1 ? 2 * tj : (tj >> 2) * 10 + 2 * (tj & 3)) * kWCS + 4 * lq;
+    const float* pbase = lds + (2 * ti) * kWRP + (NIMG == 1 ? tj : (tj >> 2) * 10 + 2 * (tj & 3)) * kWCS + 4 * lq;
     const float* p1 = pbase + a1 * kWRP;
     const float* p2 = pbase + a2 * kWRP;
 
@@ -115,8 +119,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             f32x4 t[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 d1 = *(const f32x4*)(p1 + c * kWCS + 8 * g);
-                const f32x4 d2 = *(const f32x4*)(p2 + c * kWCS + 8 * g);
+                constexpr int cs = NIMG == 1 ? 1 : 0;          // column c of the tile: slot offset (c & 1) * 9 + (c >> 1) in the de-interleaved image
+                const int co = (cs ? (c & 1) * 9 + (c >> 1) : c) * kWCS;
+                const f32x4 d1 = *(const f32x4*)(p1 + co + 8 * g);
+                const f32x4 d2 = *(const f32x4*)(p2 + co + 8 * g);
                 t[c] = s1 * d1 + s2 * d2;
             }
             f32x4 v[4];
