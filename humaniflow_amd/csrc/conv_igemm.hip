@@ -215,7 +215,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 using namespace hmf;
 
-// tile: 0 = auto, else BM*1000 + BN (128128, 128064, 64128, 64064)
+// tile: 0 = auto, else BM*1000 + BN (64128, 64064; 128-row tiles were measured and lose on every ResNet shape: 2 work-groups per CU only)
 extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int H, int W,
                                int Cin, int Cout, int ks, int stride, int relu, int tile, void* stream) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: bad args");
@@ -243,8 +243,6 @@ extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias
     if (ks == 1) launch_conv<BM, BN, 1>(a, st); else launch_conv<BM, BN, 3>(a, st); \
     break;
     switch (tile) {
-        case 128128: if (Cout % 128) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: tile 128x128 needs Cout %% 128 == 0"); CONV_CASE(128, 128)
-        case 128064: CONV_CASE(128, 64)
         case 64128: if (Cout % 128) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: tile 64x128 needs Cout %% 128 == 0"); CONV_CASE(64, 128)
         case 64064: CONV_CASE(64, 64)
         default: return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: unknown tile %d", tile);

@@ -197,10 +197,10 @@ static void launch_patch(PatchArgs a, hipStream_t st) {
 
 using namespace hmf;
 
-// cfg = TW*1000 + PG*100 + TN*10 + (SC == 128 ? 1 : 0): 16420/16421 (8x16 px, 64 ch), 16410/16411 (8x16 px, 32 ch), 8210/8211 (8x8 px, 64 ch)
-static int patch_cfg_ok(int cfg) { return cfg == 16420 || cfg == 16421 || cfg == 16410 || cfg == 16411 || cfg == 8210 || cfg == 8211; }
+// cfg = TW*1000 + PG*100 + TN*10: 16420 (8x16 pixels x 64 channels), 16410 (8x16 x 32), 8210 (8x8 x 64)
+static int patch_cfg_ok(int cfg) { return cfg == 16420 || cfg == 16410 || cfg == 8210; }
 static int patch_cfg_bn(int cfg) { const int pg = (cfg / 100) % 10, tn = (cfg / 10) % 10; return (4 / pg) * tn * 32; }
-static int patch_cfg_sc(int cfg) { return (cfg % 10) ? 128 : 64; }
+static int patch_cfg_sc(int) { return 64; }
 
 extern "C" long long hmf_conv_patch_packed_floats(int Cin, int Cout, int ks) { return (long long)Cout * ks * ks * Cin; }
 
@@ -228,8 +228,7 @@ extern "C" int hmf_conv_patch(const float* x, const float* w_packed, const float
                               int Cin, int Cout, int ks, int stride, int relu, int cfg, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_patch: bad args");
     if (!patch_cfg_ok(cfg)) return fail(HMF_ERR_INVALID, "hmf_conv_patch: unknown cfg %d", cfg);
-    if (!((ks == 3 || ks == 1) && (stride == 1 || stride == 2)))
-        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: ks=%d stride=%d", ks, stride);
+    if (ks != 3 || (stride != 1 && stride != 2)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: ks=%d stride=%d (3x3, stride 1 or 2)", ks, stride);
     if (ks == 3 && stride == 2 && cfg != 8210) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: 3x3 / stride 2 is built for cfg 8210 only");
     const int SC = patch_cfg_sc(cfg), BN = patch_cfg_bn(cfg);
     if (Cin % SC || Cout % BN) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: Cin=%d %% %d or Cout=%d %% %d", Cin, SC, Cout, BN);
@@ -246,8 +245,8 @@ extern "C" int hmf_conv_patch(const float* x, const float* w_packed, const float
     if (cfg == CFG && ks == KS_) { launch_patch<KS_, TW_, PG_, TN_, SC_, 1>(a, st); HMF_LAUNCH_CHECK(); return HMF_OK; }
     if (ks == 3 && stride == 2) { launch_patch<3, 8, 2, 1, 64, 2>(a, st); HMF_LAUNCH_CHECK(); return HMF_OK; }
     PCASE(16420, 3, 16, 4, 2, 64) PCASE(16410, 3, 16, 4, 1, 64) PCASE(8210, 3, 8, 2, 1, 64)
-    PCASE(16420, 1, 16, 4, 2, 64) PCASE(16410, 1, 16, 4, 1, 64) PCASE(8210, 1, 8, 2, 1, 64)
-    PCASE(16421, 1, 16, 4, 2, 128) PCASE(16411, 1, 16, 4, 1, 128) PCASE(8211, 1, 8, 2, 1, 128)
+    // 1x1 layers were measured on this kernel as well (64- and 128-channel slabs, single- and double-buffered patches): equal to or slower than
+    // k_conv_igemm on every ResNet shape, so those instantiations are not built
 #undef PCASE
     return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: cfg %d is not built for ks=%d", cfg, ks);
 }

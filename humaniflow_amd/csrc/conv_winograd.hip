@@ -226,10 +226,9 @@ extern "C" int hmf_conv_winograd_pack_host(const float* w /*[Cout][3][3][Cin]*/,
 extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }
 
 extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
-                                 int Cin, int Cout, int relu, int tile_channels, void* stream) {
+                                 int Cin, int Cout, int relu, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: bad args");
     if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: Cin=%d must be a multiple of 64 and Cout=%d of 32", Cin, Cout);
-    if (tile_channels != 0 && tile_channels != 32 && tile_channels != 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: tile_channels in {0,32,64}");
     if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: x and w_packed must be 16-byte aligned");
     if ((long long)B * H * W * Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29))
         return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
@@ -239,22 +238,15 @@ extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const fl
     const bool pair = W <= 8;                        // narrow maps: two images per work-group tile
     a.tiles_w = pair ? 1 : (W + kWTW - 1) / kWTW;
     a.tiles_hw = a.tiles_w * ((H + kWTH - 1) / kWTH);
-    // two n-tiles (64 channels) per work-group halve the patch loads and input transforms per MFMA but need all 256 VGPRs; measured on
-    // MI355X (tools/conv_probe.py) it only wins on the 128-channel layers (57 vs 62 us) and loses elsewhere: auto = 32 channels
-    const int tn = tile_channels == 64 ? 2 : 1;
-    if (tn == 2 && Cout % 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: 64-channel tiles need Cout %% 64 == 0");
-    a.n_tiles = Cout / (32 * tn);
+    // (a 64-channel work-group tile -- two n-tiles per wave -- was measured too: it needs all 256 VGPRs, spills, and loses on every layer but the
+    // 128-channel ones (57 vs 62 us); removed)
+    a.n_tiles = Cout / 32;
     const long long blocks = (long long)(pair ? (B + 1) / 2 : B) * a.tiles_hw * a.n_tiles;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, B * H * W, st);
-    if (pair) {
-        if (tn == 2) hipLaunchKernelGGL((k_conv_winograd<2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_conv_winograd<1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    } else {
-        if (tn == 2) hipLaunchKernelGGL((k_conv_winograd<2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_conv_winograd<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    }
+    if (pair) hipLaunchKernelGGL((k_conv_winograd<1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_winograd<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

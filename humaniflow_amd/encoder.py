@@ -235,7 +235,7 @@ class ResNetEncoder(nn.Module):
         if wk is not None and stride == 1 and (W >= 16 or W == 8):
             _lib.check(lib.hmf_conv_winograd(x.data_ptr(), wk.data_ptr(), None if bias is None else bias.data_ptr(),
                                              None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout,
-                                             int(relu), 0, _lib.current_stream()), 'hmf_conv_winograd')
+                                             int(relu), _lib.current_stream()), 'hmf_conv_winograd')
             return y
         pk = self._plan['packed'].get(id(w)) if self._plan is not None else None
         if pk is not None:

@@ -186,7 +186,7 @@ int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int 
  *   y = relu?(conv(x, w, stride, padding = ks/2) + bias (+ residual)).
  * x (B,H,W,Cin), w (Cout,ks,ks,Cin) [= a channels_last (Cout,Cin,ks,ks) tensor], bias (Cout) or NULL, residual/y (B,OH,OW,Cout);
  * ks in {1,3}, stride in {1,2}, Cin % 32 == 0, Cout % 64 == 0.  tile: 0 = pick by work-group count, else BM*1000+BN in
- * {128128, 128064, 64128, 64064}.  Profiler tag 8. */
+ * {64128, 64064}.  Profiler tag 8. */
 int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int H, int W,
                     int Cin, int Cout, int ks, int stride, int relu, int tile, void* stream);
 
@@ -196,25 +196,24 @@ int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const flo
 int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const float* bias, float* y, int B, int OH, int OW, int Cin,
                           int H2, int W2, int Cin2, int stride2, int Cout, int relu, void* stream);
 
-/* Patch-resident variant of hmf_conv2d_nhwc for stride-1 3x3 and 1x1 (stride 1 or 2) layers: the input patch of a pixel tile lives in
- * LDS for a whole slab of input channels and the weights stream from L2 in MFMA lane order (no barrier inside a slab).
- * w_packed = hmf_conv_patch_pack_host(w (Cout,ks,ks,Cin) channels_last, ..., cfg) uploaded to the device
- * (hmf_conv_patch_packed_floats floats).  cfg = TW*1000 + PG*100 + TN*10 + (SC==128): 16420/16421 = 8x16-pixel tile x 64 channels,
- * 16410/16411 = 8x16 x 32 channels, 8210/8211 = 8x8 x 64 channels; SC = input channels per slab (64, or 128 for 1x1 only);
- * Cin % SC == 0, Cout % (channels per tile) == 0.  Same epilogue as hmf_conv2d_nhwc; profiler tag 10. */
+/* Patch-resident direct 3x3 convolution (stride 1 or 2; the encoder uses it where the Winograd kernel does not apply): the input patch of a
+ * pixel tile lives in LDS for a whole slab of 64 input channels and the weights stream from L2 in MFMA lane order (no barrier inside a slab).
+ * w_packed = hmf_conv_patch_pack_host(w (Cout,3,3,Cin) channels_last, ..., cfg) uploaded to the device (hmf_conv_patch_packed_floats floats).
+ * cfg = TW*1000 + PG*100 + TN*10: 16420 = 8x16-pixel tile x 64 channels, 16410 = 8x16 x 32, 8210 = 8x8 x 64 (the only one for stride 2);
+ * Cin % 64 == 0, Cout % (channels per tile) == 0.  Same epilogue as hmf_conv2d_nhwc; profiler tag 10. */
 long long hmf_conv_patch_packed_floats(int Cin, int Cout, int ks);
 int hmf_conv_patch_pack_host(const float* w, float* packed, int Cin, int Cout, int ks, int cfg);
 int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                    int Cin, int Cout, int ks, int stride, int relu, int cfg, void* stream);
 
 /* Winograd F(2x2,3x3) variant for stride-1 3x3 layers (same result as hmf_conv2d_nhwc with ks = 3, 2.25x fewer MFMA k-steps): 8x16-pixel
- * tiles x 32 channels, input transform in registers, output transform through LDS, same fused epilogue.  w_packed =
+ * tiles x 32 channels (maps at most 8 pixels wide: 8x8 pixels of two consecutive images), input transform in registers, output transform through LDS, same fused epilogue.  w_packed =
  * hmf_conv_winograd_pack_host(w (Cout,3,3,Cin) channels_last, ...) [the transformed weights G g G^T in MFMA lane order,
  * hmf_conv_winograd_packed_floats = 16*Cout*Cin floats] uploaded to the device.  Cin % 64 == 0, Cout % 32 == 0.  Profiler tag 11. */
 long long hmf_conv_winograd_packed_floats(int Cin, int Cout);
 int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout);
 int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
-                      int Cin, int Cout, int relu, int tile_channels /* 0 = auto, 32 or 64 output channels per work-group */, void* stream);
+                      int Cin, int Cout, int relu, void* stream);
 
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
  * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.

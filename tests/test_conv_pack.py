@@ -9,7 +9,7 @@ from humaniflow_amd import _lib
 def test_patch_pack_is_the_documented_permutation():
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
-    for cin, cout, ks, cfg, sc in [(128, 64, 3, 8210, 64), (64, 96, 3, 16410, 64), (256, 64, 1, 16421, 128), (128, 32, 1, 8210, 64)]:
+    for cin, cout, ks, cfg, sc in [(128, 64, 3, 8210, 64), (64, 96, 3, 16410, 64), (256, 64, 3, 16420, 64)]:
         w = torch.randn(cout, ks, ks, cin, generator=g)                  # channels_last weight: [Cout][kh][kw][Cin]
         packed = torch.empty(int(lib.hmf_conv_patch_packed_floats(cin, cout, ks)))
         assert packed.numel() == w.numel()

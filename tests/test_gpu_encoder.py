@@ -34,7 +34,7 @@ def _case(B, H, W, cin, cout, ks, stride, res, relu, tile, seed=0):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, ks, stride, res, relu, tile, err)
 
 
-@pytest.mark.parametrize('tile', [0, 128128, 128064, 64128, 64064])
+@pytest.mark.parametrize('tile', [0, 64128, 64064])
 @pytest.mark.parametrize('ks,stride', [(1, 1), (1, 2), (3, 1), (3, 2)])
 def test_conv_matches_float64_reference(tile, ks, stride):
     _case(2, 12, 12, 64, 128, ks, stride, res=True, relu=True, tile=tile)
@@ -43,9 +43,9 @@ def test_conv_matches_float64_reference(tile, ks, stride):
 def test_conv_ragged_rows_and_flags():
     # M = 49 / 147 rows: partial tiles, rows beyond M neither read nor written; bias-only / residual-only / no ReLU paths
     _case(1, 7, 7, 32, 64, 3, 1, res=False, relu=False, tile=64064, seed=1)
-    _case(3, 7, 7, 96, 192, 3, 1, res=True, relu=False, tile=128064, seed=2)
+    _case(3, 7, 7, 96, 192, 3, 1, res=True, relu=False, tile=64064, seed=2)
     _case(3, 7, 7, 96, 192, 1, 1, res=False, relu=True, tile=64064, seed=3)
-    _case(1, 9, 5, 64, 128, 3, 2, res=True, relu=True, tile=128128, seed=4)          # non-square, odd sizes, stride 2
+    _case(1, 9, 5, 64, 128, 3, 2, res=True, relu=True, tile=64128, seed=4)          # non-square, odd sizes, stride 2
     _case(2, 8, 8, 2048, 512, 1, 1, res=False, relu=True, tile=0, seed=5)           # deepest K of the 1x1 layers
 
 
@@ -81,18 +81,12 @@ def test_patch_conv3x3_matches_float64_reference(cfg):
     _patch_case(1, 11, 19, 64, 64, 3, 1, False, False, cfg, seed=1)         # ragged tiles: masked stores, zero-filled patch borders
 
 
-@pytest.mark.parametrize('cfg', [16420, 16421, 16410, 16411, 8210, 8211])
-def test_patch_conv1x1_matches_float64_reference(cfg):
-    _patch_case(2, 16, 16, 256, 128, 1, 1, True, True, cfg)
-    _patch_case(2, 14, 10, 128, 64, 1, 2, False, True, cfg, seed=2)         # strided 1x1 (downsample branch), ragged
-
-
 def test_patch_conv3x3_stride2():
     _patch_case(2, 16, 16, 128, 64, 3, 2, False, True, 8210)
     _patch_case(1, 13, 9, 64, 128, 3, 2, True, False, 8210, seed=3)
 
 
-def _wino_case(B, H, W, cin, cout, res, relu, seed=0, tc=0):
+def _wino_case(B, H, W, cin, cout, res, relu, seed=0):
     from humaniflow_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(seed)
@@ -112,7 +106,7 @@ def _wino_case(B, H, W, cin, cout, res, relu, seed=0, tc=0):
     rd = r.cuda().contiguous(memory_format=torch.channels_last) if res else None
     y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
     _lib.check(lib.hmf_conv_winograd(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
-                                     B, H, W, cin, cout, int(relu), tc, _lib.current_stream()), 'hmf_conv_winograd')
+                                     B, H, W, cin, cout, int(relu), _lib.current_stream()), 'hmf_conv_winograd')
     torch.cuda.synchronize()
     err = (y.cpu().double() - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, res, relu, err)      # Winograd: a few more roundings than direct
@@ -123,12 +117,10 @@ def test_winograd_conv3x3_matches_float64_reference():
     _wino_case(1, 8, 32, 64, 32, False, False, seed=1)          # one tile row, two tile columns
     _wino_case(2, 11, 19, 64, 96, True, True, seed=2)           # ragged: odd sizes, masked stores, zero padding inside tiles
     _wino_case(1, 32, 32, 256, 256, False, True, seed=3)        # l3-like depth
-    _wino_case(2, 16, 16, 128, 64, True, True, seed=4, tc=64)   # 64-channel work-group tiles
     _wino_case(4, 8, 8, 128, 64, True, True, seed=6)            # 8-pixel maps: two images per tile
     _wino_case(3, 8, 8, 64, 32, False, False, seed=7)           # ... odd batch: the last tile holds one image
     _wino_case(2, 5, 7, 64, 32, True, True, seed=8)             # ... ragged narrow map
-    _wino_case(2, 11, 19, 64, 128, True, False, seed=5, tc=64)
-    _wino_case(2, 11, 19, 64, 128, True, False, seed=5, tc=32)
+    _wino_case(2, 11, 19, 64, 128, True, False, seed=5)
 
 
 def test_dual_1x1_matches_float64_reference():
