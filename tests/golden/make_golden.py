@@ -176,6 +176,16 @@ def main():
     for k in names:
         tr['frames_' + k] = np.concatenate(trk.per_frame_metrics[k])
     np.savez_compressed(os.path.join(OUT, 'tracker_golden.npz'), **tr)
+    # sampling helpers that import here: quaternion -> rotation, heat-map arg-max (joints2D_error_sorted_verts_sampling itself needs pytorch3d)
+    import utils.label_conversions as lc
+    import utils.rigid_transform_utils as rtu
+    quat = torch.from_numpy(rng.randn(16, 4))
+    hm = torch.from_numpy(rng.rand(2, 17, 24, 24)).float()
+    hm[0, 3] = 0.0                                    # an undetected joint
+    hm[1, 5] *= 1e-8
+    j2d, vis = lc.convert_heatmaps_to_2Djoints_coordinates_torch(hm, eps=1e-6)
+    np.savez_compressed(os.path.join(OUT, 'sampling_golden.npz'), quat=quat.numpy(), rotmat=rtu.quat_to_rotmat(quat).numpy(),
+                        heatmaps=hm.numpy(), joints2D=j2d.numpy(), vis=vis.numpy())
     np.savez_compressed(os.path.join(OUT, 'metrics_golden.npz'), P=P, T=T, pa=eu.procrustes_analysis_batch(P, T),
                         sc=eu.scale_and_translation_transform_batch(P, T), cam_pts=rng.randn(4, 17, 3), cam=rng.randn(4, 3))
     # ---------------- proxy-representation front end (Canny + heat-maps; both importable as they are) ----------

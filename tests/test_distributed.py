@@ -140,3 +140,30 @@ def test_two_rank_gloo_eval_equals_single_process():
             ref = np.empty(n)
             ref[:] = frames1[k].numpy()
             assert np.allclose(frames[k], ref[order], atol=1e-6)
+
+
+def test_sampling_helpers_match_reference():
+    """quat_to_rotmat and the heat-map arg-max against the reference's own functions (golden); the error-sorted sample selection against
+    a direct restatement (the reference function needs pytorch3d for its 180-degree flip and cannot run here)."""
+    from humaniflow_amd import sampling_utils as su
+    z = np.load(os.path.join(GOLDEN, 'sampling_golden.npz'))
+    assert np.abs(su.quat_to_rotmat(torch.from_numpy(z['quat'])).numpy() - z['rotmat']).max() < 1e-14
+    j2d, vis = su.convert_heatmaps_to_2Djoints_coordinates_torch(torch.from_numpy(z['heatmaps']))
+    assert np.array_equal(j2d.numpy(), z['joints2D']) and np.array_equal(vis.numpy(), z['vis'])
+    R = su.so3_uniform_sampling_torch(64, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(64, 3, 3), atol=1e-5) and torch.allclose(torch.linalg.det(R), torch.ones(64), atol=1e-5)
+    g = torch.Generator().manual_seed(3)
+    N, S = 7, 64
+    verts, joints = torch.randn(N, 50, 3, generator=g), torch.randn(N, 90, 3, generator=g) * 0.3
+    cam = torch.tensor([[0.9, 0.05, -0.02]])
+    hm = torch.zeros(1, 17, S, S)
+    tgt = torch.randint(8, S - 8, (17, 2), generator=g)
+    for k in range(17):
+        if k not in (2, 9):                                    # two invisible joints
+            hm[0, k, tgt[k, 1], tgt[k, 0]] = 1.0
+    out = su.joints2D_error_sorted_verts_sampling(verts, joints, hm, cam)
+    jc = joints[:, ev.ALL_JOINTS_TO_COCO_MAP] * torch.tensor([1.0, -1.0, -1.0])
+    p2 = (cam[:, None, :1] * (jc[..., :2] + cam[:, None, 1:]) + 1) * (S / 2.0)
+    keep = [k for k in range(17) if k not in (2, 9)]
+    worst = torch.stack([torch.norm(p2[n, keep] - tgt[keep].float(), dim=-1).max() for n in range(N)])
+    assert torch.equal(out, verts[torch.argsort(worst)])
