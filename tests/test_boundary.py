@@ -188,3 +188,33 @@ def test_tuned_miopen_db_is_installed_for_the_encoder(tmp_path, monkeypatch):
     files = sorted(os.listdir(dst))
     assert any(f.endswith('.ufdb.txt') for f in files) and any(f.endswith('.udb.txt') for f in files)
     assert encoder.enable_tuned_miopen_db() == dst                         # idempotent; respects a user-provided path
+
+
+def test_encoder_bn_fold_host_logic():
+    """Host side of the encoder's inference plan (no GPU): eval-mode BatchNorm folded into (weight, bias) reproduces bn(conv(x)); the
+    downsample branch concatenated along K reproduces conv3 + downsample; the plan is dropped when parameters can have changed."""
+    import torch.nn.functional as F
+    from humaniflow_amd.encoder import ResNetEncoder
+    torch.manual_seed(0)
+    enc = ResNetEncoder(50, 18).eval()
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    blk = enc.layer2[0]                                              # has a stride-2 downsample branch
+    x = torch.randn(2, 256, 12, 12)
+    with torch.no_grad():
+        w, b, s, p = enc._fold(blk.conv1, blk.bn1)
+        assert torch.allclose(F.conv2d(x, w, b, s, p), blk.bn1(blk.conv1(x)), atol=1e-5)
+        plan = enc._build_plan()
+        stages, ds, dual = plan['blocks'][3]                         # layer2[0]
+        assert dual is not None and dual[0].shape == (512, 128 + 256) and dual[2] == 2
+        h = torch.randn(2, 128, 6, 6)
+        ref = blk.bn3(blk.conv3(h)) + blk.downsample[1](blk.downsample[0](x))
+        wcat, bias, stride = dual
+        got = F.conv2d(h, wcat[:, :128, None, None]) + F.conv2d(x, wcat[:, 128:, None, None], None, stride) + bias[None, :, None, None]
+        assert torch.allclose(got, ref, atol=1e-4)
+    enc._plan = plan
+    enc.train(); assert enc._plan is None
+    enc._plan = plan
+    enc.load_state_dict(enc.state_dict()); assert enc._plan is None
+    assert len(enc.state_dict()) == 318 and 'layer1.0.downsample.0.weight' in enc.state_dict()     # torchvision names, no fc
