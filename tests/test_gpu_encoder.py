@@ -201,3 +201,29 @@ def test_folded_encoder_matches_module_path():
             ref = enc.forward_module(x.double()) if False else enc.double().forward_module(x.double())
         assert got.shape == (2, enc.out_dim)
         assert (got.double() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_encoder_full_size_properties():
+    """BASELINE size (B=32, 256x256, ResNet-50): size-independent properties of the hand-written encoder -- run-to-run determinism (bitwise),
+    independence of the images of a batch (an image's features do not depend on its neighbours or on the batch size), agreement of the
+    Winograd / direct 3x3 kernels through the whole network, and finite outputs."""
+    import humaniflow_amd as H
+    from humaniflow_amd.encoder import ResNetEncoder
+    from humaniflow_amd.synthetic import synthetic_proxy_input
+    torch.manual_seed(1)
+    enc = ResNetEncoder(50, 18).eval().cuda()
+    x = synthetic_proxy_input(32, 256, seed=5).cuda()
+    with torch.no_grad():
+        a, b = enc(x), enc(x)
+        assert torch.equal(a, b) and torch.isfinite(a).all() and a.shape == (32, 2048)
+        sub = enc(x[5:8])
+        scale = a.abs().max().item()
+        assert (sub - a[5:8]).abs().max().item() <= 1e-6 * scale
+        one = enc(x[31:32])
+        assert (one - a[31:32]).abs().max().item() <= 1e-6 * scale
+        # same network with the Winograd layers forced onto the direct patch kernel
+        plan = enc._plan
+        saved, plan['wino'] = plan['wino'], {}
+        c = enc(x)
+        plan['wino'] = saved
+        assert (c - a).abs().max().item() <= 2e-5 * scale and not torch.equal(c, a)
