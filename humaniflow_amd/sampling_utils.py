@@ -9,14 +9,15 @@ from .smpl import compute_vertex_variance_from_samples  # noqa: F401  (re-export
 
 
 def quat_to_rotmat(quat):
-    """utils/rigid_transform_utils.py:119-139: (B,4) (w,x,y,z), normalised here -> (B,3,3)."""
+    """utils/rigid_transform_utils.py:119-139: (B,4) quaternions (w, x, y, z), normalised here -> (B,3,3).
+    Written in the vector form  R = (w^2 - |v|^2) I + 2 v v^T + 2 w [v]_x  (same matrix as the reference's component-wise table)."""
     q = quat / quat.norm(p=2, dim=1, keepdim=True)
-    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-    w2, x2, y2, z2 = w * w, x * x, y * y, z * z
-    wx, wy, wz, xy, xz, yz = w * x, w * y, w * z, x * y, x * z, y * z
-    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
-                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
-                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(-1, 3, 3)
+    w, v = q[:, :1], q[:, 1:]
+    eye = torch.eye(3, dtype=q.dtype, device=q.device)
+    cross = torch.zeros(q.shape[0], 3, 3, dtype=q.dtype, device=q.device)
+    cross[:, 0, 1], cross[:, 0, 2], cross[:, 1, 2] = -v[:, 2], v[:, 1], -v[:, 0]
+    cross = cross - cross.transpose(1, 2)
+    return (w * w - (v * v).sum(1, keepdim=True))[:, :, None] * eye + 2.0 * v[:, :, None] * v[:, None, :] + 2.0 * w[:, :, None] * cross
 
 
 def so3_uniform_sampling_torch(num_matrices, device=None, generator=None):
