@@ -16,7 +16,8 @@ LIB = os.path.join(HERE, 'libhumaniflow_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -packed-fp32-ops: no v_pk_{fma,mul,add}_f32.  Packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X guide, price
 # list): the skinning epilogue of k_lbs_mfma was emitted as ~24 v_pk_fma_f32 per (row, vertex) and did not overlap the
-# partner wave's MFMAs at all (tools/lbs_tune.py).
+# partner wave's MFMAs at all (tools/lbs_tune.py).  The x86 host pass of hipcc prints "'-packed-fp32-ops' is not a recognized feature for this
+# target (ignoring feature)": harmless, the device pass honours it (5036 -> 0 v_pk_*_f32 in smpl_kernels).
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
          '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
