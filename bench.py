@@ -72,6 +72,7 @@ def parse():
     ap.add_argument('--blend-dtype', choices=['fp32', 'bf16'], default='fp32',
                     help="'bf16': BASELINE configs[2] (use with --batch 64): SMPL blend-shape GEMM operands in bf16, fp32 accumulate -- a parity-test "
                          'configuration, not the headline line')
+    ap.add_argument('--dry-run-cpu', action='store_true', help='exercise only the rank plumbing (gloo, CPU, stand-in step): used by the CPU tests')
     ap.add_argument('--chain-encoders', action='store_true',
                     help='serialise the encoders of consecutive steps with an event (cleaner per-kernel timings, ~10 %% less throughput): '
                          'by default batches on different streams overlap freely')
@@ -134,18 +135,82 @@ def log(msg):
         print('[bench %7.1fs] %s' % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
+# ---- multi-rank scaffolding (one process per GPU), shared by the real run and by --dry-run-cpu (gloo; tests/test_distributed.py) ----
+def dist_setup(dev, backend):
+    """RANK / WORLD_SIZE / MASTER_* come from the launcher (torch.distributed.run).  Returns (dist module or None, world, rank)."""
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world == 1:
+        return None, 1, 0
+    import torch.distributed as dist
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=dev)          # RCCL on ROCm
+    else:
+        dist.init_process_group(backend)
+    return dist, world, rank
+
+
+def dist_sync(dist, dev):
+    """barrier + device synchronise on both sides of the timed region."""
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
+
+
+def dist_elapsed(t0, dist, dev):
+    """Elapsed time of the timed region: sync + barrier, then the MAX over ranks."""
+    dist_sync(dist, dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def dist_gather_metrics(vec, dist, world):
+    """The one exchange step of the data-parallel path: every rank's metric vector, all-gathered (RCCL over xGMI on the GPU box)."""
+    if dist is None:
+        return vec[None]
+    out = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
+    dist.all_gather_into_tensor(out, vec)
+    return out.reshape(world, -1)
+
+
+def dry_run_cpu(args):
+    """The rank plumbing of main() with a stand-in CPU step (no model, no HIP): what tests/test_distributed.py launches with 2 gloo ranks."""
+    dev = torch.device('cpu')
+    dist, world, rank = dist_setup(dev, 'gloo')
+    B, N = args.batch, args.samples
+    step = lambda: torch.full((4,), float(rank + 1), dtype=torch.float64) * torch.randn(1000).square().mean().clamp(1, 1)
+    for _ in range(args.warmup):
+        step()
+    dist_sync(dist, dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vec = step()
+    gathered = dist_gather_metrics(vec, dist, world)
+    elapsed = dist_elapsed(t0, dist, dev)
+    if rank == 0:
+        print(json.dumps({'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': world * B * N * args.steps / elapsed, 'unit': 'images*samples/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dry_run': True,
+                          'gathered_rank_sums': gathered.sum(dim=1).tolist()}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (the hot path has no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)          # RCCL on ROCm
+    dist, world, rank = dist_setup(dev, 'nccl')
     if args.gpus != world and rank == 0:
         print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 
@@ -187,11 +252,7 @@ def main():
                 extra = (smpl.tpose(pred['shape_mode']), smpl.tpose(pred['shape_samples'].reshape(-1, 10)))
         return pred, pe, sa, extra
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    sync_all = lambda: dist_sync(dist, dev)
 
     log('model + SMPL on device; warm-up (%d steps; the first one includes MIOpen kernel selection)' % args.warmup)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
@@ -223,15 +284,8 @@ def main():
     pred, pe, sa, _ = out
     metric_vec = torch.stack([sa.vertices.abs().mean(), sa.joints.abs().mean(), pe.vertices.abs().mean(),
                               pred['pose_rotmats_samples'].mean()]).double()
-    if dist is not None:
-        gathered = torch.empty(world * metric_vec.numel(), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, metric_vec)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    gathered = dist_gather_metrics(metric_vec, dist, world)
+    elapsed = dist_elapsed(t0, dist, dev)
     log('timed region done: %.3f ms/step' % (elapsed / args.steps * 1e3))
     # ---- per-kernel times from the HIP events recorded on the launch stream during the timed region ----
     ms = np.zeros(16384)

@@ -167,3 +167,24 @@ def test_sampling_helpers_match_reference():
     keep = [k for k in range(17) if k not in (2, 9)]
     worst = torch.stack([torch.norm(p2[n, keep] - tgt[keep].float(), dim=-1).max() for n in range(N)])
     assert torch.equal(out, verts[torch.argsort(worst)])
+
+
+def test_bench_rank_plumbing_two_gloo_ranks():
+    """bench.py's multi-rank scaffolding (env parsing, barrier + max-over-ranks timing, the metric all-gather, rank-0-only JSON line) launched the
+    way the driver launches it -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` -- with the CPU stand-in step."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--dry-run-cpu']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                           # rank 0 prints the one JSON line
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['higher_is_better'] is True
+    assert d['gathered_rank_sums'] == [4.0, 8.0]                     # rank r contributed (r+1) * ones(4)
+    assert abs(d['value'] - 2 * 32 * 100 * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']     # whole-job aggregate over both ranks
