@@ -18,4 +18,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $BENCH >/dev/nu
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_m -o m -- $BENCH --streams 1 >/dev/null 2>/tmp/m.log
 python tools/pmc_mfma.py "$(find /tmp/prof_m -name '*.db' | head -1)" > "$OUT/${R}_mfma_busy.txt"
 python tools/pmc_summary.py "$(find /tmp/prof_f -name '*.db' | head -1)" "$(find /tmp/prof_w -name '*.db' | head -1)" > "$OUT/${R}_pmc.json"
+mkdir -p /tmp/rt && cp "$OUT"/${R}_* profiles/ && python tools/roofline_table.py $R > "$OUT/${R}_roofline.md"
 ls -la "$OUT"
