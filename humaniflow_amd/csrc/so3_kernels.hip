@@ -25,18 +25,32 @@ constexpr int kProfMax = 16384;
 struct ProfRec { hipEvent_t a, b; int tag, rows; };
 ProfRec g_prof[kProfMax];
 int g_prof_n = 0;
+int g_prof_pool = 0;               // events [0, g_prof_pool) exist (created outside any stream capture, reused across enable() calls)
+bool g_prof_skip = false;
 bool g_prof_on = false;
 }  // namespace
 bool prof_on() { return g_prof_on; }
+// Launches issued while their stream is being captured into a HIP graph are not timed: a captured event is graph-internal (it cannot be
+// synchronised or timed from the host), and the external-event-node form (hipEventRecordWithFlags(..., hipEventRecordExternal)) returns
+// "invalid argument" under the HIP runtime PyTorch 2.10+rocm7.0 loads (it works against /opt/rocm 7.2: tools/micro/graph_event.hip).
+static bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+}
 void prof_begin(int tag, int rows, hipStream_t st) {
-    if (g_prof_n >= kProfMax) return;
+    g_prof_skip = true;
+    if (g_prof_n >= kProfMax || capturing(st)) return;
     ProfRec& r = g_prof[g_prof_n];
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    if (g_prof_n >= g_prof_pool) {                 // pool exhausted: create on demand
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        g_prof_pool = g_prof_n + 1;
+    }
+    g_prof_skip = false;
     r.tag = tag; r.rows = rows;
     (void)hipEventRecord(r.a, st);
 }
 void prof_end(hipStream_t st) {
-    if (g_prof_n >= kProfMax) return;
+    if (g_prof_skip) return;
     (void)hipEventRecord(g_prof[g_prof_n].b, st);
     ++g_prof_n;
 }
@@ -104,9 +118,12 @@ int hmf_device_count(void) {
 }
 
 int hmf_profile_enable(int enable) {
-    for (int i = 0; i < g_prof_n; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
     g_prof_n = 0;
     g_prof_on = enable != 0;
+    // events are pooled: hipEventCreate is not allowed while a stream capture is active, so a first block exists before any launch
+    if (g_prof_on)
+        for (; g_prof_pool < 2048; ++g_prof_pool)
+            if (hipEventCreate(&g_prof[g_prof_pool].a) != hipSuccess || hipEventCreate(&g_prof[g_prof_pool].b) != hipSuccess) break;
     return HMF_OK;
 }
 

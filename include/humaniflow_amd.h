@@ -241,7 +241,7 @@ int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial,
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */
 /* ------------------------------------------------------------------------------------------ */
 /* While enabled, every launch of the kernels tagged below is bracketed by hipEventRecord on ITS stream
- * (no synchronisation, <= 16384 launches kept).  hmf_profile_collect synchronises the recorded events and
+ * (no synchronisation, <= 16384 launches kept; launches issued while their stream is being captured into a HIP graph are not timed).  hmf_profile_collect synchronises the recorded events and
  * copies out, per launch: duration in ms, kernel tag, and the launch's row count M (or B*N for flow).
  * Tags: 1 = k_lbs_mfma, 2 = k_rigid_chain, 3 = k_joints, 4 = k_tpose, 5 = k_flow_ctx0, 6 = k_flow_chain,
  * 7 = k_isgc, 8 = k_conv_igemm, 9 = k_stem_conv, 10 = k_conv_patch, 11 = k_conv_winograd (rows = output pixels B*OH*OW; stem: B).  Returns the number of launches copied (<= max), or a negative error.                */

@@ -40,7 +40,7 @@ for s in streams:
         for _ in range(2):
             step()
     torch.cuda.synchronize()
-    with torch.cuda.graph(g, stream=s):
+    with torch.cuda.graph(g, stream=s, capture_error_mode=os.environ.get("CAPMODE", "global")):
         o = step()
     graphs.append(g); outs.append(o)
 torch.cuda.synchronize()
