@@ -4,8 +4,6 @@ Public API mirrors the reference: ``HumaniflowModel`` (models/humaniflow_model.p
 ``get_humaniflow_cfg_defaults`` (configs/humaniflow_config.py) and the SO(3) helpers of
 utils/rigid_transform_utils.py; all arithmetic of the path runs in libhumaniflow_amd.so (include/humaniflow_amd.h).
 """
-from .encoder import enable_tuned_miopen_db
-enable_tuned_miopen_db()      # before any convolution runs
 from .config import get_humaniflow_cfg_defaults, get_benchmark_cfg, CfgNode
 from .humaniflow_model import HumaniflowModel, immediate_parent_to_all_ancestors
 from .smpl import SMPL, SMPLOutput, synthetic_smpl_model, compute_vertex_variance_from_samples, SMPL_PARENTS

@@ -1,6 +1,6 @@
 """ctypes binding of libhumaniflow_amd.so (the C ABI declared in include/humaniflow_amd.h).
 
-There is NO fallback: if the shared library is missing it is built with hipcc (in-tree); if
+There is NO fallback: if the shared library is missing or stale it is (re)built with hipcc (in-tree); if
 that fails, or a compute entry point is reached without a HIP device, a RuntimeError is raised.
 """
 import ctypes as C
@@ -59,7 +59,6 @@ _SIGS = {
     'hmf_flow_log_prob_so3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
     'hmf_proxy_rep': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                 _VP, _VP, _VP, _VP, _VP]),
-    'hmf_bias_act': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     'hmf_stem_packed_floats': (C.c_longlong, []),
     'hmf_stem_pack_host': (C.c_int, [_VP, _VP]),
     'hmf_stem_conv': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
@@ -94,9 +93,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from .build import build_library
-        build_library()
+    from .build import build_library
+    build_library()          # no-op unless the library is missing or older than its sources (content hash); serialised across ranks
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

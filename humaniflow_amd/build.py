@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['so3_kernels.hip', 'smpl_kernels.hip', 'flow_pack.hip', 'flow_kernels.hip', 'encoder_epilogue.hip', 'proxy_kernels.hip', 'conv_igemm.hip', 'conv_patch.hip', 'conv_winograd.hip', 'stem_conv.hip', 'eval_kernels.hip']
+SOURCES = ['so3_kernels.hip', 'smpl_kernels.hip', 'flow_pack.hip', 'flow_kernels.hip', 'proxy_kernels.hip', 'conv_igemm.hip', 'conv_patch.hip', 'conv_winograd.hip', 'stem_conv.hip', 'eval_kernels.hip']
 HEADERS = ['hmf_common.h', 'so3_math.h', 'flow_common.h', 'flow_handle.h', '../../include/humaniflow_amd.h']
 LIB = os.path.join(HERE, 'libhumaniflow_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -22,18 +22,50 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', 
          '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
+STAMP = LIB + '.stamp'
+LOCK = os.path.join(HERE, '.build.lock')
+
+
+def source_hash():
+    """Content hash of everything the library is built from (sources, headers, flags, this file): staleness is decided by content, not
+    by mtimes -- the snapshot that carries the tree to the GPU box does not preserve them."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for d in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, d), 'rb') as f:
+            h.update(d.encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build_library(force=False, verbose=False):
-    """Compile every HIP source into one shared library; returns its path."""
+    """Compile every HIP source into one shared library; returns its path.  Cheap when nothing changed.  Safe under N ranks starting
+    together: one process builds under an exclusive file lock, the others wait and find a fresh library; the link goes to a temporary
+    file that is renamed into place, so a concurrent CDLL never sees a half-written .so."""
     if not force and not _stale():
         return LIB
+    import fcntl
+    with open(LOCK, 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():             # another rank built it while we waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
+    want = source_hash()
     objs = []
     procs = []
     for s in SOURCES:
@@ -49,10 +81,15 @@ def build_library(force=False, verbose=False):
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode(errors='replace')))
         if verbose and out:
             print(out.decode(errors='replace'))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    tmp = '%s.%d.tmp' % (LIB, os.getpid())
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s' % r.stdout.decode(errors='replace'))
+    os.replace(tmp, LIB)
+    with open(STAMP + '.tmp', 'w') as f:
+        f.write(want + '\n')
+    os.replace(STAMP + '.tmp', STAMP)
     return LIB
 
 

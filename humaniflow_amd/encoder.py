@@ -6,40 +6,23 @@ buffer names follow torchvision (`conv1`, `bn1`, `layerL.B.convK/bnK`, `layerL.B
 so a reference checkpoint loads with ``strict=True``.
 
 On the GPU the eval-mode forward runs an *inference plan*: eval-mode BatchNorm folded into the
-preceding convolution's weight plus a per-channel bias, activations kept NHWC, and every 1x1 / 3x3
-convolution executed by the library's fused implicit-GEMM kernel (hmf_conv2d_nhwc: fp32 MFMA, bias +
-residual + ReLU in the epilogue, one launch and one HBM write per convolution).  The plan is built lazily
-from the live parameters and invalidated when they change, so the checkpoint layout is untouched.
-Only the 7x7 stem convolution and the max-pool still go through MIOpen / ATen.
+preceding convolution's weight plus a per-channel bias, activations kept NHWC, and every convolution
+executed by a hand-written fp32-MFMA kernel of the library with bias + residual + ReLU in its epilogue
+(one launch and one HBM write per convolution): hmf_stem_conv (7x7/2, reads the NCHW input directly) +
+hmf_maxpool3x3s2_nhwc, hmf_conv_winograd (stride-1 3x3), hmf_conv_patch (stride-2 3x3), hmf_conv2d_nhwc /
+hmf_conv1x1_dual_nhwc (1x1; a downsample branch rides in its block's conv3 as a K-concatenated GEMM).
+The plan is built lazily from the live parameters and rebuilt when they change (parameter version
+counters), so the checkpoint layout is untouched.  There is no vendor-library inference path
+and no CPU path: `forward` on a CPU tensor raises.  Training (grad mode / train()) uses batch-statistics
+BatchNorm, for which the folded plan does not apply: that mode runs the plain module graph under autograd
+(`forward_module`; the hand-written dgrad/wgrad kernels are not built yet -- DESIGN.md section 7).
 """
-import os
-import shutil
-import tempfile
+import warnings
 
 import torch
 from torch import nn
 import torch.nn.functional as F
 
-
-def enable_tuned_miopen_db():
-    """Point MIOpen at the find-db tuned for this encoder on MI355X (humaniflow_amd/miopen_db/, produced by MIOpen's own
-    search: `MIOPEN_FIND_MODE=1 python tools/encoder_find.py`).  Without it MIOpen's immediate-mode heuristics pick fp32
-    solvers that are ~25 % slower for these shapes.  MIOpen wants a writable directory, so the shipped files are copied to
-    a per-user temp dir.  No-op if the user already set MIOPEN_USER_DB_PATH; must run before the first convolution."""
-    if os.environ.get('MIOPEN_USER_DB_PATH') or os.environ.get('HUMANIFLOW_AMD_NO_MIOPEN_DB'):
-        return os.environ.get('MIOPEN_USER_DB_PATH')
-    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'miopen_db')
-    if not os.path.isdir(src):
-        return None
-    dst = os.path.join(tempfile.gettempdir(), 'humaniflow_amd_miopen_%d' % os.getuid())
-    os.makedirs(dst, exist_ok=True)
-    for f in os.listdir(src):
-        if f.endswith('.txt') and not os.path.exists(os.path.join(dst, f)):
-            tmp = os.path.join(dst, '.%s.%d.tmp' % (f, os.getpid()))          # atomic: 8 ranks of one node start together
-            shutil.copy(os.path.join(src, f), tmp)
-            os.replace(tmp, os.path.join(dst, f))
-    os.environ['MIOPEN_USER_DB_PATH'] = dst
-    return dst
 
 _SPECS = {18: (False, [2, 2, 2, 2]), 34: (False, [3, 4, 6, 3]), 50: (True, [3, 4, 6, 3])}
 
@@ -100,8 +83,9 @@ class ResNetEncoder(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
         self._plan = None
         self._plan_key = None
+        self.__dict__['_plan_tensors'] = None
 
-    # ---- plain module path (training / CPU / debugging) ----------------------------------
+    # ---- plain module graph: batch-statistics BatchNorm under autograd (training), and the float64 reference of the tests ----
     def forward_module(self, x):
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), kernel_size=3, stride=2, padding=1)
         for li in range(1, 5):
@@ -109,45 +93,55 @@ class ResNetEncoder(nn.Module):
         return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
 
     # ---- folded inference plan ----------------------------------------------------------
-    # eval-mode BatchNorm folded into the conv weight + a per-channel bias; convolutions run bias-free on MIOpen and
-    # ONE fused HIP pass (hmf_bias_act: + bias, + identity, ReLU, in place) follows each of them.  The stem's
-    # bias+ReLU commutes with max-pooling (both monotone), so it runs on the 4x smaller pooled tensor; a downsample
-    # branch's bias is added to the block's last bias so that branch needs no pass of its own.
+    # eval-mode BatchNorm folded into the conv weight + a per-channel bias that the convolution kernel adds in its epilogue; a
+    # downsample branch's bias is added to the block's last bias so that branch needs no pass of its own.
     fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_dual_nhwc)
-    conv_impl = 'hip'        # 'hip': hmf_conv2d_nhwc for the residual stages; 'miopen': MIOpen + hmf_bias_act (tools/encoder_probe.py A/B)
-    layout = 'nhwc'          # with the tuned find-db: nhwc 4.45 ms vs nchw 4.97 ms (B=32, ResNet-50; tools/encoder_find.py)
-
-    def _fmt(self):
-        return torch.channels_last if self.layout == 'nhwc' else torch.contiguous_format
 
     def _fold(self, conv, bn):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        w = (conv.weight * scale[:, None, None, None]).float().contiguous(memory_format=self._fmt())
+        w = (conv.weight * scale[:, None, None, None]).float().contiguous(memory_format=torch.channels_last)
         b = (bn.bias - bn.running_mean * scale).float().contiguous()
         return w, b, conv.stride, conv.padding
 
-    # The plan is a cache of the live parameters: drop it whenever they can have changed
-    # (train()/eval() toggles, .to()/.cuda(), load_state_dict).  Callers that mutate
-    # ``param.data`` by hand in eval mode must call invalidate_plan() themselves.
+    # The plan is a cache of the live parameters and BatchNorm statistics.  It is dropped by train()/eval(), .to()/.cuda() and
+    # load_state_dict, and -- for in-place updates such as optimizer.step(), p.data.copy_() or EMA swaps -- re-validated on every
+    # forward against the tensors' version counters and storage pointers (_params_key).
     def invalidate_plan(self):
         self._plan = None
+        self.__dict__['_plan_tensors'] = None
+
+    def _params_key(self):
+        ts = self.__dict__.get('_plan_tensors')
+        if ts is None:                                        # tensor list cached with the plan (~75 us per call for ResNet-50)
+            ts = self.__dict__['_plan_tensors'] = list(self.parameters()) + list(self.buffers())
+        return tuple([t._version for t in ts] + [t.data_ptr() for t in ts])
 
     def train(self, mode=True):
-        self._plan = None
+        self.invalidate_plan()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
-        self._plan = None
+        self.invalidate_plan()
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self._plan = None
+        self.invalidate_plan()
         return super()._load_from_state_dict(*a, **k)
+
+    def __getstate__(self):                                   # the packed device copies are a cache: never pickled / deep-copied
+        st = self.__dict__.copy()
+        st['_plan'] = None
+        st['_plan_key'] = None
+        st['_plan_tensors'] = None
+        return st
 
     @torch.no_grad()
     def _build_plan(self):
         plan = {'stem': self._fold(self.conv1, self.bn1), 'blocks': []}
-        if self.conv1.weight.is_cuda and self.conv1.in_channels == 18:
+        if self.conv1.weight.is_cuda:
+            if self.conv1.in_channels != 18:
+                raise NotImplementedError('humaniflow_amd: the stem kernel is built for the 18-channel proxy representation '
+                                          '(NUM_IN_CHANNELS = 18), got %d' % self.conv1.in_channels)
             from . import _lib
             lib = _lib.load()
             w = plan['stem'][0].detach().cpu().contiguous()                      # (64,18,7,7) row-major, BN scale folded in
@@ -263,62 +257,44 @@ class ResNetEncoder(nn.Module):
         _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
         return z
 
-    def _epilogue(self, x, bias, residual, relu):
-        from . import _lib
-        lib = _lib.load()
-        N, C, H, W = x.shape
-        nhwc = self.layout == 'nhwc'
-        fmt = self._fmt()
-        if not x.is_contiguous(memory_format=fmt):
-            x = x.contiguous(memory_format=fmt)
-        if residual is not None and not residual.is_contiguous(memory_format=fmt):
-            residual = residual.contiguous(memory_format=fmt)
-        _lib.check(lib.hmf_bias_act(x.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(), N, C, H * W,
-                                    int(nhwc), int(relu), _lib.current_stream()), 'hmf_bias_act')
-        return x
-
     @torch.no_grad()
     def forward_folded(self, x):
-        if not torch.backends.cudnn.benchmark:
-            torch.backends.cudnn.benchmark = True      # route convs through MIOpen's find path so the find-db is consulted
-        key = self.layout
+        """Inference plan on the HIP kernels: (B, 18, H, W) NCHW proxy input on a HIP device -> (B, out_dim)."""
+        from . import _lib
+        _lib.require_cuda(x, 'input')
+        key = self._params_key()
         if self._plan is None or self._plan_key != key:
             self._plan, self._plan_key = self._build_plan(), key
         p = self._plan
         with torch.cuda.device(x.device):
-            hip = self.layout == 'nhwc' and self.conv_impl == 'hip'
-            if hip and 'stem_packed' in p:
-                x = self._stem_hip(x.float().contiguous(), p['stem_packed'], p['stem'][1])
-            else:
-                x = x.float().contiguous(memory_format=self._fmt())
-                w, b, s, pad = p['stem']
-                x = F.max_pool2d(F.conv2d(x, w, None, s, pad), kernel_size=3, stride=2, padding=1)
-                x = self._epilogue(x, b, None, True)
-            if hip:
-                for stages, ds, dual in p['blocks']:
-                    if dual is not None:
-                        h = x
-                        for w, b, s, pad in stages[:-1]:
-                            h = self._conv_hip(h, w, b, s[0], None, True)
-                        x = self._conv_dual(h, x, dual[0], dual[1], dual[2])
-                        continue
-                    idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
+            x = self._stem_hip(x.float().contiguous(), p['stem_packed'], p['stem'][1])
+            for stages, ds, dual in p['blocks']:
+                if dual is not None:
+                    h = x
                     for w, b, s, pad in stages[:-1]:
-                        x = self._conv_hip(x, w, b, s[0], None, True)
-                    w, b, s, pad = stages[-1]
-                    x = self._conv_hip(x, w, b, s[0], idt, True)
-                return x.mean(dim=(2, 3))
-            for stages, ds, dual in p['blocks']:                      # MIOpen convolutions + one fused epilogue pass each (A/B reference)
-                idt = x if ds is None else F.conv2d(x, ds[0], None, ds[2], ds[3])
+                        h = self._conv_hip(h, w, b, s[0], None, True)
+                    x = self._conv_dual(h, x, dual[0], dual[1], dual[2])
+                    continue
+                idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
                 for w, b, s, pad in stages[:-1]:
-                    x = self._epilogue(F.conv2d(x, w, None, s, pad), b, None, True)
+                    x = self._conv_hip(x, w, b, s[0], None, True)
                 w, b, s, pad = stages[-1]
-                x = self._epilogue(F.conv2d(x, w, None, s, pad), b, idt, True)
+                x = self._conv_hip(x, w, b, s[0], idt, True)
             return x.mean(dim=(2, 3))
 
+    _warned_autograd = False
+
     def forward(self, x):
-        if (not self.training) and (not torch.is_grad_enabled()) and x.is_cuda:
+        from . import _lib
+        _lib.require_cuda(x, 'input')
+        if (not self.training) and (not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())) \
+                and not x.requires_grad:
             return self.forward_folded(x)
+        # training / gradients wanted: batch-statistics BatchNorm + backward.  The hand-written kernels cover inference only; say so once.
+        if not ResNetEncoder._warned_autograd:
+            ResNetEncoder._warned_autograd = True
+            warnings.warn('humaniflow_amd: the ResNet encoder runs its TRAINING graph (batch-statistics BatchNorm + backward) through '
+                          'torch autograd on ATen convolutions; only the inference plan is hand-written HIP (DESIGN.md section 7)')
         return self.forward_module(x)
 
 

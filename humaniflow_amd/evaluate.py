@@ -6,8 +6,10 @@ exchange is the metric state -- running SUMS and counts (metrics/eval_metrics_tr
 all-reduced ONCE at the end (final metrics are ratios of sums, :437-494), plus an all-gather of the per-frame arrays.
 `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm; the same code runs on gloo (CPU tests).
 
-The metric functions are torch restatements of utils/eval_utils.py:62-125 (Procrustes, scale+translation correction) and of the
-tracker's update rules; they run on the device, so the 0.53 GB/batch device->host copy of the reference (:227-252) disappears.
+The point-set errors (plain / scale+translation-corrected / Procrustes-aligned, utils/eval_utils.py:62-125) and the sample diversity
+run in the fused HIP epilogue of the library (csrc/eval_kernels.hip), so the 0.53 GB/batch device->host copy of the reference
+(:227-252) disappears; the tracker keeps the reference's running sums (metrics/eval_metrics_tracker.py:95-433) on the device in fp64.
+The numpy/torch restatement of those metric functions lives in oracle/metrics.py (checker only).
 """
 import torch
 
@@ -24,34 +26,6 @@ METRICS = ['PVE', 'PVE-SC', 'PVE-PA', 'PVE-T', 'PVE-T-SC', 'MPJPE', 'MPJPE-SC', 
 # not built: silhouette IOUs (need the pytorch3d renderer) and the input_joints2D / (in)visible-joint variants (need HRNet heat-maps)
 
 
-def procrustes_analysis_batch(S1, S2):
-    """utils/eval_utils.py:62-104: similarity-align S1 (B,N,3) onto S2."""
-    S1t, S2t = S1.transpose(1, 2), S2.transpose(1, 2)
-    mu1, mu2 = S1t.mean(dim=2, keepdim=True), S2t.mean(dim=2, keepdim=True)
-    X1, X2 = S1t - mu1, S2t - mu2
-    var1 = (X1 ** 2).sum(dim=(1, 2))
-    K = X1 @ X2.transpose(1, 2)
-    U, s, Vh = torch.linalg.svd(K)
-    V = Vh.transpose(1, 2)
-    Z = torch.eye(3, dtype=S1.dtype, device=S1.device).repeat(S1.shape[0], 1, 1)
-    Z[:, -1, -1] *= torch.sign(torch.linalg.det(U @ Vh))
-    R = V @ Z @ U.transpose(1, 2)
-    trace = torch.diagonal(R @ K, dim1=-2, dim2=-1).sum(-1)
-    scale = (trace / var1)[:, None, None]
-    t = mu2 - scale * (R @ mu1)
-    return (scale * (R @ S1t) + t).transpose(1, 2)
-
-
-def scale_and_translation_transform_batch(P, T):
-    """utils/eval_utils.py:107-125."""
-    P_mean = P.mean(dim=-2, keepdim=True)
-    P_trans = P - P_mean
-    P_scale = torch.sqrt((P_trans ** 2).sum(dim=(-2, -1), keepdim=True) / P.shape[-2])
-    T_mean = T.mean(dim=-2, keepdim=True)
-    T_scale = torch.sqrt(((T - T_mean) ** 2).sum(dim=(-2, -1), keepdim=True) / T.shape[-2])
-    return P_trans / P_scale * T_scale + T_mean
-
-
 def orthographic_project_torch(points3D, cam_params):
     """utils/cam_utils.py:9-17: s * (xy + t)."""
     return cam_params[:, None, [0]] * (points3D[:, :, :2] + cam_params[:, None, 1:])
@@ -66,11 +40,6 @@ def flip_about_x(points):
     """aa_rotate_translate_points_pytorch3d(points, axes=[1,0,0], angles=pi, translations=0) (utils/rigid_transform_utils.py:67-83,
     call sites evaluate_humaniflow.py:141-143,197-203): a 180-degree rotation about x, i.e. (x, -y, -z)."""
     return points * points.new_tensor([1.0, -1.0, -1.0])
-
-
-def _pa_many(P, T):
-    sh = P.shape
-    return procrustes_analysis_batch(P.reshape(-1, *sh[-2:]), T.expand_as(P).reshape(-1, *sh[-2:])).reshape(sh)
 
 
 class EvalMetricsTracker:
@@ -94,11 +63,13 @@ class EvalMetricsTracker:
             self.per_frame[name].append(err.flatten(1).mean(dim=-1) if frame is None else frame)
 
     def update_per_batch(self, pred, target):
-        """Device tensors go through the fused HIP epilogue (hmf_pointset_errors / hmf_sample_diversity); host tensors (the reference's
-        own numpy setting, used by the CPU tests of the exchange step) through the op-for-op torch restatement below."""
-        if pred['verts3D'].is_cuda:
-            return self._update_hip(pred, target)
-        return self._update_torch(pred, target)
+        """pred: verts3D (B,V,3), tpose_verts3D, joints3D (B,14,3) [+ joints2D (B,17,2)] and optionally verts3D_samples (B,N,V,3),
+        tpose_verts3D_samples, joints3D_samples (B,N,14,3), joints2Dsamples (B,N,17,2), joints3D_coco_samples (B,N,17,3);
+        target: verts3D, tpose_verts3D, joints3D [+ joints2D, joints2D_vis].  Device tensors only: the point-set errors run in the fused
+        HIP epilogue (hmf_pointset_errors / hmf_sample_diversity); there is no host path."""
+        from . import _lib
+        _lib.require_cuda(pred['verts3D'], "pred['verts3D']")
+        return self._update(pred, target)
 
     def _pointset(self, P, T, want_pa):
         """P (..., npts, 3) vs T (Bt, npts, 3) with P's leading dims = (Bt,) or (Bt, N): -> (..., 3) mean errors [plain, SC, PA]."""
@@ -110,8 +81,9 @@ class EvalMetricsTracker:
             npairs *= d
         Pc, Tc = P.float().contiguous(), T.float().contiguous()
         out = torch.empty(npairs, 3, device=P.device, dtype=torch.float32)
-        _lib.check(lib.hmf_pointset_errors(Pc.data_ptr(), Tc.data_ptr(), npairs, npairs // Tc.shape[0], npts, int(want_pa), out.data_ptr(),
-                                           _lib.current_stream()), 'hmf_pointset_errors')
+        with torch.cuda.device(P.device):                  # the launch stream must be the one of the tensors' device, not of device 0
+            _lib.check(lib.hmf_pointset_errors(_lib.dptr(Pc), _lib.dptr(Tc), npairs, npairs // Tc.shape[0], npts, int(want_pa), _lib.dptr(out),
+                                               _lib.current_stream()), 'hmf_pointset_errors')
         return out.reshape(*lead, 3)
 
     def _diversity(self, S):
@@ -120,7 +92,8 @@ class EvalMetricsTracker:
         B, N, npts = S.shape[:3]
         Sc = S.float().contiguous()
         part = torch.empty(B, (npts + 255) // 256, device=S.device, dtype=torch.float32)
-        _lib.check(lib.hmf_sample_diversity(Sc.data_ptr(), B, N, npts, part.data_ptr(), _lib.current_stream()), 'hmf_sample_diversity')
+        with torch.cuda.device(S.device):
+            _lib.check(lib.hmf_sample_diversity(_lib.dptr(Sc), B, N, npts, _lib.dptr(part), _lib.current_stream()), 'hmf_sample_diversity')
         return part.double().sum(dim=1)                                   # (B,) sum over n, p of the distances
 
     def _addf(self, name, frame, npts):
@@ -129,7 +102,7 @@ class EvalMetricsTracker:
             self._acc(name, frame.double().sum() * npts)
             self.per_frame[name].append(frame)
 
-    def _update_hip(self, pred, target):
+    def _update(self, pred, target):
         B, self.num_verts = pred['verts3D'].shape[:2]
         self._acc('num_total_test_data', B)
         tv, tt, tj = target['verts3D'], target['tpose_verts3D'], target['joints3D']
@@ -162,49 +135,6 @@ class EvalMetricsTracker:
             d = self._diversity(jc)
             self._acc('joints3D_sample_diversity', d.sum())
             self.per_frame['joints3D_sample_diversity'].append((d / (jc.shape[1] * jc.shape[2])).float())
-        self._update_2d(pred, target)
-
-    def _update_torch(self, pred, target):
-        """pred: verts3D (B,V,3), tpose_verts3D, joints3D (B,14,3) [+ joints2D (B,17,2)] and optionally verts3D_samples (B,N,V,3),
-        tpose_verts3D_samples, joints3D_samples (B,N,14,3), joints2Dsamples (B,N,17,2), joints3D_coco_samples (B,N,17,3);
-        target: verts3D, tpose_verts3D, joints3D [+ joints2D, joints2D_vis]."""
-        B, self.num_verts = pred['verts3D'].shape[:2]
-        self._acc('num_total_test_data', B)
-        nrm = lambda a, b: torch.linalg.norm(a - b, dim=-1)
-        sc = scale_and_translation_transform_batch
-        tv, tt, tj = target['verts3D'], target['tpose_verts3D'], target['joints3D']
-        self._add('PVE', nrm(pred['verts3D'], tv))
-        self._add('PVE-SC', nrm(sc(pred['verts3D'], tv), tv))
-        self._add('PVE-PA', nrm(procrustes_analysis_batch(pred['verts3D'], tv), tv))
-        self._add('PVE-T', nrm(pred['tpose_verts3D'], tt))
-        self._add('PVE-T-SC', nrm(sc(pred['tpose_verts3D'], tt), tt))
-        self._add('MPJPE', nrm(pred['joints3D'], tj))
-        self._add('MPJPE-SC', nrm(sc(pred['joints3D'], tj), tj))
-        self._add('MPJPE-PA', nrm(procrustes_analysis_batch(pred['joints3D'], tj), tj))
-        ar = torch.arange(B, device=self.sums.device)
-
-        def sample_min(name, e):                         # e (B, N, P): error of the sample with the smallest mean error
-            self._add(name, e[ar, e.mean(-1).argmin(-1)])
-        if 'verts3D_samples' in pred:
-            vs, js = pred['verts3D_samples'], pred['joints3D_samples']
-            sample_min('PVE_samples_min', nrm(vs, tv[:, None]))
-            sample_min('PVE-SC_samples_min', nrm(sc(vs, tv[:, None].expand_as(vs)), tv[:, None]))
-            if 'PVE-PA_samples_min' in self.metrics:
-                sample_min('PVE-PA_samples_min', nrm(_pa_many(vs, tv[:, None]), tv[:, None]))
-            if 'tpose_verts3D_samples' in pred:
-                ts = pred['tpose_verts3D_samples']
-                sample_min('PVE-T_samples_min', nrm(ts, tt[:, None]))
-                sample_min('PVE-T-SC_samples_min', nrm(sc(ts, tt[:, None].expand_as(ts)), tt[:, None]))
-            sample_min('MPJPE_samples_min', nrm(js, tj[:, None]))
-            sample_min('MPJPE-SC_samples_min', nrm(sc(js, tj[:, None].expand_as(js)), tj[:, None]))
-            sample_min('MPJPE-PA_samples_min', nrm(_pa_many(js, tj[:, None]), tj[:, None]))
-            d = torch.linalg.norm(vs - vs.mean(dim=1, keepdim=True), dim=-1)                      # (B, N, V)
-            self._add('verts3D_sample_diversity', d, d.mean(dim=(1, 2)))
-            self.num_samples = vs.shape[1]
-        if 'joints3D_coco_samples' in pred:
-            jc = pred['joints3D_coco_samples']
-            d = torch.linalg.norm(jc - jc.mean(dim=1, keepdim=True), dim=-1)
-            self._add('joints3D_sample_diversity', d, d.mean(dim=(1, 2)))
         self._update_2d(pred, target)
 
     def _update_2d(self, pred, target):
@@ -346,9 +276,9 @@ def target_batch(smpl, batch):
     return out
 
 
-def evaluate_humaniflow(dataset, batch_size, device, predict_fn, target_fn, dist=None, rank=0, world_size=1):
+def evaluate_humaniflow(dataset, batch_size, device, predict_fn, target_fn, dist=None, rank=0, world_size=1, tracker=None):
     """Sharded evaluation loop.  predict_fn(batch) / target_fn(batch) return the dicts EvalMetricsTracker consumes."""
-    tracker = EvalMetricsTracker(device)
+    tracker = EvalMetricsTracker(device) if tracker is None else tracker
     mine = shard_indices(len(dataset), rank, world_size)
     for s in range(0, len(mine), batch_size):
         batch = dataset.batch(mine[s:s + batch_size], device)

@@ -174,13 +174,8 @@ int hmf_proxy_rep(const float* img, const float* joints2D, const float* visib, i
                   float* proxy, float* grad_magnitude, float* grad_orientation, float* thin_edges, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
-/* Encoder glue (models/resnet.py:102-122: bn -> relu / bn -> += identity -> relu after each conv)   */
+/* Encoder convolutions (models/resnet.py:102-122,202-217)                                          */
 /* ------------------------------------------------------------------------------------------ */
-/* In place, one pass: x = relu?(x + bias[channel] (+ residual)) for a conv output with eval-mode BatchNorm folded into
- * the conv weight and `bias`.  x/residual: N x C x HW (nhwc = 0) or N x HW x C (nhwc = 1), 16-byte aligned.          */
-int hmf_bias_act(float* x, const float* bias, const float* residual, int N, int C, int HW, int nhwc, int relu,
-                 void* stream);
-
 /* Fused convolution of the encoder (models/resnet.py:24-31 conv3x3/conv1x1 + :72-76,111-127 BatchNorm/ReLU/residual of
  * BasicBlock/Bottleneck.forward, with eval-mode BN folded into w and bias): NHWC fp32 implicit GEMM on the fp32 MFMA,
  *   y = relu?(conv(x, w, stride, padding = ks/2) + bias (+ residual)).

