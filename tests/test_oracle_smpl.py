@@ -77,3 +77,45 @@ def test_extra_regressors_are_the_reference_data():
     assert r['J_regressor_cocoplus'].shape == (19, 6890) and (r['J_regressor_cocoplus'] != 0).sum() == 86
     assert r['J_regressor_h36m'].shape == (17, 6890) and (r['J_regressor_h36m'] != 0).sum() == 107
     assert np.allclose(r['J_regressor_extra'].sum(1), 1.0, atol=2e-4)
+
+
+def test_lbs_matches_an_independent_per_vertex_statement_of_the_smpl_paper():
+    """SMPL (Loper et al. 2015, eqs. 2-10) written per vertex in float64 numpy, not in smplx's batched op order:
+        t'_i = sum_k w_ki G'_k (T_i + B_S(beta)_i + B_P(theta)_i),   G'_k = G_k(theta, J) G_k(theta*, J)^-1,
+        G_k = prod_{j in A(k)} [[R_j, J_j - J_parent(j)], [0, 1]],   B_P = sum_n (R_n - I)_n P_n,   J = Jreg (T + B_S).
+    Pins the meaning of every model array (shapedirs (V,3,nb), posedirs (207, 3V) with feature index 9*(joint-1) + 3*row + col,
+    lbs_weights (V,24), J_regressor (24,V)) against the oracle's LBS."""
+    m = _model()
+    f64 = {k: v.double().numpy() for k, v in m.items() if k != 'parents'}
+    par = SMPL_PARENTS
+    g = torch.Generator().manual_seed(7)
+    betas = torch.randn(2, 10, generator=g)
+    R = random_rotmats(2 * 24, 0.6, seed=8).view(2, 24, 3, 3)
+    verts, joints = osmpl.smpl_forward(m, betas, R[:, 1:], R[:, :1], pose2rot=False)
+    vids = [0, 1, 331, 332, 1000, 3216, 4071, 5000, 6617, 6889] + list(range(2000, 2040))
+    for b in range(2):
+        be, Rb = betas[b].double().numpy(), R[b].double().numpy()
+        T = f64['v_template'] + f64['shapedirs'] @ be                       # (V,3): template + shape blend-shapes
+        J = f64['J_regressor'] @ T                                          # (24,3) rest joints
+        feat = np.concatenate([(Rb[j] - np.eye(3)).reshape(9) for j in range(1, 24)])           # (207,)
+        G = [None] * 24
+        for k in range(24):
+            loc = np.eye(4)
+            loc[:3, :3] = Rb[k]
+            loc[:3, 3] = J[k] - (J[par[k]] if par[k] >= 0 else 0.0)
+            G[k] = loc if par[k] < 0 else G[par[k]] @ loc
+        Gp = []
+        for k in range(24):                                                 # remove the rest pose: G_k(theta*)^-1 = translate by -J_k
+            rest_inv = np.eye(4)
+            rest_inv[:3, 3] = -J[k]
+            Gp.append(G[k] @ rest_inv)
+        for i in vids:
+            tp = T[i] + np.array([feat @ f64['posedirs'][:, 3 * i + c] for c in range(3)])
+            out = np.zeros(4)
+            for k in range(24):
+                w = f64['lbs_weights'][i, k]
+                if w != 0.0:
+                    out += w * (Gp[k] @ np.append(tp, 1.0))
+            assert np.abs(out[:3] - verts[b, i].double().numpy()).max() < 2e-5, (b, i)
+        for k in range(24):                                                 # posed joints = translation of the world transforms
+            assert np.abs(G[k][:3, 3] - joints[b, k].double().numpy()).max() < 2e-5

@@ -101,3 +101,112 @@ def test_part_flow_density_integrates_and_inverts():
         J = torch.autograd.functional.jacobian(lambda t: pf.forward(t[None], ctx[i:i + 1])[0], z)
         ref = torch.distributions.Normal(0, 0.6).log_prob(z.detach()).sum() - torch.linalg.slogdet(J)[1]
         assert abs(ref.item() - lp[i].item()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parameter SEMANTICS, stated independently of the restated pyro code path ("which parameter means what").
+# The hyper-network emits the 62-vector in the order of `param_dims` at the reference call site
+# (models/norm_flows/transforms/conditional_spline_coupling_transform.py:64-70): [widths 2x8 | heights 2x8 | derivatives 2x7 |
+# lambdas 2x8].  Below, the knots are rebuilt with plain numpy from the slices of that vector and the SPLINE FUNCTION is probed
+# as a black box: it must interpolate them, have the stated slopes at them, and react to a perturbation of ONE raw entry only
+# where that entry's meaning says it should.  A swapped w/h or d/l slice, a transposed (2,8) view or a shifted derivative index
+# fails these.
+# ---------------------------------------------------------------------------------------------------------------------
+import numpy as np
+
+
+def _np_softmax(a):
+    e = np.exp(a - a.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def _np_knots(raw_slice):                       # (2, 8) logits -> (2, 9) knot positions on [-B, B] with >= 1e-3 relative bin size
+    frac = 1e-3 + (1 - 8e-3) * _np_softmax(raw_slice)
+    k = np.concatenate([np.zeros((2, 1)), np.cumsum(frac, -1)], -1) * 2 * B - B
+    k[:, 0], k[:, -1] = -B, B
+    return k
+
+
+def _spline_from_raw(raw, x, inverse=False):
+    """raw (62,) float64, x (n, 2) -> (y, logdet) through the oracle's split + activations + spline."""
+    r = torch.as_tensor(raw)[None].expand(x.shape[0], -1)
+    w, h, d, l = spline_params(split_params(r), 2, 8)
+    return rational_linear_spline(torch.as_tensor(x), w, h, d, l, B, inverse=inverse)
+
+
+def test_semantics_knots_are_interpolated_and_knot_slopes_are_the_derivative_slice():
+    rng = np.random.RandomState(11)
+    raw = rng.randn(62) * 1.5
+    kx = _np_knots(raw[0:16].reshape(2, 8))             # widths slice: x-knots
+    ky = _np_knots(raw[16:32].reshape(2, 8))            # heights slice: y-knots
+    dk = 1e-3 + np.log1p(np.exp(raw[32:46].reshape(2, 7)))          # derivative slice: slopes at the 7 INTERIOR knots
+    # f(x_k) = y_k at every knot (evaluated a hair inside so the bin search picks either neighbour; both must agree)
+    for off in (-1e-9, 1e-9):
+        xs = np.clip(kx.T + off, -B, B)                 # (9, 2): row k = knot k of both dimensions
+        y, _ = _spline_from_raw(raw, xs)
+        assert np.abs(y.numpy() - ky.T).max() < 1e-7, 'knots (x_k, y_k) are not interpolated'
+    # slope at the interior knots from BOTH sides = 1e-3 + softplus(raw_d); slope at the two end knots = 1 - 1e-3
+    xs_in = kx.T[1:-1]
+    for off in (-1e-8, 1e-8):
+        _, ld = _spline_from_raw(raw, xs_in + off)
+        assert np.abs(np.exp(ld.numpy()) - dk.T).max() < 1e-5, 'interior knot slopes are not 1e-3 + softplus(d_k)'
+    _, ld = _spline_from_raw(raw, np.stack([kx[:, 0] + 1e-8, kx[:, -1] - 1e-8]))
+    assert np.abs(np.exp(ld.numpy()) - (1 - 1e-3)).max() < 1e-5
+    # the inverse direction searches the HEIGHT knots: g(y_k) = x_k
+    xb, _ = _spline_from_raw(raw, np.clip(ky.T + 1e-9, -B, B), inverse=True)
+    assert np.abs(xb.numpy() - kx.T).max() < 1e-6
+
+
+def test_semantics_one_raw_entry_moves_only_what_it_means():
+    rng = np.random.RandomState(12)
+    raw = rng.randn(62)
+    kx = _np_knots(raw[0:16].reshape(2, 8))
+    grid = np.stack([np.linspace(-B * 0.98, B * 0.98, 1501)] * 2, 1)
+    y0, ld0 = (t.numpy() for t in _spline_from_raw(raw, grid))
+
+    def bins_changed(idx, delta=0.7):
+        r = raw.copy()
+        r[idx] += delta
+        y1, ld1 = (t.numpy() for t in _spline_from_raw(r, grid))
+        out = []
+        for q in range(2):
+            b = np.clip(np.searchsorted(kx[q], grid[:, q]) - 1, 0, 7)               # bins of the UNPERTURBED spline
+            ch = (np.abs(y1[:, q] - y0[:, q]) > 1e-10) | (np.abs(ld1[:, q] - ld0[:, q]) > 1e-10)
+            out.append(sorted(set(b[ch].tolist())))
+        return out
+    # lambda of (dim q, bin k) lives at 46 + 8 q + k and touches ONLY that bin (knots and knot slopes are unchanged)
+    for q, k in ((0, 0), (0, 5), (1, 3), (1, 7)):
+        ch = bins_changed(46 + 8 * q + k)
+        assert ch[q] == [k] and ch[1 - q] == [], ('lambda', q, k, ch)
+    # derivative j of dim q lives at 32 + 7 q + j = slope at interior knot j + 1: touches exactly the two bins that meet there
+    for q, j in ((0, 0), (0, 6), (1, 2)):
+        ch = bins_changed(32 + 7 * q + j)
+        assert ch[q] == [j, j + 1] and ch[1 - q] == [], ('derivative', q, j, ch)
+    # a height logit moves y-knots but no x-knot: the bin membership of every grid point (decided on x) is unchanged,
+    # a width logit moves the x-knots
+    r = raw.copy(); r[16 + 3] += 0.7
+    assert np.array_equal(_np_knots(r[0:16].reshape(2, 8)), kx)
+    y1, _ = _spline_from_raw(r, kx.T[1:-1] + 1e-9)
+    assert np.abs(y1.numpy()[:, 0] - _np_knots(r[16:32].reshape(2, 8))[0, 1:-1]).max() < 1e-7
+    assert np.abs(y1.numpy()[:, 0] - _np_knots(raw[16:32].reshape(2, 8))[0, 1:-1]).max() > 1e-3      # dim 0 y-knots moved ...
+    y1b, _ = _spline_from_raw(raw, kx.T[1:-1] + 1e-9)
+    assert np.abs(y1.numpy()[:, 1] - y1b.numpy()[:, 1]).max() < 1e-12                                # ... dim 1 untouched
+
+
+def test_semantics_lambda_places_the_break_point_inside_its_bin():
+    """Within a bin the map is two linear-rational pieces glued at x_k + lambda_k w_k, lambda_k = 0.025 + 0.95 sigmoid(raw_l):
+    the second derivative of a linear-rational piece never changes sign, so the only point of a bin where the (numerical) third-difference
+    signature jumps is that break point."""
+    rng = np.random.RandomState(13)
+    raw = rng.randn(62)
+    kx = _np_knots(raw[0:16].reshape(2, 8))
+    lam = 0.025 + 0.95 / (1 + np.exp(-raw[46:62].reshape(2, 8)))
+    for q, k in ((0, 2), (1, 5)):
+        a, b = kx[q, k], kx[q, k + 1]
+        xs = np.linspace(a + 1e-6, b - 1e-6, 20001)
+        g = np.zeros((xs.size, 2)); g[:, q] = xs
+        _, ld = _spline_from_raw(raw, g)
+        s = ld.numpy()[:, q]                                 # log f'(x): smooth on each piece, kinked (C^0 only) at the break point
+        kink = np.abs(np.diff(s, 2))
+        x_break = xs[1:-1][np.argmax(kink)]
+        assert abs(x_break - (a + lam[q, k] * (b - a))) < 2 * (xs[1] - xs[0]), (q, k, x_break, a + lam[q, k] * (b - a))
