@@ -2,20 +2,25 @@
 """bench.py -- images.samples/sec of the HuManiFlow inference hot path on MI355X (BASELINE.json metric).
 
 One step = one batch of B synthetic 256x256 proxy inputs through
-    ResNet-50 encoder -> heads -> flow (N pose samples + point estimate) -> SMPL on the point estimate (M = B)
-    -> SMPL on the samples (M = B*N)  [--tpose adds the evaluate-flavour T-pose bodies],
+    ResNet-50 encoder -> heads -> flow (N pose samples + point estimate) -> SMPL on samples AND point estimate (one launch, M = B*N + B)
 all resident in HBM; fp32 throughout (BASELINE configs[1]); outputs stay on the device.
+    --eval   BASELINE configs[3] per-GPU step: + T-pose bodies, target bodies from the 3DPW-style labels and the device metric-tracker update
+    --train  BASELINE configs[4] per-GPU step: forward under grad (pose/shape NLL + 2D reprojection + global-rotation losses), backward,
+             gradient all-reduce (RCCL when WORLD_SIZE > 1), Adam step
 
     python bench.py                     # 1 GPU, B=32, N=100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
         bench.py --gpus 8 --steps 20 --warmup 5
 
-Prints ONE JSON line (rank 0): the throughput, the roofline of the dominant hand-written kernel (k_lbs_mfma: HIP
-events on its own launch stream via hmf_profile_*), and the CPU baseline (the oracle in reference mode, a bounded
-sample, rank 0 at N=1 only).
+How the step is issued: NB >= 3 DISTINCT input batches live in HBM; the step on batch i is captured once into a HIP graph on stream
+i % S and the timed region replays the graphs round-robin (every one of the K steps completes inside it; no per-launch events, no
+profiler in the timed region).  Per-kernel figures come from a separate pass after the timed region: the same step eagerly on ONE stream
+with a HIP event pair around every launch (hmf_profile_*), i.e. kernel EXECUTION time with nothing else on the device.
+
+Prints ONE JSON line (rank 0): throughput, `roofline` of the dominant kernel family (algorithmic FLOPs / execution time, vs the dense
+fp32 MFMA peak), and `cpu_baseline` (the oracle in reference mode on a bounded sample, rank 0 at N=1 only).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -31,6 +36,7 @@ sys.path.insert(0, ROOT)
 # 4-nnz skinning blend 0.66 + transform apply 0.145 MFLOP
 LBS_FLOP_PER_UNIT = 9.775e6
 FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+WINOGRAD_MFMA_FRACTION = 4.0 / 9.0     # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed MFMA FLOPs = 4/9 of direct
 
 
 def encoder_conv_flops(enc, B, size):
@@ -61,24 +67,29 @@ def encoder_conv_flops(enc, B, size):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--samples', type=int, default=100)
-    ap.add_argument('--layers', type=int, default=50)
-    ap.add_argument('--tpose', action='store_true', help='add the evaluate-flavour T-pose bodies to the step')
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--batch', type=int, default=None, help='images per step and GPU (default 32; --train: 72 = TRAIN.BATCH_SIZE)')
+    ap.add_argument('--samples', type=int, default=None, help='pose samples per image (default 100; --train: 8 = LOSS.NUM_J2D_SAMPLES)')
+    ap.add_argument('--layers', type=int, default=None, help='ResNet depth (default 50; --train: 18, the reference training default)')
+    ap.add_argument('--eval', action='store_true', help='BASELINE configs[3] flavour: + T-pose bodies, target bodies, device tracker update')
+    ap.add_argument('--train', action='store_true', help='BASELINE configs[4] flavour: one training step (forward under grad, losses, backward, all-reduce, Adam)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=32, help='images of the bounded CPU-baseline sample')
     ap.add_argument('--blend-dtype', choices=['fp32', 'bf16'], default='fp32',
                     help="'bf16': BASELINE configs[2] (use with --batch 64): SMPL blend-shape GEMM operands in bf16, fp32 accumulate -- a parity-test "
                          'configuration, not the headline line')
     ap.add_argument('--dry-run-cpu', action='store_true', help='exercise only the rank plumbing (gloo, CPU, stand-in step): used by the CPU tests')
-    ap.add_argument('--chain-encoders', action='store_true',
-                    help='serialise the encoders of consecutive steps with an event (cleaner per-kernel timings, ~10 %% less throughput): '
-                         'by default batches on different streams overlap freely')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the steps are round-robined over (batches are independent: the '
                     'low-occupancy flow kernels of step i overlap the encoder convolutions of step i+1)')
-    return ap.parse_args()
+    ap.add_argument('--batches', type=int, default=3, help='distinct input batches rotated through (>= 3: the inputs do not sit in the 256 MB Infinity Cache)')
+    ap.add_argument('--no-graph', action='store_true', help='issue the steps eagerly instead of replaying one captured HIP graph per batch')
+    ap.add_argument('--profile-steps', type=int, default=5, help='steps of the per-kernel measurement pass after the timed region (0 = skip)')
+    a = ap.parse_args()
+    a.batch = a.batch if a.batch is not None else (72 if a.train else 32)
+    a.samples = a.samples if a.samples is not None else (8 if a.train else 100)
+    a.layers = a.layers if a.layers is not None else (18 if a.train else 50)
+    return a
 
 
 def cpu_baseline(model_sd, cfg, smpl_model_dict, images, N, seed=0):
@@ -180,7 +191,7 @@ def dist_gather_metrics(vec, dist, world):
 
 
 def dry_run_cpu(args):
-    """The rank plumbing of main() with a stand-in CPU step (no model, no HIP): what tests/test_distributed.py launches with 2 gloo ranks."""
+    """The rank plumbing of main() with a stand-in CPU step (no model, no HIP): what tests/test_distributed.py launches with gloo ranks."""
     dev = torch.device('cpu')
     dist, world, rank = dist_setup(dev, 'gloo')
     B, N = args.batch, args.samples
@@ -197,9 +208,60 @@ def dry_run_cpu(args):
         print(json.dumps({'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': world * B * N * args.steps / elapsed, 'unit': 'images*samples/s',
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dry_run': True,
-                          'gathered_rank_sums': gathered.sum(dim=1).tolist()}))
+                          'rccl_ranks_seen': int(gathered.shape[0]), 'gathered_rank_sums': gathered.sum(dim=1).tolist()}))
     if dist is not None:
         dist.destroy_process_group()
+
+
+KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
+CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_igemm (1x1)', 11: 'k_conv_winograd (3x3)'}
+
+
+def collect_profile(lib, _lib, cap=65536):
+    ms = np.zeros(cap)
+    tag = np.zeros(cap, np.int32)
+    rows = np.zeros(cap, np.int32)
+    n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), cap)
+    return ms[:n], tag[:n], rows[:n]
+
+
+def conv_families(ms_, tag_, reps, conv_flops):
+    """Per-family table of the encoder convolutions from `reps` recorded encoder passes (one record per launch, plan order)."""
+    csel = (tag_ >= 8) & (tag_ <= 11)
+    if csel.sum() != reps * len(conv_flops) or reps == 0:
+        return None
+    cms = ms_[csel].reshape(reps, len(conv_flops)).mean(0)                      # ms per launch, per layer
+    ctag = tag_[csel].reshape(reps, len(conv_flops))[0]
+    fam = {}
+    for f, t, tg in zip(conv_flops, cms, ctag):
+        d = fam.setdefault(CONV_TAGS[int(tg)], {'launches_per_step': 0, 'us_per_step': 0.0, 'flop': 0.0})
+        d['launches_per_step'] += 1
+        d['us_per_step'] += t * 1e3
+        d['flop'] += f
+    for name, d in fam.items():
+        d['tflops'] = round(d['flop'] / (d['us_per_step'] * 1e-6) / 1e12, 2)
+        if 'winograd' in name:               # what the MFMA pipe executes: 4/9 of the direct-form multiplies
+            d['tflops_executed_mfma'] = round(d['tflops'] * WINOGRAD_MFMA_FRACTION, 2)
+        d['us_per_step'] = round(d['us_per_step'], 1)
+        d['gflop_per_step'] = round(d.pop('flop') / 1e9, 2)
+    return fam
+
+
+def load_pmc_traffic(source_hash):
+    """HBM bytes per launch from the separate `rocprofv3 --pmc` passes summarised by tools/pmc_summary.py.  PMC counters cannot be read
+    from inside the process; the file is stamped with the library source hash it was profiled at and is IGNORED when that differs from
+    the library being benchmarked (no silent stale figure)."""
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith('_pmc.json'):
+            try:
+                d = json.load(open(os.path.join(pdir, f)))
+            except Exception:
+                continue
+            if isinstance(d, dict) and d.get('lib_source_hash') == source_hash:
+                best = (f, d)
+    return best
 
 
 def main():
@@ -213,9 +275,13 @@ def main():
     dist, world, rank = dist_setup(dev, 'nccl')
     if args.gpus != world and rank == 0:
         print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    if args.train:
+        from humaniflow_amd.train import bench_train
+        return bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist_gather_metrics)
 
     import humaniflow_amd as H
-    from humaniflow_amd import _lib
+    from humaniflow_amd import _lib, evaluate as ev
+    from humaniflow_amd.build import source_hash
     from humaniflow_amd.synthetic import synthetic_proxy_input, init_benchmark_weights
     lib = _lib.load()
     cfg = H.get_humaniflow_cfg_defaults()
@@ -226,216 +292,179 @@ def main():
     model = model.to(dev)
     smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=args.batch, create_transl=False, blend_dtype=args.blend_dtype).to(dev)
     B, N = args.batch, args.samples
-    x = synthetic_proxy_input(B, 256, seed=100 + rank).to(dev)      # each rank its own shard of the synthetic set
+    NB = max(1, args.batches)
+    S = max(1, args.streams)
+    # each rank its own shard of the synthetic set, NB distinct batches per rank
+    if args.eval:
+        dset = ev.SyntheticEvalSet(world * NB * B, size=256, seed=7)
+        batches = [dset.batch(ev.shard_indices(len(dset), rank, world)[i * B:(i + 1) * B], dev) for i in range(NB)]
+        trackers = [ev.EvalMetricsTracker(dev) for _ in range(NB)]
+    else:
+        batches = [{'input': synthetic_proxy_input(B, 256, seed=100 + rank * NB + i).to(dev)} for i in range(NB)]
     torch.manual_seed(1234 + rank)
 
-    enc_done = [None]
-
-    def step():
+    def step(i):
+        """One step on batch i; returns a small tuple of device tensors (kept alive as the graph's outputs)."""
         with torch.no_grad():
-            # the encoders of consecutive steps (on different streams) are chained through an event: what overlaps the convolutions
-            # of batch i+1 is the low-occupancy flow + SMPL tail of batch i, not another encoder competing for the same CUs
-            if args.chain_encoders and enc_done[0] is not None:
-                torch.cuda.current_stream().wait_event(enc_done[0])
-            feats = model(x, return_input_feats_only=True)['input_feats']
-            if args.chain_encoders:
-                enc_done[0] = torch.cuda.Event()
-                enc_done[0].record()
-            pred = model(None, input_feats=feats, num_samples=N)
-            g = pred['glob_rotmat']
-            pe = smpl(body_pose=pred['pose_rotmats_point_est'], global_orient=g[:, None], betas=pred['shape_mode'], pose2rot=False)
-            sa = smpl(body_pose=pred['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
-                      global_orient=g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3),
-                      betas=pred['shape_samples'].reshape(-1, 10), pose2rot=False)
-            extra = None
-            if args.tpose:
-                extra = (smpl.tpose(pred['shape_mode']), smpl.tpose(pred['shape_samples'].reshape(-1, 10)))
-        return pred, pe, sa, extra
+            if args.eval:
+                pred = ev.predict_batch(model, smpl, batches[i], N)
+                targ = ev.target_batch(smpl, batches[i])
+                trackers[i].update_per_batch(pred, targ)
+                return pred['verts3D_samples'], pred['joints3D_samples'], pred['verts3D'], trackers[i].sums
+            pred = model(batches[i]['input'], num_samples=N)
+            pe, sa = smpl.forward_samples_and_point_est(pred)
+            return sa.vertices, sa.joints, pe.vertices, pred['pose_rotmats_samples']
 
-    sync_all = lambda: dist_sync(dist, dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    use_graph = not args.no_graph
+    log('model + SMPL on device; %d distinct batches, %d streams, %s' % (NB, S, 'HIP-graph replay' if use_graph else 'eager'))
+    outs = [None] * NB
+    for i in range(NB):                                         # eager warm-up of every batch on its stream (builds plans, workspaces)
+        with torch.cuda.stream(streams[i % S]):
+            outs[i] = step(i)
+    torch.cuda.synchronize()
+    graphs = [None] * NB
+    if use_graph:
+        for i in range(NB):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=streams[i % S], capture_error_mode='thread_local'):
+                outs[i] = step(i)
+            graphs[i] = g
+        torch.cuda.synchronize()
+        log('captured %d step graphs' % NB)
 
-    log('model + SMPL on device; warm-up (%d steps; the first one includes MIOpen kernel selection)' % args.warmup)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
-
-    def run_steps(n):
-        out = None
+    def issue(k0, n):
         cur = torch.cuda.current_stream()
         for s_ in streams:
             s_.wait_stream(cur)
-        for i in range(n):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                out = step()
+        for k in range(k0, k0 + n):
+            i = k % NB
+            with torch.cuda.stream(streams[i % S]):
+                if use_graph:
+                    graphs[i].replay()
+                else:
+                    outs[i] = step(i)
         for s_ in streams:
             cur.wait_stream(s_)
-        return out
 
-    for i in range(args.warmup):
-        out = run_steps(1)
-        if i == 0:
-            torch.cuda.synchronize()
-            log('first step done')
-    sync_all()
+    issue(0, args.warmup)
+    dist_sync(dist, dev)
     log('timing %d steps' % args.steps)
-    lib.hmf_profile_enable(1)
     t0 = time.perf_counter()
-    out = run_steps(args.steps)
+    issue(args.warmup, args.steps)
     host_issue = time.perf_counter() - t0          # host time to ISSUE the steps (no sync yet): CPU-bound if ~ elapsed
     # the one exchange step of the data-parallel eval path: per-rank metric sums gathered over RCCL/xGMI
-    pred, pe, sa, _ = out
-    metric_vec = torch.stack([sa.vertices.abs().mean(), sa.joints.abs().mean(), pe.vertices.abs().mean(),
-                              pred['pose_rotmats_samples'].mean()]).double()
+    if args.eval:
+        metric_vec = torch.stack([t.sums for t in trackers]).sum(0)
+    else:
+        o = outs[(args.warmup + args.steps - 1) % NB]
+        metric_vec = torch.stack([o[0].abs().mean(), o[1].abs().mean(), o[2].abs().mean(), o[3].mean()]).double()
     gathered = dist_gather_metrics(metric_vec, dist, world)
     elapsed = dist_elapsed(t0, dist, dev)
     log('timed region done: %.3f ms/step' % (elapsed / args.steps * 1e3))
-    # ---- per-kernel times from the HIP events recorded on the launch stream during the timed region ----
-    ms = np.zeros(16384)
-    tag = np.zeros(16384, np.int32)
-    rows = np.zeros(16384, np.int32)
-    n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), 16384)
-    lib.hmf_profile_enable(0)
-    ms, tag, rows = ms[:n], tag[:n], rows[:n]
-    names = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
-    kern = {}
-    for tg, nm in names.items():
-        for r in sorted(set(rows[tag == tg].tolist())):
-            sel = (tag == tg) & (rows == r)
-            kern['%s[M=%d]' % (nm, r)] = round(float(ms[sel].mean()) * 1e3, 2)      # us
-    # encoder convolutions: one record per launch in plan order (stem, then per block [downsample,] conv1..convK)
-    conv_flops, conv_kind = encoder_conv_flops(model.image_encoder, B, x.shape[-1])
 
-    def conv_families(ms_, tag_, reps):
-        csel = (tag_ >= 8) & (tag_ <= 11)
-        if csel.sum() != reps * len(conv_flops):
-            return None
-        cms = ms_[csel].reshape(reps, len(conv_flops)).mean(0)                      # ms per launch, per layer
-        ctag = tag_[csel].reshape(reps, len(conv_flops))[0]
-        fam = {}
-        for f, k, t, tg in zip(conv_flops, conv_kind, cms, ctag):
-            name = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (%s)' % k, 8: 'k_conv_igemm (%s)' % k, 11: 'k_conv_winograd (%s)' % k}[int(tg)]
-            d = fam.setdefault(name, {'launches_per_step': 0, 'us_per_step': 0.0, 'flop': 0.0})
-            d['launches_per_step'] += 1
-            d['us_per_step'] += t * 1e3
-            d['flop'] += f
-        for d in fam.values():
-            d['tflops'] = round(d['flop'] / (d['us_per_step'] * 1e-6) / 1e12, 2)
-            d['us_per_step'] = round(d['us_per_step'], 1)
-            d['gflop_per_step'] = round(d.pop('flop') / 1e9, 2)
-        return fam
-    conv = conv_families(ms, tag, args.steps)
-    lbs_sel = (tag == 1) & (rows == B * N)
-    lbs_ms = float(ms[lbs_sel].mean()) if lbs_sel.any() else float('nan')
-    achieved = LBS_FLOP_PER_UNIT * B * N / (lbs_ms * 1e-3) / 1e12
-    # ---- stage breakdown (separate untimed pass, torch events on the current stream) ----
-    def timed(fn, reps=5):
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            r = fn()
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / reps, r
-    with torch.no_grad():
-        enc_ms, feats = timed(lambda: model(x, return_input_feats_only=True)['input_feats'])
-        # the convolution kernels once more with nothing else on the device: what each family achieves by itself
+    # ---- per-kernel measurement pass: eager, ONE stream, HIP events around every launch (execution time, nothing else running) ----
+    conv_flops, conv_kind = encoder_conv_flops(model.image_encoder, B, 256)
+    P = args.profile_steps
+    kern, conv, stages = {}, None, {}
+    lbs_rows = B * N + B
+    lbs_ms = float('nan')
+    if P > 0:
         lib.hmf_profile_enable(1)
-        for _ in range(5):
-            model(x, return_input_feats_only=True)
-        ms3 = np.zeros(1024); tag3 = np.zeros(1024, np.int32); rows3 = np.zeros(1024, np.int32)
-        n3 = lib.hmf_profile_collect(ms3.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag3), _lib.iptr(rows3), 1024)
+        for k in range(P):
+            step(k % NB)
+        ms, tag, rows = collect_profile(lib, _lib)
         lib.hmf_profile_enable(0)
-        conv_iso = conv_families(ms3[:n3], tag3[:n3], 5)
-        flow_ms, pred = timed(lambda: model(None, input_feats=feats, num_samples=N))
-        g = pred['glob_rotmat']
-        go = g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3).contiguous()
-        bp = pred['pose_rotmats_samples'].reshape(-1, 23, 3, 3)
-        be = pred['shape_samples'].reshape(-1, 10)
-        smpl_ms, _ = timed(lambda: smpl(body_pose=bp, global_orient=go, betas=be, pose2rot=False))
-        tp_ms, _ = timed(lambda: smpl.tpose(be))
-        # the dominant kernel once more, alone on the device (no other stream active): what the kernel itself achieves
-        lib.hmf_profile_enable(1)
-        for _ in range(5):
-            smpl(body_pose=bp, global_orient=go, betas=be, pose2rot=False)
-        ms2 = np.zeros(64); tag2 = np.zeros(64, np.int32); rows2 = np.zeros(64, np.int32)
-        n2 = lib.hmf_profile_collect(ms2.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag2), _lib.iptr(rows2), 64)
-        lib.hmf_profile_enable(0)
-        iso = [ms2[i] for i in range(n2) if tag2[i] == 1 and rows2[i] == B * N]
-        lbs_iso_ms = float(np.mean(iso)) if iso else float('nan')
+        for tg, nm in KERNEL_TAGS.items():
+            for r in sorted(set(rows[tag == tg].tolist())):
+                sel = (tag == tg) & (rows == r)
+                kern['%s[M=%d]' % (nm, r)] = {'us': round(float(ms[sel].mean()) * 1e3, 2), 'launches_per_step': int(sel.sum()) // P}
+        conv = conv_families(ms, tag, P, conv_flops)
+        ltag = 12 if args.blend_dtype == 'bf16' else 1
+        lsel = (tag == ltag) & (rows == lbs_rows)
+        lbs_ms = float(ms[lsel].mean()) if lsel.any() else float('nan')
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; they come from the two separate
-    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command summarised in profiles/r01_pmc.json
-    # (tools/pmc_summary.py: FETCH_SIZE doubled per the gfx950 note of the MI355X guide, WRITE_SIZE calibrated on k_tpose).
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-        cand = [v for k, v in pmc.items() if 'k_lbs_mfma' in k]
-        if cand and B * N == 3200:
-            traffic = max(c['hbm_bytes_per_launch'] for c in cand)
-    except Exception:
-        pass
-    def conv_traffic(family):
-        key = {'k_conv_igemm (1x1)': 'k_conv_igemm', 'k_conv_patch (3x3)': 'k_conv_patch<3', 'k_conv_winograd (3x3)': 'k_conv_winograd',
-               'k_stem_conv (7x7/2)': 'k_stem_conv'}.get(family)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-            cand = [v for k, v in pmc.items() if key and key in k]
-            if cand and B == 32:
-                return int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
-        except Exception:
-            pass
-        return None
+        def timed(fn, reps=5):
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                r = fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps, r
+        with torch.no_grad():
+            x0 = batches[0]['input']
+            stages['encoder_resnet%d' % args.layers], feats = timed(lambda: model(x0, return_input_feats_only=True)['input_feats'])
+            stages['heads+flow'], pred = timed(lambda: model(None, input_feats=feats, num_samples=N))
+            stages['smpl_samples+point_est'], _ = timed(lambda: smpl.forward_samples_and_point_est(pred))
+            stages['smpl_tpose(B*N+B)'], _ = timed(lambda: smpl.tpose(pred['smpl_packed_inputs']['betas']))
+            stages['whole_step_one_stream_eager'], _ = timed(lambda: step(0))
+        stages = {k: round(v, 3) for k, v in stages.items()}
+
     if rank == 0:
         value = world * B * N * args.steps / elapsed
+        flavour = 'configs[3] eval step' if args.eval else ('configs[1]' if args.blend_dtype == 'fp32' else 'configs[2]')
         res = {
             'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': round(value, 1), 'unit': 'images*samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.blend_dtype == 'fp32' else 'bf16 blend-shape GEMM operands (f32 accumulate), f32 elsewhere', 'data': 'synthetic',
-            'config': {'workload': ('configs[1]' if args.blend_dtype == 'fp32' else 'configs[2]') + ': B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL '
-                                   '%s, random-init weights, synthetic SMPL-shaped body model%s'
+            'config': {'workload': flavour + ': B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL %s, random-init weights, '
+                                   'synthetic SMPL-shaped body model%s'
                                    % (B, N, args.layers, 'fp32' if args.blend_dtype == 'fp32' else 'fp32 with bf16 blend-shape GEMM operands',
-                                      ' + T-pose bodies' if args.tpose else ''),
-                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'streams_per_gpu': len(streams),
+                                      '; + T-pose bodies, target bodies, device metric-tracker update' if args.eval else ''),
+                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'streams_per_gpu': S,
+                       'distinct_input_batches': NB, 'issue': 'HIP graph replay (one captured graph per batch)' if use_graph else 'eager',
                        'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},
+            'rccl_ranks_seen': int(gathered.shape[0]),
             'roofline': None,
-            'roofline_lbs': {'kernel': 'k_lbs_mfma (SMPL pose-blend GEMM + skinning, M=%d rows)' % (B * N), 'bound': 'mfma',
-                         'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_note': 'HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/r01_pmc.json); algorithmic: 264.6 MB vertex write + 25 MB reads',
-                         'avg_launch_us': round(lbs_ms * 1e3, 2), 'launches': int(lbs_sel.sum()),
-                         'note': 'timed-region launches share the GPU with the other stream(s) (encoder convolutions of the next batch)',
-                         'isolated': {'avg_launch_us': round(lbs_iso_ms * 1e3, 2),
-                                      'achieved': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12, 2),
-                                      'frac': round(LBS_FLOP_PER_UNIT * B * N / (lbs_iso_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
-                         'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * B * N},
             'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 3),
-            'conv_kernels': conv, 'conv_kernels_isolated': conv_iso,
-            'stages_ms': {'encoder_resnet%d' % args.layers: round(enc_ms, 3), 'heads+flow': round(flow_ms, 3),
-                          'smpl_samples': round(smpl_ms, 3), 'smpl_tpose': round(tp_ms, 3)},
-            'kernels_us': kern,
+            'conv_kernels': conv, 'stages_ms': stages, 'kernels_us': kern,
+            'measurement_pass': '%d eager steps on one stream after the timed region, HIP event pair around every launch (kernel execution time with nothing '
+                                'else on the device); the timed region itself carries no events' % P,
         }
-        # the dominant kernel of the step = the kernel family with the largest share of the step's kernel time
-        dom_name = None if conv is None else max(conv, key=lambda k: conv[k]['us_per_step'])
-        if dom_name:
+        step_flops = sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)
+        agg = step_flops / (elapsed / args.steps) / 1e12
+        pmc = load_pmc_traffic(source_hash())
+
+        def traffic_of(key):
+            if pmc is None:
+                return None
+            cand = [v for k, v in pmc[1].get('kernels', {}).items() if key in k]
+            if not cand:
+                return None
+            return int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
+        if conv:
+            dom_name = max(conv, key=lambda k: conv[k]['us_per_step'])
             dom = conv[dom_name]
-            iso = conv_iso.get(dom_name) if conv_iso else None
             per_launch_flop = dom['gflop_per_step'] * 1e9 / dom['launches_per_step']
-            res['roofline'] = {'kernel': '%s convolutions of the encoder: %d launches/step, largest share of the step' % (dom_name, dom['launches_per_step']),
-                               'bound': 'mfma', 'achieved': dom['tflops'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': conv_traffic(dom_name),
-                               'traffic_note': 'mean HBM bytes/launch over these launches from separate rocprofv3 --pmc passes (profiles/r01_pmc.json)',
-                               'avg_launch_us': round(dom['us_per_step'] / dom['launches_per_step'], 2),
-                               'launches': dom['launches_per_step'] * args.steps, 'algorithmic_flop_per_launch': per_launch_flop,
-                               'isolated': None if not iso else {'avg_launch_us': round(iso['us_per_step'] / iso['launches_per_step'], 2),
-                                                                 'achieved': iso['tflops'], 'frac': round(iso['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)},
-                               'step_aggregate': {'what': 'algorithmic FLOPs (2MNK of every convolution + SMPL blend GEMMs) of a step / step time',
-                                                  'achieved': round((sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)) / (elapsed / args.steps) / 1e12, 2),
-                                                  'frac': round((sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)) / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
-                               'note': 'HIP events on the launch stream inside the timed region; with %d streams the launches share the CUs with the kernels of the other in-flight batches, which stretches every launch: `isolated` is the same kernel family with one stream' % len(streams)}
-        else:
+            key = {'k_conv_igemm (1x1)': 'k_conv_igemm', 'k_conv_patch (3x3)': 'k_conv_patch', 'k_conv_winograd (3x3)': 'k_conv_winograd',
+                   'k_stem_conv (7x7/2)': 'k_stem_conv'}[dom_name]
+            res['roofline'] = {
+                'kernel': '%s convolutions of the encoder: %d launches/step, the kernel family with the largest share of the step' % (dom_name, dom['launches_per_step']),
+                'bound': 'mfma', 'achieved': dom['tflops'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4),
+                'traffic': traffic_of(key),
+                'traffic_note': ('mean HBM bytes/launch over this family from separate rocprofv3 --pmc passes (profiles/%s, same library source hash)' % pmc[0]) if pmc
+                                else 'null: no profiles/*_pmc.json was collected at this library source hash',
+                'avg_launch_us': round(dom['us_per_step'] / dom['launches_per_step'], 2), 'launches_measured': dom['launches_per_step'] * P,
+                'algorithmic_flop_per_launch': per_launch_flop,
+                'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (measurement pass: HIP events on the launch stream, one stream)',
+                'step_aggregate': {'what': 'algorithmic FLOPs of every convolution (Winograd layers at direct-form FLOPs) + SMPL blend GEMMs of a step / step time of the timed region',
+                                   'achieved': round(agg, 2), 'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4)}}
+        res['roofline_lbs'] = {'kernel': 'k_lbs_mfma%s (SMPL pose-blend GEMM + skinning, M=%d rows)' % ('16' if args.blend_dtype == 'bf16' else '', lbs_rows),
+                               'bound': 'mfma' if args.blend_dtype == 'fp32' else 'hbm',
+                               'achieved': round(LBS_FLOP_PER_UNIT * lbs_rows / (lbs_ms * 1e-3) / 1e12, 2) if lbs_ms == lbs_ms else None,
+                               'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(LBS_FLOP_PER_UNIT * lbs_rows / (lbs_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if lbs_ms == lbs_ms else None,
+                               'avg_launch_us': round(lbs_ms * 1e3, 2) if lbs_ms == lbs_ms else None, 'traffic': traffic_of('k_lbs_mfma'),
+                               'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * lbs_rows,
+                               'algorithmic_bytes_per_launch': lbs_rows * (82680 + 1080 + 868) + 19.3e6}
+        if res['roofline'] is None:
             res['roofline'] = res['roofline_lbs']
         if world == 1 and not args.no_cpu_baseline:
-            log('stage breakdown done; timing the CPU baseline (oracle, %d images x %d samples)' % (args.cpu_images, N))
+            log('measurement pass done; timing the CPU baseline (oracle, %d images x %d samples)' % (args.cpu_images, N))
             res['cpu_baseline'] = cpu_baseline(model_sd, cfg, smpl.model_dict(), args.cpu_images, N)
             res['speedup_vs_cpu_baseline'] = round(value / res['cpu_baseline']['value'], 1)
         else:

@@ -33,6 +33,7 @@ class FlowHost(C.Structure):
 
 
 _VP = C.c_void_p
+HMF_FLOW_POINT_EST, HMF_FLOW_PACKED_ROWS = 1, 2          # flags of hmf_flow_forward (include/humaniflow_amd.h)
 _SIGS = {
     'hmf_abi_version': (C.c_int, []),
     'hmf_last_error': (C.c_char_p, []),
@@ -104,7 +105,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.hmf_abi_version() != 1:
+    if lib.hmf_abi_version() != 2:
         raise RuntimeError('humaniflow_amd: ABI version mismatch')
     _lib = lib
     return lib

@@ -137,8 +137,8 @@ constexpr int kGroups0 = (kP + kPartsPerWave0 - 1) / kPartsPerWave0;   // 8
 
 __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __restrict__ G, const float* __restrict__ shape_mode,
                                                       const float* __restrict__ shape_log_std, const float* __restrict__ eps_shape,
-                                                      int B, int N, int Mtot, int ntiles, float* __restrict__ shape_samples,
-                                                      float* __restrict__ C0) {
+                                                      int B, int N, int Mtot, int ntiles, int packed_rows,
+                                                      float* __restrict__ shape_samples, float* __restrict__ C0) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, q = lane >> 5;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int tile = gw / kGroups0, pg = gw % kGroups0;
@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __
         }
         beta[i] = v;
     }
-    if (pg == 0 && q == 0 && ri.live && !ri.is_point && shape_samples)
-        for (int i = 0; i < nb; ++i) shape_samples[((size_t)ri.b * N + ri.n) * nb + i] = beta[i];
+    // row id = b*N + n for samples, B*N + b for point-estimate rows: with HMF_FLOW_PACKED_ROWS the shape buffer carries both
+    if (pg == 0 && q == 0 && ri.live && shape_samples && (!ri.is_point || packed_rows))
+        for (int i = 0; i < nb; ++i) shape_samples[((size_t)tile * 32 + l31) * nb + i] = beta[i];
     // h = ELU(G[b] + W_beta . beta) for the 256 isgc channels, produced directly in ARL registers: the rank-nb
     // update is itself an MFMA (A = packed W_beta, B = this lane's beta pair), G[b] is gathered as float4.
     f32x16 h[8];
@@ -623,27 +624,30 @@ extern "C" {
 /* diagnostic (tools/flow_timeline.py): device buffer of 23 x 8 int64 shader-clock stamps written by tile 0, or NULL */
 int hmf_debug_set_timeline(void* dev_ptr) { g_timeline = (long long*)dev_ptr; return HMF_OK; }
 
-static int n_tiles(int B, int N, int pe) { return ((B * N + (pe ? B : 0)) + 31) / 32; }
+static int n_tiles(int B, int N, int flags) { return ((B * N + ((flags & HMF_FLOW_POINT_EST) ? B : 0)) + 31) / 32; }
 
-size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int compute_point_est) {
+size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int flags) {
     (void)h;
     const size_t g = align_up((size_t)std::max(B, 1) * kIsgc * 4, 256);
-    const size_t c0 = (size_t)std::max(n_tiles(B, N, compute_point_est), 1) * kP * 2 * 64 * 16 * 4;
+    const size_t c0 = (size_t)std::max(n_tiles(B, N, flags), 1) * kP * 2 * 64 * 16 * 4;
     return g + c0;
 }
 
 int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* cam, const float* shape_mode,
                      const float* shape_log_std, const float* eps_shape, const float* eps_pose, int B, int N,
-                     int compute_point_est, float* shape_samples, float* rotmats_samples, float* rotmats_point, float* so3_point,
+                     int flags, float* shape_samples, float* rotmats_samples, float* rotmats_point, float* so3_point,
                      void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !feats || !glob_R || !cam || !shape_mode) return fail(HMF_ERR_INVALID, "hmf_flow_forward: null input");
     if (B <= 0 || N < 0) return fail(HMF_ERR_INVALID, "hmf_flow_forward: B=%d N=%d", B, N);
     if (N > 0 && (!eps_pose || !rotmats_samples)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: N>0 needs eps_pose and rotmats_samples");
     if (N > 0 && eps_shape && !shape_log_std) return fail(HMF_ERR_INVALID, "hmf_flow_forward: eps_shape needs shape_log_std");
+    const int compute_point_est = flags & HMF_FLOW_POINT_EST;
+    const int packed_rows = (flags & HMF_FLOW_PACKED_ROWS) ? 1 : 0;
     if (compute_point_est && (!rotmats_point || !so3_point)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: point-estimate outputs missing");
+    if (packed_rows && (!compute_point_est || !shape_samples)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: HMF_FLOW_PACKED_ROWS needs the point estimate and shape_samples");
     if (N == 0 && !compute_point_est) return HMF_OK;
     if ((long long)B * N + B > (1LL << 30)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: B*N too large");
-    const size_t need = hmf_flow_forward_workspace_bytes(h, B, N, compute_point_est);
+    const size_t need = hmf_flow_forward_workspace_bytes(h, B, N, flags);
     if (!workspace || workspace_bytes < need) return fail(HMF_ERR_WORKSPACE, "hmf_flow_forward: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     float* G = (float*)workspace;
@@ -660,7 +664,7 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
         const int nw = ntiles * kGroups0;
         ProfScope ps(5, Mtot, st);
         hipLaunchKernelGGL(k_flow_ctx0, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, eps_shape, B, N, Mtot,
-                           ntiles, shape_samples, C0);
+                           ntiles, packed_rows, shape_samples, C0);
         HMF_LAUNCH_CHECK();
     }
     {

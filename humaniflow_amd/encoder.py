@@ -104,17 +104,18 @@ class ResNetEncoder(nn.Module):
         return w, b, conv.stride, conv.padding
 
     # The plan is a cache of the live parameters and BatchNorm statistics.  It is dropped by train()/eval(), .to()/.cuda() and
-    # load_state_dict, and -- for in-place updates such as optimizer.step(), p.data.copy_() or EMA swaps -- re-validated on every
-    # forward against the tensors' version counters and storage pointers (_params_key).
+    # load_state_dict, and -- for in-place updates such as optimizer.step(), p.data.copy_() or in-place EMA swaps -- re-validated on
+    # every forward against the tensors' version counters (_params_key).  Re-binding `p.data = other` does not bump a version
+    # counter: call invalidate_plan() after that.
     def invalidate_plan(self):
         self._plan = None
         self.__dict__['_plan_tensors'] = None
 
     def _params_key(self):
         ts = self.__dict__.get('_plan_tensors')
-        if ts is None:                                        # tensor list cached with the plan (~75 us per call for ResNet-50)
+        if ts is None:                                        # tensor list cached with the plan (~25 us per call for ResNet-50)
             ts = self.__dict__['_plan_tensors'] = list(self.parameters()) + list(self.buffers())
-        return tuple([t._version for t in ts] + [t.data_ptr() for t in ts])
+        return tuple([t._version for t in ts])
 
     def train(self, mode=True):
         self.invalidate_plan()

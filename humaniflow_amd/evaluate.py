@@ -240,24 +240,28 @@ class SyntheticEvalSet:
 
 @torch.no_grad()
 def predict_batch(model, smpl, batch, num_samples, noise=None):
-    """evaluate/evaluate_humaniflow.py:113-192 on the device: model -> SMPL point estimate + T-pose -> SMPL on the B*N samples."""
+    """evaluate/evaluate_humaniflow.py:113-192 on the device: model -> SMPL point estimate + samples (ONE launch of B*N + B bodies) ->
+    T-pose bodies of both (one launch)."""
     N = num_samples
     pred = model(batch['input'], num_samples=N, noise=noise)
     g = pred['glob_rotmat']
-    pe = smpl(body_pose=pred['pose_rotmats_point_est'], global_orient=g[:, None], betas=pred['shape_mode'], pose2rot=False)
+    B = g.shape[0]
     img_wh = batch['input'].shape[-1]
     proj = lambda j3d, cam: undo_keypoint_normalisation(orthographic_project_torch(flip_about_x(j3d), cam), img_wh)     # :138-143
-    out = {'verts3D': pe.vertices, 'joints3D': pe.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14],
-           'tpose_verts3D': smpl.tpose(pred['shape_mode']), 'joints2D': proj(pe.joints[:, ALL_JOINTS_TO_COCO_MAP], pred['cam_wp'])}
     if N > 0:
-        B = g.shape[0]
-        sa = smpl(body_pose=pred['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
-                  global_orient=g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3),
-                  betas=pred['shape_samples'].reshape(-1, pred['shape_samples'].shape[-1]), pose2rot=False)
+        pe, sa = smpl.forward_samples_and_point_est(pred)
+        tp = smpl.tpose(pred['smpl_packed_inputs']['betas'])                 # rows: B*N sampled shapes, then the B shape modes
+        tp_s, tp_p = tp[:B * N], tp[B * N:]
+    else:
+        pe = smpl(body_pose=pred['pose_rotmats_point_est'], global_orient=g[:, None], betas=pred['shape_mode'], pose2rot=False)
+        tp_p = smpl.tpose(pred['shape_mode'])
+    out = {'verts3D': pe.vertices, 'joints3D': pe.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14],
+           'tpose_verts3D': tp_p, 'joints2D': proj(pe.joints[:, ALL_JOINTS_TO_COCO_MAP], pred['cam_wp'])}
+    if N > 0:
         out['verts3D_samples'] = sa.vertices.reshape(B, N, -1, 3)
         out['joints3D_samples'] = sa.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14].reshape(B, N, 14, 3)
         out['joints3D_coco_samples'] = sa.joints[:, ALL_JOINTS_TO_COCO_MAP].reshape(B, N, 17, 3)                            # :180-183
-        out['tpose_verts3D_samples'] = smpl.tpose(pred['shape_samples'].reshape(B * N, -1)).reshape(B, N, -1, 3)             # :186-192
+        out['tpose_verts3D_samples'] = tp_s.reshape(B, N, -1, 3)                                                             # :186-192
         cam_s = pred['cam_wp'][:, None].expand(-1, N, -1).reshape(B * N, 3)
         out['joints2Dsamples'] = proj(sa.joints[:, ALL_JOINTS_TO_COCO_MAP], cam_s).reshape(B, N, 17, 2)                      # :197-206
     return out

@@ -1,8 +1,8 @@
 """HumaniflowModel with the reference's constructor, forward signature, return dict and checkpoint layout,
 running its flow on the HIP kernels of libhumaniflow_amd.
 
-Mirror of models/humaniflow_model.py:33-340.  What stays PyTorch (as the north star prescribes): the ResNet
-encoder (MIOpen) and the four small head GEMMs fc1/fc_shape/fc_glob/fc_cam (:232-252).  Everything from
+Mirror of models/humaniflow_model.py:33-340.  The ResNet encoder runs on the library's hand-written convolution
+kernels (encoder.py); what stays PyTorch are the four small head GEMMs fc1/fc_shape/fc_glob/fc_cam (:232-252).  Everything from
 `rot6d_to_rotmat` on -- shape sampling, input/shape/glob/cam features (:116-150), the 23 per-part context
 layers (:152-186), the ancestor-conditioned flows in kinematic order (:286-311) and the teacher-forced
 log-likelihood objects (:314-320) -- is one C-ABI call sequence (hmf_flow_forward / hmf_flow_context /
@@ -158,17 +158,33 @@ class HumaniflowModel(nn.Module):
                                               nf.COMPACT_SUPPORT_RADIUS))
             self.pose_so3flow_dists.append(_FlowDistHandle(self, bodypart, group=False))
             self.pose_SO3flow_dists.append(_FlowDistHandle(self, bodypart, group=True))
-        self._handles = {}
-        self._ws = {}
+        self.__dict__.update(_handles={}, _ws={}, _flow_tensors=None, _flow_key=None)
         self.to(device)
 
     # ---- packed-weight handle: a cache of the live parameters ------------------------------------------------------
+    # Dropped by train()/eval(), .to() and load_state_dict; re-validated on every use against the parameters' version counters, so
+    # in-place updates (optimizer.step(), p.data.copy_(), load_state_dict on a sub-module, in-place EMA swaps) re-pack.  Re-binding
+    # `p.data = other` does not bump a version counter: call invalidate_flow_weights() after that.
     def invalidate_flow_weights(self):
-        if getattr(self, '_handles', None):
+        if self.__dict__.get('_handles'):
             lib = _lib.load()
             for h in self._handles.values():
                 lib.hmf_flow_destroy(h)
-        self._handles = {}
+        self.__dict__['_handles'] = {}
+        self.__dict__['_flow_tensors'] = None
+        self.__dict__['_flow_key'] = None
+
+    def _flow_params(self):
+        ts = self.__dict__.get('_flow_tensors')
+        if ts is None:
+            mods = [self.fc_input_shape_glob_cam_feats] + list(self.fc_flow_context) + list(self.pose_so3flow_transform_modules)
+            ts = self.__dict__['_flow_tensors'] = [p for m in mods for p in m.parameters()]
+        return ts
+
+    def __getstate__(self):                       # handles and workspaces are device-side caches: never pickled / deep-copied
+        st = self.__dict__.copy()
+        st['_handles'], st['_ws'], st['_flow_tensors'], st['_flow_key'] = {}, {}, None, None
+        return st
 
     def train(self, mode=True):
         self.invalidate_flow_weights()
@@ -225,6 +241,10 @@ class HumaniflowModel(nn.Module):
         return hs, keep
 
     def _flow_handle(self, device):
+        vkey = tuple([t._version for t in self._flow_params()])
+        if self.__dict__.get('_flow_key') != vkey:
+            self.invalidate_flow_weights()
+            self.__dict__['_flow_key'] = tuple([t._version for t in self._flow_params()])
         key = (device.type, device.index)
         h = self._handles.get(key)
         if h is None:
@@ -337,19 +357,28 @@ class HumaniflowModel(nn.Module):
                     if not use_shape_mode_for_samples:
                         eps_shape = torch.randn(N, batch_size, nb, device=device)          # :258 rsample([N])
                     eps_pose = torch.randn(P, batch_size, N, 3, device=device)             # :309, parts 0..22 in order
-            shape_samples = torch.empty(batch_size, N, nb, dtype=torch.float32, device=device) if N > 0 else None
-            rot_s = torch.empty(batch_size, N, P, 3, 3, dtype=torch.float32, device=device) if N > 0 else None
-            rot_p = torch.empty(batch_size, P, 3, 3, dtype=torch.float32, device=device) if compute_point_est else None
+            # Sample rows (b*N + n) and point-estimate rows (B*N + b) share one buffer each, so that ONE SMPL launch of M = B*N + B
+            # rows can consume them (SMPL.forward_samples_and_point_est); the reference's separate tensors are views of it.
+            BN = batch_size * N
+            packed = compute_point_est and N > 0
+            flags = (_lib.HMF_FLOW_POINT_EST if compute_point_est else 0) | (_lib.HMF_FLOW_PACKED_ROWS if packed else 0)
+            rot_all = torch.empty(BN + (batch_size if compute_point_est else 0), P, 3, 3, dtype=torch.float32, device=device)
+            shape_all = torch.empty(BN + (batch_size if packed else 0), nb, dtype=torch.float32, device=device) if N > 0 else None
+            rot_s = rot_all[:BN].view(batch_size, N, P, 3, 3) if N > 0 else None
+            rot_p = rot_all[BN:] if compute_point_est else None
+            shape_samples = shape_all[:BN].view(batch_size, N, nb) if N > 0 else None
             so3_p = torch.empty(batch_size, P, 3, dtype=torch.float32, device=device) if compute_point_est else None
             with torch.cuda.device(device):
                 h = self._flow_handle(device)
-                nbytes = lib.hmf_flow_forward_workspace_bytes(h, batch_size, N, int(compute_point_est))
+                nbytes = lib.hmf_flow_forward_workspace_bytes(h, batch_size, N, flags)
                 ws = self._workspace(device, nbytes)
                 _lib.check(lib.hmf_flow_forward(h, _lib.dptr(feats_c), _lib.dptr(glob_c), _lib.dptr(cam_c), _lib.dptr(mode_c),
                                                 _lib.dptr(lstd_c), _lib.dptr(eps_shape), _lib.dptr(eps_pose), batch_size, N,
-                                                int(compute_point_est), _lib.dptr(shape_samples), _lib.dptr(rot_s), _lib.dptr(rot_p),
+                                                flags, _lib.dptr(shape_all), _lib.dptr(rot_s), _lib.dptr(rot_p),
                                                 _lib.dptr(so3_p), _lib.dptr(ws), ws.numel(), _lib.current_stream()),
                            'hmf_flow_forward')
+            if packed:                # extension key (not in the reference dict): inputs of the single fused SMPL launch
+                return_dict['smpl_packed_inputs'] = {'body_pose': rot_all, 'betas': shape_all, 'num_samples': N}
             if compute_point_est:
                 return_dict['pose_axisangle_point_est'] = so3_p
                 return_dict['pose_rotmats_point_est'] = rot_p

@@ -31,13 +31,14 @@ def predict_humaniflow(humaniflow_model, smpl_model, proxy_inputs, names, save_d
         if save_dir is not None:
             os.makedirs(save_dir, exist_ok=True)
             np.savez(os.path.join(save_dir, os.path.splitext(name)[0] + '_pred.npz'), proxy_rep=x.cpu().numpy()[0], **out_np)
-        pe = smpl_model(body_pose=pred['pose_rotmats_point_est'], global_orient=pred['glob_rotmat'][:, None, :, :],
-                        betas=pred['shape_mode'], pose2rot=False)                                            # :128-131
+        if N > 0:                                                                                             # :128-131 and :160-165 in one launch
+            pe, sa = smpl_model.forward_samples_and_point_est(pred)
+        else:
+            pe = smpl_model(body_pose=pred['pose_rotmats_point_est'], global_orient=pred['glob_rotmat'][:, None, :, :],
+                            betas=pred['shape_mode'], pose2rot=False)
         res = {'name': name, 'pred': pred, 'vertices_point_est': pe.vertices, 'joints_point_est': pe.joints,
                'tpose_vertices_point_est': smpl_model.tpose(pred['shape_mode'])}                              # :147
         if N > 0:
-            sa = smpl_model(body_pose=pred['pose_rotmats_samples'][0], global_orient=pred['glob_rotmat'][:, None].expand(N, -1, -1, -1),
-                            betas=pred['shape_samples'][0], pose2rot=False)                                   # :160-165
             avg, xyz = compute_vertex_variance_from_samples(sa.vertices)                                      # :169
             res.update(vertices_samples=sa.vertices, joints_samples=sa.joints, per_vertex_avg_dist_from_mean=avg,
                        per_vertex_xyz_variance=xyz)

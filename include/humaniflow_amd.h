@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMF_ABI_VERSION 1
+#define HMF_ABI_VERSION 2
 
 #define HMF_OK 0
 #define HMF_ERR_INVALID (-1)     /* bad argument / shape                                  */
@@ -127,18 +127,22 @@ typedef struct {
 int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* weights);
 void hmf_flow_destroy(hmf_flow_t* h);
 
-size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int compute_point_est);
+/* flags of hmf_flow_forward */
+#define HMF_FLOW_POINT_EST 1    /* also push z = 0 through every flow (compute_point_est, :294-300)                      */
+#define HMF_FLOW_PACKED_ROWS 2  /* shape_samples has B*N + B rows: the point-estimate rows' shape (= shape_mode) is appended, so that
+                                 * (rotmats_samples | rotmats_point) and shape_samples feed ONE hmf_smpl_lbs call of M = B*N + B rows */
+size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int flags);
 /* Kinematic-chain pass: N pose samples per image and/or the z=0 point estimate, all 23 parts in
  * dependency order inside one launch sequence (replaces the Python loop :286-311).
  *   feats B x feat_dim; glob_R B x 9; cam B x 3; shape_mode/shape_log_std B x nb;
  *   eps_shape N x B x nb standard normal (NULL = use_shape_mode_for_samples, :255-256);
  *   eps_pose 23 x B x N x 3 standard normal, in the reference's draw order (:309);
  * outputs (nullable when not requested):
- *   shape_samples B x N x nb; rotmats_samples B x N x 23 x 9 (fp64 exp rounded to fp32, :311);
+ *   shape_samples B x N x nb (+ B x nb with HMF_FLOW_PACKED_ROWS); rotmats_samples B x N x 23 x 9 (fp64 exp rounded to fp32, :311);
  *   rotmats_point B x 23 x 9 (batch_rodrigues, :299); so3_point B x 23 x 3 (:300).               */
 int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* cam,
                      const float* shape_mode, const float* shape_log_std, const float* eps_shape,
-                     const float* eps_pose, int B, int N, int compute_point_est, float* shape_samples,
+                     const float* eps_pose, int B, int N, int flags, float* shape_samples,
                      float* rotmats_samples, float* rotmats_point, float* so3_point, void* workspace,
                      size_t workspace_bytes, void* stream);
 

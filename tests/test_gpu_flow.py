@@ -81,7 +81,7 @@ def test_end_to_end_forward_dict_with_encoder_and_smpl():
     with torch.no_grad():
         out = model(x.cuda(), num_samples=N, noise=_cuda(noise), return_input_feats=True)
     scale = ref['input_feats'].abs().max().item()
-    assert (out['input_feats'].cpu() - ref['input_feats']).abs().max() < 2e-4 * max(1.0, scale)
+    assert (out["input_feats"].cpu() - ref["input_feats"]).abs().max() < 2e-5 * max(1.0, scale)
     # feed the ORACLE's features to isolate the flow from conv round-off, then compare the whole dict
     with torch.no_grad():
         out = model(None, input_feats=ref['input_feats'].cuda(), num_samples=N, noise=_cuda(noise), return_input_feats=True)
@@ -257,3 +257,109 @@ def test_log_prob_at_training_batch_size_72():
     assert lp.mean().item() > lp_perm.mean().item()
     ref = omodel.log_prob_SO3(sd, oracle_cfg_from(cfg.MODEL), out['flow_context_for_loglik'][:5].cpu(), R[:5].cpu().double())
     assert (lp[:5].cpu() - ref).abs().max() < 1e-3
+
+
+def test_end_to_end_from_gpu_encoder_features_within_north_star_tolerances():
+    """The north-star bar asserted END TO END on the product path (nothing taken from the oracle in between): hand-written encoder ->
+    heads -> flow -> ONE fused SMPL launch, vs the oracle's reference-mode forward on the same proxy input, weights and noise:
+    vertices / joints within 1e-4 m, log-probs within 1e-3 (ResNet-50, 256x256: BASELINE configs[1] shapes at B=2, N=6)."""
+    model, sd, cfg = _model(50, seed=5)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B, N = 2, 6
+    x = synthetic_proxy_input(B, 256, seed=0)
+    noise = _noise(B, N, seed=2)
+    ref = omodel.forward(sd, ocfg, input=x, num_samples=N, noise=noise)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    with torch.no_grad():
+        out = model(x.cuda(), num_samples=N, noise=_cuda(noise), return_input_feats=True)
+        pe, sa = smpl.forward_samples_and_point_est(out)
+    scale = ref['input_feats'].abs().max().item()
+    assert (out['input_feats'].cpu() - ref['input_feats']).abs().max() < 2e-5 * max(1.0, scale)
+    om = smpl_oracle_model(smpl.model_dict())
+    g = ref['glob_rotmat']
+    v_ref, j_ref = osmpl.smpl_forward(om, ref['shape_samples'].reshape(-1, 10), ref['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
+                                      g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3), pose2rot=False)
+    vp_ref, jp_ref = osmpl.smpl_forward(om, ref['shape_mode'], ref['pose_rotmats_point_est'], g[:, None], pose2rot=False)
+    assert (sa.vertices.cpu() - v_ref).abs().max() < 1e-4 and (sa.joints.cpu() - j_ref).abs().max() < 1e-4
+    assert (pe.vertices.cpu() - vp_ref).abs().max() < 1e-4 and (pe.joints.cpu() - jp_ref).abs().max() < 1e-4
+    for k in ('pose_rotmats_samples', 'pose_rotmats_point_est', 'pose_axisangle_point_est', 'cam_wp', 'glob_rotmat', 'shape_mode'):
+        assert (out[k].cpu() - ref[k]).abs().max() < 1e-4, k
+    # teacher-forced log-likelihood from the GPU features as well
+    R_gt = random_rotmats(B * 23, 0.7, seed=1).view(B, 23, 3, 3)
+    shape_gt = torch.randn(B, 10, generator=torch.Generator().manual_seed(3))
+    glob_gt = random_rotmats(B, 1.0, seed=2)
+    refl = omodel.forward(sd, ocfg, input=x, compute_for_loglik=True, shape_for_loglik=shape_gt, pose_R_for_loglik=R_gt, glob_R_for_loglik=glob_gt)
+    lp_ref = omodel.log_prob_SO3(sd, ocfg, refl['flow_context_for_loglik'], R_gt.double())
+    with torch.no_grad():
+        outl = model(x.cuda(), compute_for_loglik=True, shape_for_loglik=shape_gt.cuda(), pose_R_for_loglik=R_gt.cuda(), glob_R_for_loglik=glob_gt.cuda())
+        lp = model.log_prob_all_parts(outl['flow_context_for_loglik'], R_gt.cuda()).cpu()
+    assert (lp - lp_ref).abs().max() < 1e-3
+
+
+def test_fused_smpl_launch_equals_the_two_reference_calls():
+    model, sd, cfg = _model(18, seed=11)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    for B, N, use_mode in ((3, 7, False), (2, 33, True), (1, 1, False)):
+        feats = torch.randn(B, 512, generator=torch.Generator().manual_seed(B + N)) * 0.5
+        with torch.no_grad():
+            out = model(None, input_feats=feats.cuda(), num_samples=N, noise=_cuda(_noise(B, N, seed=B)), use_shape_mode_for_samples=use_mode)
+            pe, sa = smpl.forward_samples_and_point_est(out)
+            g = out['glob_rotmat']
+            pe2 = smpl(body_pose=out['pose_rotmats_point_est'], global_orient=g[:, None], betas=out['shape_mode'], pose2rot=False)
+            sa2 = smpl(body_pose=out['pose_rotmats_samples'].reshape(-1, 23, 3, 3), global_orient=g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3),
+                       betas=out['shape_samples'].reshape(-1, 10), pose2rot=False)
+        assert torch.equal(pe.vertices, pe2.vertices) and torch.equal(pe.joints, pe2.joints)
+        assert torch.equal(sa.vertices, sa2.vertices) and torch.equal(sa.joints, sa2.joints)
+        assert torch.equal(out['smpl_packed_inputs']['betas'][B * N:], out['shape_mode'])
+
+
+def test_configs2_flow_and_encoder_at_B64():
+    """BASELINE configs[2] batch: encoder + flow at B = 64, N = 100 (6,464 rows = 202 tiles): determinism, orthonormality, batch-row
+    independence of the encoder, and slices against the oracle."""
+    model, sd, cfg = _model(50, seed=12)
+    B, N = 64, 100
+    x = synthetic_proxy_input(B, 256, seed=4).cuda()
+    noise = _noise(B, N, seed=13)
+    with torch.no_grad():
+        feats = model(x, return_input_feats_only=True)['input_feats']
+        feats2 = model(x[40:44], return_input_feats_only=True)['input_feats']
+        out = model(None, input_feats=feats, num_samples=N, noise=_cuda(noise))
+    assert feats.shape == (B, 2048) and (feats[40:44] - feats2).abs().max().item() < 1e-5 * feats.abs().max().item()
+    Rs = out['pose_rotmats_samples']
+    I = torch.eye(3, device='cuda')
+    assert (Rs @ Rs.transpose(-1, -2) - I).abs().max().item() < 1e-5
+    sub = {'shape': noise['shape'][:5, 62:64].contiguous(), 'pose': noise['pose'][:, 62:64, :5].contiguous()}
+    ref = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input_feats=feats[62:64].cpu(), num_samples=5, noise=sub)
+    assert (Rs[62:64, :5].cpu() - ref['pose_rotmats_samples']).abs().max() < RTOL
+    assert (out['pose_rotmats_point_est'][62:64].cpu() - ref['pose_rotmats_point_est']).abs().max() < RTOL
+    fr = omodel.forward(sd, oracle_cfg_from(cfg.MODEL), input=x[:1].cpu(), compute_point_est=False)['input_feats']
+    assert (feats[:1].cpu() - fr).abs().max() < 2e-5 * max(1.0, fr.abs().max().item())
+
+
+def test_configs3_eval_step_at_B32_N100():
+    """BASELINE configs[3] per-GPU step at ITS size: 32 3DPW-shaped synthetic items, N = 100: model -> fused SMPL (3,232 bodies) -> T-pose
+    bodies -> target bodies -> device tracker update.  Tracker sums vs the oracle metric functions on a slice of the same tensors."""
+    from humaniflow_amd import evaluate as ev
+    from oracle import metrics as om
+    model, sd, cfg = _model(50, seed=14)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    dev = torch.device('cuda:0')
+    ds = ev.SyntheticEvalSet(32, size=256, seed=2)
+    batch = ds.batch(list(range(32)), dev)
+    pred = ev.predict_batch(model, smpl, batch, 100)
+    targ = ev.target_batch(smpl, batch)
+    assert pred['verts3D_samples'].shape == (32, 100, 6890, 3) and pred['tpose_verts3D_samples'].shape == (32, 100, 6890, 3)
+    trk = ev.EvalMetricsTracker(dev)
+    trk.update_per_batch(pred, targ)
+    final, frames = trk.compute_final_metrics()
+    assert final['num_total_test_data'] == 32 and all(np.isfinite(v) for v in final.values())
+    assert frames['PVE_samples_min'].shape == (32,)
+    sl = slice(5, 8)
+    P, T = pred['verts3D_samples'][sl].double().cpu(), targ['verts3D'][sl].double().cpu()
+    e = om.pointset_errors(P, T, True)                                               # (3, 100, 3)
+    for c, name in enumerate(('PVE_samples_min', 'PVE-SC_samples_min', 'PVE-PA_samples_min')):
+        assert torch.allclose(frames[name][sl].double().cpu(), e[..., c].min(dim=1).values, rtol=2e-5, atol=1e-7), name
+    e = om.pointset_errors(pred['tpose_verts3D_samples'][sl].double().cpu(), targ['tpose_verts3D'][sl].double().cpu(), False)
+    assert torch.allclose(frames['PVE-T-SC_samples_min'][sl].double().cpu(), e[..., 1].min(dim=1).values, rtol=2e-5, atol=1e-7)
+    d = om.sample_diversity(P) / (100 * 6890)
+    assert torch.allclose(frames['verts3D_sample_diversity'][sl].double().cpu(), d, rtol=2e-5)

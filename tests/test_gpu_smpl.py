@@ -169,3 +169,30 @@ def test_bf16_blend_variant_configs2():
     v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(smpl.model_dict()), betas, pose[:, 3:], pose[:, :3], pose2rot=True)
     a = smpl(body_pose=pose[:, 3:].cuda(), global_orient=pose[:, :3].cuda(), betas=betas.cuda())
     assert (a.vertices.cpu() - v_ref).abs().max().item() < 1.5e-3 and (a.joints.cpu() - j_ref).abs().max().item() < 1.5e-3
+
+
+def test_configs2_bf16_kernel_at_full_size_M6400():
+    """BASELINE configs[2] at ITS size: the bf16 blend-GEMM kernel (impl=2) on M = 64*100 rows -- finite, identity-pose rows reproduce the
+    shaped template, ragged tail rows, a strided set of rows against the fp32 kernel and a 32-row slice against the oracle (1.5e-3 m)."""
+    data = H.synthetic_smpl_model(seed=0)
+    s16 = H.SMPL(model_data=data, create_transl=False, blend_dtype='bf16').to('cuda:0')
+    s32 = H.SMPL(model_data=data, create_transl=False).to('cuda:0')
+    M = 6400
+    g = torch.Generator().manual_seed(26)
+    betas = (torch.randn(M, 10, generator=g) * 1.25).cuda()
+    R = random_rotmats(M * 24, 0.6, seed=27).view(M, 24, 3, 3).cuda()
+    R[4000:4010] = torch.eye(3, device='cuda')                                   # identity pose rows
+    a = s16(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+    assert a.vertices.shape == (M, 6890, 3) and torch.isfinite(a.vertices).all() and torch.isfinite(a.joints).all()
+    tp = s32.tpose(betas[4000:4010])
+    assert (a.vertices[4000:4010] - tp).abs().max().item() < 1.5e-3
+    sel = torch.arange(0, M, 97)
+    b = s32(body_pose=R[sel, 1:], global_orient=R[sel, :1], betas=betas[sel], pose2rot=False)
+    assert (a.vertices[sel] - b.vertices).abs().max().item() < 1.5e-3 and (a.joints[sel] - b.joints).abs().max().item() < 1.5e-3
+    assert (a.vertices[sel] - b.vertices).abs().max().item() > 0
+    v_ref, j_ref = osmpl.smpl_forward(smpl_oracle_model(s16.model_dict()), betas[6368:6400].cpu(), R[6368:6400, 1:].cpu(),
+                                      R[6368:6400, :1].cpu(), pose2rot=False)
+    assert (a.vertices[6368:6400].cpu() - v_ref).abs().max() < 1.5e-3 and (a.joints[6368:6400].cpu() - j_ref).abs().max() < 1.5e-3
+    # same inputs again: deterministic
+    a2 = s16(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+    assert torch.equal(a.vertices, a2.vertices)

@@ -2,11 +2,19 @@
 TCC slots do not fit both).  Units: the counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane)
 coalesced reads -> doubled (guide, HBM section); WRITE_SIZE calibrated on k_tpose (writes exactly M*82680 B): ratio printed.
 
-    python tools/pmc_summary.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db > profiles/r01_pmc.json
+    python tools/pmc_summary.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db > profiles/r02_pmc.json
+
+The output is stamped with the library source hash (humaniflow_amd.build.source_hash) it was collected at: bench.py only quotes
+`traffic` from a file whose stamp matches the library it is benchmarking.
 """
 import json
+import os
 import sqlite3
+import subprocess
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from humaniflow_amd.build import source_hash
 
 
 def load(db):
@@ -29,4 +37,10 @@ for key in sorted(set(f) | set(w)):
     out['%s[grid=%d]' % (name, grid)] = {'FETCH_SIZE_KiB': round(fk, 1), 'WRITE_SIZE_KiB': round(wk, 1), 'fetch_correction': ff,
                                          'hbm_read_bytes_corrected': int(ff * fk * 1024), 'hbm_write_bytes': int(wk * 1024),
                                          'hbm_bytes_per_launch': int((ff * fk + wk) * 1024), 'launches': f.get(key, (0, 0))[1]}
-json.dump(out, sys.stdout, indent=1)
+try:
+    head = subprocess.run(['git', 'rev-parse', 'HEAD'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.decode().strip() or None
+except Exception:
+    head = None
+json.dump({'lib_source_hash': source_hash(), 'git_head': head,
+           'how': 'two separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --no-cpu-baseline`; KiB units; FETCH x2 on gfx950 for 16 B/lane reads',
+           'kernels': out}, sys.stdout, indent=1)

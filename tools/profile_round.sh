@@ -1,22 +1,23 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root: regenerates every file under profiles/ that bench.py's numbers are
-# checked against.  Usage: tools/profile_round.sh r01     -> writes gpurun_out/profiles/r01_*; copy those into profiles/.
-# Counter passes are separate runs with --kernel-trace only (no sys/hip/hsa traces), one counter per pass.
+# checked against.  Usage: tools/profile_round.sh r02     -> writes gpurun_out/profiles/r02_*; copy those into profiles/.
+# Counter passes are separate runs with --kernel-trace only (no sys/hip/hsa traces), one counter group per pass.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles
 mkdir -p "$OUT"
-STEPS=20; WARM=6
-BENCH="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline"
+STEPS=30; WARM=6
+# the profiled command = the default bench without its trailing measurement pass / CPU baseline, so that the timed region ends the process
+BENCH="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --profile-steps 0"
 python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.log"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH > "$OUT/${R}_bench_under_rocprof.json" 2>/tmp/kt.log
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 python tools/rocpd_stats.py "$DB" 48 --steps $STEPS > "$OUT/${R}_kernel_stats.md"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $BENCH >/dev/null 2>/tmp/f.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $BENCH >/dev/null 2>/tmp/w.log
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_m -o m -- $BENCH --streams 1 >/dev/null 2>/tmp/m.log
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_m -o m -- $BENCH --streams 1 --no-graph >/dev/null 2>/tmp/m.log
 python tools/pmc_mfma.py "$(find /tmp/prof_m -name '*.db' | head -1)" > "$OUT/${R}_mfma_busy.txt"
 python tools/pmc_summary.py "$(find /tmp/prof_f -name '*.db' | head -1)" "$(find /tmp/prof_w -name '*.db' | head -1)" > "$OUT/${R}_pmc.json"
-mkdir -p /tmp/rt && cp "$OUT"/${R}_* profiles/ && python tools/roofline_table.py $R > "$OUT/${R}_roofline.md"
+cp "$OUT"/${R}_* profiles/ && python tools/roofline_table.py $R > "$OUT/${R}_roofline.md"
 ls -la "$OUT"

@@ -5,7 +5,7 @@
 --steps K restricts the table to the bench's TIMED region: one hmf::k_isgc is launched per step, so the window opens at the end of
 the k_isgc that precedes the last K of them (= the last warm-up step's; with 2 streams the first timed step's encoder may already
 be running, i.e. the window holds K steps' worth of every kernel, shifted by at most one encoder) and closes at the last dispatch.
-MIOpen's find-time kernels (naive reference convolutions, candidates that lost) therefore stay out of the table.
+Run the bench with --profile-steps 0 --no-cpu-baseline so that the timed region is the end of the process.
 """
 import sqlite3
 import sys
@@ -23,7 +23,7 @@ if steps:
     if len(marks) > steps:
         t0 = marks[len(marks) - steps - 1][0]
         where = ' where start >= %d' % t0
-        note = 'timed region: the last %d steps (window opens at the end of the last warm-up step\'s k_isgc)' % steps
+        note = 'timed region: the last %d steps of the process (run bench.py with --profile-steps 0 so that nothing follows the timed region; window opens at the end of the last warm-up step\'s k_isgc)' % steps
 rows = con.execute("select name || case when name like '%hmf::%' then ' [grid ' || grid_x || ']' else '' end as nm, count(*), sum(duration), "
                    "avg(duration), min(duration), max(duration), max(vgpr_count), max(accum_vgpr_count), max(lds_size), max(scratch_size), "
                    "max(grid_x), max(workgroup_x) from kernels" + where + " group by nm order by sum(duration) desc").fetchall()
@@ -39,7 +39,7 @@ for r in rows[:int(args[1]) if len(args) > 1 else 40]:
 print('\ntotal kernel time: %.3f ms over %d dispatches; wall span of the window %.3f ms' % (total / 1e6, sum(r[1] for r in rows), span / 1e6))
 if steps:
     print('per step: %.3f ms of kernel time, %.3f ms of wall span' % (total / 1e6 / steps, span / 1e6 / steps))
-    groups = [('encoder convolutions (hmf::k_stem_conv, k_conv_patch, k_conv_igemm)', "(name like '%hmf::k_stem_conv%' or name like '%hmf::k_conv_%')"),
+    groups = [('encoder convolutions (hmf::k_stem_conv, k_conv_winograd, k_conv_patch, k_conv_igemm)', "(name like '%hmf::k_stem_conv%' or name like '%hmf::k_conv_%')"),
               ('encoder max-pool (hmf::k_maxpool_nhwc)', "name like '%k_maxpool_nhwc%'"),
               ('flow (hmf::k_isgc, k_flow_*)', "(name like '%hmf::k_isgc%' or name like '%hmf::k_flow%')"),
               ('SMPL (hmf::k_lbs_mfma, k_rigid_chain, k_joints, k_tpose)', "(name like '%hmf::k_lbs%' or name like '%hmf::k_rigid%' or name like '%hmf::k_joints%' or name like '%hmf::k_tpose%')")]
