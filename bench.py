@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOPs per image.sample of the SMPL stage: shape blend 0.413 + pose blend 8.557 +
 # 4-nnz skinning blend 0.66 + transform apply 0.145 MFLOP
 LBS_FLOP_PER_UNIT = 9.775e6
+HBM_PEAK_GBS = 8000.0                  # guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 WINOGRAD_MFMA_FRACTION = 4.0 / 9.0     # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed MFMA FLOPs = 4/9 of direct
 
@@ -453,14 +454,19 @@ def main():
                 'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (measurement pass: HIP events on the launch stream, one stream)',
                 'step_aggregate': {'what': 'algorithmic FLOPs of every convolution (Winograd layers at direct-form FLOPs) + SMPL blend GEMMs of a step / step time of the timed region',
                                    'achieved': round(agg, 2), 'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4)}}
-        res['roofline_lbs'] = {'kernel': 'k_lbs_mfma%s (SMPL pose-blend GEMM + skinning, M=%d rows)' % ('16' if args.blend_dtype == 'bf16' else '', lbs_rows),
-                               'bound': 'mfma' if args.blend_dtype == 'fp32' else 'hbm',
-                               'achieved': round(LBS_FLOP_PER_UNIT * lbs_rows / (lbs_ms * 1e-3) / 1e12, 2) if lbs_ms == lbs_ms else None,
-                               'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(LBS_FLOP_PER_UNIT * lbs_rows / (lbs_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if lbs_ms == lbs_ms else None,
-                               'avg_launch_us': round(lbs_ms * 1e3, 2) if lbs_ms == lbs_ms else None, 'traffic': traffic_of('k_lbs_mfma'),
-                               'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * lbs_rows,
-                               'algorithmic_bytes_per_launch': lbs_rows * (82680 + 1080 + 868) + 19.3e6}
+        lbs_bytes = lbs_rows * (82680 + 1080 + 868) + 19.3e6          # vertices + joints written, rotations + betas read, constants once
+        if args.blend_dtype == 'fp32':
+            ach = LBS_FLOP_PER_UNIT * lbs_rows / (lbs_ms * 1e-3) / 1e12 if lbs_ms == lbs_ms else None
+            res['roofline_lbs'] = {'kernel': 'k_lbs_mfma (SMPL pose-blend GEMM + skinning, M=%d rows)' % lbs_rows, 'bound': 'mfma',
+                                   'achieved': round(ach, 2) if ach else None, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4) if ach else None}
+        else:                                                          # bf16 operands: 1/16 of the MFMA time -> bound by the vertex write
+            ach = lbs_bytes / (lbs_ms * 1e-3) / 1e9 if lbs_ms == lbs_ms else None
+            res['roofline_lbs'] = {'kernel': 'k_lbs_mfma16 (SMPL pose-blend GEMM in bf16 + fp32 skinning, M=%d rows)' % lbs_rows, 'bound': 'hbm',
+                                   'achieved': round(ach, 1) if ach else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None}
+        res['roofline_lbs'].update({'avg_launch_us': round(lbs_ms * 1e3, 2) if lbs_ms == lbs_ms else None, 'traffic': traffic_of('k_lbs_mfma'),
+                                    'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * lbs_rows, 'algorithmic_bytes_per_launch': lbs_bytes})
         if res['roofline'] is None:
             res['roofline'] = res['roofline_lbs']
         if world == 1 and not args.no_cpu_baseline:

@@ -32,6 +32,11 @@ class FlowHost(C.Structure):
                 ('w_nn_host', C.POINTER(c_float_p)), ('b_nn_host', C.POINTER(c_float_p))]
 
 
+class FlowGradRecords(C.Structure):
+    """hmf_flow_grad_records_t (include/humaniflow_amd.h): device pointers of the per-(part, row) deltas / activations."""
+    _fields_ = [(k, C.c_void_p) for k in ('D1', 'D2', 'D3', 'D4', 'A1', 'A2', 'A3', 'XIN', 'ACTX', 'DCTX')] + [('rows', C.c_int)]
+
+
 _VP = C.c_void_p
 HMF_FLOW_POINT_EST, HMF_FLOW_PACKED_ROWS = 1, 2          # flags of hmf_flow_forward (include/humaniflow_amd.h)
 _SIGS = {
@@ -58,6 +63,9 @@ _SIGS = {
     'hmf_flow_context': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_SO3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_so3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
+    'hmf_flow_log_prob_SO3_backward': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP, C.POINTER(FlowGradRecords), _VP]),
+    'hmf_flow_sample_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.POINTER(FlowGradRecords), _VP]),
+    'hmf_smpl_joints_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
     'hmf_proxy_rep': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                 _VP, _VP, _VP, _VP, _VP]),
     'hmf_stem_packed_floats': (C.c_longlong, []),

@@ -1,0 +1,250 @@
+"""torch.autograd glue for the training step (BASELINE configs[4]).
+
+What the reference differentiates in train/train_humaniflow.py:248-330 and where its backward runs here:
+
+  teacher-forced pose NLL   conditioned_pose_SO3flow_dists_for_loglik[j].log_prob(R_j)     FlowLogProbSO3   (k_flow_logprob_bwd)
+  teacher-forced contexts   compute_flow_context on the target rotations                     FlowContext      (dense reductions)
+  reparameterised samples   pose_SO3_samples, ancestors feeding descendants (:302-311)       FlowSampleChain  (k_flow_chain_bwd, 8 rounds reversed)
+  2D reprojection           SMPL joints of the samples / point estimate                      SmplJoints       (k_smpl_joints_bwd)
+  6D -> R of the global rotation                                                              Rot6dToRotmat
+
+The HIP kernels do the structured part (spline / hyper-network / kinematic-chain / skinning reverse sweeps) and emit per-row deltas
+and activations; the weight gradients are dense reductions over the row axis, done with library GEMMs (torch.matmul) below.
+Forward values always come from the same inference kernels as under no_grad.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+# ---- records of the flow backward kernels ---------------------------------------------------------------------------------
+class _Records:
+    """Device buffers for hmf_flow_grad_records_t: part-major [P][2][rows][width]."""
+
+    def __init__(self, P, rows, device, with_dctx):
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        self.P, self.rows = P, rows
+        self.D1, self.D4, self.A1 = f(P, 2, rows, 64), f(P, 2, rows, 64), f(P, 2, rows, 64)
+        self.D2, self.D3, self.A2, self.A3 = f(P, 2, rows, 32), f(P, 2, rows, 32), f(P, 2, rows, 32), f(P, 2, rows, 32)
+        self.XIN = f(P, 2, rows)
+        self.ACTX = f(P, rows, 64)
+        self.DCTX = f(P, rows, 64) if with_dctx else None
+
+    def struct(self):
+        s = _lib.FlowGradRecords()
+        for k in ('D1', 'D2', 'D3', 'D4', 'A1', 'A2', 'A3', 'XIN', 'ACTX'):
+            setattr(s, k, getattr(self, k).data_ptr())
+        s.DCTX = self.DCTX.data_ptr() if self.DCTX is not None else None
+        s.rows = self.rows
+        return s
+
+    def hypernet_grads(self):
+        """[(dW, db) for layer 1..4], each (P, 2, out, in) / (P, 2, out): dW_l = D_l^T . A_{l-1} over the row axis."""
+        a0 = torch.cat([self.ACTX[:, None].expand(-1, 2, -1, -1), self.XIN[..., None]], dim=-1)           # (P,2,rows,65) = [context | x1]
+        tm = lambda d, a: torch.matmul(d.transpose(-1, -2), a)
+        d4 = self.D4[..., :62]
+        return [(tm(self.D1, a0), self.D1.sum(2)), (tm(self.D2, self.A1), self.D2.sum(2)),
+                (tm(self.D3, self.A2), self.D3.sum(2)), (tm(d4, self.A3), d4.sum(2))]
+
+
+def _hypernet_params(model, part0, P):
+    """Flat list [part][coupling][layer](weight, bias) of parts part0 .. part0+P-1: 16 tensors per part (2 couplings x 4 layers)."""
+    T = model.model_cfg.NORM_FLOW.NUM_TRANSFORMS
+    out = []
+    for j in range(part0, part0 + P):
+        for t in range(T):
+            for lin in model.pose_so3flow_transform_modules[T * j + t].nn.layers:
+                out += [lin.weight, lin.bias]
+    return out
+
+
+def _hypernet_grad_list(rec, P, needs):
+    """Gradients in the order of _hypernet_params; `needs` = ctx.needs_input_grad slice for those tensors."""
+    grads = rec.hypernet_grads()
+    out = []
+    for p in range(P):
+        for c in range(2):
+            for l in range(4):
+                out += [grads[l][0][p, c], grads[l][1][p, c]]
+    return [g if n else None for g, n in zip(out, needs)]
+
+
+# ---- context layers: shared dense pull-back ---------------------------------------------------------------------------------
+def _anc_index(model, device):
+    """Per part: column indices of its ancestors' flattened rotations inside a (rows, 23*9) rotation matrix block."""
+    key = ('anc_idx', str(device))
+    cache = model.__dict__.setdefault('_grad_cache', {})
+    if key not in cache:
+        cache[key] = [torch.tensor([a * 9 + e for a in model.ancestors_dict[j] for e in range(9)], dtype=torch.long, device=device)
+                      for j in range(model.num_bodyparts)]
+    return cache[key]
+
+
+def _context_layer_grads(model, delta, isgc_rows, rot_rows):
+    """delta (P, rows, 64) = d L / d (pre-activation of fc_flow_context[j]); isgc_rows (rows, 256); rot_rows (rows, 23, 9).
+    Returns ([dW_j (64, 256 + 9 a_j)], [db_j], g_isgc (rows, 256))."""
+    P = delta.shape[0]
+    x_full = torch.cat([isgc_rows, rot_rows.reshape(rot_rows.shape[0], -1)], dim=1)                       # (rows, 256 + 207)
+    g_full = torch.matmul(delta.transpose(1, 2), x_full)                                                   # (P, 64, 463)
+    idx = _anc_index(model, delta.device)
+    nin = isgc_rows.shape[1]
+    dW = [torch.cat([g_full[j, :, :nin], g_full[j].index_select(1, idx[j] + nin)], dim=1) for j in range(P)]
+    db = list(delta.sum(1))
+    w0 = torch.stack([m.weight.detach()[:, :nin] for m in model.fc_flow_context])                           # (P, 64, 256)
+    g_isgc = torch.einsum('pro,pok->rk', delta, w0)
+    return dW, db, g_isgc
+
+
+def _ctx_params(model):
+    out = []
+    for m in model.fc_flow_context:
+        out += [m.weight, m.bias]
+    return out
+
+
+class FlowContext(torch.autograd.Function):
+    """compute_flow_context for all 23 parts from GIVEN (teacher-forced) rotations: (B,256), (B,23,3,3) -> (B,23,64)."""
+
+    @staticmethod
+    def forward(ctx, model, isgc, pose_R, *params):
+        out = model._flow_context_kernel(isgc.detach(), pose_R.detach())
+        ctx.model = model
+        ctx.save_for_backward(isgc.detach(), pose_R.detach().float().reshape(pose_R.shape[0], 23, 9), out)
+        ctx.r_needs_grad = pose_R.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.r_needs_grad:
+            raise NotImplementedError('humaniflow_amd: gradient w.r.t. the teacher-forced rotations (pose_R_for_loglik) is not built')
+        isgc, rot, out = ctx.saved_tensors
+        delta = (g * torch.where(out > 0, torch.ones_like(out), out + 1.0)).transpose(0, 1).contiguous()   # ELU', (P, B, 64)
+        dW, db, g_isgc = _context_layer_grads(ctx.model, delta, isgc, rot)
+        grads = []
+        for j in range(len(dW)):
+            grads += [dW[j], db[j]]
+        return (None, g_isgc, None) + tuple(grads)
+
+
+class FlowLogProbSO3(torch.autograd.Function):
+    """log p(R_j | ctx_j) for parts part0 .. part0+P-1: ctx (B,P,64) fp32, R (B,P,3,3) fp64 -> (B,P) fp32."""
+
+    @staticmethod
+    def forward(ctx, model, part0, P, cvec, R64, *params):
+        out = model._log_prob_kernel(cvec.detach(), R64, part0, P, group=True)
+        ctx.model, ctx.part0, ctx.P = model, part0, P
+        ctx.save_for_backward(cvec.detach().contiguous(), R64)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cvec, R64 = ctx.saved_tensors
+        model, P, part0 = ctx.model, ctx.P, ctx.part0
+        B = cvec.shape[0]
+        lib = _lib.load()
+        rec = _Records(P, 3 * B, cvec.device, with_dctx=False)
+        g_ctx = torch.empty_like(cvec)
+        gc = g.detach().to(torch.float32).contiguous()
+        ids = (C.c_int32 * P)(*range(part0, part0 + P)) if P != model.num_bodyparts else None
+        st = rec.struct()
+        with torch.cuda.device(cvec.device):
+            _lib.check(lib.hmf_flow_log_prob_SO3_backward(model._flow_handle(cvec.device), _lib.dptr(cvec), ids, P, _lib.dptr(R64), B,
+                                                          _lib.dptr(gc), _lib.dptr(g_ctx), C.byref(st), _lib.current_stream()),
+                       'hmf_flow_log_prob_SO3_backward')
+        pg = _hypernet_grad_list(rec, P, ctx.needs_input_grad[5:])
+        return (None, None, None, g_ctx if ctx.needs_input_grad[3] else None, None) + tuple(pg)
+
+
+class FlowSampleChain(torch.autograd.Function):
+    """Attaches the reparameterised-sample graph to the rotations hmf_flow_forward produced: inputs are the per-row isgc features
+    H (B*N, 256) (differentiable), the forward's rotations and base noise; output = the same rotations, now differentiable w.r.t.
+    H, the 23 context layers and the 46 hyper-networks (ancestor recursion included)."""
+
+    @staticmethod
+    def forward(ctx, model, H, rot_samples, eps_pose, *params):
+        B, N = rot_samples.shape[:2]
+        ctx.model, ctx.B, ctx.N = model, B, N
+        ctx.save_for_backward(H.detach().contiguous(), rot_samples.detach().contiguous(), eps_pose.detach().contiguous())
+        return rot_samples.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        H, rot, eps = ctx.saved_tensors
+        model, B, N = ctx.model, ctx.B, ctx.N
+        P = model.num_bodyparts
+        lib = _lib.load()
+        rec = _Records(P, B * N, H.device, with_dctx=True)
+        g_rot = g.detach().to(torch.float32).contiguous().clone()                                       # in/out: descendants add to ancestors
+        st = rec.struct()
+        with torch.cuda.device(H.device):
+            _lib.check(lib.hmf_flow_sample_backward(model._flow_handle(H.device), _lib.dptr(H), _lib.dptr(rot), _lib.dptr(eps), B, N,
+                                                    _lib.dptr(g_rot), C.byref(st), _lib.current_stream()), 'hmf_flow_sample_backward')
+        dW, db, g_H = _context_layer_grads(model, rec.DCTX, H, rot.reshape(B * N, P, 9))
+        grads = []
+        for j in range(P):
+            grads += [dW[j], db[j]]
+        grads += _hypernet_grad_list(rec, P, [True] * (16 * P))
+        needs = ctx.needs_input_grad[4:]
+        return (None, g_H, None, None) + tuple(gr if n else None for gr, n in zip(grads, needs))
+
+
+class SmplJoints(torch.autograd.Function):
+    """hmf_smpl_lbs with a backward for the JOINTS output (vertex gradients are not built)."""
+
+    @staticmethod
+    def forward(ctx, smpl, glob9, body207, betas, impl):
+        verts, joints = smpl._lbs_kernel(glob9.detach(), body207.detach(), betas.detach(), impl)
+        ctx.smpl = smpl
+        ctx.save_for_backward(glob9.detach(), body207.detach(), betas.detach())
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(verts)
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, g_verts, g_joints):
+        if g_verts is not None:
+            raise NotImplementedError('humaniflow_amd: SMPL vertex gradients are not built (LOSS.APPLY_POINT_EST_LOSS); only the joints backward is')
+        if g_joints is None:
+            return None, None, None, None, None
+        glob9, body207, betas = ctx.saved_tensors
+        M = body207.shape[0]
+        lib = _lib.load()
+        gj = g_joints.detach().to(torch.float32).contiguous()
+        gg, gb, gbe = torch.empty_like(glob9), torch.empty_like(body207), torch.empty_like(betas)
+        with torch.cuda.device(gj.device):
+            _lib.check(lib.hmf_smpl_joints_backward(ctx.smpl._handle(gj.device), _lib.dptr(glob9), _lib.dptr(body207), _lib.dptr(betas), M,
+                                                    _lib.dptr(gj), _lib.dptr(gg), _lib.dptr(gb), _lib.dptr(gbe), _lib.current_stream()),
+                       'hmf_smpl_joints_backward')
+        return None, gg, gb, gbe, None
+
+
+def _rot6d_torch(x):
+    """utils/rigid_transform_utils.py:86-100 in torch ops (used for the pull-back only)."""
+    x = x.reshape(-1, 3, 2)
+    a1, a2 = x[:, :, 0], x[:, :, 1]
+    b1 = F.normalize(a1)
+    b2 = F.normalize(a2 - torch.einsum('bi,bi->b', b1, a2).unsqueeze(-1) * b1)
+    b3 = torch.linalg.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-1)
+
+
+class Rot6dToRotmat(torch.autograd.Function):
+    """hmf_rot6d_to_rotmat forward; the pull-back of the 6 -> 9 Gram-Schmidt map by re-tracing it in torch ops (B x 6 values)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from .rigid_transform_utils import rot6d_to_rotmat_kernel
+        ctx.save_for_backward(x.detach())
+        return rot6d_to_rotmat_kernel(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        with torch.enable_grad():
+            xi = x.clone().requires_grad_(True)
+            y = _rot6d_torch(xi)
+            (gx,) = torch.autograd.grad(y, xi, g.reshape(y.shape))
+        return gx.reshape(x.shape)

@@ -1,0 +1,632 @@
+// Backward (vector-Jacobian) kernels of the ancestor-conditioned SO(3) flow: the training step of BASELINE configs[4] / SURVEY 8f-3.
+//
+// What the reference differentiates (train/train_humaniflow.py:248-330, losses/humaniflow_loss.py:23-79):
+//   * the teacher-forced pose NLL: sum_j log p(R_j | ctx_j) through LocalDiffeoTransformedDistribution.log_prob
+//     (local_diffeo_transformed_distribution.py:84-142) -> d/d ctx and d/d hyper-network weights        k_flow_logprob_bwd
+//   * the reparameterised samples pose_SO3_samples[:, :, j] (models/humaniflow_model.py:302-311) that feed the 2D reprojection loss:
+//     d/d ctx-layer inputs, d/d ancestors' rotations (the kinematic recursion, reversed), d/d weights      k_flow_chain_bwd
+//
+// Design: one wave per (row, part), lane = channel, exactly the op order of the teacher-forced forward kernels of flow_kernels.hip.
+// The wave recomputes the part's forward pass from the saved inputs, runs the reverse sweep in registers and writes, per (row, part),
+// the pre-activation gradients ("deltas") and the activations of every dense layer.  The weight gradients are then plain dense
+// reductions over the row axis, dW_l = delta_l^T . act_{l-1}, which the host side does with library GEMMs (torch.bmm): small
+// (K = rows), order-independent of the kinematic tree, and exactly the kind of GEMM hipBLASLt is for.
+// The spline's derivatives with respect to its 31 raw parameters come from forward-mode dual numbers through the ~20 scalar
+// operations of the selected bin (one evaluation, 8 tangents), followed by the closed-form softmax / cumsum / softplus / sigmoid
+// pull-backs -- no hand-derived rational-spline Jacobian to get wrong.
+#include "flow_common.h"
+#include "flow_handle.h"
+#include "so3_math.h"
+
+namespace hmf {
+
+// ---------------------------------------------------------------------------------------------------
+// forward-mode dual numbers
+// ---------------------------------------------------------------------------------------------------
+template <class F, int N>
+struct DualT {
+    F v;
+    F d[N];
+};
+#define HMF_DUAL_LOOP _Pragma("unroll") for (int i_ = 0; i_ < N; ++i_)
+template <class F, int N> __device__ __forceinline__ DualT<F, N> dconst(F c) { DualT<F, N> r; r.v = c; HMF_DUAL_LOOP r.d[i_] = F(0); return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> dvar(F c, int idx) { DualT<F, N> r; r.v = c; HMF_DUAL_LOOP r.d[i_] = (i_ == idx) ? F(1) : F(0); return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator+(const DualT<F, N>& a, const DualT<F, N>& b) { DualT<F, N> r; r.v = a.v + b.v; HMF_DUAL_LOOP r.d[i_] = a.d[i_] + b.d[i_]; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator-(const DualT<F, N>& a, const DualT<F, N>& b) { DualT<F, N> r; r.v = a.v - b.v; HMF_DUAL_LOOP r.d[i_] = a.d[i_] - b.d[i_]; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator*(const DualT<F, N>& a, const DualT<F, N>& b) { DualT<F, N> r; r.v = a.v * b.v; HMF_DUAL_LOOP r.d[i_] = a.d[i_] * b.v + a.v * b.d[i_]; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator/(const DualT<F, N>& a, const DualT<F, N>& b) {
+    DualT<F, N> r; const F inv = F(1) / b.v; r.v = a.v * inv; HMF_DUAL_LOOP r.d[i_] = (a.d[i_] - r.v * b.d[i_]) * inv; return r;
+}
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator+(const DualT<F, N>& a, F b) { DualT<F, N> r = a; r.v += b; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator-(const DualT<F, N>& a, F b) { DualT<F, N> r = a; r.v -= b; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator-(F a, const DualT<F, N>& b) { DualT<F, N> r; r.v = a - b.v; HMF_DUAL_LOOP r.d[i_] = -b.d[i_]; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator*(const DualT<F, N>& a, F b) { DualT<F, N> r; r.v = a.v * b; HMF_DUAL_LOOP r.d[i_] = a.d[i_] * b; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> operator*(F a, const DualT<F, N>& b) { return b * a; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> dsqrt(const DualT<F, N>& a) { DualT<F, N> r; r.v = sqrt(a.v); const F k = F(0.5) / r.v; HMF_DUAL_LOOP r.d[i_] = a.d[i_] * k; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> dlog(const DualT<F, N>& a) { DualT<F, N> r; r.v = log(a.v); const F k = F(1) / a.v; HMF_DUAL_LOOP r.d[i_] = a.d[i_] * k; return r; }
+template <class F, int N> __device__ __forceinline__ DualT<F, N> dabs(const DualT<F, N>& a) { DualT<F, N> r; const F s = a.v < F(0) ? F(-1) : F(1); r.v = a.v * s; HMF_DUAL_LOOP r.d[i_] = a.d[i_] * s; return r; }
+
+// ---------------------------------------------------------------------------------------------------
+// rational-linear spline: value, log|derivative| and their pull-back to (x, 31 raw parameters)
+// ---------------------------------------------------------------------------------------------------
+template <bool INVERSE, int N>
+__device__ __forceinline__ void rls_core(const DualT<float, N>& x, const DualT<float, N>& k_lo, const DualT<float, N>& k_hi, const DualT<float, N>& c_lo,
+                                         const DualT<float, N>& c_hi, const DualT<float, N>& d0, const DualT<float, N>& d1, const DualT<float, N>& lam,
+                                         DualT<float, N>& out, DualT<float, N>& ld) {
+    typedef DualT<float, N> D;
+    const D in_w = k_hi - k_lo, in_h = c_hi - c_lo;
+    const D delta = in_h / in_w;
+    const D wb = dsqrt(d0 / d1);
+    const D one_m = 1.f - lam;
+    const D wc = (lam * d0 + one_m * wb * d1) / delta;
+    const D ya = c_lo, yb = c_hi;
+    const D yc = (one_m * ya + lam * wb * yb) / (one_m + lam * wb);
+    D num, den, dnum;
+    if (INVERSE) {
+        if (x.v <= yc.v) {
+            num = lam * (ya - x); den = (wc - 1.f) * x + ya - wc * yc; dnum = wc * lam * (yc - ya) * in_w;
+        } else {
+            num = (wc - lam * wb) * x + lam * wb * yb - wc * yc; den = (wc - wb) * x + wb * yb - wc * yc; dnum = wb * wc * one_m * (yb - yc) * in_w;
+        }
+        out = (num / den) * in_w + k_lo;
+    } else {
+        const D th = (x - k_lo) / in_w;
+        if (th.v <= lam.v) {
+            num = ya * (lam - th) + wc * yc * th; den = (lam - th) + wc * th; dnum = wc * lam * (yc - ya) / in_w;
+        } else {
+            num = wc * yc * (1.f - th) + wb * yb * (th - lam); den = wc * (1.f - th) + wb * (th - lam); dnum = wb * wc * one_m * (yb - yc) / in_w;
+        }
+        out = num / den;
+    }
+    ld = dlog(dnum) - 2.f * dlog(dabs(den));
+}
+
+struct SplineGrad {
+    float g_x, g_rw[8], g_rh[8], g_rd[7], g_rl[8];
+};
+
+// out/ld as rational_linear_spline<INVERSE>; G = g_out * d out/d(.) + g_ld * d ld/d(.)
+template <bool INVERSE>
+__device__ __forceinline__ void spline_vjp(float x, const float (&rw)[8], const float (&rh)[8], const float (&rd)[7], const float (&rl)[8], float bound,
+                                           float g_out, float g_ld, float& out, float& ld, SplineGrad& G) {
+    constexpr float kScale = 1.0f - 1e-3f * 8;
+    float smw[8], smh[8], cw[9], chh[9], dv[9];
+    {
+        float m = rw[0], n = rh[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { m = fmaxf(m, rw[i]); n = fmaxf(n, rh[i]); }
+        float s = 0.f, t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { smw[i] = expf(rw[i] - m); s += smw[i]; smh[i] = expf(rh[i] - n); t += smh[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { smw[i] /= s; smh[i] /= t; }
+        float a = 0.f, b = 0.f;
+        cw[0] = -bound; chh[0] = -bound;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a += 1e-3f + kScale * smw[i]; b += 1e-3f + kScale * smh[i];
+            cw[i + 1] = (2.f * bound) * a + (-bound);
+            chh[i + 1] = (2.f * bound) * b + (-bound);
+        }
+        cw[8] = bound; chh[8] = bound;
+    }
+    dv[0] = 1.0f - 1e-3f; dv[8] = 1.0f - 1e-3f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) dv[i + 1] = 1e-3f + softplus1(rd[i]);
+    int bin = -1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bin += (x >= (INVERSE ? chh[i] : cw[i]) + 1e-6f) ? 1 : 0;
+    bin = min(max(bin, 0), 7);
+    float k_lo = cw[0], k_hi = cw[1], c_lo = chh[0], c_hi = chh[1], d0 = dv[0], d1 = dv[1], rls = rl[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const bool sel = bin == i;
+        k_lo = sel ? cw[i] : k_lo; k_hi = sel ? cw[i + 1] : k_hi; c_lo = sel ? chh[i] : c_lo; c_hi = sel ? chh[i + 1] : c_hi;
+        d0 = sel ? dv[i] : d0; d1 = sel ? dv[i + 1] : d1; rls = sel ? rl[i] : rls;
+    }
+    const float sl = sigmoid1(rls);
+    const float lamv = (1.f - 2.f * 0.025f) * sl + 0.025f;
+    typedef DualT<float, 8> D;
+    D O, L;
+    rls_core<INVERSE, 8>(dvar<float, 8>(x, 0), dvar<float, 8>(k_lo, 1), dvar<float, 8>(k_hi, 2), dvar<float, 8>(c_lo, 3), dvar<float, 8>(c_hi, 4),
+                         dvar<float, 8>(d0, 5), dvar<float, 8>(d1, 6), dvar<float, 8>(lamv, 7), O, L);
+    const bool inside = (x >= -bound) && (x <= bound);
+    out = inside ? O.v : x;
+    ld = inside ? L.v : 0.f;
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = inside ? (g_out * O.d[i] + g_ld * L.d[i]) : 0.f;
+    G.g_x = inside ? g[0] : g_out;
+    // knots -> bin lengths -> softmax logits.  cw[i] = 2B sum_{m<i} w'_m - B for 1 <= i <= 7 (the end knots are pinned constants)
+    float g_wp[8], g_hp[8];
+    {
+        float accw = 0.f, acch = 0.f;
+#pragma unroll
+        for (int m = 7; m >= 0; --m) {
+            g_wp[m] = 2.f * bound * accw; g_hp[m] = 2.f * bound * acch;
+            // add the gradient of knot m (i = m) for the next (smaller) m; knot 0 is never needed
+            accw += ((bin == m) ? g[1] : 0.f) + ((bin + 1 == m) ? g[2] : 0.f);
+            acch += ((bin == m) ? g[3] : 0.f) + ((bin + 1 == m) ? g[4] : 0.f);
+        }
+        float dotw = 0.f, doth = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { dotw += g_wp[m] * smw[m]; doth += g_hp[m] * smh[m]; }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { G.g_rw[m] = kScale * smw[m] * (g_wp[m] - dotw); G.g_rh[m] = kScale * smh[m] * (g_hp[m] - doth); }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {                   // dv[i + 1] = 1e-3 + softplus(rd[i]); d0 = dv[bin], d1 = dv[bin + 1]
+        const float gd = ((bin == i + 1) ? g[5] : 0.f) + ((bin == i) ? g[6] : 0.f);
+        G.g_rd[i] = gd * sigmoid1(rd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) G.g_rl[i] = (bin == i) ? g[7] * (1.f - 2.f * 0.025f) * sl * (1.f - sl) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wave-level helpers (lane = channel)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// "transpose-reduce": lane l ends with sum over all lanes of v[l % K] (63 shuffles for K = 64 instead of K full reductions)
+template <int K>
+__device__ __forceinline__ float xreduce(float (&v)[K], int lane) {
+    if (K == 32) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] += __shfl_xor(v[i], 32);
+    }
+#pragma unroll
+    for (int s = (K == 64 ? 32 : 16); s >= 1; s >>= 1) {
+        const bool up = (lane & s) != 0;
+#pragma unroll
+        for (int i = 0; i < s; ++i) {
+            const float send = up ? v[i] : v[i + s];
+            const float keep = up ? v[i + s] : v[i];
+            v[i] = keep + __shfl_xor(send, s);
+        }
+    }
+    return v[0];
+}
+
+struct NetAct {
+    float h1, h2, h3;          // post-ReLU activations of this lane's channel (h2, h3: lanes < 32, else 0)
+};
+
+// pyro ConditionalDenseNN([context, x1]) of coupling c (65 -> 64 -> 32 -> 32 -> 62, ReLU): raw[lane], activations kept for the reverse sweep
+__device__ __forceinline__ float hypernet_fwd(const FlowDev& d, const PartTab& pt, int c, int lane, float ctx_lane, float x1, NetAct& A) {
+    const float* W = d.arena + pt.o_nnT[c][0];
+    float a = d.arena[pt.o_nnb[c][0] + lane];
+    for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(ctx_lane, k), a);
+    a = fmaf(W[64 * 64 + lane], x1, a);
+    A.h1 = fmaxf(a, 0.f);
+    W = d.arena + pt.o_nnT[c][1];
+    a = d.arena[pt.o_nnb[c][1] + lane];
+    for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h1, k), a);
+    A.h2 = lane < 32 ? fmaxf(a, 0.f) : 0.f;
+    W = d.arena + pt.o_nnT[c][2];
+    a = d.arena[pt.o_nnb[c][2] + lane];
+    for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h2, k), a);
+    A.h3 = lane < 32 ? fmaxf(a, 0.f) : 0.f;
+    W = d.arena + pt.o_nnT[c][3];
+    a = d.arena[pt.o_nnb[c][3] + lane];
+    for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h3, k), a);
+    return a;
+}
+
+struct NetDelta {
+    float d1, d2, d3, d4;      // pre-activation gradients of the four layers, this lane's channel
+};
+
+// reverse sweep of the hyper-network: g_raw (lane < 62) -> deltas, d L / d context (lane = context channel), d L / d x1 (wave-uniform)
+__device__ __forceinline__ void hypernet_bwd(const FlowDev& d, const PartTab& pt, int c, int lane, const NetAct& A, float g_raw, NetDelta& D,
+                                             float& g_ctx, float& g_x1) {
+    D.d4 = lane < 62 ? g_raw : 0.f;
+    {
+        const float* W = d.arena + pt.o_nnT[c][3];
+        float p[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) p[k] = W[k * 64 + lane] * D.d4;
+        const float g = xreduce<32>(p, lane);
+        D.d3 = (lane < 32 && A.h3 > 0.f) ? g : 0.f;
+    }
+    {
+        const float* W = d.arena + pt.o_nnT[c][2];
+        float p[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) p[k] = W[k * 64 + lane] * D.d3;
+        const float g = xreduce<32>(p, lane);
+        D.d2 = (lane < 32 && A.h2 > 0.f) ? g : 0.f;
+    }
+    {
+        const float* W = d.arena + pt.o_nnT[c][1];
+        float p[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) p[k] = W[k * 64 + lane] * D.d2;
+        const float g = xreduce<64>(p, lane);
+        D.d1 = A.h1 > 0.f ? g : 0.f;
+    }
+    {
+        const float* W = d.arena + pt.o_nnT[c][0];
+        float p[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) p[k] = W[k * 64 + lane] * D.d1;
+        g_ctx = xreduce<64>(p, lane);
+        g_x1 = wave_sum(W[64 * 64 + lane] * D.d1);
+    }
+}
+
+// spline parameters of dimension `dim` out of the 62-vector raw[lane]: (w 16 | h 16 | d 14 | l 16)
+__device__ __forceinline__ void gather_raw(float raw, int dim, float (&rw)[8], float (&rh)[8], float (&rd)[7], float (&rl)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        rw[i] = __shfl(raw, dim * 8 + i);
+        rh[i] = __shfl(raw, 16 + dim * 8 + i);
+        rl[i] = __shfl(raw, 46 + dim * 8 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) rd[i] = __shfl(raw, 32 + dim * 7 + i);
+}
+
+// inverse of gather_raw for gradients: lanes 0 and 1 hold dimension 0 / 1's SplineGrad; returns d L / d raw[lane]
+__device__ __forceinline__ float scatter_raw_grad(const SplineGrad& S, int lane) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = __shfl(S.g_rw[i], q), b = __shfl(S.g_rh[i], q), c = __shfl(S.g_rl[i], q);
+            g = (lane == q * 8 + i) ? a : g;
+            g = (lane == 16 + q * 8 + i) ? b : g;
+            g = (lane == 46 + q * 8 + i) ? c : g;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const float a = __shfl(S.g_rd[i], q);
+            g = (lane == 32 + q * 7 + i) ? a : g;
+        }
+    }
+    return g;
+}
+
+// Per-(part, row) records for the host-side weight-gradient GEMMs.  R = rows per part; every array is [P][...][R][width].
+struct GradRec {
+    float* D1;      // [P][2][R][64]   delta of hyper-net layer 1, coupling c
+    float* D2;      // [P][2][R][32]
+    float* D3;      // [P][2][R][32]
+    float* D4;      // [P][2][R][64]   (62 valid)
+    float* A1;      // [P][2][R][64]   ReLU output of layer 1 (input of layer 2)
+    float* A2;      // [P][2][R][32]
+    float* A3;      // [P][2][R][32]
+    float* XIN;     // [P][2][R]       scalar input x1 of the hyper-network
+    float* ACTX;    // [P][R][64]      context vector (input of layer 1, both couplings)
+    float* DCTX;    // [P][R][64]      delta of the context layer (sampling path only, else NULL)
+    int R;
+};
+
+__device__ __forceinline__ void store_net(const GradRec& G, int p, int c, int r, int lane, const NetDelta& D, const NetAct& A, float x1) {
+    const size_t pc = (size_t)(p * 2 + c) * G.R + r;
+    G.D1[pc * 64 + lane] = D.d1;
+    G.D4[pc * 64 + lane] = D.d4;
+    G.A1[pc * 64 + lane] = A.h1;
+    if (lane < 32) {
+        G.D2[pc * 32 + lane] = D.d2;
+        G.D3[pc * 32 + lane] = D.d3;
+        G.A2[pc * 32 + lane] = A.h2;
+        G.A3[pc * 32 + lane] = A.h3;
+    }
+    if (lane == 0) G.XIN[pc] = x1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// log p(v | ctx) on the algebra with its reverse sweep (mirrors log_prob_so3 of flow_kernels.hip).
+// g: upstream gradient of this term (wave-uniform).  do_bwd = false: value only.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float algebra_logprob(const FlowDev& d, const PartTab& pt, int lane, float ctx_lane, const float (&v)[3], bool do_bwd,
+                                                 float g, float& g_ctx_acc, const GradRec& G, int p, int row) {
+    const float r = d.radius;
+    float x[3] = {v[0], v[1], v[2]};
+    {
+        const double yd[3] = {(double)v[0], (double)v[1], (double)v[2]};
+        const double n = sqrt(yd[0] * yd[0] + yd[1] * yd[1] + yd[2] * yd[2]);
+        if (n > 1e-7) {
+            const double s = atanh(n / (double)r);
+            x[0] = (float)(s * (yd[0] / n) * (double)r); x[1] = (float)(s * (yd[1] / n) * (double)r); x[2] = (float)(s * (yd[2] / n) * (double)r);
+        }
+    }
+    const float yn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float xn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    float lp = 0.f;
+    if (yn > 1e-7f) lp = -(2.f * (logf(yn) - logf(xn)) + log1pf(-((yn / r) * (yn / r))));
+    const int dim = lane & 1;
+    // coupling 1 inverse: hyper-net on (ctx, x0); dims (x1, x2) -> (a, b)
+    NetAct A1;
+    const float raw1 = hypernet_fwd(d, pt, 1, lane, ctx_lane, x[0], A1);
+    float w1[8], h1[8], d1[7], l1[8];
+    gather_raw(raw1, dim, w1, h1, d1, l1);
+    const float in1 = dim ? x[2] : x[1];
+    float ld1;
+    const float o1 = rational_linear_spline<true>(in1, w1, h1, d1, l1, r, &ld1);
+    const float a = __shfl(o1, 0), b = __shfl(o1, 1);
+    lp += __shfl(ld1, 0) + __shfl(ld1, 1);
+    // Permute([1,2,0]) inverse: u = (b, x0, a); coupling 0 inverse: hyper-net on (ctx, u0); dims (u1, u2) -> (z1, z2)
+    const float u0 = b, u1 = x[0], u2 = a;
+    NetAct A0;
+    const float raw0 = hypernet_fwd(d, pt, 0, lane, ctx_lane, u0, A0);
+    float w0[8], h0[8], d0[7], l0[8];
+    gather_raw(raw0, dim, w0, h0, d0, l0);
+    const float in0 = dim ? u2 : u1;
+    float ld0;
+    const float o0 = rational_linear_spline<true>(in0, w0, h0, d0, l0, r, &ld0);
+    const float z1 = __shfl(o0, 0), z2 = __shfl(o0, 1);
+    lp += __shfl(ld0, 0) + __shfl(ld0, 1);
+    const float var = d.base_std * d.base_std, lsc = logf(d.base_std), hl2pi = 0.91893853320467274178f;
+    lp += -(u0 * u0 + z1 * z1 + z2 * z2) / (2.f * var) - 3.f * (lsc + hl2pi);
+    if (!do_bwd) return lp;
+    // ---- reverse sweep ----
+    const float g_z0 = -g * u0 / var, g_z1 = -g * z1 / var, g_z2 = -g * z2 / var;
+    SplineGrad S0;
+    float t0, t1;
+    spline_vjp<true>(in0, w0, h0, d0, l0, r, dim ? g_z2 : g_z1, g, t0, t1, S0);
+    NetDelta D0;
+    float g_ctx0, g_x1_0;
+    hypernet_bwd(d, pt, 0, lane, A0, scatter_raw_grad(S0, lane), D0, g_ctx0, g_x1_0);
+    const float g_u0 = g_z0 + g_x1_0;
+    const float g_u2 = __shfl(S0.g_x, 1);                       // u2 is the input of dimension 1 of spline 0
+    SplineGrad S1;
+    spline_vjp<true>(in1, w1, h1, d1, l1, r, dim ? g_u0 : g_u2, g, t0, t1, S1);     // a = out of dim 0 -> u2; b = out of dim 1 -> u0
+    NetDelta D1;
+    float g_ctx1, g_x1_1;
+    hypernet_bwd(d, pt, 1, lane, A1, scatter_raw_grad(S1, lane), D1, g_ctx1, g_x1_1);
+    g_ctx_acc += g_ctx0 + g_ctx1;
+    store_net(G, p, 0, row, lane, D0, A0, u0);
+    store_net(G, p, 1, row, lane, D1, A1, x[0]);
+    return lp;
+}
+
+// Teacher-forced NLL, reverse sweep.  Records: R = 3 * B rows per part, row = term * B + b (terms of out-of-support pre-images: zeros).
+__global__ __launch_bounds__(256) void k_flow_logprob_bwd(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids, int P,
+                                                          const double* __restrict__ Rin, int B, const float* __restrict__ g_logp,
+                                                          float* __restrict__ g_ctx, GradRec G) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= B * P) return;
+    const int b = gw / P, p = gw % P;
+    const int j = part_ids ? part_ids[p] : p;
+    const PartTab& pt = d.tab[j];
+    const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
+    double R[9], x[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = Rin[(size_t)gw * 9 + e];
+    so3_log_f64(R, x);
+    const double kTwoPi = 6.28318530717958647692;
+    const double n = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    float cand[3][3], terms[3], ldexp[3];
+    bool ok[3];
+    float dummy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double cd[3] = {x[0], x[1], x[2]};
+        ok[c] = true;
+        if (c > 0) {
+            const double k = c == 1 ? -1.0 : 1.0;
+            const double sc = (n + kTwoPi * k);
+            cd[0] = x[0] / n * sc; cd[1] = x[1] / n * sc; cd[2] = x[2] / n * sc;
+            const double cn = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
+            ok[c] = cn < (double)d.radius;
+            if (!ok[c]) { cd[0] = 0.0; cd[1] = 0.0; cd[2] = 0.0; }
+        }
+        ldexp[c] = -(float)so3_logdet_f64(cd);
+        cand[c][0] = (float)cd[0]; cand[c][1] = (float)cd[1]; cand[c][2] = (float)cd[2];
+        const float lp = ok[c] ? algebra_logprob(d, pt, lane, ctx_lane, cand[c], false, 0.f, dummy, G, p, 0) : 0.f;
+        terms[c] = ok[c] ? (ldexp[c] + lp) : -INFINITY;
+    }
+    const float m = fmaxf(terms[0], fmaxf(terms[1], terms[2]));
+    const float s = expf(terms[0] - m) + expf(terms[1] - m) + expf(terms[2] - m);
+    const float gup = g_logp[gw];
+    float g_acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int row = c * B + b;
+        if (ok[c]) {
+            const float wgt = expf(terms[c] - m) / s;                 // d logsumexp / d term_c
+            algebra_logprob(d, pt, lane, ctx_lane, cand[c], true, gup * wgt, g_acc, G, p, row);
+        } else {                                                      // masked pre-image: no contribution
+            NetDelta Z = {0.f, 0.f, 0.f, 0.f};
+            NetAct ZA = {0.f, 0.f, 0.f};
+            store_net(G, p, 0, row, lane, Z, ZA, 0.f);
+            store_net(G, p, 1, row, lane, Z, ZA, 0.f);
+        }
+        G.ACTX[((size_t)p * G.R + row) * 64 + lane] = ctx_lane;
+    }
+    g_ctx[(size_t)gw * kCtx + lane] = g_acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sampling path, reverse sweep of one round of the kinematic schedule.  Launched for rounds nlev-1 .. 0 on one stream:
+// when part j runs, g_rot[row][j] already holds the loss gradient plus every descendant's contribution.
+// rows = B*N sample rows (point-estimate rows carry no gradient: torch.set_grad_enabled(grad_for_pose_point_est), :294).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_chain_bwd(FlowDev d, int lev, const float* __restrict__ H, const float* __restrict__ rot,
+                                                        const float* __restrict__ eps, int B, int N, float* __restrict__ g_rot, GradRec G) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = B * N;
+    const int nparts = d.lev.start[lev + 1] - d.lev.start[lev];
+    if (gw >= rows * nparts) return;
+    const int row = gw / nparts;
+    const int j = d.lev.parts[d.lev.start[lev] + gw % nparts];
+    const PartTab& pt = d.tab[j];
+    const float bound = d.radius;
+    // ---- forward recompute: context layer (models/humaniflow_model.py:152-186) ----
+    const float* WT = d.arena + pt.o_wctxT;
+    float pre = d.arena[pt.o_bctx + lane];
+    {
+        const float* h = H + (size_t)row * kIsgc;
+        for (int k = 0; k < kIsgc; ++k) pre = fmaf(WT[(size_t)k * kCtx + lane], h[k], pre);
+        for (int a = 0; a < pt.n_anc; ++a) {
+            const float* ra = rot + ((size_t)row * kP + pt.anc[a]) * 9;
+            for (int e = 0; e < 9; ++e) pre = fmaf(WT[(size_t)(kIsgc + a * 9 + e) * kCtx + lane], ra[e], pre);
+        }
+    }
+    const float ctx = elu1(pre);
+    const int bi = row / N, ni = row - bi * N;
+    const float* e3 = eps + (((size_t)j * B + bi) * N + ni) * 3;
+    const float z0 = e3[0] * d.base_std, z1 = e3[1] * d.base_std, z2 = e3[2] * d.base_std;
+    const int dim = lane & 1;
+    // coupling 0 (Permute [0,1,2]): z0 passes, (z1, z2) -> (x1n, x2n)
+    NetAct A0;
+    const float raw0 = hypernet_fwd(d, pt, 0, lane, ctx, z0, A0);
+    float w0[8], h0[8], d0[7], l0[8];
+    gather_raw(raw0, dim, w0, h0, d0, l0);
+    const float in0 = dim ? z2 : z1;
+    const float o0 = rational_linear_spline<false>(in0, w0, h0, d0, l0, bound, nullptr);
+    const float x1n = __shfl(o0, 0), x2n = __shfl(o0, 1);
+    // coupling 1 (Permute [1,2,0]): y = (x1n, x2n, z0); y0 passes, (y1, y2) -> (y1', y2')
+    NetAct A1;
+    const float raw1 = hypernet_fwd(d, pt, 1, lane, ctx, x1n, A1);
+    float w1[8], h1[8], d1[7], l1[8];
+    gather_raw(raw1, dim, w1, h1, d1, l1);
+    const float in1 = dim ? z0 : x2n;
+    const float o1 = rational_linear_spline<false>(in1, w1, h1, d1, l1, bound, nullptr);
+    const float y1 = __shfl(o1, 0), y2 = __shfl(o1, 1);
+    // ---- reverse: exp map (fp64), radial tanh ----
+    float gv[3] = {0.f, 0.f, 0.f};          // d L / d v, v = scaled radial tanh of (x1n, y1, y2)
+    float gpre[3];
+    {
+        typedef DualT<float, 3> D3;
+        const D3 a0 = dvar<float, 3>(x1n, 0), a1 = dvar<float, 3>(y1, 1), a2 = dvar<float, 3>(y2, 2);
+        D3 v[3] = {a0, a1, a2};
+        const float nrm = sqrtf(x1n * x1n + y1 * y1 + y2 * y2);
+        if (nrm > 1e-7f) {                                         // scaled_radial_tanh_transform.py:28-35
+            const D3 nd = dsqrt(a0 * a0 + a1 * a1 + a2 * a2);
+            const D3 q = nd * (1.f / bound);
+            D3 th;                                                 // tanh(q)
+            th.v = tanhf(q.v);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) th.d[i] = (1.f - th.v * th.v) * q.d[i];
+            const D3 sc = th * bound / nd;
+            v[0] = sc * a0; v[1] = sc * a1; v[2] = sc * a2;
+        }
+        // R = so3_exp(v) in fp64 (utils/rigid_transform_utils.py:182-201), dual numbers over v
+        typedef DualT<double, 3> E3;
+        const E3 vd[3] = {dvar<double, 3>((double)v[0].v, 0), dvar<double, 3>((double)v[1].v, 1), dvar<double, 3>((double)v[2].v, 2)};
+        const double th0 = sqrt(vd[0].v * vd[0].v + vd[1].v * vd[1].v + vd[2].v * vd[2].v);
+        E3 alpha, beta;
+        if (th0 > 1e-10) {
+            const E3 t = dsqrt(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+            double s, c;
+            sincos(t.v, &s, &c);
+            E3 sn, cs;
+            sn.v = s; cs.v = c;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { sn.d[i] = c * t.d[i]; cs.d[i] = -s * t.d[i]; }
+            alpha = sn / t;
+            beta = (1.0 - cs) / (t * t);
+        } else {                                                   // quirk 1: Taylor branch evaluated at theta = 1, constants
+            alpha = dconst<double, 3>(1.0 - 1.0 / 6.0);
+            beta = dconst<double, 3>(0.5 - 1.0 / 24.0);
+        }
+        const E3 zero = dconst<double, 3>(0.0);
+        const E3 X[9] = {zero, 0.0 - vd[2], vd[1], vd[2], zero, 0.0 - vd[0], 0.0 - vd[1], vd[0], zero};
+        double gvd[3] = {0.0, 0.0, 0.0};
+        const float* gr = g_rot + ((size_t)row * kP + j) * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                E3 acc = (beta * X[i * 3 + 0]) * X[0 * 3 + k] + (beta * X[i * 3 + 1]) * X[1 * 3 + k] + (beta * X[i * 3 + 2]) * X[2 * 3 + k];
+                const E3 Rik = alpha * X[i * 3 + k] + acc;          // + identity: constant
+                const double gg = (double)gr[i * 3 + k];
+                gvd[0] += gg * Rik.d[0]; gvd[1] += gg * Rik.d[1]; gvd[2] += gg * Rik.d[2];
+            }
+        gv[0] = (float)gvd[0]; gv[1] = (float)gvd[1]; gv[2] = (float)gvd[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gpre[i] = gv[0] * v[0].d[i] + gv[1] * v[1].d[i] + gv[2] * v[2].d[i];
+    }
+    // ---- reverse: coupling 1, coupling 0 ----
+    SplineGrad S1;
+    float t0, t1;
+    spline_vjp<false>(in1, w1, h1, d1, l1, bound, dim ? gpre[2] : gpre[1], 0.f, t0, t1, S1);
+    const float g_x2n = __shfl(S1.g_x, 0);                         // x2n is the input of dimension 0 of spline 1
+    NetDelta D1;
+    float g_ctx1, g_y0;
+    hypernet_bwd(d, pt, 1, lane, A1, scatter_raw_grad(S1, lane), D1, g_ctx1, g_y0);
+    const float g_x1n = gpre[0] + g_y0;
+    SplineGrad S0;
+    spline_vjp<false>(in0, w0, h0, d0, l0, bound, dim ? g_x2n : g_x1n, 0.f, t0, t1, S0);
+    NetDelta D0;
+    float g_ctx0, g_z0;
+    hypernet_bwd(d, pt, 0, lane, A0, scatter_raw_grad(S0, lane), D0, g_ctx0, g_z0);
+    const float dctx = (g_ctx0 + g_ctx1) * (pre > 0.f ? 1.f : ctx + 1.f);          // ELU'
+    // ---- ancestors: d L / d R_anc += W_ctx[:, 256 + k]^T . delta ----
+    {
+        float p[64];
+        const int ka = 9 * pt.n_anc;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) p[k] = k < ka ? WT[(size_t)(kIsgc + k) * kCtx + lane] * dctx : 0.f;
+        const float ga = xreduce<64>(p, lane);
+        if (lane < ka) atomicAdd(g_rot + ((size_t)row * kP + pt.anc[lane / 9]) * 9 + lane % 9, ga);
+    }
+    store_net(G, j, 0, row, lane, D0, A0, z0);
+    store_net(G, j, 1, row, lane, D1, A1, x1n);
+    G.ACTX[((size_t)j * G.R + row) * 64 + lane] = ctx;
+    G.DCTX[((size_t)j * G.R + row) * 64 + lane] = dctx;
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+extern "C" {
+
+static int rec_from(const hmf_flow_grad_records_t* r, GradRec& G, bool need_dctx) {
+    if (!r || !r->D1 || !r->D2 || !r->D3 || !r->D4 || !r->A1 || !r->A2 || !r->A3 || !r->XIN || !r->ACTX || r->rows <= 0 || (need_dctx && !r->DCTX))
+        return fail(HMF_ERR_INVALID, "hmf_flow_*_backward: incomplete gradient-record struct");
+    G.D1 = r->D1; G.D2 = r->D2; G.D3 = r->D3; G.D4 = r->D4; G.A1 = r->A1; G.A2 = r->A2; G.A3 = r->A3; G.XIN = r->XIN; G.ACTX = r->ACTX; G.DCTX = r->DCTX;
+    G.R = r->rows;
+    return HMF_OK;
+}
+
+int hmf_flow_log_prob_SO3_backward(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const double* R, int B,
+                                   const float* g_logp, float* g_ctx, const hmf_flow_grad_records_t* rec, void* stream) {
+    if (!h || !ctx || !R || !g_logp || !g_ctx || B <= 0 || P <= 0 || P > kP) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_SO3_backward: bad args");
+    if (!part_ids_host && P != kP) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_SO3_backward: part_ids NULL requires P == 23");
+    const int* dev_ids = nullptr;
+    if (part_ids_host) {
+        for (int i = 0; i < P; ++i)
+            if (part_ids_host[i] < 0 || part_ids_host[i] >= kP || part_ids_host[i] != part_ids_host[0] + i)
+                return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_log_prob_SO3_backward: part ids must be a contiguous ascending range inside [0, 23)");
+        dev_ids = h->d_ids + part_ids_host[0];
+    }
+    GradRec G;
+    int rc = rec_from(rec, G, false);
+    if (rc) return rc;
+    if (G.R != 3 * B) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_SO3_backward: records need rows == 3 * B");
+    const int nw = B * P;
+    hipLaunchKernelGGL(k_flow_logprob_bwd, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, B, g_logp, g_ctx, G);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const float* rotmats_samples, const float* eps_pose, int B, int N,
+                             float* g_rotmats, const hmf_flow_grad_records_t* rec, void* stream) {
+    if (!h || !isgc_rows || !rotmats_samples || !eps_pose || !g_rotmats || B <= 0 || N <= 0)
+        return fail(HMF_ERR_INVALID, "hmf_flow_sample_backward: bad args");
+    GradRec G;
+    int rc = rec_from(rec, G, true);
+    if (rc) return rc;
+    if (G.R != B * N) return fail(HMF_ERR_INVALID, "hmf_flow_sample_backward: records need rows == B * N");
+    for (int lev = h->d.lev.nlev - 1; lev >= 0; --lev) {
+        const int nw = B * N * (h->d.lev.start[lev + 1] - h->d.lev.start[lev]);
+        hipLaunchKernelGGL(k_flow_chain_bwd, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, lev, isgc_rows, rotmats_samples, eps_pose, B, N,
+                           g_rotmats, G);
+        HMF_LAUNCH_CHECK();
+    }
+    return HMF_OK;
+}
+
+}  // extern "C"

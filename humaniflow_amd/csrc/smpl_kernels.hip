@@ -10,6 +10,7 @@
 //   3. k_joints        21 vertex picks + 45 sparse regressed joints gathered from the written vertices
 // Data layout and roofline: DESIGN.md "hmf_smpl_lbs".
 #include <vector>
+#include <utility>
 #include <cmath>
 #include "hmf_common.h"
 
@@ -41,7 +42,14 @@ struct SmplDev {
     float* tp_dirs;                  // [nb][3V]
     float* tp_tmpl;                  // [3V]
     unsigned short* blend16;         // bf16 operand of the configs[2] variant: [kVT][kKG16][3][64 lanes][8]
+    // vertex-major transpose of the gathered-joint CSR (backward of joints 24..89): unique vertices and, per vertex, (output joint, weight)
+    int n_ju;
+    int* ju_vid;                     // [n_ju]
+    int* ju_ptr;                     // [n_ju + 1]
+    int* ju_out;                     // output joint index 0..65 (joint 24 + i)
+    float* ju_w;
 };
+constexpr int kMaxJU = 320;          // >= 21 picks + 255 regressor non-zeros of the reference's tables
 
 }  // namespace hmf
 
@@ -613,6 +621,147 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Backward of the 90 output joints w.r.t. (global_orient, body_pose, betas) -- what the 2D reprojection loss of the training step needs
+// (losses/humaniflow_loss.py:44-60 on joints[:, ALL_JOINTS_TO_COCO_MAP]; train/train_humaniflow.py:283-318).  One work-group per row:
+// rest joints and the 24-joint chain are recomputed, the <= 276 vertices that the gathered joints touch are pushed back through the
+// skinning blend, the pose/shape blend-shapes (sparse rows of the packed operand) and the chain.  Vertex gradients are not built
+// (LOSS.APPLY_POINT_EST_LOSS = False in the reference configuration).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_smpl_joints_bwd(SmplDev d, const float* __restrict__ glob, const float* __restrict__ body,
+                                                         const float* __restrict__ betas, int M, const float* __restrict__ g_joints,
+                                                         float* __restrict__ g_glob, float* __restrict__ g_body, float* __restrict__ g_betas) {
+    __shared__ float sR[kJ][9], sJ[kJ][3], sG[kJ][12], sA[kJ][12], s_gA[kJ][12], s_gG[kJ][12], s_gJ[kJ][3], s_gR[kJ][9];
+    __shared__ float s_gj[kOutJ][3], s_feat[kKpad], s_gfeat[kKpad], s_gvp[kMaxJU][3];
+    const int tid = threadIdx.x, row = blockIdx.x, nb = d.num_betas;
+    const float* beta = betas + (size_t)row * nb;
+    for (int i = tid; i < kJ * 9; i += 256) {
+        const int j = i / 9, e = i % 9;
+        sR[j][e] = j == 0 ? glob[(size_t)row * 9 + e] : body[((size_t)row * 23 + (j - 1)) * 9 + e];
+    }
+    for (int i = tid; i < kOutJ * 3; i += 256) s_gj[i / 3][i % 3] = g_joints[(size_t)row * kOutJ * 3 + i];
+    for (int i = tid; i < kJ * 12; i += 256) { s_gA[i / 12][i % 12] = 0.f; s_gG[i / 12][i % 12] = 0.f; }
+    for (int i = tid; i < kJ * 3; i += 256) {
+        const int j = i / 3, c = i % 3;
+        float acc = d.j_template[j * 3 + c];
+        for (int k = 0; k < nb; ++k) acc = fmaf(d.j_dirs[(j * 3 + c) * nb + k], beta[k], acc);
+        sJ[j][c] = acc;
+        s_gJ[j][c] = 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < kKpad; k += 256) { s_feat[k] = pose_feature(k, nb, &sR[1][0], beta); s_gfeat[k] = 0.f; }
+    if (tid == 0) {                                     // smplx batch_rigid_transform, sequential over the 24 joints
+        for (int j = 0; j < kJ; ++j) {
+            const int par = d.parents[j];
+            float rel[3] = {sJ[j][0], sJ[j][1], sJ[j][2]};
+            if (j > 0) { rel[0] -= sJ[par][0]; rel[1] -= sJ[par][1]; rel[2] -= sJ[par][2]; }
+            for (int i = 0; i < 3; ++i) {
+                if (j == 0) {
+                    for (int c = 0; c < 3; ++c) sG[0][i * 4 + c] = sR[0][i * 3 + c];
+                    sG[0][i * 4 + 3] = rel[i];
+                } else {
+                    for (int c = 0; c < 3; ++c)
+                        sG[j][i * 4 + c] = sG[par][i * 4 + 0] * sR[j][0 * 3 + c] + sG[par][i * 4 + 1] * sR[j][1 * 3 + c] + sG[par][i * 4 + 2] * sR[j][2 * 3 + c];
+                    sG[j][i * 4 + 3] = sG[par][i * 4 + 0] * rel[0] + sG[par][i * 4 + 1] * rel[1] + sG[par][i * 4 + 2] * rel[2] + sG[par][i * 4 + 3];
+                }
+            }
+            for (int i = 0; i < 3; ++i) {
+                for (int c = 0; c < 3; ++c) sA[j][i * 4 + c] = sG[j][i * 4 + c];
+                sA[j][i * 4 + 3] = sG[j][i * 4 + 3] - (sG[j][i * 4 + 0] * sJ[j][0] + sG[j][i * 4 + 1] * sJ[j][1] + sG[j][i * 4 + 2] * sJ[j][2]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the vertices the gathered joints read: joint gradient -> vertex gradient -> skinning blend / posed-vertex gradients ----
+    const int kdata = kPoseFeat + nb + 1;
+    for (int u = tid; u < d.n_ju; u += 256) {
+        float gv[3] = {0.f, 0.f, 0.f};
+        for (int e = d.ju_ptr[u]; e < d.ju_ptr[u + 1]; ++e) {
+            const float w = d.ju_w[e];
+            const float* gj = s_gj[kJ + d.ju_out[e]];
+            gv[0] = fmaf(w, gj[0], gv[0]); gv[1] = fmaf(w, gj[1], gv[1]); gv[2] = fmaf(w, gj[2], gv[2]);
+        }
+        const int v = d.ju_vid[u], vt = v >> 5, l31 = v & 31;
+        float vp[4] = {0.f, 0.f, 0.f, 1.f};
+        for (int k = 0; k < kdata; ++k) {
+            const float a = s_feat[k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vp[c] = fmaf(a, d.blend[blend_index(k, v, c)], vp[c]);
+        }
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = 0.f;
+        for (int s = 0; s < d.skin_slots; ++s) {
+            const int jn = d.skin_off[((size_t)vt * d.skin_slots + s) * 32 + l31] / 48;
+            const float w = d.skin_w[((size_t)vt * d.skin_slots + s) * 32 + l31];
+            if (w != 0.f) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    T[i] = fmaf(w, sA[jn][i], T[i]);
+                    atomicAdd(&s_gA[jn][i], w * gv[i >> 2] * vp[i & 3]);        // d L / d A_j = w * gv (x) [v_posed; 1]
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_gvp[u][c] = T[0 * 4 + c] * gv[0] + T[1 * 4 + c] * gv[1] + T[2 * 4 + c] * gv[2];
+    }
+    __syncthreads();
+    for (int k = tid; k < kPoseFeat + nb; k += 256) {     // blend-shape rows of the touched vertices: d L / d pose feature, d L / d beta
+        float acc = 0.f;
+        for (int u = 0; u < d.n_ju; ++u) {
+            const int v = d.ju_vid[u];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc = fmaf(d.blend[blend_index(k, v, c)], s_gvp[u][c], acc);
+        }
+        s_gfeat[k] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {                                     // reverse of the chain
+        for (int j = 0; j < kJ; ++j) {
+            // A_R = G_R, A_t = G_t - G_R J;  posed joint j = G_t
+            for (int i = 0; i < 3; ++i) {
+                const float gat = s_gA[j][i * 4 + 3];
+                for (int c = 0; c < 3; ++c) {
+                    s_gG[j][i * 4 + c] = s_gA[j][i * 4 + c] - gat * sJ[j][c];
+                    s_gJ[j][c] -= sG[j][i * 4 + c] * gat;
+                }
+                s_gG[j][i * 4 + 3] = gat + s_gj[j][i];
+            }
+        }
+        for (int j = kJ - 1; j >= 1; --j) {
+            const int par = d.parents[j];
+            const float rel[3] = {sJ[j][0] - sJ[par][0], sJ[j][1] - sJ[par][1], sJ[j][2] - sJ[par][2]};
+            for (int a = 0; a < 3; ++a)                 // g_R_j = G_R_par^T g_G_R_j
+                for (int c = 0; c < 3; ++c)
+                    s_gR[j][a * 3 + c] = sG[par][0 * 4 + a] * s_gG[j][0 * 4 + c] + sG[par][1 * 4 + a] * s_gG[j][1 * 4 + c] + sG[par][2 * 4 + a] * s_gG[j][2 * 4 + c];
+            for (int a = 0; a < 3; ++a) {               // g_rel = G_R_par^T g_G_t_j
+                const float gr = sG[par][0 * 4 + a] * s_gG[j][0 * 4 + 3] + sG[par][1 * 4 + a] * s_gG[j][1 * 4 + 3] + sG[par][2 * 4 + a] * s_gG[j][2 * 4 + 3];
+                s_gJ[j][a] += gr;
+                s_gJ[par][a] -= gr;
+            }
+            for (int i = 0; i < 3; ++i) {               // g_G_R_par += g_G_R_j R_j^T + g_G_t_j (x) rel;  g_G_t_par += g_G_t_j
+                for (int a = 0; a < 3; ++a)
+                    s_gG[par][i * 4 + a] += s_gG[j][i * 4 + 0] * sR[j][a * 3 + 0] + s_gG[j][i * 4 + 1] * sR[j][a * 3 + 1] + s_gG[j][i * 4 + 2] * sR[j][a * 3 + 2]
+                                            + s_gG[j][i * 4 + 3] * rel[a];
+                s_gG[par][i * 4 + 3] += s_gG[j][i * 4 + 3];
+            }
+        }
+        for (int i = 0; i < 3; ++i) {
+            for (int c = 0; c < 3; ++c) s_gR[0][i * 3 + c] = s_gG[0][i * 4 + c];
+            s_gJ[0][i] += s_gG[0][i * 4 + 3];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9; i += 256) g_glob[(size_t)row * 9 + i] = s_gR[0][i];
+    for (int i = tid; i < kPoseFeat; i += 256) g_body[(size_t)row * kPoseFeat + i] = s_gR[1 + i / 9][i % 9] + s_gfeat[i];
+    for (int k = tid; k < nb; k += 256) {
+        float acc = s_gfeat[kPoseFeat + k];
+        for (int j = 0; j < kJ; ++j)
+            for (int c = 0; c < 3; ++c) acc = fmaf(s_gJ[j][c], d.j_dirs[(j * 3 + c) * nb + k], acc);
+        g_betas[(size_t)row * nb + k] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side packing
 // ---------------------------------------------------------------------------------------------------
 static int validate(const hmf_smpl_host_t* m) {
@@ -729,6 +878,23 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
         }
         ptr.push_back((int)idx.size());
     }
+    // --- vertex-major transpose of that CSR (joints backward) ------------------------------------------
+    std::vector<int> ju_vid, ju_ptr(1, 0), ju_out;
+    std::vector<float> ju_w;
+    {
+        std::vector<int> slot(kV, -1);
+        std::vector<std::vector<std::pair<int, float>>> per;
+        for (int i = 0; i < 66; ++i)
+            for (int e = ptr[i]; e < ptr[i + 1]; ++e) {
+                if (slot[idx[e]] < 0) { slot[idx[e]] = (int)ju_vid.size(); ju_vid.push_back(idx[e]); per.emplace_back(); }
+                per[slot[idx[e]]].push_back({i, wts[e]});
+            }
+        for (auto& l : per) {
+            for (auto& pr : l) { ju_out.push_back(pr.first); ju_w.push_back(pr.second); }
+            ju_ptr.push_back((int)ju_out.size());
+        }
+        if ((int)ju_vid.size() > kMaxJU) return fail(HMF_ERR_UNSUPPORTED, "hmf_smpl_create: %zu vertices feed the gathered joints (> %d)", ju_vid.size(), kMaxJU);
+    }
     // --- T-pose basis [nb][3V] -----------------------------------------------------------------------
     std::vector<float> tpd((size_t)nb * kV * 3);
     for (int v = 0; v < kV; ++v)
@@ -746,6 +912,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     const size_t o_jt = place(jt.size() * 4), o_jd = place(jd.size() * 4), o_ptr = place(ptr.size() * 4);
     const size_t o_idx = place(idx.size() * 4), o_w = place(wts.size() * 4), o_tpd = place(tpd.size() * 4);
     const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2);
+    const size_t o_jv = place(ju_vid.size() * 4 + 4), o_jp = place(ju_ptr.size() * 4), o_jo = place(ju_out.size() * 4 + 4), o_jw = place(ju_w.size() * 4 + 4);
     void* arena = nullptr;
     HMF_HIP(hipMalloc(&arena, off));
     char* base = (char*)arena;
@@ -761,6 +928,10 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     if (e == hipSuccess) e = up(o_tpd, tpd.data(), tpd.size() * 4);
     if (e == hipSuccess) e = up(o_tpt, m->v_template_host, (size_t)kV * 3 * 4);
     if (e == hipSuccess) e = up(o_b16, blend16.data(), blend16.size() * 2);
+    if (e == hipSuccess && !ju_vid.empty()) e = up(o_jv, ju_vid.data(), ju_vid.size() * 4);
+    if (e == hipSuccess) e = up(o_jp, ju_ptr.data(), ju_ptr.size() * 4);
+    if (e == hipSuccess && !ju_out.empty()) e = up(o_jo, ju_out.data(), ju_out.size() * 4);
+    if (e == hipSuccess && !ju_w.empty()) e = up(o_jw, ju_w.data(), ju_w.size() * 4);
     if (e != hipSuccess) {
         (void)hipFree(arena);
         return fail(HMF_ERR_HIP, "hmf_smpl_create: upload failed: %s", hipGetErrorString(e));
@@ -787,6 +958,11 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     d.tp_dirs = (float*)(base + o_tpd);
     d.tp_tmpl = (float*)(base + o_tpt);
     d.blend16 = (unsigned short*)(base + o_b16);
+    d.n_ju = (int)ju_vid.size();
+    d.ju_vid = (int*)(base + o_jv);
+    d.ju_ptr = (int*)(base + o_jp);
+    d.ju_out = (int*)(base + o_jo);
+    d.ju_w = (float*)(base + o_jw);
     *out = h;
     return HMF_OK;
 }
@@ -886,6 +1062,17 @@ int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts,
         hipLaunchKernelGGL(k_joints, dim3((n + 255) / 256), dim3(256), 0, st, h->d, verts, M, joints);
         HMF_LAUNCH_CHECK();
     }
+    return HMF_OK;
+}
+
+int hmf_smpl_joints_backward(const hmf_smpl_t* h, const float* global_orient, const float* body_pose, const float* betas, int M,
+                             const float* g_joints, float* g_global_orient, float* g_body_pose, float* g_betas, void* stream) {
+    if (M == 0) return HMF_OK;
+    if (!h || !global_orient || !body_pose || !betas || !g_joints || !g_global_orient || !g_body_pose || !g_betas || M < 0)
+        return fail(HMF_ERR_INVALID, "hmf_smpl_joints_backward: bad args");
+    hipLaunchKernelGGL(k_smpl_joints_bwd, dim3(M), dim3(256), 0, (hipStream_t)stream, h->d, global_orient, body_pose, betas, M, g_joints,
+                       g_global_orient, g_body_pose, g_betas);
+    HMF_LAUNCH_CHECK();
     return HMF_OK;
 }
 

@@ -26,9 +26,27 @@ METRICS = ['PVE', 'PVE-SC', 'PVE-PA', 'PVE-T', 'PVE-T-SC', 'MPJPE', 'MPJPE-SC', 
 # not built: silhouette IOUs (need the pytorch3d renderer) and the input_joints2D / (in)visible-joint variants (need HRNet heat-maps)
 
 
+_INDEX_CACHE = {}
+
+
+def joint_index(name, device):
+    """Device-resident index tensors of the joint maps (built once per device: indexing with a Python list would upload the indices on
+    every call, which also cannot be captured into a HIP graph).  'h36m_j14' = ALL_JOINTS_TO_H36M_MAP then H36M_TO_J14, composed."""
+    key = (name, str(device))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        idx = {'coco': ALL_JOINTS_TO_COCO_MAP, 'h36m_j14': [ALL_JOINTS_TO_H36M_MAP[i] for i in H36M_TO_J14]}[name]
+        t = _INDEX_CACHE[key] = torch.tensor(idx, dtype=torch.long, device=device)
+    return t
+
+
+def select_joints(joints, name):
+    return joints.index_select(1, joint_index(name, joints.device))
+
+
 def orthographic_project_torch(points3D, cam_params):
     """utils/cam_utils.py:9-17: s * (xy + t)."""
-    return cam_params[:, None, [0]] * (points3D[:, :, :2] + cam_params[:, None, 1:])
+    return cam_params[:, None, 0:1] * (points3D[:, :, :2] + cam_params[:, None, 1:])
 
 
 def undo_keypoint_normalisation(normalised_keypoints, img_wh):
@@ -39,7 +57,7 @@ def undo_keypoint_normalisation(normalised_keypoints, img_wh):
 def flip_about_x(points):
     """aa_rotate_translate_points_pytorch3d(points, axes=[1,0,0], angles=pi, translations=0) (utils/rigid_transform_utils.py:67-83,
     call sites evaluate_humaniflow.py:141-143,197-203): a 180-degree rotation about x, i.e. (x, -y, -z)."""
-    return points * points.new_tensor([1.0, -1.0, -1.0])
+    return torch.stack([points[..., 0], -points[..., 1], -points[..., 2]], dim=-1)
 
 
 class EvalMetricsTracker:
@@ -255,15 +273,16 @@ def predict_batch(model, smpl, batch, num_samples, noise=None):
     else:
         pe = smpl(body_pose=pred['pose_rotmats_point_est'], global_orient=g[:, None], betas=pred['shape_mode'], pose2rot=False)
         tp_p = smpl.tpose(pred['shape_mode'])
-    out = {'verts3D': pe.vertices, 'joints3D': pe.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14],
-           'tpose_verts3D': tp_p, 'joints2D': proj(pe.joints[:, ALL_JOINTS_TO_COCO_MAP], pred['cam_wp'])}
+    out = {'verts3D': pe.vertices, 'joints3D': select_joints(pe.joints, 'h36m_j14'),
+           'tpose_verts3D': tp_p, 'joints2D': proj(select_joints(pe.joints, 'coco'), pred['cam_wp'])}
     if N > 0:
         out['verts3D_samples'] = sa.vertices.reshape(B, N, -1, 3)
-        out['joints3D_samples'] = sa.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14].reshape(B, N, 14, 3)
-        out['joints3D_coco_samples'] = sa.joints[:, ALL_JOINTS_TO_COCO_MAP].reshape(B, N, 17, 3)                            # :180-183
+        out['joints3D_samples'] = select_joints(sa.joints, 'h36m_j14').reshape(B, N, 14, 3)
+        jc = select_joints(sa.joints, 'coco')
+        out['joints3D_coco_samples'] = jc.reshape(B, N, 17, 3)                            # :180-183
         out['tpose_verts3D_samples'] = tp_s.reshape(B, N, -1, 3)                                                             # :186-192
         cam_s = pred['cam_wp'][:, None].expand(-1, N, -1).reshape(B * N, 3)
-        out['joints2Dsamples'] = proj(sa.joints[:, ALL_JOINTS_TO_COCO_MAP], cam_s).reshape(B, N, 17, 2)                      # :197-206
+        out['joints2Dsamples'] = proj(jc, cam_s).reshape(B, N, 17, 2)                      # :197-206
     return out
 
 
@@ -271,7 +290,7 @@ def predict_batch(model, smpl, batch, num_samples, noise=None):
 def target_batch(smpl, batch):
     """evaluate/evaluate_humaniflow.py:83-110 (single body model: the synthetic set has no gender split)."""
     t = smpl(body_pose=batch['pose'][:, 3:], global_orient=batch['pose'][:, :3], betas=batch['shape'])
-    out = {'verts3D': t.vertices, 'joints3D': t.joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14],
+    out = {'verts3D': t.vertices, 'joints3D': select_joints(t.joints, 'h36m_j14'),
            'tpose_verts3D': smpl.tpose(batch['shape'])}
     if 'joints2D' in batch:
         out['joints2D'] = batch['joints2D']

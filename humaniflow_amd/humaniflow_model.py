@@ -13,6 +13,9 @@ fc_input_shape_glob_cam_feats, fc_flow_context.{0..22}, pose_so3flow_transform_m
 
 Only the default flow configuration is built (spline_coupling + permute, hidden [64,32,32], 8 bins); other
 TRANSFORM_TYPE / PERMUTE_TYPE values raise NotImplementedError at construction.
+
+Training (BASELINE configs[4]): forward under autograd returns differentiable samples / log-likelihood objects; the backward
+passes of the flow live in csrc/flow_grad.hip and are wired up in autograd.py.
 """
 import ctypes as C
 from collections import defaultdict
@@ -68,30 +71,26 @@ class ConditionalSplineCoupling(nn.Module):
 class _ConditionedFlowDist:
     """What `.condition(ctx)` returns in the reference: an object exposing log_prob().  group=True mirrors
     LocalDiffeoTransformedDistribution (R (B,3,3) fp64 -> (B,) fp32, local_diffeo_transformed_distribution.py:84-142),
-    group=False the algebra density (v (B,3) fp32)."""
+    group=False the algebra density (v (B,3) fp32).  log_prob on the group is differentiable w.r.t. the context and the
+    hyper-network weights (training, losses/humaniflow_loss.py:30-31).  `parent` = (ctx_all (B,23,64), part): lets a loss that
+    receives the whole list evaluate all 23 densities in one launch (humaniflow_amd.losses)."""
 
-    def __init__(self, model, part, ctx, group, check_finite=False):
-        self.model, self.part, self.ctx, self.group, self.check_finite = model, part, ctx, group, check_finite
+    def __init__(self, model, part, ctx, group, check_finite=False, parent=None):
+        self.model, self.part, self.ctx, self.group, self.check_finite, self.parent = model, part, ctx, group, check_finite, parent
 
     def log_prob(self, value):
         m = self.model
         _lib.require_cuda(value, 'value')
-        lib = _lib.load()
         B = self.ctx.shape[0]
-        ids = (C.c_int32 * 1)(self.part)
-        out = torch.empty(B, dtype=torch.float32, device=value.device)
         if self.check_finite:                      # the reference's NaN/Inf asserts (:94-95), opt-in: they force a sync
             assert torch.isnan(value).sum() == 0 and not torch.isinf(value).any()
-        with torch.cuda.device(value.device):
-            h = m._flow_handle(value.device)
-            if self.group:
-                R = value.detach().to(torch.float64).contiguous().reshape(B, 9)
-                _lib.check(lib.hmf_flow_log_prob_SO3(h, _lib.dptr(self.ctx), ids, 1, _lib.dptr(R), B, _lib.dptr(out),
-                                                     _lib.current_stream()), 'hmf_flow_log_prob_SO3')
-            else:
-                v = value.detach().to(torch.float32).contiguous().reshape(B, 3)
-                _lib.check(lib.hmf_flow_log_prob_so3(h, _lib.dptr(self.ctx), ids, 1, _lib.dptr(v), B, _lib.dptr(out),
-                                                     _lib.current_stream()), 'hmf_flow_log_prob_so3')
+        if self.group:
+            out = m.log_prob_parts(self.ctx[:, None, :], value.reshape(B, 1, 3, 3), self.part, 1)[:, 0]
+        else:
+            if torch.is_grad_enabled() and (value.requires_grad or self.ctx.requires_grad):
+                raise NotImplementedError('humaniflow_amd: the algebra density so3flow_dists.log_prob is inference-only (the training loss uses the '
+                                          'SO(3) push-forward, losses/humaniflow_loss.py:26-31)')
+            out = m._log_prob_kernel(self.ctx[:, None, :], value.reshape(B, 1, 3), self.part, 1, group=False)[:, 0]
         if self.check_finite:
             assert torch.isnan(out).sum() == 0
         return out
@@ -104,8 +103,8 @@ class _FlowDistHandle:
     def __init__(self, model, part, group):
         self.model, self.part, self.group = model, part, group
 
-    def condition(self, context):
-        return _ConditionedFlowDist(self.model, self.part, context.detach().to(torch.float32).contiguous(), self.group)
+    def condition(self, context, parent=None):
+        return _ConditionedFlowDist(self.model, self.part, context.to(torch.float32), self.group, parent=parent)
 
     def clear_cache(self):
         pass
@@ -207,11 +206,18 @@ class HumaniflowModel(nn.Module):
     def flow_host_struct(self):
         """(hmf_flow_host_t, keep-alive list) from the live parameters."""
         keep = []
+        # one device -> host copy for all ~420 tensors (a training step re-packs after every optimiser step)
+        ts = self._flow_params()
+        flat = np.ascontiguousarray(torch.cat([t.detach().reshape(-1).float() for t in ts]).cpu().numpy())
+        keep.append(flat)
+        offs, o = {}, 0
+        for t in ts:
+            offs[id(t)] = (o, t.numel())
+            o += t.numel()
 
         def arr(t):
-            a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
-            keep.append(a)
-            return a
+            a, n = offs[id(t)]
+            return flat[a:a + n]
         nf = self.model_cfg.NORM_FLOW
         P, T = self.num_bodyparts, nf.NUM_TRANSFORMS
         hs = _lib.FlowHost()
@@ -266,44 +272,93 @@ class HumaniflowModel(nn.Module):
         return ws
 
     # ---- reference helper methods (kept for API parity; single calls into the library) -----------------------------
-    def compute_input_shape_glob_cam_feats(self, input_feats, shape, glob_R, cam):
-        """models/humaniflow_model.py:116-150.  (B,F),(B,nb),(B,3,3),(B,3) -> (B,256); the 3-D (per-sample) variant of
-        the reference is fused into hmf_flow_forward and is not exposed separately."""
-        if shape.dim() != 2:
-            raise NotImplementedError('per-sample features are computed inside hmf_flow_forward')
+    def _needs_grad(self, *tensors):
+        return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
+                                            or any(p.requires_grad for p in self._flow_params()))
+
+    def _isgc_kernel(self, input_feats, shape, glob_R, cam):
         lib = _lib.load()
         B = shape.shape[0]
-        f = input_feats.detach().float().contiguous()
+        f32c = lambda t: t.detach().to(torch.float32).contiguous()
+        f = f32c(input_feats)
         out = torch.empty(B, self.model_cfg.INPUT_SHAPE_GLOB_CAM_FEATS_DIM, dtype=torch.float32, device=f.device)
         with torch.cuda.device(f.device):
-            _lib.check(lib.hmf_flow_isgc(self._flow_handle(f.device), _lib.dptr(f), _lib.dptr(shape.detach().float().contiguous()),
-                                         _lib.dptr(glob_R.detach().float().contiguous()), _lib.dptr(cam.detach().float().contiguous()),
-                                         B, _lib.dptr(out), _lib.current_stream()), 'hmf_flow_isgc')
+            _lib.check(lib.hmf_flow_isgc(self._flow_handle(f.device), _lib.dptr(f), _lib.dptr(f32c(shape)), _lib.dptr(f32c(glob_R)),
+                                         _lib.dptr(f32c(cam)), B, _lib.dptr(out), _lib.current_stream()), 'hmf_flow_isgc')
         return out
 
-    def compute_flow_context_all(self, input_shape_glob_cam_feats, pose_SO3):
-        """models/humaniflow_model.py:152-186 for all 23 parts at once from GIVEN rotations: (B,256),(B,23,3,3) -> (B,23,64)."""
+    def _isgc_autograd(self, input_feats, shape, glob_R, cam):
+        """The same layer in torch ops (training: W.[f, shape, vec(R), cam] split so that per-sample shapes (B,N,nb) do not replicate the
+        2048-wide feature product).  shape (B,nb) -> (B,256); shape (B,N,nb) -> (B,N,256)."""
+        lin = self.fc_input_shape_glob_cam_feats
+        Fd, nb = self.input_feats_dim, self.num_shape_params
+        W = lin.weight
+        img = torch.nn.functional.linear(torch.cat([input_feats, glob_R.reshape(glob_R.shape[0], 9), cam], dim=1),
+                                         torch.cat([W[:, :Fd], W[:, Fd + nb:]], dim=1), lin.bias)
+        sh = torch.nn.functional.linear(shape, W[:, Fd:Fd + nb])
+        return torch.nn.functional.elu(img[:, None] + sh if shape.dim() == 3 else img + sh)
+
+    def compute_input_shape_glob_cam_feats(self, input_feats, shape, glob_R, cam):
+        """models/humaniflow_model.py:116-150.  (B,F),(B,nb),(B,3,3),(B,3) -> (B,256); the per-sample variant (B,N,nb) of the reference is
+        fused into hmf_flow_forward on the inference path and only exists here in its differentiable (training) form."""
+        if self._needs_grad(input_feats, shape, glob_R, cam):
+            return self._isgc_autograd(input_feats, shape, glob_R, cam)
+        if shape.dim() != 2:
+            raise NotImplementedError('per-sample features are computed inside hmf_flow_forward')
+        return self._isgc_kernel(input_feats, shape, glob_R, cam)
+
+    def _flow_context_kernel(self, isgc, pose_R):
         lib = _lib.load()
-        B = pose_SO3.shape[0]
-        x = input_shape_glob_cam_feats.detach().float().contiguous()
-        R = pose_SO3.detach().float().contiguous()
+        B = pose_R.shape[0]
+        x = isgc.detach().float().contiguous()
+        R = pose_R.detach().float().contiguous()
         ctx = torch.empty(B, self.num_bodyparts, self.model_cfg.NORM_FLOW.CONTEXT_DIM, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.hmf_flow_context(self._flow_handle(x.device), _lib.dptr(x), _lib.dptr(R), B, _lib.dptr(ctx),
                                             _lib.current_stream()), 'hmf_flow_context')
         return ctx
 
+    def compute_flow_context_all(self, input_shape_glob_cam_feats, pose_SO3):
+        """models/humaniflow_model.py:152-186 for all 23 parts at once from GIVEN rotations: (B,256),(B,23,3,3) -> (B,23,64)."""
+        if self._needs_grad(input_shape_glob_cam_feats, pose_SO3):
+            from .autograd import FlowContext, _ctx_params
+            return FlowContext.apply(self, input_shape_glob_cam_feats, pose_SO3, *_ctx_params(self))
+        return self._flow_context_kernel(input_shape_glob_cam_feats, pose_SO3)
+
+    def _log_prob_kernel(self, ctx, value, part0, P, group):
+        """ctx (B,P,64) fp32; value (B,P,3,3) fp64 rotations (group) or (B,P,3) fp32 algebra vectors -> (B,P) fp32."""
+        lib = _lib.load()
+        B = ctx.shape[0]
+        ids = (C.c_int32 * P)(*range(part0, part0 + P)) if P != self.num_bodyparts else None
+        out = torch.empty(B, P, dtype=torch.float32, device=ctx.device)
+        cc = ctx.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(ctx.device):
+            h = self._flow_handle(ctx.device)
+            if group:
+                R = value.detach().to(torch.float64).contiguous()
+                _lib.check(lib.hmf_flow_log_prob_SO3(h, _lib.dptr(cc), ids, P, _lib.dptr(R), B, _lib.dptr(out), _lib.current_stream()),
+                           'hmf_flow_log_prob_SO3')
+            else:
+                v = value.detach().to(torch.float32).contiguous()
+                _lib.check(lib.hmf_flow_log_prob_so3(h, _lib.dptr(cc), ids, P, _lib.dptr(v), B, _lib.dptr(out), _lib.current_stream()),
+                           'hmf_flow_log_prob_so3')
+        return out
+
+    def log_prob_parts(self, ctx, R, part0, P):
+        """log p(R_j | ctx_j), j = part0 .. part0+P-1; differentiable w.r.t. ctx and the hyper-network weights."""
+        _lib.require_cuda(R, 'value')
+        if torch.is_grad_enabled() and R.requires_grad:
+            raise NotImplementedError('humaniflow_amd: gradients w.r.t. the rotation a flow density is evaluated AT are not built (the optimise driver, '
+                                      'optimise/optimise_humaniflow.py:96-109); training differentiates w.r.t. the context and the weights')
+        if self._needs_grad(ctx):
+            from .autograd import FlowLogProbSO3, _hypernet_params
+            return FlowLogProbSO3.apply(self, part0, P, ctx, R.detach().to(torch.float64).contiguous(), *_hypernet_params(self, part0, P))
+        return self._log_prob_kernel(ctx, R, part0, P, group=True)
+
     def log_prob_all_parts(self, ctx, R):
         """Batched form of `[d.log_prob(R[:, j]) for j, d in enumerate(conditioned_pose_SO3flow_dists_for_loglik)]`
-        (losses/humaniflow_loss.py:30-31): ctx (B,23,64), R (B,23,3,3) -> (B,23) fp32, one launch."""
-        lib = _lib.load()
-        B = R.shape[0]
-        R64 = R.detach().to(torch.float64).contiguous()
-        out = torch.empty(B, self.num_bodyparts, dtype=torch.float32, device=R.device)
-        with torch.cuda.device(R.device):
-            _lib.check(lib.hmf_flow_log_prob_SO3(self._flow_handle(R.device), _lib.dptr(ctx.contiguous()), None, self.num_bodyparts,
-                                                 _lib.dptr(R64), B, _lib.dptr(out), _lib.current_stream()), 'hmf_flow_log_prob_SO3')
-        return out
+        (losses/humaniflow_loss.py:30-31): ctx (B,23,64), R (B,23,3,3) -> (B,23) fp32, one launch (and one backward launch)."""
+        return self.log_prob_parts(ctx, R, 0, self.num_bodyparts)
 
     # ---- forward ----------------------------------------------------------------------------------------------------
     def forward(self, input, compute_point_est=True, num_samples=0, use_shape_mode_for_samples=False, compute_for_loglik=False,
@@ -311,7 +366,9 @@ class HumaniflowModel(nn.Module):
                 grad_for_pose_point_est=False, return_input_feats=False, return_input_feats_only=False, noise=None):
         """models/humaniflow_model.py:188-340.  Extra keyword `noise` = {'shape': (N,B,nb), 'pose': (23,B,N,3)} standard-normal
         tensors injects the base noise (exact-parity tests); otherwise it is drawn from the device generator in the reference's
-        order (shape first, then the body parts)."""
+        order (shape first, then the body parts).  Under autograd (training, train/train_humaniflow.py:248-256) the returned samples,
+        shape samples and log-likelihood objects are differentiable; the point estimate is not, exactly as in the reference
+        (`torch.set_grad_enabled(grad_for_pose_point_est)`, :294) -- grad_for_pose_point_est=True is not built."""
         if input_feats is None:
             _lib.require_cuda(input, 'input')
             input_feats = self.image_encoder(input)
@@ -324,9 +381,9 @@ class HumaniflowModel(nn.Module):
             assert pose_R_for_loglik is not None and pose_R_for_loglik.shape[0] == batch_size
             assert shape_for_loglik is not None and shape_for_loglik.shape[0] == batch_size
             assert glob_R_for_loglik is not None and glob_R_for_loglik.shape[0] == batch_size
-        if grad_for_pose_point_est or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError('humaniflow_amd round 1 implements the inference path only: call under torch.no_grad() '
-                                      '(gradients through the flow kernels are a "next" row, see DESIGN.md)')
+        if grad_for_pose_point_est:
+            raise NotImplementedError('humaniflow_amd: grad_for_pose_point_est=True (gradients through the z = 0 point-estimate chain) is not built')
+        grad = torch.is_grad_enabled() and (input_feats.requires_grad or any(p.requires_grad for p in self.parameters()))
         lib = _lib.load()
         nb, P, N = self.num_shape_params, self.num_bodyparts, int(num_samples)
 
@@ -377,6 +434,19 @@ class HumaniflowModel(nn.Module):
                                                 flags, _lib.dptr(shape_all), _lib.dptr(rot_s), _lib.dptr(rot_p),
                                                 _lib.dptr(so3_p), _lib.dptr(ws), ws.numel(), _lib.current_stream()),
                            'hmf_flow_forward')
+            if grad and N > 0:
+                # Training: attach the reparameterised-sample graph to the kernel's results (:255-258, :302-311).  The shape samples and the
+                # per-row isgc features are re-expressed in torch ops (tiny), the kinematic chain's backward is the HIP reverse sweep.
+                from .autograd import FlowSampleChain, _ctx_params, _hypernet_params
+                if use_shape_mode_for_samples:
+                    shape_samples = shape_mode[:, None, :].expand(-1, N, -1)
+                else:
+                    shape_samples = (shape_mode + eps_shape * torch.exp(shape_log_std)).transpose(0, 1)        # (B,N,nb), = the kernel's values
+                H = self._isgc_autograd(input_feats, shape_samples, glob_R, cam).reshape(BN, -1)
+                rot_s = FlowSampleChain.apply(self, H, rot_s, eps_pose, *(_ctx_params(self) + _hypernet_params(self, 0, P)))
+                if packed:
+                    rot_all = torch.cat([rot_s.reshape(BN, P, 3, 3), rot_p], dim=0)
+                    shape_all = torch.cat([shape_samples.reshape(BN, nb), shape_mode], dim=0)
             if packed:                # extension key (not in the reference dict): inputs of the single fused SMPL launch
                 return_dict['smpl_packed_inputs'] = {'body_pose': rot_all, 'betas': shape_all, 'num_samples': N}
             if compute_point_est:
@@ -391,9 +461,9 @@ class HumaniflowModel(nn.Module):
             isgc = self.compute_input_shape_glob_cam_feats(input_feats, shape_for_loglik, glob_R_for_loglik, cam)    # :279-283
             ctx = self.compute_flow_context_all(isgc, pose_R_for_loglik)                                              # :315-318
             return_dict['conditioned_pose_so3flow_dists_for_loglik'] = [
-                self.pose_so3flow_dists[j].condition(ctx[:, j]) for j in range(P)]
+                self.pose_so3flow_dists[j].condition(ctx[:, j], parent=(ctx, j)) for j in range(P)]
             return_dict['conditioned_pose_SO3flow_dists_for_loglik'] = [
-                self.pose_SO3flow_dists[j].condition(ctx[:, j]) for j in range(P)]
+                self.pose_SO3flow_dists[j].condition(ctx[:, j], parent=(ctx, j)) for j in range(P)]
             return_dict['flow_context_for_loglik'] = ctx          # extension: feed log_prob_all_parts() for one-launch NLL
 
         if return_input_feats:

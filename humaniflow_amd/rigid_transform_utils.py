@@ -25,10 +25,17 @@ def _run(fn_name, x, in_cols, out_cols, dtype):
     return out, lead
 
 
-def rot6d_to_rotmat(x):
-    """(B,6) or (B,24*6) -> (B',3,3)."""
+def rot6d_to_rotmat_kernel(x):
     out, _ = _run('hmf_rot6d_to_rotmat', x.reshape(-1, 6), (6, None), 9, torch.float32)
     return out.view(-1, 3, 3)
+
+
+def rot6d_to_rotmat(x):
+    """(B,6) or (B,24*6) -> (B',3,3).  Differentiable (training: the global-rotation loss and everything downstream of glob_R)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        from .autograd import Rot6dToRotmat
+        return Rot6dToRotmat.apply(x)
+    return rot6d_to_rotmat_kernel(x)
 
 
 def rotmat_to_rot6d(R, stack_columns=False):

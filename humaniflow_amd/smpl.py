@@ -201,9 +201,27 @@ class SMPL(nn.Module):
         _lib.check(lib.hmf_batch_rodrigues(_lib.dptr(v), n, _lib.dptr(R), _lib.current_stream()), 'hmf_batch_rodrigues')
         return R
 
+    def _lbs_kernel(self, g, b, be, impl=None):
+        """g (Mg, 9), b (M, 207), be (Mb, nb) contiguous fp32 device tensors (Mg, Mb in {1, M}) -> vertices (M,6890,3), joints (M,90,3)."""
+        lib = _lib.load()
+        dev = b.device
+        M = b.shape[0]
+        verts = torch.empty(M, NUM_VERTS, 3, dtype=torch.float32, device=dev)
+        joints = torch.empty(M, 90, 3, dtype=torch.float32, device=dev)
+        if M == 0:
+            return verts, joints
+        with torch.cuda.device(dev):
+            ws = self._workspace(dev, M)
+            _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
+                                        _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(),
+                                        int((2 if self.blend_dtype == 'bf16' else 0) if impl is None else impl),
+                                        _lib.current_stream()), 'hmf_smpl_lbs')
+        return verts, joints
+
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, impl=None, **kwargs):
         """models/smpl.py:27-41 over smplx SMPL.forward.  `get_skin`/`return_verts` kwargs are accepted and ignored
-        (vertices are always produced, as the reference forces)."""
+        (vertices are always produced, as the reference forces).  With rotation-matrix inputs (pose2rot=False) under autograd the JOINTS
+        are differentiable w.r.t. global_orient / body_pose / betas (the training step's 2D reprojection loss); vertices are not."""
         global_orient = self.global_orient if global_orient is None else global_orient
         body_pose = self.body_pose if body_pose is None else body_pose
         betas = self.betas if betas is None else betas
@@ -213,29 +231,30 @@ class SMPL(nn.Module):
         _lib.require_cuda(body_pose, 'body_pose')
         _lib.require_cuda(global_orient, 'global_orient')
         dev = betas.device
-        lib = _lib.load()
         M = max(betas.shape[0], global_orient.shape[0], body_pose.shape[0])
+        wants_grad = torch.is_grad_enabled() and (betas.requires_grad or body_pose.requires_grad or global_orient.requires_grad)
         with torch.cuda.device(dev):
-            if pose2rot:
-                g = self._rodrigues(global_orient, global_orient.shape[0])
-                b = self._rodrigues(body_pose, body_pose.shape[0] * 23).reshape(body_pose.shape[0], 23 * 9)
+            if wants_grad:
+                if pose2rot:
+                    raise NotImplementedError('humaniflow_amd: SMPL gradients are built for rotation-matrix inputs (pose2rot=False), as the training '
+                                              'step uses them (train/train_humaniflow.py:283-307)')
+                if global_orient.shape[0] != M or betas.shape[0] != M or body_pose.shape[0] != M:
+                    raise ValueError('SMPL.forward under autograd: expand global_orient / betas to the pose batch (M = %d) first' % M)
+                from .autograd import SmplJoints
+                verts, joints = SmplJoints.apply(self, global_orient.to(torch.float32).reshape(M, 9).contiguous(),
+                                                 body_pose.to(torch.float32).reshape(M, 23 * 9).contiguous(),
+                                                 betas.to(torch.float32).contiguous(), impl)
             else:
-                g = self._f32c(global_orient).reshape(global_orient.shape[0], 9)
-                b = self._f32c(body_pose).reshape(body_pose.shape[0], 23 * 9)
-            if b.shape[0] != M or g.shape[0] not in (1, M) or betas.shape[0] not in (1, M):
-                raise ValueError('SMPL.forward: batch sizes betas=%d global_orient=%d body_pose=%d are not broadcastable '
-                                 '(smplx rule: 1 or M)' % (betas.shape[0], g.shape[0], b.shape[0]))
-            be = self._f32c(betas)
-            verts = torch.empty(M, NUM_VERTS, 3, dtype=torch.float32, device=dev)
-            joints = torch.empty(M, 90, 3, dtype=torch.float32, device=dev)
-            if M == 0:
-                return SMPLOutput(vertices=verts, joints=joints, full_pose=None, betas=betas, global_orient=global_orient,
-                                  body_pose=body_pose)
-            ws = self._workspace(dev, M)
-            _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
-                                        _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(),
-                                        int((2 if self.blend_dtype == 'bf16' else 0) if impl is None else impl),
-                                        _lib.current_stream()), 'hmf_smpl_lbs')
+                if pose2rot:
+                    g = self._rodrigues(global_orient, global_orient.shape[0])
+                    b = self._rodrigues(body_pose, body_pose.shape[0] * 23).reshape(body_pose.shape[0], 23 * 9)
+                else:
+                    g = self._f32c(global_orient).reshape(global_orient.shape[0], 9)
+                    b = self._f32c(body_pose).reshape(body_pose.shape[0], 23 * 9)
+                if b.shape[0] != M or g.shape[0] not in (1, M) or betas.shape[0] not in (1, M):
+                    raise ValueError('SMPL.forward: batch sizes betas=%d global_orient=%d body_pose=%d are not broadcastable '
+                                     '(smplx rule: 1 or M)' % (betas.shape[0], g.shape[0], b.shape[0]))
+                verts, joints = self._lbs_kernel(g, b, self._f32c(betas), impl)
         if transl is not None:
             joints = joints + transl.unsqueeze(1)
             verts = verts + transl.unsqueeze(1)

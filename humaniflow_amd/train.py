@@ -1,0 +1,225 @@
+"""Training step of the hot path: the differentiable part of train/train_humaniflow.py:248-335, data-parallel.
+
+  forward    HumaniflowModel(proxy, compute_point_est=True, num_samples=LOSS.NUM_J2D_SAMPLES, compute_for_loglik=True, targets...)   :250-256
+  SMPL       joints of the point estimate and of the samples in ONE launch, flip about x, orthographic projection                     :283-318
+  loss       HumaniflowLoss: pose NLL + shape NLL + visible-2D-joint MSE + global-rotation MSE                                        :323-343
+  backward   HIP reverse sweeps of the flow / SMPL (autograd.py), torch autograd for the heads and -- for now -- the encoder
+  exchange   gradients bucketed (25 MB) and all-reduced over RCCL while the rest of the backward still runs (xGMI rings are per-link bound)
+  update     Adam; a non-finite loss or gradient skips the update instead of the reference's deep-copy / reload roll-back (:264-278, :345-347)
+
+What the reference's loop does around this (pytorch3d rendering of the synthetic person, texture / background / occlusion
+augmentation, :113-246) is data generation outside the path: `synthetic_train_batch` stands in with SMPL-consistent targets
+(2D joints projected from the target body) and a proxy representation built by the library's front end (hmf_proxy_rep).
+"""
+import math
+import time
+
+import torch
+
+from . import _lib
+from .evaluate import flip_about_x, orthographic_project_torch, select_joints
+from .losses import HumaniflowLoss
+
+
+def train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=None, input_feats=None):
+    """targets: pose_rotmats (B,23,3,3), glob_rotmats (B,3,3), shape (B,nb), joints2D (B,17,2) pixels, joints2D_vis (B,17) bool.
+    Returns (loss, pred).  J2D_LOSS_ON = 'point_est+samples' | 'samples' | 'point_est' as LOSS.J2D_LOSS_ON."""
+    N = num_samples
+    pred = model(proxy_input, compute_point_est=True, num_samples=N, compute_for_loglik=True, shape_for_loglik=targets['shape'],
+                 pose_R_for_loglik=targets['pose_rotmats'], glob_R_for_loglik=targets['glob_rotmats'], noise=noise, input_feats=input_feats)
+    B = pred['glob_rotmat'].shape[0]
+    pe, sa = smpl.forward_samples_and_point_est(pred)                                   # :283-287 and :300-304 in one launch
+    cam = pred['cam_wp']
+    proj = lambda joints, c: orthographic_project_torch(flip_about_x(select_joints(joints, 'coco')), c)            # :289-297
+    j2d_pe = proj(pe.joints, cam)[:, None]
+    on = criterion.loss_cfg.J2D_LOSS_ON
+    if 'samples' in on:
+        j2d = proj(sa.joints, cam[:, None].expand(-1, N, -1).reshape(B * N, 3)).reshape(B, N, 17, 2)
+        if on == 'point_est+samples':
+            j2d = torch.cat([j2d_pe, j2d], dim=1)                                       # :312-314
+    else:
+        j2d = j2d_pe
+    pred_for_loss = {'pose_dist': pred['conditioned_pose_SO3flow_dists_for_loglik'], 'shape_dist': pred['shape_dist_for_loglik'],
+                     'joints2D': j2d, 'glob_rotmats': pred['glob_rotmat']}
+    targ_for_loss = {'pose_params_rotmats': targets['pose_rotmats'], 'shape_params': targets['shape'], 'joints2D': targets['joints2D'],
+                     'joints2D_vis': targets['joints2D_vis'], 'glob_rotmats': targets['glob_rotmats']}
+    return criterion(targ_for_loss, pred_for_loss), pred
+
+
+@torch.no_grad()
+def synthetic_train_batch(smpl, B, size, device, seed, data_cfg=None, shape_std=1.25):
+    """on_the_fly_smpl_train_dataset stand-in (train/train_humaniflow.py:113-246 without the renderer): random axis-angle poses and
+    N(0, 1.25^2) shapes, targets from the body model, 2D joints = orthographic projection of the target COCO joints, proxy representation =
+    Canny edges of a random image + heat-maps of those joints (hmf_proxy_rep)."""
+    from .proxy import proxy_representation
+    from .rigid_transform_utils import batch_rodrigues
+    g = torch.Generator().manual_seed(seed)
+    pose = (torch.randn(B, 72, generator=g) * 0.3).to(device)
+    shape = (torch.randn(B, 10, generator=g) * shape_std).to(device)
+    R = batch_rodrigues(pose.reshape(-1, 3)).view(B, 24, 3, 3)
+    glob, body = R[:, 0].contiguous(), R[:, 1:].contiguous()
+    out = smpl(body_pose=body, global_orient=glob[:, None], betas=shape, pose2rot=False)
+    cam = torch.tensor([0.9, 0.0, 0.0], device=device).expand(B, 3)
+    j2d_n = orthographic_project_torch(flip_about_x(select_joints(out.joints, 'coco')), cam)       # normalised [-1, 1]
+    j2d = (j2d_n + 1.0) * (size / 2.0)
+    vis = ((j2d > 0) & (j2d < size)).all(dim=-1) & (torch.rand(B, 17, generator=g) > 0.1).to(device)
+    img = torch.rand(B, 3, size, size, generator=g).to(device)
+    proxy = proxy_representation(img, j2d, vis.float(), data_cfg)
+    return proxy, {'pose_rotmats': body, 'glob_rotmats': glob, 'shape': shape, 'joints2D': j2d, 'joints2D_vis': vis}
+
+
+class GradBucketReducer:
+    """Data-parallel gradient exchange: parameters are grouped (in reverse registration order, i.e. roughly the order their gradients
+    become ready) into flat buckets of <= bucket_mb; a post-accumulate hook counts a bucket's parameters in, and the moment the last one
+    arrives the bucket is flattened and all-reduced asynchronously (RCCL's own stream) while autograd keeps producing the earlier
+    layers' gradients.  finish() waits, averages and scatters the results back into .grad."""
+
+    def __init__(self, params, dist, bucket_mb=25.0):
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_mb * 2 ** 20:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.where = {id(p): bi for bi, b in enumerate(self.buckets) for p in b}
+        self.pending = [len(b) for b in self.buckets]
+        self.inflight = []
+        self.hooks = []
+        if self.world > 1:
+            for p in self.params:
+                self.hooks.append(p.register_post_accumulate_grad_hook(self._ready))
+
+    def _ready(self, p):
+        bi = self.where[id(p)]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        ps = self.buckets[bi]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
+        work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True)
+        self.inflight.append((bi, flat, work))
+
+    def finish(self):
+        """Call after backward(): launches buckets whose parameters never produced a gradient hook, waits, writes the averages back."""
+        if self.world == 1:
+            return
+        for bi, n in enumerate(self.pending):
+            if n > 0:                                    # parameters unused by this step's graph: still exchange (zeros) so ranks agree
+                self.pending[bi] = 0
+                self._launch(bi)
+        for bi, flat, work in self.inflight:
+            work.wait()
+            flat.div_(self.world)
+            o = 0
+            for p in self.buckets[bi]:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = flat[o:o + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[o:o + n].view_as(p))
+                o += n
+        self.inflight = []
+        self.pending = [len(b) for b in self.buckets]
+
+
+def grads_finite(params):
+    """Device-side finite check of all gradients: one stacked reduction, one host read."""
+    norms = torch._foreach_norm([p.grad for p in params if p.grad is not None])
+    return bool(torch.isfinite(torch.stack(norms)).all())
+
+
+def train_step(model, smpl, criterion, optimiser, reducer, proxy_input, targets, num_samples, noise=None):
+    """One optimisation step.  Returns (loss tensor, skipped flag)."""
+    optimiser.zero_grad(set_to_none=True)
+    loss, _ = train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=noise)
+    loss.backward()
+    reducer.finish()
+    params = [p for g in optimiser.param_groups for p in g['params']]
+    if not (bool(torch.isfinite(loss)) and grads_finite(params)):       # the reference reloads the previous state dicts (:264-278)
+        optimiser.zero_grad(set_to_none=True)
+        return loss.detach(), True
+    optimiser.step()
+    for d in model.pose_SO3flow_dists:                                  # :353-354 (no caches here; kept for call parity)
+        d.clear_cache()
+    return loss.detach(), False
+
+
+def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist_gather_metrics):
+    """bench.py --train: BASELINE configs[4] per-GPU step (B = TRAIN.BATCH_SIZE = 72, N = LOSS.NUM_J2D_SAMPLES = 8, ResNet-18 by default,
+    the reference's training configuration), weak scaling, gradients all-reduced over RCCL."""
+    import json
+    import humaniflow_amd as H
+    from .synthetic import init_benchmark_weights
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_RESNET_LAYERS = args.layers
+    torch.manual_seed(0)
+    model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).to(dev)
+    model.train()
+    model.pose_so3flow_transform_modules.train()                        # :103 call parity
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=args.batch, create_transl=False).to(dev)
+    for p in smpl.parameters():
+        p.requires_grad_(False)
+    criterion = HumaniflowLoss(cfg.LOSS, cfg.DATA.PROXY_REP_SIZE)
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimiser = torch.optim.Adam(params, lr=cfg.TRAIN.LR)
+    reducer = GradBucketReducer(params, dist if world > 1 else None)
+    B, N = args.batch, args.samples
+    NB = max(1, args.batches)
+    batches = [synthetic_train_batch(smpl, B, cfg.DATA.PROXY_REP_SIZE, dev, seed=1000 + rank * NB + i, data_cfg=cfg.DATA) for i in range(NB)]
+    torch.manual_seed(1234 + rank)
+    losses, skipped = [], 0
+    log('train flavour: B=%d, N=%d, ResNet-%d, %d parameters (%.1f MB of gradients per step), %d ranks'
+        % (B, N, args.layers, sum(p.numel() for p in params), sum(p.numel() for p in params) * 4 / 2 ** 20, world))
+    for k in range(args.warmup):
+        train_step(model, smpl, criterion, optimiser, reducer, *batches[k % NB], N)
+    dist_sync(dist, dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        loss, sk = train_step(model, smpl, criterion, optimiser, reducer, *batches[(args.warmup + k) % NB], N)
+        losses.append(loss)
+        skipped += int(sk)
+    metric_vec = torch.stack([torch.stack(losses).double().mean(), torch.tensor(float(skipped), dtype=torch.float64, device=dev)])
+    gathered = dist_gather_metrics(metric_vec, dist, world)
+    elapsed = dist_elapsed(t0, dist, dev)
+    # stage split of one step (separate, untimed): forward+loss / backward / exchange+update
+    stages = {}
+
+    def tm(fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) * 1e3, r
+    optimiser.zero_grad(set_to_none=True)
+    stages['forward+loss_ms'], (loss, _) = tm(lambda: train_forward_loss(model, smpl, criterion, *batches[0], N))
+    stages['backward_ms'], _ = tm(lambda: loss.backward())
+    stages['exchange+update_ms'], _ = tm(lambda: (reducer.finish(), optimiser.step()))
+    with torch.no_grad():
+        feats_ms, feats = tm(lambda: model.image_encoder.forward_module(batches[0][0]))
+    stages['of_forward: encoder (ATen, train-mode BatchNorm)_ms'] = feats_ms
+    if rank == 0:
+        value = world * B * N * args.steps / elapsed
+        print(json.dumps({
+            'metric': 'images*samples/sec, training step (B=%d, N=%d)' % (B, N), 'value': round(value, 1), 'unit': 'images*samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[4] train step: B=%d synthetic on-the-fly SMPL batch, N=%d reparameterised samples, ResNet-%d + flow + SMPL joints, '
+                                   'HumaniflowLoss (pose NLL + shape NLL + 2D reprojection + global rotation), Adam' % (B, N, args.layers),
+                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world,
+                       'exchange': ('gradient all-reduce over RCCL, %d buckets of <= 25 MB, launched from gradient-ready hooks' % len(reducer.buckets))
+                       if world > 1 else 'none'},
+            'rccl_ranks_seen': int(gathered.shape[0]), 'mean_loss': float(gathered[:, 0].mean()), 'skipped_steps': int(gathered[:, 1].sum()),
+            'train_images_per_s': round(world * B * args.steps / elapsed, 1), 'stages_ms': {k: round(v, 3) for k, v in stages.items()},
+            'hand_written': 'flow forward/backward (hmf_flow_forward, hmf_flow_log_prob_SO3[_backward], hmf_flow_sample_backward), SMPL forward + joints '
+                            'backward, proxy front end; encoder training graph on ATen autograd (DESIGN.md section 7)',
+            'roofline': None, 'cpu_baseline': None}))
+    if dist is not None:
+        dist.destroy_process_group()

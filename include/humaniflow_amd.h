@@ -96,6 +96,12 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
  * v_template + shapedirs . beta.  joints nullable.                                                */
 int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts, float* joints,
                    void* stream);
+/* Backward of the 90 joints of hmf_smpl_lbs w.r.t. its inputs (the 2D reprojection loss of the training step,
+ * losses/humaniflow_loss.py:44-60): g_joints M x 90 x 3 -> g_global_orient M x 9, g_body_pose M x 23 x 9, g_betas M x nb.
+ * All three inputs must be per-row (no broadcast).  Vertex gradients are not built (LOSS.APPLY_POINT_EST_LOSS = False).          */
+int hmf_smpl_joints_backward(const hmf_smpl_t* h, const float* global_orient, const float* body_pose, const float* betas, int M,
+                             const float* g_joints, float* g_global_orient, float* g_body_pose, float* g_betas, void* stream);
+
 /* utils/sampling_utils.py:22-33 over N samples of one image.  verts: N x V x 3 ->
  * avg_l2: V, dir_std: V x 3.                                                                      */
 int hmf_vertex_variance(const float* verts, int N, int V, float* avg_l2, float* dir_std, void* stream);
@@ -164,6 +170,41 @@ int hmf_flow_log_prob_SO3(const hmf_flow_t* h, const float* ctx, const int32_t* 
 /* Density on the algebra (conditioned_pose_so3flow_dists_for_loglik, :318): v B x P x 3 fp32.    */
 int hmf_flow_log_prob_so3(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P,
                           const float* v, int B, float* logp, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Training step (BASELINE configs[4]): vector-Jacobian products of the flow       */
+/* train/train_humaniflow.py:248-330 differentiates forward(compute_for_loglik=True, num_samples=NUM_J2D_SAMPLES)                 */
+/* ------------------------------------------------------------------------------------------ */
+/* Per-(part, row) records written by the backward kernels.  The weight gradients are dense reductions over the row axis,
+ *   dW_l[part, coupling] = D_l^T . A_{l-1},   db_l = sum_rows D_l,   with A_0 = [ACTX | XIN]
+ * which the caller does with library GEMMs.  Every array is part-major: [P][2 couplings][rows][width] (ACTX, DCTX: [P][rows][64]).  */
+typedef struct {
+    float* D1;   /* [P][2][rows][64]  delta of hyper-network layer 1 (65 -> 64)                         */
+    float* D2;   /* [P][2][rows][32]  layer 2 (64 -> 32)                                               */
+    float* D3;   /* [P][2][rows][32]  layer 3 (32 -> 32)                                               */
+    float* D4;   /* [P][2][rows][64]  layer 4 (32 -> 62; columns 62, 63 are zero)                      */
+    float* A1;   /* [P][2][rows][64]  ReLU output of layer 1                                           */
+    float* A2;   /* [P][2][rows][32]                                                                   */
+    float* A3;   /* [P][2][rows][32]                                                                   */
+    float* XIN;  /* [P][2][rows]      the scalar x1 fed to the hyper-network next to the context        */
+    float* ACTX; /* [P][rows][64]     context vector                                                   */
+    float* DCTX; /* [P][rows][64]     delta of the context layer (hmf_flow_sample_backward only; else NULL) */
+    int rows;
+} hmf_flow_grad_records_t;
+
+/* Reverse sweep of hmf_flow_log_prob_SO3 (losses/humaniflow_loss.py:26-31 pose NLL): g_logp B x P upstream gradients ->
+ * g_ctx B x P x 64 and the records with rows = 3 B (row = pre-image term * B + b; masked pre-images contribute zeros).
+ * The targets R are constants (teacher forcing).                                                                      */
+int hmf_flow_log_prob_SO3_backward(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const double* R, int B,
+                                   const float* g_logp, float* g_ctx, const hmf_flow_grad_records_t* rec, void* stream);
+/* Reverse sweep of the reparameterised samples of hmf_flow_forward (models/humaniflow_model.py:302-311): rounds of the kinematic
+ * schedule in reverse order, one launch each.  isgc_rows (B N) x 256 = ELU(fc_input_shape_glob_cam_feats(...)) per sample row,
+ * rotmats_samples (B N) x 23 x 9 the forward result, eps_pose as in the forward; g_rotmats (B N) x 23 x 9 holds d L / d samples on entry
+ * and additionally every descendant's contribution on exit (in/out).  Records: rows = B N, P = 23, DCTX filled.
+ * Point-estimate rows carry no gradient in the reference (torch.set_grad_enabled(grad_for_pose_point_est), :294).          */
+int hmf_flow_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const float* rotmats_samples, const float* eps_pose, int B, int N,
+                             float* g_rotmats, const hmf_flow_grad_records_t* rec, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------ */
 /* Proxy-representation front end: models/canny_edge_detector.py:104-166 +          */

@@ -167,10 +167,23 @@ def test_full_size_B32_N100_properties():
     assert rnd['shape_samples'].std(dim=1).mean().item() > 1e-3
 
 
-def test_grad_mode_fails_loudly():
+def test_unbuilt_gradient_paths_fail_loudly():
+    """Gradient paths that are not built raise instead of returning tensors without a graph: the rotation a density is
+    evaluated at (the optimise driver), the z = 0 point-estimate chain, the algebra density."""
     model, _, _ = _model(18)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    feats = torch.zeros(2, 512).cuda()
+    R = random_rotmats(2 * 23, 0.5, seed=1).view(2, 23, 3, 3).cuda()
+    out = model(None, input_feats=feats, compute_for_loglik=True, shape_for_loglik=torch.zeros(2, 10).cuda(), pose_R_for_loglik=R,
+                glob_R_for_loglik=R[:, 0])
+    Rg = R[:, 0].double().clone().requires_grad_(True)
     with pytest.raises(NotImplementedError):
-        model(None, input_feats=torch.zeros(1, 512).cuda())
+        out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(Rg)
+    with pytest.raises(NotImplementedError):
+        model(None, input_feats=feats, grad_for_pose_point_est=True)
+    lp = out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(R[:, 0].double())            # frozen weights, plain inputs: inference path
+    assert lp.shape == (2,) and not lp.requires_grad
 
 
 def test_sharded_eval_driver_on_device():

@@ -1,0 +1,210 @@
+"""GPU parity of the training step's backward passes (BASELINE configs[4]): every gradient the HIP reverse sweeps produce
+vs torch autograd through the float64 oracle (oracle/train.py) on the same weights, inputs, targets and base noise.
+Tolerance: 2e-4 of each tensor's largest reference gradient entry (fp32 kernels and fp32 reductions over up to 576 rows vs float64)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import humaniflow_amd as H
+from helpers import init_model_for_tests, oracle_cfg_from, random_rotmats, smpl_oracle_model
+from oracle import model as omodel
+from oracle import smpl as osmpl
+from oracle import train as ot
+
+pytestmark = pytest.mark.gpu
+REL = 2e-4
+
+
+def _model(layers=18, seed=3):
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_RESNET_LAYERS = layers
+    m = init_model_for_tests(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=seed).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m.to('cuda:0'), sd, cfg
+
+
+def _sd64(sd):
+    return {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()
+            if not k.startswith('image_encoder')}
+
+
+def _check(name, got, ref, rel=REL):
+    ref = ref.detach().double().cpu()
+    got = got.detach().double().cpu()
+    scale = max(ref.abs().max().item(), 1e-12)
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, '%s: max |diff| %.3e vs scale %.3e (rel %.2e)' % (name, err, scale, err / scale)
+
+
+def _check_params(model, sd64, prefixes, rel=REL):
+    worst = 0.0
+    n = 0
+    for name, p in model.named_parameters():
+        if not name.startswith(tuple(prefixes)):
+            continue
+        ref = sd64[name].grad
+        assert ref is not None and p.grad is not None, name
+        _check(name, p.grad, ref, rel)
+        n += 1
+    assert n > 0
+    return n
+
+
+def test_log_prob_backward_matches_oracle_autograd():
+    model, sd, cfg = _model(seed=4)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B = 9
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn(B, 23, 64, generator=g) * 0.7
+    R_gt = random_rotmats(B * 23, 0.7, seed=1).view(B, 23, 3, 3)
+    R_gt[0, 0] = torch.eye(3)                                                  # identity target (quirk 1/2)
+    from oracle.so3 import so3_exp
+    ax = torch.tensor([[0.6, 0.0, 0.8]], dtype=torch.float64)
+    R_gt[1, 1] = so3_exp(ax * (math.pi - 1e-4))[0].float()                      # near-pi branch
+    R_gt[2, 2] = so3_exp(ax * 2.0)[0].float()                                  # second pre-image inside the support
+    w = torch.randn(B, 23, generator=g)
+    sd64 = _sd64(sd)
+    c64 = ctx.double().requires_grad_(True)
+    with ot.float64_defaults():
+        lp_ref = ot.log_prob_SO3_grad(sd64, ocfg, c64, R_gt.double())
+    (lp_ref * w.double()).sum().backward()
+    cg = ctx.cuda().requires_grad_(True)
+    model.zero_grad()
+    lp = model.log_prob_all_parts(cg, R_gt.cuda())
+    assert (lp.detach().cpu() - lp_ref.detach().float()).abs().max() < 1e-3
+    (lp * w.cuda()).sum().backward()
+    _check('d ctx', cg.grad, c64.grad)
+    assert _check_params(model, sd64, ['pose_so3flow_transform_modules']) == 23 * 16
+    # per-part call pattern of the reference loss (one Function per part) gives the same gradients
+    ref_grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    cg2 = ctx.cuda().requires_grad_(True)
+    tot = 0
+    for j in range(23):
+        tot = tot + (model.log_prob_parts(cg2[:, j:j + 1], R_gt[:, j:j + 1].cuda(), j, 1)[:, 0] * w[:, j].cuda()).sum()
+    tot.backward()
+    _check('d ctx (per part)', cg2.grad, cg.grad, 1e-5)
+    for n, p in model.named_parameters():
+        if n in ref_grads:
+            _check(n + ' (per part)', p.grad, ref_grads[n], 1e-5)
+
+
+def test_teacher_forced_path_backward_through_context_and_isgc_layers():
+    model, sd, cfg = _model(seed=5)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B = 6
+    g = torch.Generator().manual_seed(6)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    R_gt = random_rotmats(B * 23, 0.6, seed=7).view(B, 23, 3, 3)
+    shape_gt, glob_gt = torch.randn(B, 10, generator=g), random_rotmats(B, 1.0, seed=8)
+    w = torch.randn(B, 23, generator=g)
+    sd64 = _sd64(sd)
+    f64 = feats.double().requires_grad_(True)
+    with ot.float64_defaults():
+        out = ot.forward_grad(sd64, ocfg, input_feats=f64, compute_for_loglik=True, shape_for_loglik=shape_gt.double(),
+                              pose_R_for_loglik=R_gt.double(), glob_R_for_loglik=glob_gt.double(), compute_point_est=False)
+        lp_ref = ot.log_prob_SO3_grad(sd64, ocfg, out['flow_context_for_loglik'], R_gt.double())
+    (lp_ref * w.double()).sum().backward()
+    fg = feats.cuda().requires_grad_(True)
+    model.zero_grad()
+    o = model(None, input_feats=fg, compute_for_loglik=True, shape_for_loglik=shape_gt.cuda(), pose_R_for_loglik=R_gt.cuda(),
+              glob_R_for_loglik=glob_gt.cuda(), compute_point_est=False)
+    dists = o['conditioned_pose_SO3flow_dists_for_loglik']
+    lp = torch.stack([dists[j].log_prob(R_gt[:, j].double().cuda()) for j in range(23)], dim=1)          # the reference's loop
+    assert (lp.detach().cpu() - lp_ref.detach().float()).abs().max() < 1e-3
+    (lp * w.cuda()).sum().backward()
+    _check('d input_feats', fg.grad, f64.grad)
+    _check_params(model, sd64, ['pose_so3flow_transform_modules', 'fc_flow_context', 'fc_input_shape_glob_cam_feats', 'fc_cam', 'fc1'])
+
+
+def test_sample_chain_backward_matches_oracle_autograd():
+    """Reparameterised samples: d (sum w . R_samples) / d every flow parameter, the features and the heads, ancestors feeding descendants."""
+    model, sd, cfg = _model(seed=6)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B, N = 3, 5
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    noise = {'shape': torch.randn(N, B, 10, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+    w = torch.randn(B, N, 23, 3, 3, generator=g)
+    ws = torch.randn(B, N, 10, generator=g)
+    sd64 = _sd64(sd)
+    f64 = feats.double().requires_grad_(True)
+    with ot.float64_defaults():
+        out = ot.forward_grad(sd64, ocfg, input_feats=f64, num_samples=N, noise={k: v.double() for k, v in noise.items()})
+    ((out['pose_rotmats_samples'] * w.double()).sum() + (out['shape_samples'] * ws.double()).sum()).backward()
+    fg = feats.cuda().requires_grad_(True)
+    model.zero_grad()
+    o = model(None, input_feats=fg, num_samples=N, noise={k: v.cuda() for k, v in noise.items()})
+    assert (o['pose_rotmats_samples'].detach().cpu() - out['pose_rotmats_samples'].detach().float()).abs().max() < 5e-5
+    assert not o['pose_rotmats_point_est'].requires_grad                        # as the reference: no graph through the z = 0 chain
+    ((o['pose_rotmats_samples'] * w.cuda()).sum() + (o['shape_samples'] * ws.cuda()).sum()).backward()
+    _check('d input_feats', fg.grad, f64.grad)
+    n = _check_params(model, sd64, ['pose_so3flow_transform_modules', 'fc_flow_context', 'fc_input_shape_glob_cam_feats', 'fc_cam', 'fc_glob',
+                                    'fc_shape', 'fc1'])
+    assert n >= 23 * 16 + 46 + 2
+
+
+def test_smpl_joints_backward_matches_oracle_autograd():
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    om = {k: (v.double() if v.is_floating_point() else v) for k, v in smpl_oracle_model(smpl.model_dict()).items()}
+    M = 7
+    g = torch.Generator().manual_seed(12)
+    R = random_rotmats(M * 24, 0.6, seed=13).view(M, 24, 3, 3)
+    betas = torch.randn(M, 10, generator=g)
+    w = torch.randn(M, 90, 3, generator=g)
+    R64, b64 = R.double().requires_grad_(True), betas.double().requires_grad_(True)
+    with ot.float64_defaults():
+        _, j_ref = osmpl.smpl_forward(om, b64, R64[:, 1:], R64[:, :1], pose2rot=False)
+    (j_ref * w.double()).sum().backward()
+    body = R[:, 1:].cuda().requires_grad_(True)
+    glob = R[:, :1].cuda().requires_grad_(True)
+    be = betas.cuda().requires_grad_(True)
+    out = smpl(body_pose=body, global_orient=glob, betas=be, pose2rot=False)
+    assert (out.joints.detach().cpu() - j_ref.detach().float()).abs().max() < 1e-4
+    (out.joints * w.cuda()).sum().backward()
+    _check('d body_pose', body.grad, R64.grad[:, 1:])
+    _check('d global_orient', glob.grad, R64.grad[:, :1])
+    _check('d betas', be.grad, b64.grad)
+    with pytest.raises(NotImplementedError):                                    # vertex gradients are not built: loud, not silent
+        out2 = smpl(body_pose=body, global_orient=glob, betas=be, pose2rot=False)
+        out2.vertices.sum().backward()
+
+
+def test_full_train_step_loss_and_gradients_at_batch_72():
+    """TRAIN.BATCH_SIZE = 72, LOSS.NUM_J2D_SAMPLES = 8 (configs/humaniflow_config.py:40,99): the reference's scalar loss from the encoder
+    features onwards and the gradient of every parameter it reaches, vs the float64 oracle."""
+    from humaniflow_amd.train import train_forward_loss
+    model, sd, cfg = _model(seed=7)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    om = {k: (v.double() if v.is_floating_point() else v) for k, v in smpl_oracle_model(smpl.model_dict()).items()}
+    B, N = 72, 8
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    targets = {'pose_rotmats': random_rotmats(B * 23, 0.5, seed=22).view(B, 23, 3, 3), 'glob_rotmats': random_rotmats(B, 1.0, seed=23),
+               'shape': torch.randn(B, 10, generator=g) * 1.25, 'joints2D': torch.rand(B, 17, 2, generator=g) * 256,
+               'joints2D_vis': torch.rand(B, 17, generator=g) > 0.2}
+    noise = {'shape': torch.randn(N, B, 10, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+    sd64 = _sd64(sd)
+    f64 = feats.double().requires_grad_(True)
+    t64 = {k: (v.double() if v.is_floating_point() else v) for k, v in targets.items()}
+    with ot.float64_defaults():
+        loss_ref, _ = ot.train_step_loss(sd64, ocfg, om, cfg.LOSS, 256, f64, t64, {k: v.double() for k, v in noise.items()}, N)
+    loss_ref.backward()
+    fg = feats.cuda().requires_grad_(True)
+    model.zero_grad()
+    loss, _ = train_forward_loss(model, smpl, H.HumaniflowLoss(cfg.LOSS, 256), None, {k: v.cuda() for k, v in targets.items()}, N,
+                                 noise={k: v.cuda() for k, v in noise.items()}, input_feats=fg)
+    assert abs(loss.item() - loss_ref.item()) <= 2e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    loss.backward()
+    _check('d input_feats', fg.grad, f64.grad, 5e-4)
+    n = 0
+    for name, p in model.named_parameters():
+        if name.startswith('image_encoder'):
+            continue
+        assert p.grad is not None, name
+        _check(name, p.grad, sd64[name].grad, 5e-4)
+        n += 1
+    assert n == 424                                                              # every non-encoder parameter of the checkpoint layout
