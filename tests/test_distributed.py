@@ -190,3 +190,76 @@ def test_bench_rank_plumbing_two_gloo_ranks():
     assert d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['higher_is_better'] is True
     assert d['gathered_rank_sums'] == [4.0, 8.0]                     # rank r contributed (r+1) * ones(4)
     assert abs(d['value'] - 2 * 32 * 100 * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']     # whole-job aggregate over both ranks
+
+
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from humaniflow_amd.train import GradBucketReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300), torch.nn.ReLU(), torch.nn.Linear(300, 5),
+                              torch.nn.Linear(5, 5))        # the last layer is NOT used below: its gradient never becomes ready
+    params = list(net.parameters())
+    red = GradBucketReducer(params, dist, bucket_mb=0.04)    # several buckets
+    x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + rank))
+    for step in range(2):                                    # twice: the bookkeeping must reset
+        for p in params:
+            p.grad = None
+        net[:5](x).square().sum().backward()
+        red.finish()
+    q.put((rank, len(red.buckets), [None if p.grad is None else p.grad.numpy().copy() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_reducer_two_gloo_ranks_equals_mean_of_local_gradients():
+    """The training step's exchange (humaniflow_amd.train.GradBucketReducer): bucketed asynchronous all-reduce launched from gradient-ready
+    hooks, incl. a parameter that receives no gradient; every rank ends with the mean of the per-rank gradients."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300), torch.nn.ReLU(), torch.nn.Linear(300, 5),
+                              torch.nn.Linear(5, 5))
+    local = []
+    for rank in range(2):
+        net.zero_grad()
+        x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + rank))
+        net[:5](x).square().sum().backward()
+        local.append([None if p.grad is None else p.grad.clone() for p in net.parameters()])
+    assert res[0][1] >= 3, res[0][1]
+    for rank, _, grads in res:
+        for i, g in enumerate(grads):
+            if local[0][i] is None:
+                assert g is not None and np.abs(g).max() == 0          # unused parameter: exchanged as zeros so the ranks stay in step
+            else:
+                assert np.allclose(g, ((local[0][i] + local[1][i]) / 2).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_bench_rank_plumbing_eight_gloo_ranks():
+    """The driver's 8-GPU launch line with the CPU stand-in step: 8 ranks rendezvous, the gathered tensor proves 8 ranks took part."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--dry-run-cpu']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['rccl_ranks_seen'] == 8 and d['gathered_rank_sums'] == [4.0 * (r_ + 1) for r_ in range(8)]
