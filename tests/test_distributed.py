@@ -238,7 +238,7 @@ def test_gradient_bucket_reducer_two_gloo_ranks_equals_mean_of_local_gradients()
         x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + rank))
         net[:5](x).square().sum().backward()
         local.append([None if p.grad is None else p.grad.clone() for p in net.parameters()])
-    assert res[0][1] >= 3, res[0][1]
+    assert res[0][1] >= 2, res[0][1]
     for rank, _, grads in res:
         for i, g in enumerate(grads):
             if local[0][i] is None:
