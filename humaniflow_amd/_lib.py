@@ -29,7 +29,11 @@ class FlowHost(C.Structure):
                 ('radius', C.c_float), ('base_std', C.c_float),
                 ('parents_host', c_int_p), ('w_isgc_host', c_float_p), ('b_isgc_host', c_float_p),
                 ('w_ctx_host', C.POINTER(c_float_p)), ('b_ctx_host', C.POINTER(c_float_p)),
-                ('w_nn_host', C.POINTER(c_float_p)), ('b_nn_host', C.POINTER(c_float_p))]
+                ('w_nn_host', C.POINTER(c_float_p)), ('b_nn_host', C.POINTER(c_float_p)),
+                ('transform_type', C.c_int), ('permute_type', C.c_int), ('num_hidden', C.c_int), ('hidden_dims', C.c_int * 4),
+                ('plu_num_hidden', C.c_int), ('plu_hidden_dims', C.c_int * 4),
+                ('w_plu_host', C.POINTER(c_float_p)), ('b_plu_host', C.POINTER(c_float_p)), ('lu_host', C.POINTER(c_float_p)),
+                ('force_generic', C.c_int)]
 
 
 class FlowGradRecords(C.Structure):

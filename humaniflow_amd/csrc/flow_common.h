@@ -54,6 +54,24 @@ struct FlowDev {
     Levels lev;
 };
 
+// ---- non-default flow variants (flow_generic.hip): lane-per-channel kernels, every dense layer stored transposed [K][64] -----------
+constexpr int kMaxT = 8;          // transforms per part
+constexpr int kMaxLayers = 5;     // up to 4 hidden layers + output
+struct GenNet {
+    int nl;                       // number of layers (0 = absent)
+    int K[kMaxLayers], N[kMaxLayers];
+    int o_w[kMaxLayers], o_b[kMaxLayers];     // arena offsets: W^T [K][64] (columns >= N zero), bias [64]
+};
+struct GenPartTab {
+    GenNet tr[kMaxT];             // transform hyper-network ConditionalDenseNN([context, x1]) -> 62 (spline) | 2 (additive)
+    GenNet plu[kMaxT];            // conditional_linear_plu: DenseNN(context) -> 9
+    int o_lu[kMaxT];              // linear_plu: 9 floats, row-major LU
+};
+struct GenDev {
+    int enabled, T, transform_type, permute_type;
+    const GenPartTab* tab;        // [23] device copy
+};
+
 __host__ __device__ inline int arl_channel(int t, int reg, int q) { return 32 * t + 8 * (reg >> 2) + 4 * q + (reg & 3); }
 
 // packed spline-parameter channel -> index into pyro's 62-vector (w 16 | h 16 | d 14 | l 16), -1 = pad.

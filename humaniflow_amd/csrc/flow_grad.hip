@@ -602,6 +602,7 @@ int hmf_flow_log_prob_SO3_backward(const hmf_flow_t* h, const float* ctx, const 
                 return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_log_prob_SO3_backward: part ids must be a contiguous ascending range inside [0, 23)");
         dev_ids = h->d_ids + part_ids_host[0];
     }
+    if (h->g.enabled) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_log_prob_SO3_backward: gradients are built for the default flow configuration only");
     GradRec G;
     int rc = rec_from(rec, G, false);
     if (rc) return rc;
@@ -616,6 +617,7 @@ int hmf_flow_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const 
                              float* g_rotmats, const hmf_flow_grad_records_t* rec, void* stream) {
     if (!h || !isgc_rows || !rotmats_samples || !eps_pose || !g_rotmats || B <= 0 || N <= 0)
         return fail(HMF_ERR_INVALID, "hmf_flow_sample_backward: bad args");
+    if (h->g.enabled) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_sample_backward: gradients are built for the default flow configuration only");
     GradRec G;
     int rc = rec_from(rec, G, true);
     if (rc) return rc;

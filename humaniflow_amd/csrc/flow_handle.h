@@ -13,6 +13,9 @@ struct FlowPack {
     std::vector<PartTab> tab;
     std::vector<int> anc_off;
     Levels lev;
+    bool generic = false;            // non-default variant (or force_generic): the MFMA operand blocks are not packed
+    int T = 2, transform_type = 0, permute_type = 0;
+    std::vector<GenPartTab> gtab;
 };
 
 int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp);
@@ -21,6 +24,7 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp);
 
 struct hmf_flow {
     hmf::FlowDev d;
+    hmf::GenDev g;
     std::vector<hmf::PartTab> host_tab;
     const int* d_ids;   // device table 0..22
     void* mem;

@@ -615,6 +615,13 @@ __global__ __launch_bounds__(256) void k_flow_logprob(FlowDev d, const float* __
 
 }  // namespace hmf
 
+namespace hmf {
+// flow_generic.hip: the non-default flow variants
+int generic_forward(const hmf_flow* h, const float* G, const float* shape_mode, const float* shape_log_std, const float* eps_shape, const float* eps_pose,
+                    int B, int N, int Mtot, int packed_rows, float* shape_samples, float* rot_samples, float* rot_point, float* so3_point, hipStream_t st);
+int generic_logprob(const hmf_flow* h, const float* ctx, const int* dev_ids, int P, const double* R, const float* v, int B, int mode, float* logp, hipStream_t st);
+}  // namespace hmf
+
 using namespace hmf;
 
 static long long* g_timeline = nullptr;
@@ -660,6 +667,9 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
         hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, feats, (const float*)nullptr, glob_R, cam, B, 0, G);
         HMF_LAUNCH_CHECK();
     }
+    if (h->g.enabled)
+        return generic_forward(h, G, shape_mode, shape_log_std, eps_shape, eps_pose, B, N, Mtot, packed_rows, shape_samples, rotmats_samples, rotmats_point,
+                               so3_point, st);
     {
         const int nw = ntiles * kGroups0;
         ProfScope ps(5, Mtot, st);
@@ -706,6 +716,7 @@ static int logprob_common(const hmf_flow_t* h, const float* ctx, const int32_t* 
                 return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_log_prob: part ids must be a contiguous ascending range");
         dev_ids = h->d_ids + part_ids_host[0];   // identity table 0..22 on the device
     }
+    if (h->g.enabled) return generic_logprob(h, ctx, dev_ids, P, R, v, B, mode, logp, (hipStream_t)stream);
     const int nw = B * P;
     hipLaunchKernelGGL(k_flow_logprob, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, v, B, mode, logp);
     HMF_LAUNCH_CHECK();

@@ -7,16 +7,44 @@
 
 namespace hmf {
 
+// default configuration = what the MFMA kernels are built for; anything else (or force_generic) goes to flow_generic.hip
+static bool is_generic(const hmf_flow_host_t* w) {
+    if (w->force_generic || w->transform_type != 0 || w->permute_type != 0 || w->num_transforms != 2) return true;
+    if (w->num_hidden != 0) return !(w->num_hidden == 3 && w->hidden_dims[0] == 64 && w->hidden_dims[1] == 32 && w->hidden_dims[2] == 32);
+    return !(w->hidden[0] == 64 && w->hidden[1] == 32 && w->hidden[2] == 32);
+}
+static const int* gen_hidden(const hmf_flow_host_t* w, int& nh) {
+    if (w->num_hidden != 0) { nh = w->num_hidden; return w->hidden_dims; }
+    nh = 3;
+    return w->hidden;
+}
+
 static int validate(const hmf_flow_host_t* w) {
     if (!w || !w->parents_host || !w->w_isgc_host || !w->b_isgc_host || !w->w_ctx_host || !w->b_ctx_host ||
         !w->w_nn_host || !w->b_nn_host)
         return fail(HMF_ERR_INVALID, "hmf_flow: null weight array");
-    if (w->isgc_dim != kIsgc || w->ctx_dim != kCtx || w->num_transforms != 2 || w->hidden[0] != 64 ||
-        w->hidden[1] != 32 || w->hidden[2] != 32 || w->count_bins != kBins)
-        return fail(HMF_ERR_UNSUPPORTED,
-                    "hmf_flow: only the default flow (isgc 256, ctx 64, 2 spline couplings, hidden [64,32,32], 8 bins) "
-                    "is built; got isgc=%d ctx=%d T=%d hidden=[%d,%d,%d] bins=%d",
-                    w->isgc_dim, w->ctx_dim, w->num_transforms, w->hidden[0], w->hidden[1], w->hidden[2], w->count_bins);
+    if (w->isgc_dim != kIsgc || w->ctx_dim != kCtx || w->count_bins != kBins)
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: INPUT_SHAPE_GLOB_CAM_FEATS_DIM 256, CONTEXT_DIM 64 and 8 spline bins are built; got isgc=%d ctx=%d bins=%d",
+                    w->isgc_dim, w->ctx_dim, w->count_bins);
+    if (is_generic(w)) {
+        if (w->num_transforms < 1 || w->num_transforms > kMaxT) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: NUM_TRANSFORMS=%d outside [1,%d]", w->num_transforms, kMaxT);
+        if (w->transform_type < 0 || w->transform_type > 1 || w->permute_type < 0 || w->permute_type > 2)
+            return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: transform_type=%d permute_type=%d", w->transform_type, w->permute_type);
+        int nh;
+        const int* hd = gen_hidden(w, nh);
+        if (nh < 1 || nh > kMaxLayers - 1) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: %d hidden layers (1..%d are built)", nh, kMaxLayers - 1);
+        for (int i = 0; i < nh; ++i)
+            if (hd[i] < 1 || hd[i] > 64) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: hidden width %d outside [1,64]", hd[i]);
+        if (w->permute_type == 2) {
+            if (w->plu_num_hidden < 1 || w->plu_num_hidden > kMaxLayers - 1 || !w->w_plu_host || !w->b_plu_host)
+                return fail(HMF_ERR_INVALID, "hmf_flow: conditional_linear_plu needs PERMUTE_NN_HIDDEN_DIMS (1..%d layers) and its weights", kMaxLayers - 1);
+            for (int i = 0; i < w->plu_num_hidden; ++i)
+                if (w->plu_hidden_dims[i] < 1 || w->plu_hidden_dims[i] > 64) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: PLU hidden width %d", w->plu_hidden_dims[i]);
+        }
+        if (w->permute_type == 1 && !w->lu_host) return fail(HMF_ERR_INVALID, "hmf_flow: linear_plu needs the LU parameters");
+    } else if (w->num_transforms != 2 || w->hidden[0] != 64 || w->hidden[1] != 32 || w->hidden[2] != 32) {
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: inconsistent default configuration T=%d hidden=[%d,%d,%d]", w->num_transforms, w->hidden[0], w->hidden[1], w->hidden[2]);
+    }
     if (w->num_betas < 1 || w->num_betas > 16) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: num_betas=%d", w->num_betas);
     if (w->feat_dim < 4 || (w->feat_dim % 256) != 0)
         return fail(HMF_ERR_UNSUPPORTED, "hmf_flow: feat_dim=%d must be a multiple of 256", w->feat_dim);
@@ -26,7 +54,10 @@ static int validate(const hmf_flow_host_t* w) {
             return fail(HMF_ERR_INVALID, "hmf_flow: parents[%d]=%d is not an earlier joint", j, w->parents_host[j]);
     for (int j = 0; j < kP; ++j)
         if (!w->w_ctx_host[j] || !w->b_ctx_host[j]) return fail(HMF_ERR_INVALID, "hmf_flow: null ctx layer %d", j);
-    for (int i = 0; i < kP * 8; ++i)
+    int nh;
+    gen_hidden(w, nh);
+    const int per_part = is_generic(w) ? w->num_transforms * (nh + 1) : 8;
+    for (int i = 0; i < kP * per_part; ++i)
         if (!w->w_nn_host[i] || !w->b_nn_host[i]) return fail(HMF_ERR_INVALID, "hmf_flow: null hyper-net layer %d", i);
     return HMF_OK;
 }
@@ -77,6 +108,8 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
     fp.o_bisgc = (int)P.place(kIsgc);
     std::copy(w->b_isgc_host, w->b_isgc_host + kIsgc, P.buf.begin() + fp.o_bisgc);
     // rank-nb shape update of the isgc layer as an A operand: 8 tiles, k-steps = ceil(nb/2), kidx = 2 s + q
+    fp.generic = is_generic(w);
+    fp.T = w->num_transforms; fp.transform_type = w->transform_type; fp.permute_type = w->permute_type;
     fp.o_wbeta = (int)pack_a(P, 8, (nb + 1) / 2, [&](int tl, int s, int lane) {
         const int k = 2 * s + (lane >> 5);
         return k < nb ? w->w_isgc_host[(size_t)(32 * tl + (lane & 31)) * in_dim + F + k] : 0.f;
@@ -96,12 +129,17 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
         t.kag = (t.kas + 3) / 4;
         for (int k = 0; k < ka; ++k) fp.anc_off[(size_t)j * 64 + k] = anc[k / 9] * 9 + k % 9;
         const float* wc = w->w_ctx_host[j];
+        t.o_bctx = (int)P.place(kCtx);
+        std::copy(w->b_ctx_host[j], w->b_ctx_host[j] + kCtx, P.buf.begin() + t.o_bctx);
+        // natural transposed copy of the context layer (lane = output channel): teacher-forced kernels, backward, generic variants
+        t.o_wctxT = (int)P.place((size_t)kin * kCtx);
+        for (int k = 0; k < kin; ++k)
+            for (int n = 0; n < kCtx; ++n) P.buf[t.o_wctxT + (size_t)k * kCtx + n] = wc[(size_t)n * kin + k];
+        if (fp.generic) continue;
         // context layer, isgc half: 2 tiles x 128 k-steps over the 256 isgc channels held in ARL (8 tiles)
         t.o_wc0 = (int)pack_a(P, 2, 128, [&](int tl, int s, int lane) {
             return wc[(size_t)(32 * tl + (lane & 31)) * kin + arl_channel(s >> 4, s & 15, lane >> 5)];
         });
-        t.o_bctx = (int)P.place(kCtx);
-        std::copy(w->b_ctx_host[j], w->b_ctx_host[j] + kCtx, P.buf.begin() + t.o_bctx);
         // context layer, ancestor half: kidx = 256 + 2 s + q
         t.o_wa = (int)pack_a(P, 2, t.kas, [&](int tl, int s, int lane) {
             const int k = 2 * s + (lane >> 5);
@@ -143,10 +181,7 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
                 }
             }
         }
-        // natural transposed copies for the teacher-forced kernels (lane = output channel)
-        t.o_wctxT = (int)P.place((size_t)kin * kCtx);
-        for (int k = 0; k < kin; ++k)
-            for (int n = 0; n < kCtx; ++n) P.buf[t.o_wctxT + (size_t)k * kCtx + n] = wc[(size_t)n * kin + k];
+        // natural transposed copies of the hyper-networks for the teacher-forced / backward kernels (lane = output channel)
         static const int Kd[4] = {65, 64, 32, 32}, Nd[4] = {64, 32, 32, 62};
         for (int c = 0; c < 2; ++c)
             for (int l = 0; l < 4; ++l) {
@@ -155,6 +190,44 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
                     for (int n = 0; n < Nd[l]; ++n) P.buf[t.o_nnT[c][l] + (size_t)k * 64 + n] = wn[c * 4 + l][(size_t)n * Kd[l] + k];
                 t.o_nnb[c][l] = (int)P.place(64);
                 std::copy(bn[c * 4 + l], bn[c * 4 + l] + Nd[l], P.buf.begin() + t.o_nnb[c][l]);
+            }
+    }
+    if (fp.generic) {
+        int nh;
+        const int* hd = gen_hidden(w, nh);
+        const int out_dim = w->transform_type == 0 ? 62 : 2;
+        auto pack_net = [&](GenNet& g, const float* const* W, const float* const* Bv, int in_dim, const int* hidden, int nhid, int odim) {
+            g.nl = nhid + 1;
+            int k = in_dim;
+            for (int l = 0; l <= nhid; ++l) {
+                const int n = l < nhid ? hidden[l] : odim;
+                g.K[l] = k; g.N[l] = n;
+                g.o_w[l] = (int)P.place((size_t)k * 64);
+                for (int kk = 0; kk < k; ++kk)
+                    for (int nn = 0; nn < n; ++nn) P.buf[g.o_w[l] + (size_t)kk * 64 + nn] = W[l][(size_t)nn * k + kk];
+                g.o_b[l] = (int)P.place(64);
+                std::copy(Bv[l], Bv[l] + n, P.buf.begin() + g.o_b[l]);
+                k = n;
+            }
+        };
+        fp.gtab.assign(kP, GenPartTab());
+        for (int j = 0; j < kP; ++j)
+            for (int t = 0; t < fp.T; ++t) {
+                GenPartTab& g = fp.gtab[j];
+                const size_t base = ((size_t)j * fp.T + t) * (nh + 1);
+                pack_net(g.tr[t], w->w_nn_host + base, w->b_nn_host + base, kCtx + 1, hd, nh, out_dim);
+                g.plu[t].nl = 0;
+                g.o_lu[t] = -1;
+                if (w->permute_type == 2) {
+                    const size_t pb = ((size_t)j * fp.T + t) * (w->plu_num_hidden + 1);
+                    for (int l = 0; l <= w->plu_num_hidden; ++l)
+                        if (!w->w_plu_host[pb + l] || !w->b_plu_host[pb + l]) return fail(HMF_ERR_INVALID, "hmf_flow: null PLU layer");
+                    pack_net(g.plu[t], w->w_plu_host + pb, w->b_plu_host + pb, kCtx, w->plu_hidden_dims, w->plu_num_hidden, 9);
+                } else if (w->permute_type == 1) {
+                    if (!w->lu_host[(size_t)j * fp.T + t]) return fail(HMF_ERR_INVALID, "hmf_flow: null LU parameter");
+                    g.o_lu[t] = (int)P.place(16);
+                    std::copy(w->lu_host[(size_t)j * fp.T + t], w->lu_host[(size_t)j * fp.T + t] + 9, P.buf.begin() + g.o_lu[t]);
+                }
             }
     }
     // Rounds: greedy list schedule of the kinematic tree, <= kChainWaves independent parts per round, all ancestors in
@@ -231,16 +304,18 @@ int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* w) {
     if (rc) return rc;
     if (hmf_device_count() <= 0) return fail(HMF_ERR_NO_DEVICE, "hmf_flow_create: no HIP device visible");
     const size_t b_arena = align_up(fp.arena.size() * 4, 256), b_tab = align_up((size_t)kP * sizeof(PartTab), 256);
-    const size_t b_anc = align_up((size_t)kP * 64 * 4, 256), b_ids = kP * 4;
+    const size_t b_anc = align_up((size_t)kP * 64 * 4, 256), b_ids = align_up(kP * 4, 256);
+    const size_t b_gen = fp.generic ? (size_t)kP * sizeof(GenPartTab) : 0;
     void* mem = nullptr;
-    HMF_HIP(hipMalloc(&mem, b_arena + b_tab + b_anc + b_ids));
+    HMF_HIP(hipMalloc(&mem, b_arena + b_tab + b_anc + b_ids + b_gen));
     char* base = (char*)mem;
     hipError_t e = hipMemcpy(base, fp.arena.data(), fp.arena.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(base + b_arena, fp.tab.data(), (size_t)kP * sizeof(PartTab), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(base + b_arena + b_tab, fp.anc_off.data(), (size_t)kP * 64 * 4, hipMemcpyHostToDevice);
     int ids[kP];
     for (int j = 0; j < kP; ++j) ids[j] = j;
-    if (e == hipSuccess) e = hipMemcpy(base + b_arena + b_tab + b_anc, ids, b_ids, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(base + b_arena + b_tab + b_anc, ids, kP * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && fp.generic) e = hipMemcpy(base + b_arena + b_tab + b_anc + b_ids, fp.gtab.data(), b_gen, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(mem);
         return fail(HMF_ERR_HIP, "hmf_flow_create: upload failed: %s", hipGetErrorString(e));
@@ -256,6 +331,9 @@ int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* w) {
     d.anc_off = (const int*)(base + b_arena + b_tab);
     d.o_wisgc = fp.o_wisgc; d.o_bisgc = fp.o_bisgc; d.o_wbeta = fp.o_wbeta;
     d.lev = fp.lev;
+    h->g.enabled = fp.generic ? 1 : 0;
+    h->g.T = fp.T; h->g.transform_type = fp.transform_type; h->g.permute_type = fp.permute_type;
+    h->g.tab = fp.generic ? (const GenPartTab*)(base + b_arena + b_tab + b_anc + b_ids) : nullptr;
     *out = h;
     return HMF_OK;
 }

@@ -11,8 +11,11 @@ hmf_flow_log_prob_*), with no Python loop over body parts.
 state_dict keys: init_glob, init_cam, image_encoder.*, fc1, fc_shape, fc_glob, fc_cam,
 fc_input_shape_glob_cam_feats, fc_flow_context.{0..22}, pose_so3flow_transform_modules.{0..45}.nn.layers.{0..3}.
 
-Only the default flow configuration is built (spline_coupling + permute, hidden [64,32,32], 8 bins); other
-TRANSFORM_TYPE / PERMUTE_TYPE values raise NotImplementedError at construction.
+Flow configurations (create_conditional_norm_flow): the default (spline_coupling + permute, hidden [64,32,32], 2 transforms) runs on the
+MFMA kernels; TRANSFORM_TYPE 'additive_coupling', PERMUTE_TYPE 'linear_plu' / 'conditional_linear_plu', other NUM_TRANSFORMS / hidden
+widths run on the generic kernels of csrc/flow_generic.hip (inference only).  With a PLU permutation the transform-module list interleaves
+[permutation module, coupling module] per transform, exactly as the reference builds it (pyro_conditional_norm_flow.py:115), so its
+checkpoint keys (`...LU`, `...permutation`, `...cond_plu_nn.layers.*`) line up.
 
 Training (BASELINE configs[4]): forward under autograd returns differentiable samples / log-likelihood objects; the backward
 passes of the flow live in csrc/flow_grad.hip and are wired up in autograd.py.
@@ -68,6 +71,52 @@ class ConditionalSplineCoupling(nn.Module):
                                      param_dims=[up * count_bins, up * count_bins, up * (count_bins - 1), up * count_bins])
 
 
+class ConditionalAdditiveCoupling(nn.Module):
+    """models/norm_flows/transforms/additive_coupling_transform.py:69-85,119-137 (split_dim = 1): y1 = x1, y2 = x2 + nn([context, x1]),
+    log-det 0.  `.nn` = ConditionalDenseNN(1, context_dim, hidden_dims, [2]).  (In the reference this option fails with a TypeError at the
+    first `.condition()` because `bound` / `count_bins` are forwarded into AdditiveCoupling.__init__; the transform's own arithmetic is built.)"""
+
+    def __init__(self, input_dim, context_dim, hidden_dims):
+        super().__init__()
+        self.split_dim = input_dim // 2
+        self.nn = ConditionalDenseNN(self.split_dim, context_dim, hidden_dims, param_dims=[input_dim - self.split_dim])
+
+
+class DenseNN(nn.Module):
+    """pyro.nn.DenseNN parameter container: `layers` = [Linear(input_dim, h0), ..., Linear(h_last, sum(param_dims))]."""
+
+    def __init__(self, input_dim, hidden_dims, param_dims):
+        super().__init__()
+        dims = [input_dim] + list(hidden_dims) + [sum(param_dims)]
+        self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+
+def _permutation_matrix(permutation):
+    return torch.eye(len(permutation), len(permutation))[torch.as_tensor(permutation, dtype=torch.int64)]
+
+
+class LinearPLUTransform(nn.Module):
+    """models/norm_flows/transforms/linearPLU_transform.py:85-120: y = P L U x with a dense `LU` parameter (L strictly below the diagonal,
+    unit diagonal; U on and above), initialised from the LU factors of a random orthogonal matrix; buffer `permutation` = eye[perm]."""
+
+    def __init__(self, input_dim, permutation):
+        super().__init__()
+        W, _ = torch.linalg.qr(torch.randn(input_dim, input_dim))
+        LU, _ = torch.linalg.lu_factor(W)
+        self.register_buffer('permutation', _permutation_matrix(permutation))
+        self.LU = nn.Parameter(LU)
+
+
+class ConditionalLinearPLUTransform(nn.Module):
+    """linearPLU_transform.py:123-150: LU = cond_plu_nn(context) (DenseNN -> 9), diagonal through softplus(beta=0.75); buffer `permutation`."""
+
+    def __init__(self, input_dim, context_dim, hidden_dims, permutation):
+        super().__init__()
+        self.input_dim = input_dim
+        self.cond_plu_nn = DenseNN(context_dim, hidden_dims, param_dims=[input_dim * input_dim])
+        self.register_buffer('permutation', _permutation_matrix(permutation))
+
+
 class _ConditionedFlowDist:
     """What `.condition(ctx)` returns in the reference: an object exposing log_prob().  group=True mirrors
     LocalDiffeoTransformedDistribution (R (B,3,3) fp64 -> (B,) fp32, local_diffeo_transformed_distribution.py:84-142),
@@ -114,9 +163,17 @@ class HumaniflowModel(nn.Module):
     def __init__(self, device, model_cfg, smpl_parents):
         super().__init__()
         nf = model_cfg.NORM_FLOW
-        if nf.TRANSFORM_TYPE != 'spline_coupling' or nf.PERMUTE_TYPE != 'permute':
-            raise NotImplementedError('humaniflow_amd builds the default flow only (spline_coupling + permute); got %s + %s'
-                                      % (nf.TRANSFORM_TYPE, nf.PERMUTE_TYPE))
+        # create_conditional_norm_flow (models/norm_flows/pyro_conditional_norm_flow.py:21-117): the reference's own transforms are built;
+        # pyro's stock affine_coupling / affine_masked / spline_masked options are not
+        if nf.TRANSFORM_TYPE not in ('spline_coupling', 'additive_coupling'):
+            raise NotImplementedError("humaniflow_amd builds TRANSFORM_TYPE 'spline_coupling' and 'additive_coupling'; got %r" % (nf.TRANSFORM_TYPE,))
+        if nf.PERMUTE_TYPE not in ('permute', 'linear_plu', 'conditional_linear_plu'):
+            raise NotImplementedError("humaniflow_amd builds PERMUTE_TYPE 'permute', 'linear_plu' and 'conditional_linear_plu'; got %r" % (nf.PERMUTE_TYPE,))
+        if nf.PERMUTE_TYPE == 'conditional_linear_plu':
+            assert nf.PERMUTE_NN_HIDDEN_DIMS is not None                                  # pyro_conditional_norm_flow.py:41-42
+        self.default_flow = (nf.TRANSFORM_TYPE == 'spline_coupling' and nf.PERMUTE_TYPE == 'permute' and nf.NUM_TRANSFORMS == 2
+                             and list(nf.TRANSFORM_NN_HIDDEN_DIMS) == [64, 32, 32])
+        self.force_generic_flow = False           # tests: run the default configuration through the variant kernels
         self.parents = list(smpl_parents)
         self.ancestors_dict = immediate_parent_to_all_ancestors(self.parents)
         self.num_bodyparts = len(self.ancestors_dict)
@@ -151,10 +208,19 @@ class HumaniflowModel(nn.Module):
         for bodypart in range(self.num_bodyparts):
             num_ancestors = len(self.ancestors_dict[bodypart])
             self.fc_flow_context.append(nn.Linear(model_cfg.INPUT_SHAPE_GLOB_CAM_FEATS_DIM + num_ancestors * 9, nf.CONTEXT_DIM))
-            for _ in range(nf.NUM_TRANSFORMS):        # module index = NUM_TRANSFORMS * part + t
-                self.pose_so3flow_transform_modules.append(
-                    ConditionalSplineCoupling(3, nf.CONTEXT_DIM, list(nf.TRANSFORM_NN_HIDDEN_DIMS), nf.NUM_SPLINE_SEGMENTS,
-                                              nf.COMPACT_SUPPORT_RADIUS))
+            for t in range(nf.NUM_TRANSFORMS):        # default flow: module index = NUM_TRANSFORMS * part + t
+                perm = [(m + t % 3) % 3 for m in range(3)]                                    # :46-47 cyclic shifts
+                if nf.PERMUTE_TYPE == 'linear_plu':                                           # :65-67 (an nn.Module: listed before its coupling)
+                    self.pose_so3flow_transform_modules.append(LinearPLUTransform(3, perm))
+                elif nf.PERMUTE_TYPE == 'conditional_linear_plu':                             # :68-72
+                    self.pose_so3flow_transform_modules.append(
+                        ConditionalLinearPLUTransform(3, nf.CONTEXT_DIM, list(nf.PERMUTE_NN_HIDDEN_DIMS), perm))
+                if nf.TRANSFORM_TYPE == 'spline_coupling':
+                    self.pose_so3flow_transform_modules.append(
+                        ConditionalSplineCoupling(3, nf.CONTEXT_DIM, list(nf.TRANSFORM_NN_HIDDEN_DIMS), nf.NUM_SPLINE_SEGMENTS,
+                                                  nf.COMPACT_SUPPORT_RADIUS))
+                else:
+                    self.pose_so3flow_transform_modules.append(ConditionalAdditiveCoupling(3, nf.CONTEXT_DIM, list(nf.TRANSFORM_NN_HIDDEN_DIMS)))
             self.pose_so3flow_dists.append(_FlowDistHandle(self, bodypart, group=False))
             self.pose_SO3flow_dists.append(_FlowDistHandle(self, bodypart, group=True))
         self.__dict__.update(_handles={}, _ws={}, _flow_tensors=None, _flow_key=None)
@@ -224,9 +290,14 @@ class HumaniflowModel(nn.Module):
         hs.feat_dim, hs.num_betas = self.input_feats_dim, self.num_shape_params
         hs.isgc_dim, hs.ctx_dim, hs.num_transforms = self.model_cfg.INPUT_SHAPE_GLOB_CAM_FEATS_DIM, nf.CONTEXT_DIM, T
         hd = list(nf.TRANSFORM_NN_HIDDEN_DIMS)
-        if len(hd) != 3:
-            raise NotImplementedError('TRANSFORM_NN_HIDDEN_DIMS must have 3 entries')
-        hs.hidden = (C.c_int * 3)(*hd)
+        if not 1 <= len(hd) <= 4 or max(hd) > 64:
+            raise NotImplementedError('TRANSFORM_NN_HIDDEN_DIMS: 1..4 layers of <= 64 channels are built, got %s' % (hd,))
+        hs.hidden = (C.c_int * 3)(*(hd + [0, 0, 0])[:3])
+        hs.num_hidden = len(hd)
+        hs.hidden_dims = (C.c_int * 4)(*(hd + [0, 0, 0, 0])[:4])
+        hs.transform_type = {'spline_coupling': 0, 'additive_coupling': 1}[nf.TRANSFORM_TYPE]
+        hs.permute_type = {'permute': 0, 'linear_plu': 1, 'conditional_linear_plu': 2}[nf.PERMUTE_TYPE]
+        hs.force_generic = int(self.force_generic_flow)
         hs.count_bins, hs.radius, hs.base_std = nf.NUM_SPLINE_SEGMENTS, nf.COMPACT_SUPPORT_RADIUS, nf.BASE_DIST_STD
         par = np.ascontiguousarray(np.array(self.parents, np.int32))
         keep.append(par)
@@ -235,15 +306,35 @@ class HumaniflowModel(nn.Module):
         hs.b_isgc_host = _lib.fptr(arr(self.fc_input_shape_glob_cam_feats.bias))
         wc = (_lib.c_float_p * P)(*[_lib.fptr(arr(m.weight)) for m in self.fc_flow_context])
         bc = (_lib.c_float_p * P)(*[_lib.fptr(arr(m.bias)) for m in self.fc_flow_context])
-        wn, bn = [], []
+        wn, bn, wp, bp, lu = [], [], [], [], []
         for mod in self.pose_so3flow_transform_modules:
-            for lin in mod.nn.layers:
-                wn.append(_lib.fptr(arr(lin.weight)))
-                bn.append(_lib.fptr(arr(lin.bias)))
+            if isinstance(mod, LinearPLUTransform):
+                lu.append(_lib.fptr(arr(mod.LU)))
+            elif isinstance(mod, ConditionalLinearPLUTransform):
+                for lin in mod.cond_plu_nn.layers:
+                    wp.append(_lib.fptr(arr(lin.weight)))
+                    bp.append(_lib.fptr(arr(lin.bias)))
+            else:
+                for lin in mod.nn.layers:
+                    wn.append(_lib.fptr(arr(lin.weight)))
+                    bn.append(_lib.fptr(arr(lin.bias)))
         wn_a = (_lib.c_float_p * len(wn))(*wn)
         bn_a = (_lib.c_float_p * len(bn))(*bn)
         keep += [wc, bc, wn_a, bn_a]
         hs.w_ctx_host, hs.b_ctx_host, hs.w_nn_host, hs.b_nn_host = wc, bc, wn_a, bn_a
+        if wp:
+            ph = list(nf.PERMUTE_NN_HIDDEN_DIMS)
+            if not 1 <= len(ph) <= 4 or max(ph) > 64:
+                raise NotImplementedError('PERMUTE_NN_HIDDEN_DIMS: 1..4 layers of <= 64 channels are built, got %s' % (ph,))
+            hs.plu_num_hidden = len(ph)
+            hs.plu_hidden_dims = (C.c_int * 4)(*(ph + [0, 0, 0, 0])[:4])
+            wp_a, bp_a = (_lib.c_float_p * len(wp))(*wp), (_lib.c_float_p * len(bp))(*bp)
+            keep += [wp_a, bp_a]
+            hs.w_plu_host, hs.b_plu_host = wp_a, bp_a
+        if lu:
+            lu_a = (_lib.c_float_p * len(lu))(*lu)
+            keep.append(lu_a)
+            hs.lu_host = lu_a
         return hs, keep
 
     def _flow_handle(self, device):
@@ -273,8 +364,12 @@ class HumaniflowModel(nn.Module):
 
     # ---- reference helper methods (kept for API parity; single calls into the library) -----------------------------
     def _needs_grad(self, *tensors):
-        return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
+        need = torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
                                             or any(p.requires_grad for p in self._flow_params()))
+        if need and not self.default_flow:
+            raise NotImplementedError('humaniflow_amd: gradients are built for the default flow configuration (spline_coupling + permute); call the '
+                                      'variants under torch.no_grad()')
+        return need
 
     def _isgc_kernel(self, input_feats, shape, glob_R, cam):
         lib = _lib.load()
@@ -384,6 +479,9 @@ class HumaniflowModel(nn.Module):
         if grad_for_pose_point_est:
             raise NotImplementedError('humaniflow_amd: grad_for_pose_point_est=True (gradients through the z = 0 point-estimate chain) is not built')
         grad = torch.is_grad_enabled() and (input_feats.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if grad and not self.default_flow:
+            raise NotImplementedError('humaniflow_amd: gradients are built for the default flow configuration (spline_coupling + permute); call the '
+                                      'variants under torch.no_grad()')
         lib = _lib.load()
         nb, P, N = self.num_shape_params, self.num_bodyparts, int(num_samples)
 

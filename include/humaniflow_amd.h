@@ -128,6 +128,21 @@ typedef struct {
     const float* const* b_ctx_host; /* [23]: ctx_dim                                             */
     const float* const* w_nn_host;  /* [23*num_transforms*4]: (64x65),(32x64),(32x32),(62x32)     */
     const float* const* b_nn_host;  /* same indexing                                             */
+    /* ---- non-default flow variants (models/norm_flows/pyro_conditional_norm_flow.py:60-106).  All zero / NULL = the default
+     * configuration above (spline_coupling + permute, hidden [64,32,32], 2 transforms), which runs on the MFMA kernels; anything else
+     * runs on the generic lane-per-channel kernels (csrc/flow_generic.hip).  With variants, w_nn_host / b_nn_host hold
+     * 23 * num_transforms * (num_hidden + 1) layers: (h0 x (ctx_dim + 1)), (h1 x h0), ..., (out x h_last), out = 62 (spline) or 2 (additive). */
+    int transform_type;             /* 0 spline_coupling (transforms/conditional_spline_coupling_transform.py), 1 additive_coupling
+                                       (transforms/additive_coupling_transform.py:12-85: y2 = x2 + nn([context, x1]), log-det 0)            */
+    int permute_type;               /* 0 permute, 1 linear_plu, 2 conditional_linear_plu (transforms/linearPLU_transform.py:12-150)        */
+    int num_hidden;                 /* 0 = use hidden[3] above; else 1..4 entries of hidden_dims                                          */
+    int hidden_dims[4];             /* NORM_FLOW.TRANSFORM_NN_HIDDEN_DIMS, each <= 64                                                    */
+    int plu_num_hidden;             /* conditional_linear_plu: entries of NORM_FLOW.PERMUTE_NN_HIDDEN_DIMS (1..4, each <= 64)             */
+    int plu_hidden_dims[4];
+    const float* const* w_plu_host; /* conditional_linear_plu: [23 * num_transforms * (plu_num_hidden + 1)] DenseNN layers ctx -> ... -> 9  */
+    const float* const* b_plu_host;
+    const float* const* lu_host;    /* linear_plu: [23 * num_transforms] 3x3 row-major `LU` parameters (L strictly below, U on/above)     */
+    int force_generic;              /* tests: run the default configuration through the generic kernels too                              */
 } hmf_flow_host_t;
 
 int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* weights);

@@ -50,23 +50,76 @@ def radial_tanh_log_abs_det(x, y, radius):
     return torch.where(yn > 1e-7, ld, torch.zeros_like(ld))
 
 
-class PartFlow:
-    """One body part's flow: [Permute, SplineCoupling] x T  ->  ScaledRadialTanh.
-    `couplings` is a list of T hyper-networks, each a list of (weight, bias)."""
+def plu_matrices(perm, LU):
+    """models/norm_flows/transforms/linearPLU_transform.py:23-33: P = eye[perm], L = tril(LU, -1) + I, U = triu(LU).  LU (..., 3, 3)."""
+    P = torch.eye(3, dtype=LU.dtype)[torch.tensor(perm)]
+    return P, LU.tril(diagonal=-1) + torch.eye(3, dtype=LU.dtype), LU.triu()
 
-    def __init__(self, couplings, radius, base_std, count_bins=8):
+
+def plu_forward(perm, LU, x):
+    """ConditionedLinearPLUTransform._call (:35-50): y = P L U x."""
+    P, L, U = plu_matrices(perm, LU)
+    return torch.matmul(P @ L @ U, x[..., None])[..., 0]
+
+
+def plu_inverse(perm, LU, y):
+    """ConditionedLinearPLUTransform._inverse (:52-74) and log_abs_det_jacobian (:76-82): returns (x, sum log|u_ii|)."""
+    P, L, U = plu_matrices(perm, LU)
+    LUx = torch.matmul(P.T, y[..., None])
+    Ux = torch.linalg.solve_triangular(L.expand(LUx.shape[:-2] + (3, 3)), LUx, upper=False)
+    x = torch.linalg.solve_triangular(U.expand(LUx.shape[:-2] + (3, 3)), Ux, upper=True)
+    return x[..., 0], LU.diagonal(dim1=-2, dim2=-1).abs().log().sum(dim=-1)
+
+
+def conditional_lu(layers, context):
+    """ConditionalLinearPLUTransform.condition (:138-150): DenseNN(context) -> (…,3,3), diagonal through softplus(beta=0.75)."""
+    import torch.nn.functional as F
+    h = context
+    for (w, b) in layers[:-1]:
+        h = F.relu(F.linear(h, w, b))
+    LU = F.linear(h, layers[-1][0], layers[-1][1])
+    LU = LU.view(LU.shape[:-1] + (3, 3)).clone()
+    LU[..., range(3), range(3)] = F.softplus(LU[..., range(3), range(3)], beta=0.75)
+    return LU
+
+
+def additive_coupling(layers, context, x, inverse=False):
+    """transforms/additive_coupling_transform.py:28-66 with split_dim = 1: y1 = x1, y2 = x2 +/- nn([context, x1]); log-det 0."""
+    from .spline import dense_nn
+    mean = dense_nn(layers, x[..., :1], context)
+    return torch.cat([x[..., :1], x[..., 1:] - mean if inverse else x[..., 1:] + mean], dim=-1)
+
+
+class PartFlow:
+    """One body part's flow: [Permute | LinearPLU | ConditionalLinearPLU, SplineCoupling | AdditiveCoupling] x T  ->  ScaledRadialTanh
+    (models/norm_flows/pyro_conditional_norm_flow.py:55-113).  `couplings` is a list of T hyper-networks, each a list of (weight, bias);
+    `plu` (optional) a list of T entries: a (3,3) LU tensor (linear_plu) or a list of (weight, bias) DenseNN layers (conditional)."""
+
+    def __init__(self, couplings, radius, base_std, count_bins=8, transform_type='spline_coupling', plu=None):
         self.couplings = couplings
         self.radius = radius
         self.base_std = base_std
         self.count_bins = count_bins
         self.perms = permutations(3, len(couplings))
+        self.transform_type = transform_type
+        self.plu = plu
+
+    def _lu(self, t, context):
+        p = self.plu[t]
+        return p if torch.is_tensor(p) else conditional_lu(p, context)
 
     # -- forward (sampling) direction: pyro_conditional_norm_flow.py:120-129 ------------
     def forward(self, z, context):
         x = z
-        for perm, layers in zip(self.perms, self.couplings):
-            x = x.index_select(-1, torch.tensor(perm))                 # pyro Permute._call
-            x, _ = spline_coupling(layers, context, x, self.radius, count_bins=self.count_bins)
+        for t, (perm, layers) in enumerate(zip(self.perms, self.couplings)):
+            if self.plu is None:
+                x = x.index_select(-1, torch.tensor(perm))             # pyro Permute._call
+            else:
+                x = plu_forward(perm, self._lu(t, context), x)
+            if self.transform_type == 'spline_coupling':
+                x, _ = spline_coupling(layers, context, x, self.radius, count_bins=self.count_bins)
+            else:
+                x = additive_coupling(layers, context, x)
         return radial_tanh_forward(x, self.radius)
 
     # -- density on the algebra: torch TransformedDistribution.log_prob ------------------
@@ -77,11 +130,19 @@ class PartFlow:
         x = radial_tanh_inverse(y, self.radius)
         lp = lp - radial_tanh_log_abs_det(x, y, self.radius)
         y = x
-        for perm, layers in zip(reversed(self.perms), reversed(self.couplings)):
-            x, ld = spline_coupling(layers, context, y, self.radius, inverse=True, count_bins=self.count_bins)
-            lp = lp - ld
-            inv = [perm.index(i) for i in range(3)]
-            y = x.index_select(-1, torch.tensor(inv))                  # Permute inverse, log-det 0
+        for t in reversed(range(len(self.couplings))):
+            perm, layers = self.perms[t], self.couplings[t]
+            if self.transform_type == 'spline_coupling':
+                x, ld = spline_coupling(layers, context, y, self.radius, inverse=True, count_bins=self.count_bins)
+                lp = lp - ld
+            else:
+                x = additive_coupling(layers, context, y, inverse=True)
+            if self.plu is None:
+                inv = [perm.index(i) for i in range(3)]
+                y = x.index_select(-1, torch.tensor(inv))              # Permute inverse, log-det 0
+            else:
+                y, ld = plu_inverse(perm, self._lu(t, context), x)
+                lp = lp - ld
         # pyro_conditional_norm_flow.py:49-52: Independent(Normal(0, base_std * ones(3)), 1)
         base = torch.distributions.Normal(torch.zeros(3), torch.ones(3) * self.base_std,
                                           validate_args=False).log_prob(y).sum(-1)

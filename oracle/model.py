@@ -34,7 +34,9 @@ def immediate_parent_to_all_ancestors(parents):
 
 class OracleCfg:
     def __init__(self, num_resnet_layers=50, num_betas=10, context_dim=64, num_transforms=2,
-                 radius=1.5 * 3.141592653589793, base_std=0.6, count_bins=8):
+                 radius=1.5 * 3.141592653589793, base_std=0.6, count_bins=8, transform_type='spline_coupling', permute_type='permute'):
+        self.transform_type = transform_type
+        self.permute_type = permute_type
         self.num_resnet_layers = num_resnet_layers
         self.num_betas = num_betas
         self.context_dim = context_dim
@@ -48,15 +50,25 @@ def _lin(sd, name, x):
     return F.linear(x, sd[name + '.weight'], sd[name + '.bias'])
 
 
+def _layers(sd, prefix):
+    n = len([key for key in sd if key.startswith(prefix) and key.endswith('.weight')])
+    return [(sd[prefix + '%d.weight' % i], sd[prefix + '%d.bias' % i]) for i in range(n)]
+
+
 def part_flow(sd, cfg, j):
-    """Hyper-networks of body part j: module index 2*j+t (SURVEY 8b checkpoint layout)."""
-    couplings = []
+    """Transforms of body part j.  Default flow: coupling modules at index T*j + t (SURVEY 8b checkpoint layout); with a PLU
+    permutation the reference's module list interleaves [PLU module, coupling] per transform (pyro_conditional_norm_flow.py:115)."""
+    ptype = getattr(cfg, 'permute_type', 'permute')
+    per = 1 if ptype == 'permute' else 2
+    couplings, plu = [], []
     for t in range(cfg.num_transforms):
-        k = cfg.num_transforms * j + t
-        p = 'pose_so3flow_transform_modules.%d.nn.layers.' % k
-        n = len([key for key in sd if key.startswith(p) and key.endswith('.weight')])
-        couplings.append([(sd[p + '%d.weight' % i], sd[p + '%d.bias' % i]) for i in range(n)])
-    return PartFlow(couplings, cfg.radius, cfg.base_std, cfg.count_bins)
+        k = (cfg.num_transforms * j + t) * per
+        if ptype == 'linear_plu':
+            plu.append(sd['pose_so3flow_transform_modules.%d.LU' % k])
+        elif ptype == 'conditional_linear_plu':
+            plu.append(_layers(sd, 'pose_so3flow_transform_modules.%d.cond_plu_nn.layers.' % k))
+        couplings.append(_layers(sd, 'pose_so3flow_transform_modules.%d.nn.layers.' % (k + per - 1)))
+    return PartFlow(couplings, cfg.radius, cfg.base_std, cfg.count_bins, getattr(cfg, 'transform_type', 'spline_coupling'), plu or None)
 
 
 def isgc_feats(sd, feats, shape, glob_R, cam):

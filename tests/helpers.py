@@ -53,7 +53,10 @@ def init_model_for_tests(model, seed=0, last_layer_scale=0.3):
         model.fc_shape.weight[nb:] *= 0.1
         model.fc_shape.bias[nb:] -= 1.0
         for mod in model.pose_so3flow_transform_modules:
-            mod.nn.layers[-1].weight *= last_layer_scale * 3
+            if hasattr(mod, 'nn'):
+                mod.nn.layers[-1].weight *= last_layer_scale * 3
+            elif hasattr(mod, 'LU'):                         # well-conditioned L U: unit-ish diagonal with both signs, small off-diagonal
+                mod.LU.copy_(torch.randn(3, 3, generator=g) * 0.3 + torch.diag(torch.tensor([1.2, -0.8, 0.9])))
         shapes = {k: tuple(v.shape) for k, v in model.image_encoder.state_dict().items()}
         model.image_encoder.load_state_dict(deterministic_state_dict(shapes, seed=seed + 11))
         model.fc1.weight *= 0.02          # the deterministic encoder weights give O(50) features; keep the heads O(1)
@@ -80,7 +83,7 @@ def oracle_cfg_from(model_cfg):
     nf = model_cfg.NORM_FLOW
     return OracleCfg(num_resnet_layers=model_cfg.NUM_RESNET_LAYERS, num_betas=model_cfg.NUM_SMPL_BETAS, context_dim=nf.CONTEXT_DIM,
                      num_transforms=nf.NUM_TRANSFORMS, radius=nf.COMPACT_SUPPORT_RADIUS, base_std=nf.BASE_DIST_STD,
-                     count_bins=nf.NUM_SPLINE_SEGMENTS)
+                     count_bins=nf.NUM_SPLINE_SEGMENTS, transform_type=nf.TRANSFORM_TYPE, permute_type=nf.PERMUTE_TYPE)
 
 
 def random_rotmats(n, scale=0.3, seed=0):

@@ -84,10 +84,33 @@ def test_config_mirror():
     c2 = cfg.clone()
     c2.merge_from_list(['MODEL.NUM_RESNET_LAYERS', '50', 'TRAIN.LR', '0.001'])
     assert c2.MODEL.NUM_RESNET_LAYERS == 50 and c2.TRAIN.LR == 0.001 and cfg.MODEL.NUM_RESNET_LAYERS == 18
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):                       # pyro's stock transforms are not built
         c3 = cfg.clone()
-        c3.MODEL.NORM_FLOW.PERMUTE_TYPE = 'linear_plu'
+        c3.MODEL.NORM_FLOW.TRANSFORM_TYPE = 'affine_coupling'
         H.HumaniflowModel(torch.device('cpu'), c3.MODEL, H.SMPL_PARENTS)
+
+
+def test_flow_variant_checkpoint_layouts():
+    """Non-default flows: the transform-module list interleaves [PLU module, coupling] per transform exactly as
+    create_conditional_norm_flow builds it (pyro_conditional_norm_flow.py:60-115), so the reference's checkpoint keys line up."""
+    cfg = H.get_humaniflow_cfg_defaults()
+    c = cfg.clone()
+    c.MODEL.NORM_FLOW.PERMUTE_TYPE = 'linear_plu'
+    sd = H.HumaniflowModel(torch.device('cpu'), c.MODEL, H.SMPL_PARENTS).state_dict()
+    assert tuple(sd['pose_so3flow_transform_modules.0.LU'].shape) == (3, 3) and tuple(sd['pose_so3flow_transform_modules.0.permutation'].shape) == (3, 3)
+    assert torch.equal(sd['pose_so3flow_transform_modules.2.permutation'], torch.eye(3)[torch.tensor([1, 2, 0])])       # transform 1: shift by 1
+    assert tuple(sd['pose_so3flow_transform_modules.1.nn.layers.0.weight'].shape) == (64, 65) and 'pose_so3flow_transform_modules.91.nn.layers.3.bias' in sd
+    c = cfg.clone()
+    c.MODEL.NORM_FLOW.PERMUTE_TYPE = 'conditional_linear_plu'
+    c.MODEL.NORM_FLOW.PERMUTE_NN_HIDDEN_DIMS = [30, 30]
+    c.MODEL.NORM_FLOW.TRANSFORM_TYPE = 'additive_coupling'
+    c.MODEL.NORM_FLOW.TRANSFORM_NN_HIDDEN_DIMS = [40, 20]
+    c.MODEL.NORM_FLOW.NUM_TRANSFORMS = 3
+    sd = H.HumaniflowModel(torch.device('cpu'), c.MODEL, H.SMPL_PARENTS).state_dict()
+    assert tuple(sd['pose_so3flow_transform_modules.0.cond_plu_nn.layers.0.weight'].shape) == (30, 64)
+    assert tuple(sd['pose_so3flow_transform_modules.0.cond_plu_nn.layers.2.weight'].shape) == (9, 30)
+    assert tuple(sd['pose_so3flow_transform_modules.1.nn.layers.0.weight'].shape) == (40, 65) and tuple(sd['pose_so3flow_transform_modules.1.nn.layers.2.weight'].shape) == (2, 20)
+    assert 'pose_so3flow_transform_modules.%d.nn.layers.2.bias' % (23 * 6 - 1) in sd and 'pose_so3flow_transform_modules.%d.permutation' % (23 * 6 - 2) in sd
 
 
 def test_smpl_blend_operand_pack_matches_mfma_lane_semantics(lib):
