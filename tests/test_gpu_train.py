@@ -188,24 +188,43 @@ def test_full_train_step_loss_and_gradients_at_batch_72():
                'shape': torch.randn(B, 10, generator=g) * 1.25, 'joints2D': torch.rand(B, 17, 2, generator=g) * 256,
                'joints2D_vis': torch.rand(B, 17, generator=g) > 0.2}
     noise = {'shape': torch.randn(N, B, 10, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
-    sd64 = _sd64(sd)
-    f64 = feats.double().requires_grad_(True)
-    t64 = {k: (v.double() if v.is_floating_point() else v) for k, v in targets.items()}
-    with ot.float64_defaults():
-        loss_ref, _ = ot.train_step_loss(sd64, ocfg, om, cfg.LOSS, 256, f64, t64, {k: v.double() for k, v in noise.items()}, N)
-    loss_ref.backward()
+    def oracle(dt):
+        sdd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items() if not k.startswith('image_encoder')}
+        f = feats.to(dt).requires_grad_(True)
+        t = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in targets.items()}
+        omd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in om.items()}
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dt)
+        try:
+            loss_o, _ = ot.train_step_loss(sdd, ocfg, omd, cfg.LOSS, 256, f, t, {k: v.to(dt) for k, v in noise.items()}, N)
+        finally:
+            torch.set_default_dtype(old)
+        loss_o.backward()
+        return loss_o.item(), f.grad.double(), {k: v.grad.double() for k, v in sdd.items() if v.is_floating_point()}
+    loss_ref, gf64, g64 = oracle(torch.float64)
+    # The same oracle evaluated in float32: the densities' log-derivatives are only C^0 at spline knots / break points, so a target that
+    # lands within rounding of one takes the other branch in float32 and moves a few parameter gradients by ~1e-3 of their scale
+    # (measured: modules.40.nn.layers.0 2.4e-3, fc_flow_context.20 5.3e-4 with these seeds -- in the float32 ORACLE as much as in the kernels).
+    # The bar is therefore: within 5e-4 of the float64 gradient, plus twice the float32 oracle's own distance from it.
+    _, gf32, g32 = oracle(torch.float32)
     fg = feats.cuda().requires_grad_(True)
     model.zero_grad()
     loss, _ = train_forward_loss(model, smpl, H.HumaniflowLoss(cfg.LOSS, 256), None, {k: v.cuda() for k, v in targets.items()}, N,
                                  noise={k: v.cuda() for k, v in noise.items()}, input_feats=fg)
-    assert abs(loss.item() - loss_ref.item()) <= 2e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    assert abs(loss.item() - loss_ref) <= 2e-4 * abs(loss_ref), (loss.item(), loss_ref)
     loss.backward()
-    _check('d input_feats', fg.grad, f64.grad, 1e-3)
+
+    def close(name, got, ref, ref32):
+        got = got.detach().double().cpu()
+        scale = max(ref.abs().max().item(), 1e-12)
+        err, slack = (got - ref).abs().max().item(), (ref32 - ref).abs().max().item()
+        assert err <= 5e-4 * scale + 2.0 * slack, '%s: |hip - f64| %.3e, |f32 oracle - f64| %.3e, scale %.3e' % (name, err, slack, scale)
+    close('d input_feats', fg.grad, gf64, gf32)
     n = 0
     for name, p in model.named_parameters():
         if name.startswith('image_encoder'):
             continue
         assert p.grad is not None, name
-        _check(name, p.grad, sd64[name].grad, 1e-3)     # fp32 sums over 576 sample rows of terms weighted 25,000x (measured worst: 5.3e-4)
+        close(name, p.grad, g64[name], g32[name])
         n += 1
     assert n == 424                                                              # every non-encoder parameter of the checkpoint layout
