@@ -190,7 +190,7 @@ def test_full_train_step_loss_and_gradients_at_batch_72():
     noise = {'shape': torch.randn(N, B, 10, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
     def oracle(dt):
         sdd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items() if not k.startswith('image_encoder')}
-        f = feats.to(dt).requires_grad_(True)
+        f = feats.to(dt).clone().requires_grad_(True)
         t = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in targets.items()}
         omd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in om.items()}
         old = torch.get_default_dtype()
