@@ -14,6 +14,9 @@ python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.log"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH > "$OUT/${R}_bench_under_rocprof.json" 2>/tmp/kt.log
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 python tools/rocpd_stats.py "$DB" 48 --steps $STEPS > "$OUT/${R}_kernel_stats.md"
+# the same steps on ONE stream, eagerly: kernel execution times without co-running kernels = what bench.py's measurement pass (roofline.frac) reports
+rocprofv3 --kernel-trace --stats -d /tmp/prof_k1 -o k1 -- $BENCH --streams 1 --no-graph > /dev/null 2>/tmp/k1.log
+python tools/rocpd_stats.py "$(find /tmp/prof_k1 -name '*.db' | head -1)" 48 --steps $STEPS > "$OUT/${R}_kernel_stats_1stream.md"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $BENCH >/dev/null 2>/tmp/f.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $BENCH >/dev/null 2>/tmp/w.log
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_m -o m -- $BENCH --streams 1 --no-graph >/dev/null 2>/tmp/m.log

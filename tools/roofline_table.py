@@ -28,7 +28,7 @@ def mb(key):
 
 
 print('# Per-kernel roofline, %s (1x MI355X, B=32, N=100, fp32; one stream unless noted)\n' % R)
-print('Peaks: fp32 MFMA %.1f TFLOP/s, HBM %.0f TB/s.  Durations: HIP events on the launch stream in bench.py's one-stream measurement pass (`conv_kernels` / `kernels_us`).' % (PEAK_F, PEAK_B))
+print('Peaks: fp32 MFMA %.1f TFLOP/s, HBM %.0f TB/s.  Durations: HIP events on the launch stream in the one-stream measurement pass of bench.py (`conv_kernels` / `kernels_us`).' % (PEAK_F, PEAK_B))
 print('MfmaUtil: SQ_VALU_MFMA_BUSY_CYCLES (%s_mfma_busy.txt).  HBM bytes: FETCH_SIZE x2 + WRITE_SIZE (%s_pmc.json).\n' % (R, R))
 print('| kernel | launches/step | us/step | algorithmic work/step | achieved | bound | frac of peak | MfmaUtil | HBM MB/launch (PMC) |')
 print('|---|---|---|---|---|---|---|---|---|')
