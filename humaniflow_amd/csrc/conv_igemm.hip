@@ -38,7 +38,9 @@ struct ConvArgs {
 constexpr int kConvKC = 32;             // channels per k-chunk
 constexpr int kConvS = kConvKC + 4;     // LDS row stride in floats
 
-template <int BM, int BN, int KS, bool DUAL>
+// ABL != 0: ablation builds for tools/igemm_ablate.py (timing only, results are wrong): 1 = no global fetch after the first chunk,
+// 2 = no per-chunk barrier, 4 = no epilogue loads/stores.
+template <int BM, int BN, int KS, bool DUAL, int ABL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_igemm(const ConvArgs a) {
     constexpr int KC = kConvKC, S = kConvS;
     constexpr int TM = BM / 64, TN = BN / 64;      // MFMA tiles per wave
@@ -98,9 +100,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
     }
 
-    f32x4 pa[RA], pb[RB];
+    f32x4 pa[RA], pb[RB], qa[RA], qb[RB];                // two register stages: the fetch runs up to two chunks ahead (ABL & 8: one)
     int kh = 0, kw = 0, c0 = 0;
-    auto fetch = [&]() {
+    auto fetch_into = [&](f32x4 (&pa)[RA], f32x4 (&pb)[RB]) {
         const int tapoff = ((kh * a.W + kw) * a.Cin + c0) * 4;
         const bool second = DUAL && c0 >= a.Cin;               // block-uniform: the K range of the second input
 #pragma unroll
@@ -119,12 +121,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             if (++kw == KS) { kw = 0; ++kh; }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash_from = [&](int buf, const f32x4 (&pa)[RA], const f32x4 (&pb)[RB]) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) *(f32x4*)&sA[buf][(rbase + 32 * i) * S + col4] = pa[i];
 #pragma unroll
         for (int i = 0; i < RB; ++i) *(f32x4*)&sB[buf][(rbase + 32 * i) * S + col4] = pb[i];
     };
+    auto fetch = [&]() { fetch_into(pa, pb); };
+    auto stash = [&](int buf) { stash_from(buf, pa, pb); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -147,9 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[slot][j] = *(const f32x4*)&sB[buf][rowB + j * 32 * S + g * 8];
     };
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) fetch();
+    auto compute = [&](int buf) {
         frag(buf, 0, 0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -162,8 +164,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][u], fb[g & 1][j][u], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nchunks) stash(buf ^ 1);
-        __syncthreads();
+    };
+    if (ABL & 8) {                                  // one chunk ahead (the round-1 loop)
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks && !(ABL & 1)) fetch();
+            compute(buf);
+            if (c + 1 < nchunks && !(ABL & 1)) stash(buf ^ 1);
+            if (!(ABL & 2)) __syncthreads();
+        }
+    } else {
+        // Two chunks ahead: while chunk c is multiplied out of LDS[c & 1], chunk c+1 sits in one register stage (requested one iteration ago,
+        // written to LDS at the end of this one) and chunk c+2 is requested into the other.  Measured (tools/igemm_ablate.py): the fetch
+        // wait that the one-ahead loop exposes is 4-10 us of a 40-46 us layer when only 1-2 work-groups fit a CU (layer3/layer4).
+        if (nchunks > 1 && !(ABL & 1)) fetch_into(qa, qb);                       // chunk 1
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 2 < nchunks && !(ABL & 1)) fetch_into(pa, pb);               // chunk c+2
+            compute(0);
+            if (c + 1 < nchunks && !(ABL & 1)) stash_from(1, qa, qb);            // chunk c+1
+            if (!(ABL & 2)) __syncthreads();
+            if (c + 1 >= nchunks) break;
+            if (c + 3 < nchunks && !(ABL & 1)) fetch_into(qa, qb);               // chunk c+3
+            compute(1);
+            if (c + 2 < nchunks && !(ABL & 1)) stash_from(0, pa, pb);            // chunk c+2
+            if (!(ABL & 2)) __syncthreads();
+        }
+    }
+    if (ABL & 4) {                                  // keep the accumulators alive without the epilogue traffic
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (a.M < 0) a.y[tid] = t;
+        return;
     }
 
     // ---- epilogue: + bias, + residual, ReLU, 128-byte row stores.  All residual loads of a tile column are issued before use. ----
@@ -207,7 +243,14 @@ template <int BM, int BN, int KS, bool DUAL = false>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int T = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     ProfScope ps(8, a.M, st);
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, DUAL>), dim3(T), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, DUAL, 0>), dim3(T), dim3(256), 0, st, a);
+    return 0;
+}
+
+template <int ABL>
+static int launch_conv_abl(const ConvArgs& a, hipStream_t st) {
+    const int T = ((a.M + 63) / 64) * (a.Cout / 64);
+    hipLaunchKernelGGL((k_conv_igemm<64, 64, 1, false, ABL>), dim3(T), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -245,6 +288,12 @@ extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias
     switch (tile) {
         case 64128: if (Cout % 128) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: tile 64x128 needs Cout %% 128 == 0"); CONV_CASE(64, 128)
         case 64064: CONV_CASE(64, 64)
+        case 1064064: launch_conv_abl<1>(a, st); break;
+        case 2064064: launch_conv_abl<2>(a, st); break;
+        case 3064064: launch_conv_abl<3>(a, st); break;
+        case 4064064: launch_conv_abl<4>(a, st); break;
+        case 7064064: launch_conv_abl<7>(a, st); break;
+        case 8064064: launch_conv_abl<8>(a, st); break;
         default: return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: unknown tile %d", tile);
     }
 #undef CONV_CASE

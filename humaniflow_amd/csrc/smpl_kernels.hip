@@ -222,8 +222,8 @@ struct EpiCtx {
 template <int SLOTS>
 __device__ __forceinline__ void skin_element(const SmplDev& d, const char* __restrict__ lbase, const int (&off)[SLOTS > 0 ? SLOTS : 1],
                                              const float (&w)[SLOTS > 0 ? SLOTS : 1], int nslots, int vt, int l31,
-                                             const f32x16 (&acc)[2][3], int rt, int reg, const EpiCtx& e) {
-    const int rc = rt * 32 + (reg & 3) + 8 * (reg >> 2);
+                                             const f32x16 (&acc)[2][3], int rt, int rt_row, int reg, const EpiCtx& e) {
+    const int rc = rt_row * 32 + (reg & 3) + 8 * (reg >> 2);      // rt: accumulator set, rt_row: which 32 rows of the group it holds
     const char* base = lbase + rc * kAtr * 4;
     f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
     if (SLOTS > 0) {
@@ -302,11 +302,30 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
             }
         }
         __syncthreads();
-        int tt = t + wave;
+        // Work items of this wave inside the segment: full rounds of 8 vertex tiles (64 rows x 32 vertices per wave), then the partial round.
+        // A partial round of <= 4 tiles is split by rows: two waves share a vertex tile, 32 rows each, so the 27 tiles of a range cost
+        // 3.5 rounds instead of 4 (the B operand of those tiles is fetched by both waves).
+        const int cnt = seg_end - t, rf = cnt >> 3, rem = cnt & 7;
+        const bool split = rem > 0 && rem <= 4;
+        auto item = [&](int k, int& rh) -> int {
+            rh = -1;
+            if (k < rf) return t + k * 8 + wave;
+            if (k == rf && rem > 0) {
+                if (split) {
+                    if (wave >= 2 * rem) return -1;
+                    rh = wave & 1;
+                    return t + rf * 8 + (wave >> 1);
+                }
+                return wave < rem ? t + rf * 8 + wave : -1;
+            }
+            return -1;
+        };
+        int kitem = 0, rh;
+        int tt = item(0, rh);
         f32x4 b0, b1, b2;
         int off[SLOTS > 0 ? SLOTS : 1];
         float w[SLOTS > 0 ? SLOTS : 1];
-        if (tt < seg_end) {
+        if (tt >= 0) {
             const int vt = xr * kVTperX + (tt - rg * kVTperX);
             const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
             b0 = bp[0]; b1 = bp[64]; b2 = bp[128];
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
                 }
             }
         }
-        while (tt < seg_end) {
+        while (tt >= 0) {
             const int vt = xr * kVTperX + (tt - rg * kVTperX);
             f32x16 acc[2][3];
 #pragma unroll
@@ -328,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
             const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
-            const float* ap = sPF + half * 64 + l31;
+            const float* ap = sPF + half * 64 + l31 + (rh > 0 ? 32 : 0);      // half tile: this wave's 32 rows feed accumulator set 0
             // A operands (LDS) of k-group 0; inside the loop both operand streams run one k-group ahead of the MFMAs, so a
             // wave never waits on the LDS queue behind its neighbours' epilogue gathers
             float a0[4], a1[4];
@@ -355,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], bv[u * 3 + c], acc[0][c], 0, 0, 0);
-                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], bv[u * 3 + c], acc[1][c], 0, 0, 0);
+                        if (rh < 0) acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], bv[u * 3 + c], acc[1][c], 0, 0, 0);
                     }
                 }
                 b0 = n0; b1 = n1; b2 = n2;
@@ -363,10 +382,11 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
                 for (int u = 0; u < 4; ++u) { a0[u] = m0[u]; a1[u] = m1[u]; }
             }
             // next tile's first operand group + skinning slots: in flight during this tile's epilogue
-            const int ntt = tt + 8;
+            int nrh;
+            const int ntt = item(kitem + 1, nrh);
             int noff[SLOTS > 0 ? SLOTS : 1];
             float nw[SLOTS > 0 ? SLOTS : 1];
-            if (ntt < seg_end) {
+            if (ntt >= 0) {
                 const int nvt = xr * kVTperX + (ntt - rg * kVTperX);
                 const f32x4* nbp = (const f32x4*)(d.blend + (size_t)nvt * kKG * 3 * 64 * 4) + lane;
                 b0 = nbp[0]; b1 = nbp[64]; b2 = nbp[128];
@@ -388,17 +408,24 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
                 const int v = vt * 32 + l31;
                 e.ok_v = v < kV;
                 e.full_rows = row0 + kRowsPerWG <= M;
-                e.row_lim = M - row0 - 4 * half;
-                e.obase = verts + ((size_t)(row0 + 4 * half) * kV + v) * 3;
-                const char* lbase = (const char*)(sA + 4 * half * kAtr);
+                // half tile: accumulator set 0 holds rows 32 rh .. 32 rh + 31 -> shift the row bases, run the first 16 elements of the same code
+                const int rsh = rh > 0 ? 32 : 0;
+                e.row_lim = M - row0 - 4 * half - rsh;
+                e.obase = verts + ((size_t)(row0 + 4 * half + rsh) * kV + v) * 3;
+                const char* lbase = (const char*)(sA + (4 * half + rsh) * kAtr);
 #pragma unroll
-                for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el & 15, e);
+                for (int el = 0; el < 32; ++el) {
+                    if (el == 16 && rh >= 0) break;                       // wave-uniform
+                    skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
+                }
             }
             if (SLOTS > 0) {
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) { off[s] = noff[s]; w[s] = nw[s]; }
             }
             tt = ntt;
+            rh = nrh;
+            ++kitem;
         }
         __syncthreads();
         t = seg_end;
@@ -613,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
             e.obase = verts + ((size_t)(row0 + 4 * half) * kV + v) * 3;
             const char* lbase = (const char*)(sA + 4 * half * kAtr);
 #pragma unroll
-            for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el & 15, e);
+            for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
         }
         __syncthreads();
         t = seg_end;
