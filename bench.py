@@ -386,6 +386,7 @@ def main():
         lbs_ms = float(ms[lsel].mean()) if lsel.any() else float('nan')
 
         def timed(fn, reps=5):
+            fn()                                            # warm the caching allocator for this call's output sizes
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
