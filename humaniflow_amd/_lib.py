@@ -59,6 +59,8 @@ _SIGS = {
     'hmf_smpl_tpose': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),
     'hmf_vertex_variance': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     'hmf_flow_create': (C.c_int, [C.POINTER(_VP), C.POINTER(FlowHost)]),
+    'hmf_flow_create_updatable': (C.c_int, [C.POINTER(_VP), C.POINTER(FlowHost), _VP, C.c_size_t]),
+    'hmf_flow_update_from_device': (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     'hmf_flow_destroy': (None, [_VP]),
     'hmf_flow_forward_workspace_bytes': (C.c_size_t, [_VP, C.c_int, C.c_int, C.c_int]),
     'hmf_flow_forward': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,

@@ -27,5 +27,7 @@ struct hmf_flow {
     hmf::GenDev g;
     std::vector<hmf::PartTab> host_tab;
     const int* d_ids;   // device table 0..22
+    const int* d_map = nullptr;   // arena slot -> flat parameter position + 1 (0 = padding); hmf_flow_create_updatable only
+    size_t arena_floats = 0, flat_count = 0;
     void* mem;
 };

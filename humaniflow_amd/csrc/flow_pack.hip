@@ -296,18 +296,74 @@ int hmf_flow_pack_host(const hmf_flow_host_t* w, float* out) {
     return HMF_OK;
 }
 
-int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* w) {
+// shadow of `w` whose tensors point into `idx` (values = flat position + 1) at the same offsets they have inside the caller's flat buffer
+static int shadow_struct(const hmf_flow_host_t* w, const float* flat_base, size_t flat_count, const float* idx, hmf_flow_host_t& sh,
+                         std::vector<const float*>& store) {
+    bool ok = true;
+    auto tr = [&](const float* p) -> const float* {
+        if (!p) return nullptr;
+        if (p < flat_base || p >= flat_base + flat_count) { ok = false; return nullptr; }
+        return idx + (p - flat_base);
+    };
+    sh = *w;
+    sh.w_isgc_host = tr(w->w_isgc_host);
+    sh.b_isgc_host = tr(w->b_isgc_host);
+    int nh;
+    gen_hidden(w, nh);
+    const bool generic = is_generic(w);
+    const size_t n_nn = (size_t)kP * (generic ? w->num_transforms * (nh + 1) : 8);
+    const size_t n_plu = w->permute_type == 2 ? (size_t)kP * w->num_transforms * (w->plu_num_hidden + 1) : 0;
+    const size_t n_lu = w->permute_type == 1 ? (size_t)kP * w->num_transforms : 0;
+    store.assign(2 * kP + 2 * n_nn + 2 * n_plu + n_lu, nullptr);
+    const float** q = store.data();
+    auto arr = [&](const float* const* src, size_t n) -> const float* const* {
+        if (!src || n == 0) return nullptr;
+        const float** dst = q;
+        for (size_t i = 0; i < n; ++i) dst[i] = tr(src[i]);
+        q += n;
+        return dst;
+    };
+    sh.w_ctx_host = arr(w->w_ctx_host, kP);
+    sh.b_ctx_host = arr(w->b_ctx_host, kP);
+    sh.w_nn_host = arr(w->w_nn_host, n_nn);
+    sh.b_nn_host = arr(w->b_nn_host, n_nn);
+    sh.w_plu_host = arr(w->w_plu_host, n_plu);
+    sh.b_plu_host = arr(w->b_plu_host, n_plu);
+    sh.lu_host = arr(w->lu_host, n_lu);
+    return ok ? HMF_OK : fail(HMF_ERR_INVALID, "hmf_flow_create_updatable: a weight tensor lies outside the flat host buffer");
+}
+
+static int create_impl(hmf_flow_t** out, const hmf_flow_host_t* w, const float* flat_base, size_t flat_count) {
     if (!out) return fail(HMF_ERR_INVALID, "hmf_flow_create: null out");
     *out = nullptr;
     FlowPack fp;
     int rc = build_flow_pack(w, fp);
     if (rc) return rc;
     if (hmf_device_count() <= 0) return fail(HMF_ERR_NO_DEVICE, "hmf_flow_create: no HIP device visible");
+    // index map for device-side re-packing: every packer only COPIES weights, so packing an array whose values are their own flat position
+    // (+1; 0 = padding) yields, per arena slot, where its value comes from
+    std::vector<int> map;
+    if (flat_base) {
+        if (flat_count == 0 || flat_count >= (1u << 24)) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_create_updatable: %zu parameters (must be < 2^24)", flat_count);
+        std::vector<float> idx(flat_count);
+        for (size_t i = 0; i < flat_count; ++i) idx[i] = (float)(i + 1);
+        hmf_flow_host_t sh;
+        std::vector<const float*> store;
+        rc = shadow_struct(w, flat_base, flat_count, idx.data(), sh, store);
+        if (rc) return rc;
+        FlowPack fi;
+        rc = build_flow_pack(&sh, fi);
+        if (rc) return rc;
+        if (fi.arena.size() != fp.arena.size()) return fail(HMF_ERR_INVALID, "hmf_flow_create_updatable: index pack has a different size");
+        map.resize(fi.arena.size());
+        for (size_t i = 0; i < fi.arena.size(); ++i) map[i] = (int)fi.arena[i];
+    }
     const size_t b_arena = align_up(fp.arena.size() * 4, 256), b_tab = align_up((size_t)kP * sizeof(PartTab), 256);
     const size_t b_anc = align_up((size_t)kP * 64 * 4, 256), b_ids = align_up(kP * 4, 256);
-    const size_t b_gen = fp.generic ? (size_t)kP * sizeof(GenPartTab) : 0;
+    const size_t b_gen = align_up(fp.generic ? (size_t)kP * sizeof(GenPartTab) : 0, 256);
+    const size_t b_map = map.size() * 4;
     void* mem = nullptr;
-    HMF_HIP(hipMalloc(&mem, b_arena + b_tab + b_anc + b_ids + b_gen));
+    HMF_HIP(hipMalloc(&mem, b_arena + b_tab + b_anc + b_ids + b_gen + b_map));
     char* base = (char*)mem;
     hipError_t e = hipMemcpy(base, fp.arena.data(), fp.arena.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(base + b_arena, fp.tab.data(), (size_t)kP * sizeof(PartTab), hipMemcpyHostToDevice);
@@ -315,7 +371,8 @@ int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* w) {
     int ids[kP];
     for (int j = 0; j < kP; ++j) ids[j] = j;
     if (e == hipSuccess) e = hipMemcpy(base + b_arena + b_tab + b_anc, ids, kP * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && fp.generic) e = hipMemcpy(base + b_arena + b_tab + b_anc + b_ids, fp.gtab.data(), b_gen, hipMemcpyHostToDevice);
+    if (e == hipSuccess && fp.generic) e = hipMemcpy(base + b_arena + b_tab + b_anc + b_ids, fp.gtab.data(), (size_t)kP * sizeof(GenPartTab), hipMemcpyHostToDevice);
+    if (e == hipSuccess && b_map) e = hipMemcpy(base + b_arena + b_tab + b_anc + b_ids + b_gen, map.data(), b_map, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(mem);
         return fail(HMF_ERR_HIP, "hmf_flow_create: upload failed: %s", hipGetErrorString(e));
@@ -324,6 +381,9 @@ int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* w) {
     h->mem = mem;
     h->host_tab = fp.tab;
     h->d_ids = (const int*)(base + b_arena + b_tab + b_anc);
+    h->arena_floats = fp.arena.size();
+    h->flat_count = flat_base ? flat_count : 0;
+    h->d_map = b_map ? (const int*)(base + b_arena + b_tab + b_anc + b_ids + b_gen) : nullptr;
     FlowDev& d = h->d;
     d.feat_dim = fp.feat_dim; d.nb = fp.nb; d.in_dim = fp.in_dim; d.radius = fp.radius; d.base_std = fp.base_std;
     d.arena = (const float*)base;
@@ -335,6 +395,31 @@ int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* w) {
     h->g.T = fp.T; h->g.transform_type = fp.transform_type; h->g.permute_type = fp.permute_type;
     h->g.tab = fp.generic ? (const GenPartTab*)(base + b_arena + b_tab + b_anc + b_ids) : nullptr;
     *out = h;
+    return HMF_OK;
+}
+
+int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* w) { return create_impl(out, w, nullptr, 0); }
+
+int hmf_flow_create_updatable(hmf_flow_t** out, const hmf_flow_host_t* w, const float* flat_base, size_t flat_count) {
+    if (!flat_base) return fail(HMF_ERR_INVALID, "hmf_flow_create_updatable: null flat buffer");
+    return create_impl(out, w, flat_base, flat_count);
+}
+
+__global__ void k_flow_repack(float* __restrict__ arena, const int* __restrict__ map, const float* __restrict__ flat, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int m = map[i];
+        arena[i] = m > 0 ? flat[m - 1] : 0.f;
+    }
+}
+
+int hmf_flow_update_from_device(hmf_flow_t* h, const float* flat_dev, size_t flat_count, void* stream) {
+    if (!h || !flat_dev) return fail(HMF_ERR_INVALID, "hmf_flow_update_from_device: null argument");
+    if (!h->d_map || flat_count != h->flat_count)
+        return fail(HMF_ERR_INVALID, "hmf_flow_update_from_device: handle was not created with hmf_flow_create_updatable for %zu parameters", flat_count);
+    const size_t n = h->arena_floats;
+    hipLaunchKernelGGL(k_flow_repack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float*)h->d.arena, h->d_map, flat_dev, n);
+    HMF_LAUNCH_CHECK();
     return HMF_OK;
 }
 

@@ -269,12 +269,16 @@ class HumaniflowModel(nn.Module):
         except Exception:
             pass
 
+    def _flow_flat(self):
+        """All flow parameters concatenated on their device, in _flow_params() order (the layout hmf_flow_create_updatable indexes)."""
+        return torch.cat([t.detach().reshape(-1).float() for t in self._flow_params()])
+
     def flow_host_struct(self):
         """(hmf_flow_host_t, keep-alive list) from the live parameters."""
         keep = []
         # one device -> host copy for all ~420 tensors (a training step re-packs after every optimiser step)
         ts = self._flow_params()
-        flat = np.ascontiguousarray(torch.cat([t.detach().reshape(-1).float() for t in ts]).cpu().numpy())
+        flat = np.ascontiguousarray(self._flow_flat().cpu().numpy())
         keep.append(flat)
         offs, o = {}, 0
         for t in ts:
@@ -338,19 +342,34 @@ class HumaniflowModel(nn.Module):
         return hs, keep
 
     def _flow_handle(self, device):
+        """Packed-weight handle of `device`, current with the live parameters.  A change of the parameters' version counters (optimiser
+        step, in-place copy) re-packs ON THE DEVICE: one concatenation + one gather kernel through the slot->parameter index map the
+        handle recorded at creation (hmf_flow_update_from_device) -- no host round trip, no reallocation."""
+        lib = _lib.load()
         vkey = tuple([t._version for t in self._flow_params()])
-        if self.__dict__.get('_flow_key') != vkey:
-            self.invalidate_flow_weights()
-            self.__dict__['_flow_key'] = tuple([t._version for t in self._flow_params()])
         key = (device.type, device.index)
         h = self._handles.get(key)
+        if h is not None and self.__dict__.get('_flow_key') != vkey:
+            flat = self._flow_flat()
+            if flat.device == device:
+                with torch.cuda.device(device):
+                    _lib.check(lib.hmf_flow_update_from_device(h, _lib.dptr(flat), flat.numel(), _lib.current_stream()), 'hmf_flow_update_from_device')
+                for k2, h2 in list(self._handles.items()):           # handles of other devices (rare): rebuilt on their next use
+                    if k2 != key:
+                        lib.hmf_flow_destroy(h2)
+                        del self._handles[k2]
+            else:
+                self.invalidate_flow_weights()
+                h = None
+            self.__dict__['_flow_key'] = vkey
         if h is None:
-            lib = _lib.load()
             hs, keep = self.flow_host_struct()
+            flat = keep[0]
             h = C.c_void_p()
             with torch.cuda.device(device):
-                _lib.check(lib.hmf_flow_create(C.byref(h), C.byref(hs)), 'hmf_flow_create')
+                _lib.check(lib.hmf_flow_create_updatable(C.byref(h), C.byref(hs), flat.ctypes.data, flat.size), 'hmf_flow_create_updatable')
             self._handles[key] = h
+            self.__dict__['_flow_key'] = vkey
         return h
 
     def _workspace(self, device, nbytes):

@@ -146,6 +146,12 @@ typedef struct {
 } hmf_flow_host_t;
 
 int hmf_flow_create(hmf_flow_t** out, const hmf_flow_host_t* weights);
+/* Training: the weights change every optimiser step.  If every tensor of `weights` is a slice of ONE contiguous host buffer
+ * (flat_base, flat_count floats, e.g. the concatenation of the model's flow parameters), the handle also records, per packed slot, which
+ * flat position it copies; hmf_flow_update_from_device then re-packs from the SAME concatenation held in device memory with one gather
+ * kernel (no host round trip, no reallocation), asynchronously on `stream`.                                                              */
+int hmf_flow_create_updatable(hmf_flow_t** out, const hmf_flow_host_t* weights, const float* flat_base, size_t flat_count);
+int hmf_flow_update_from_device(hmf_flow_t* h, const float* flat_dev, size_t flat_count, void* stream);
 void hmf_flow_destroy(hmf_flow_t* h);
 
 /* flags of hmf_flow_forward */

@@ -376,3 +376,37 @@ def test_configs3_eval_step_at_B32_N100():
     assert torch.allclose(frames['PVE-T-SC_samples_min'][sl].double().cpu(), e[..., 1].min(dim=1).values, rtol=2e-5, atol=1e-7)
     d = om.sample_diversity(P) / (100 * 6890)
     assert torch.allclose(frames['verts3D_sample_diversity'][sl].double().cpu(), d, rtol=2e-5)
+
+
+def test_in_place_weight_updates_repack_on_the_device():
+    """the packed-weight handle and the encoder plan follow in-place parameter updates (optimizer.step(), p.data.copy_(),
+    load_state_dict on a sub-module) through the version counters; the flow re-packs on the device through the slot->parameter index map
+    (hmf_flow_update_from_device) and must equal a handle built from scratch with the same weights."""
+    import copy
+    model, sd, cfg = _model(18, seed=13)
+    B, N = 3, 9
+    feats = torch.randn(B, 512, generator=torch.Generator().manual_seed(1)) * 0.5
+    noise = _cuda(_noise(B, N, seed=2))
+    x = synthetic_proxy_input(1, 128, seed=5).cuda()
+    with torch.no_grad():
+        before = model(None, input_feats=feats.cuda(), num_samples=N, noise=noise)['pose_rotmats_samples'].clone()
+        f0 = model(x, return_input_feats_only=True)['input_feats'].clone()
+        g = torch.Generator().manual_seed(3)
+        for name, p in model.named_parameters():                      # in-place: what an optimiser step does
+            if name.startswith(('pose_so3flow', 'fc_flow_context', 'fc_input_shape')):
+                p.mul_(1.0 + 0.05 * torch.randn(p.shape, generator=g).cuda())
+        model.image_encoder.layer1[0].conv1.weight.mul_(1.1)
+        sub = {k: v * 0.9 for k, v in model.fc_flow_context[3].state_dict().items()}
+        model.fc_flow_context[3].load_state_dict(sub)                 # sub-module load: bypasses the root module's hooks
+        after = model(None, input_feats=feats.cuda(), num_samples=N, noise=noise)['pose_rotmats_samples']
+        f1 = model(x, return_input_feats_only=True)['input_feats']
+        assert (after - before).abs().max().item() > 1e-3 and (f1 - f0).abs().max().item() > 1e-4        # the updates were seen
+        model.invalidate_flow_weights()                               # from-scratch host pack of the same weights
+        model.image_encoder.invalidate_plan()
+        fresh = model(None, input_feats=feats.cuda(), num_samples=N, noise=noise)['pose_rotmats_samples']
+        f2 = model(x, return_input_feats_only=True)['input_feats']
+    assert torch.equal(after, fresh) and torch.equal(f1, f2)
+    m2 = copy.deepcopy(model)                                         # device-side caches are not copied, the copy works on its own
+    with torch.no_grad():
+        again = m2(None, input_feats=feats.cuda(), num_samples=N, noise=noise)['pose_rotmats_samples']
+    assert torch.equal(again, fresh)
