@@ -72,11 +72,19 @@ _SIGS = {
     'hmf_flow_log_prob_SO3_backward': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP, C.POINTER(FlowGradRecords), _VP]),
     'hmf_flow_sample_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.POINTER(FlowGradRecords), _VP]),
     'hmf_smpl_joints_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    'hmf_bn_stats': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP]),
+    'hmf_bn_finalize': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_float, C.c_float] + [_VP] * 7),
+    'hmf_bn_apply': (C.c_int, [_VP] * 5 + [C.c_int] * 3 + [_VP]),
+    'hmf_bn_bwd_reduce': (C.c_int, [_VP] * 5 + [C.c_int] * 3 + [_VP, _VP]),
+    'hmf_bn_bwd_finalize': (C.c_int, [_VP, C.c_int, C.c_int] + [_VP] * 9),
+    'hmf_bn_bwd_apply': (C.c_int, [_VP] * 8 + [C.c_int] * 3 + [_VP]),
+    'hmf_maxpool3x3s2_nhwc_backward': (C.c_int, [_VP] * 3 + [C.c_int] * 4 + [_VP]),
+    'hmf_conv_wgrad': (C.c_int, [_VP] * 3 + [C.c_int] * 8 + [_VP]),
     'hmf_proxy_rep': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                 _VP, _VP, _VP, _VP, _VP]),
     'hmf_stem_packed_floats': (C.c_longlong, []),
     'hmf_stem_pack_host': (C.c_int, [_VP, _VP]),
-    'hmf_stem_conv': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
+    'hmf_stem_conv': (C.c_int, [_VP] * 4 + [C.c_int] * 5 + [_VP]),
     'hmf_maxpool3x3s2_nhwc': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP]),
     'hmf_conv_patch_packed_floats': (C.c_longlong, [C.c_int] * 3),
     'hmf_conv_patch_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 4),

@@ -23,7 +23,7 @@ constexpr int kStemGroups = (kStemSteps + 3) / 4;                         // 111
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_conv(
     const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
-    int OH, int OW, int tiles_w, int tiles_hw) {
+    int OH, int OW, int tiles_w, int tiles_hw, int relu) {
     __shared__ float patch[kStemC * kStemPlane + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * lq;
             const int oh = oh0 + 2 * wave + (i >> 4), ow = ow0 + (i & 15);
-            if (oh < OH && ow < OW) y[(((long long)b * OH + oh) * OW + ow) * kStemN + n] = fmaxf(acc[t][r] + bv, 0.f);
+            if (oh < OH && ow < OW) y[(((long long)b * OH + oh) * OW + ow) * kStemN + n] = relu ? fmaxf(acc[t][r] + bv, 0.f) : acc[t][r] + bv;
         }
     }
 }
@@ -159,7 +159,7 @@ extern "C" int hmf_stem_pack_host(const float* w /*64x18x7x7*/, float* packed) {
     return HMF_OK;
 }
 
-extern "C" int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, void* stream) {
+extern "C" int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_stem_conv: bad args");
     if (C != kStemC) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv: %d input channels (the 18-channel proxy representation is built)", C);
     if ((uintptr_t)w_packed & 15) return fail(HMF_ERR_INVALID, "hmf_stem_conv: packed weights must be 16-byte aligned");
@@ -169,7 +169,7 @@ extern "C" int hmf_stem_conv(const float* x, const float* w_packed, const float*
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(9, B, st);
-    hipLaunchKernelGGL(k_stem_conv, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw);
+    hipLaunchKernelGGL(k_stem_conv, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw, relu);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -13,9 +13,10 @@ hmf_maxpool3x3s2_nhwc, hmf_conv_winograd (stride-1 3x3), hmf_conv_patch (stride-
 hmf_conv1x1_dual_nhwc (1x1; a downsample branch rides in its block's conv3 as a K-concatenated GEMM).
 The plan is built lazily from the live parameters and rebuilt when they change (parameter version
 counters), so the checkpoint layout is untouched.  There is no vendor-library inference path
-and no CPU path: `forward` on a CPU tensor raises.  Training (grad mode / train()) uses batch-statistics
-BatchNorm, for which the folded plan does not apply: that mode runs the plain module graph under autograd
-(`forward_module`; the hand-written dgrad/wgrad kernels are not built yet -- DESIGN.md section 7).
+and no CPU path: `forward` on a CPU tensor raises.  Training (train() under autograd) uses batch-statistics
+BatchNorm, for which the folded plan does not apply: that mode runs encoder_train.py -- forward with hmf_bn_stats /
+hmf_bn_apply around the same convolution kernels and a hand-written backward (hmf_bn_bwd_*, hmf_conv_wgrad, dgrad
+through hmf_conv2d_nhwc with transformed filters, hmf_maxpool3x3s2_nhwc_backward).
 """
 import warnings
 
@@ -134,6 +135,7 @@ class ResNetEncoder(nn.Module):
         st['_plan'] = None
         st['_plan_key'] = None
         st['_plan_tensors'] = None
+        st.pop('_stem_map', None)
         return st
 
     @torch.no_grad()
@@ -253,7 +255,7 @@ class ResNetEncoder(nn.Module):
         PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
         st = _lib.current_stream()
         y = torch.empty((B, 64, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _lib.check(lib.hmf_stem_conv(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W, st), 'hmf_stem_conv')
+        _lib.check(lib.hmf_stem_conv(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), 'hmf_stem_conv')
         z = torch.empty((B, 64, PH, PW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
         return z
@@ -285,17 +287,37 @@ class ResNetEncoder(nn.Module):
 
     _warned_autograd = False
 
+    def _stem_packed_from_device(self, w):
+        """The stem kernel's packed filter operand from the live (64, 18, 7, 7) parameter without leaving the device: the host packer is a
+        pure permutation + zero padding, so packing an index-valued array ONCE yields a gather map (training re-packs every step)."""
+        from . import _lib
+        m = self.__dict__.get('_stem_map')
+        if m is None or m[0].device != w.device:
+            lib = _lib.load()
+            n = w.numel()
+            idx = torch.arange(1, n + 1, dtype=torch.float32).reshape(w.shape).contiguous()
+            packed = torch.empty(int(lib.hmf_stem_packed_floats()), dtype=torch.float32)
+            _lib.check(lib.hmf_stem_pack_host(idx.data_ptr(), packed.data_ptr()), 'hmf_stem_pack_host')
+            pm = packed.long()
+            m = self.__dict__['_stem_map'] = ((pm.clamp(min=1) - 1).to(w.device), (pm > 0).float().to(w.device))
+        return w.reshape(-1).float()[m[0]] * m[1]
+
     def forward(self, x):
         from . import _lib
         _lib.require_cuda(x, 'input')
-        if (not self.training) and (not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())) \
-                and not x.requires_grad:
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not self.training and not wants_grad:
             return self.forward_folded(x)
-        # training / gradients wanted: batch-statistics BatchNorm + backward.  The hand-written kernels cover inference only; say so once.
+        if self.training and wants_grad and not x.requires_grad and self.conv1.in_channels == 18:
+            # training step: batch-statistics BatchNorm forward + full backward on the library's kernels (encoder_train.py)
+            from .encoder_train import EncoderTrainFn
+            return EncoderTrainFn.apply(self, x, *list(self.parameters()))
+        # remaining combinations (train() without gradients, eval() with gradients = frozen statistics under autograd, gradients w.r.t. the
+        # input): the plain module graph on ATen, announced once
         if not ResNetEncoder._warned_autograd:
             ResNetEncoder._warned_autograd = True
-            warnings.warn('humaniflow_amd: the ResNet encoder runs its TRAINING graph (batch-statistics BatchNorm + backward) through '
-                          'torch autograd on ATen convolutions; only the inference plan is hand-written HIP (DESIGN.md section 7)')
+            warnings.warn('humaniflow_amd: this encoder mode (train() without gradients, eval() with gradients, or gradients w.r.t. the input) runs '
+                          'the plain module graph on ATen; the hand-written paths are inference (eval, no grad) and the training step (train, grad)')
         return self.forward_module(x)
 
 

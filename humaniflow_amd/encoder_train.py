@@ -1,0 +1,216 @@
+"""Training graph of the ResNet encoder on the library's kernels: forward with batch-statistics BatchNorm and the full backward pass.
+
+What `ResNetEncoder.forward` runs in train() mode under autograd (train/train_humaniflow.py:248-347 back-propagates the loss through
+models/resnet.py).  One `torch.autograd.Function` spans the whole encoder, so no per-layer autograd bookkeeping happens between launches:
+
+  forward, per conv + BN (+ ReLU) (+ residual) unit
+      y    = conv(x, W)                    hmf_conv2d_nhwc (1x1 / 3x3, natural channels_last filters) | hmf_stem_conv (7x7/2, filters re-packed on the device)
+      stats                                hmf_bn_stats + hmf_bn_finalize (mean, rstd, scale, shift; running statistics updated as nn.BatchNorm2d does)
+      out  = relu?(scale y + shift (+ idt)) hmf_bn_apply
+  backward, per unit (g = dL/d out)
+      gz = g * (out > 0); sums            hmf_bn_bwd_reduce + hmf_bn_bwd_finalize (d gamma, d beta, coefficients)
+      gy = a gz + b y + c                  hmf_bn_bwd_apply (also emits gz = the identity branch's gradient)
+      dW                                   hmf_conv_wgrad (MFMA GEMM over the pixel axis; the stem reads the NCHW input directly)
+      dx                                   hmf_conv2d_nhwc with the flipped / transposed filter (stride-2 layers: zero-inserted gradient map);
+                                           the identity branch's gradient rides in that launch's residual epilogue
+  max-pool: hmf_maxpool3x3s2_nhwc / hmf_maxpool3x3s2_nhwc_backward; global average pool: torch mean / broadcast (B x C values).
+Filter re-layouts (flip, transpose, channels_last) are small torch copies per step (the filters total 45-94 MB).
+"""
+import torch
+
+from . import _lib
+
+CL = torch.channels_last
+
+
+def _cl_empty(B, C, H, W, device):
+    return torch.empty((B, C, H, W), device=device, dtype=torch.float32, memory_format=CL)
+
+
+def _conv_raw(x, w_cl, stride, residual=None):
+    """Bias-free convolution on the implicit-GEMM kernel: x (B,Cin,H,W) channels_last, w_cl (Cout,Cin,k,k) channels_last -> (B,Cout,OH,OW)."""
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    Cout, _, ks, _ = w_cl.shape
+    pad = ks // 2
+    OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    y = _cl_empty(B, Cout, OH, OW, x.device)
+    _lib.check(lib.hmf_conv2d_nhwc(x.data_ptr(), w_cl.data_ptr(), None, None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W,
+                                   Cin, Cout, ks, stride, 0, 0, _lib.current_stream()), 'hmf_conv2d_nhwc')
+    return y
+
+
+class _Saved:
+    __slots__ = ('conv', 'bn', 'x', 'y', 'out', 'mean', 'rstd', 'relu', 'stride', 'stem')
+
+
+def _bn_forward(y, bn, residual, relu):
+    """Training-mode BatchNorm on the NHWC rows of y, running statistics updated in place.  Returns (out, mean, rstd)."""
+    lib = _lib.load()
+    B, C, H, W = y.shape
+    M = B * H * W
+    dev = y.device
+    acc = torch.zeros(2, C, dtype=torch.float64, device=dev)
+    st = _lib.current_stream()
+    _lib.check(lib.hmf_bn_stats(y.data_ptr(), M, C, acc.data_ptr(), st), 'hmf_bn_stats')
+    mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    track = bn.track_running_stats and bn.running_mean is not None
+    _lib.check(lib.hmf_bn_finalize(acc.data_ptr(), M, C, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(mom),
+                                   bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                   mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st), 'hmf_bn_finalize')
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    out = _cl_empty(B, C, H, W, dev)
+    _lib.check(lib.hmf_bn_apply(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if residual is None else residual.data_ptr(), out.data_ptr(),
+                                M, C, int(relu), st), 'hmf_bn_apply')
+    return out, mean, rstd
+
+
+def _bn_backward(g, s, want_gz):
+    """g = dL/d out of unit s -> (gy = dL/d conv output, gz or None, d gamma, d beta)."""
+    lib = _lib.load()
+    B, C, H, W = s.y.shape
+    M = B * H * W
+    dev = g.device
+    st = _lib.current_stream()
+    acc = torch.zeros(2, C, dtype=torch.float64, device=dev)
+    out_ptr = s.out.data_ptr() if s.relu else None
+    _lib.check(lib.hmf_bn_bwd_reduce(g.data_ptr(), out_ptr, s.y.data_ptr(), s.mean.data_ptr(), s.rstd.data_ptr(), M, C, int(s.relu), acc.data_ptr(), st),
+               'hmf_bn_bwd_reduce')
+    gg, gb, ca, cb, cc = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(5))
+    _lib.check(lib.hmf_bn_bwd_finalize(acc.data_ptr(), M, C, s.bn.weight.data_ptr(), s.mean.data_ptr(), s.rstd.data_ptr(), gg.data_ptr(), gb.data_ptr(),
+                                       ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), st), 'hmf_bn_bwd_finalize')
+    gy = _cl_empty(B, C, H, W, dev)
+    gz = _cl_empty(B, C, H, W, dev) if want_gz else None
+    _lib.check(lib.hmf_bn_bwd_apply(g.data_ptr(), out_ptr, s.y.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), gy.data_ptr(),
+                                    None if gz is None else gz.data_ptr(), M, C, int(s.relu), st), 'hmf_bn_bwd_apply')
+    return gy, gz, gg, gb
+
+
+def _wgrad(gy, s):
+    """dL/dW of unit s in the parameter's own (Cout, Cin, k, k) shape."""
+    lib = _lib.load()
+    Cout, Cin, ks, _ = s.conv.weight.shape
+    if s.stem:
+        B, _, H, W = s.x.shape                                        # NCHW proxy input
+        dw = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device=gy.device)
+        _lib.check(lib.hmf_conv_wgrad(gy.data_ptr(), s.x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, ks, s.stride, 1, _lib.current_stream()), 'hmf_conv_wgrad')
+        return dw
+    B, _, H, W = s.x.shape
+    dw = torch.empty(Cout, ks, ks, Cin, dtype=torch.float32, device=gy.device)
+    _lib.check(lib.hmf_conv_wgrad(gy.data_ptr(), s.x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, ks, s.stride, 0, _lib.current_stream()), 'hmf_conv_wgrad')
+    return dw.permute(0, 3, 1, 2).contiguous()
+
+
+def _dgrad(gy, s, residual=None):
+    """dL/dx of unit s (+ residual): a convolution of gy with the flipped, in/out-transposed filter."""
+    w = s.conv.weight.detach()
+    ks = w.shape[2]
+    wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=CL) if ks > 1 else w.transpose(0, 1).contiguous(memory_format=CL)      # (Cin, Cout, k, k)
+    B, Cin, H, W = s.x.shape
+    if s.stride == 1:
+        return _conv_raw(gy, wt, 1, residual)
+    if ks == 1:                                                       # strided 1x1 (downsample branch): only the sampled pixels receive gradient
+        gx = torch.zeros((B, Cin, H, W), device=gy.device, dtype=torch.float32).contiguous(memory_format=CL) if residual is None else residual.clone()
+        c = _conv_raw(gy, wt, 1)
+        gx[:, :, ::s.stride, ::s.stride] += c
+        return gx
+    gd = torch.zeros((B, gy.shape[1], H, W), device=gy.device, dtype=torch.float32).contiguous(memory_format=CL)    # zero-inserted gradient map
+    gd[:, :, ::s.stride, ::s.stride] = gy
+    return _conv_raw(gd, wt, 1, residual)
+
+
+class EncoderTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, x, *params):
+        lib = _lib.load()
+        dev = x.device
+        saved = []
+
+        def unit(conv, bn, xin, relu, residual=None, stem=False):
+            s = _Saved()
+            s.conv, s.bn, s.x, s.relu, s.stride, s.stem = conv, bn, xin, relu, conv.stride[0], stem
+            if stem:
+                B, C, H, W = xin.shape
+                OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                packed = enc._stem_packed_from_device(conv.weight.detach())
+                s.y = _cl_empty(B, 64, OH, OW, dev)
+                _lib.check(lib.hmf_stem_conv(xin.data_ptr(), packed.data_ptr(), None, s.y.data_ptr(), B, C, H, W, 0, _lib.current_stream()), 'hmf_stem_conv')
+            else:
+                s.y = _conv_raw(xin, conv.weight.detach().contiguous(memory_format=CL), s.stride)
+            s.out, s.mean, s.rstd = _bn_forward(s.y, bn, residual, relu)
+            saved.append(s)
+            return s.out
+
+        with torch.cuda.device(dev), torch.no_grad():
+            xin = x.detach().float().contiguous()
+            a0 = unit(enc.conv1, enc.bn1, xin, True, stem=True)
+            B, C, H, W = a0.shape
+            p0 = _cl_empty(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dev)
+            _lib.check(lib.hmf_maxpool3x3s2_nhwc(a0.data_ptr(), p0.data_ptr(), B, H, W, C, _lib.current_stream()), 'hmf_maxpool3x3s2_nhwc')
+            cur = p0
+            plan = []
+            for li in range(1, 5):
+                for blk in getattr(enc, 'layer%d' % li):
+                    first = len(saved)
+                    idt = cur
+                    if blk.downsample is not None:
+                        idt = unit(blk.downsample[0], blk.downsample[1], cur, False)
+                    h = cur
+                    st = blk.stages()
+                    for conv, bn in st[:-1]:
+                        h = unit(conv, bn, h, True)
+                    conv, bn = st[-1]
+                    cur = unit(conv, bn, h, True, residual=idt)
+                    plan.append((first, len(saved), blk.downsample is not None))
+            feats = cur.mean(dim=(2, 3))
+        ctx.enc, ctx.saved, ctx.plan, ctx.a0, ctx.final_shape = enc, saved, plan, a0, tuple(cur.shape)
+        ctx.param_ids = [id(p) for p in params]
+        return feats
+
+    @staticmethod
+    def backward(ctx, g_feats):
+        lib = _lib.load()
+        enc, saved, plan = ctx.enc, ctx.saved, ctx.plan
+        grads = {}
+        dev = g_feats.device
+        with torch.cuda.device(dev), torch.no_grad():
+            B, C, H, W = ctx.final_shape
+            g = (g_feats.detach().float() / (H * W))[:, :, None, None].expand(B, C, H, W).contiguous(memory_format=CL)
+            for first, last, has_ds in reversed(plan):
+                units = saved[first:last]
+                ds = units[0] if has_ds else None
+                main = units[1:] if has_ds else units
+                # last unit of the block: out = relu(bn(conv(h)) + idt)
+                s = main[-1]
+                gy, gz, gg, gb = _bn_backward(g, s, want_gz=True)
+                grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
+                grads[id(s.conv.weight)] = _wgrad(gy, s)
+                g_idt = gz                                            # gradient of the identity branch (masked by the block's ReLU)
+                only = len(main) == 1
+                g_h = _dgrad(gy, s, residual=g_idt if (only and ds is None) else None)
+                for k in range(len(main) - 2, -1, -1):
+                    s = main[k]
+                    gy, _, gg, gb = _bn_backward(g_h, s, want_gz=False)
+                    grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
+                    grads[id(s.conv.weight)] = _wgrad(gy, s)
+                    g_h = _dgrad(gy, s, residual=g_idt if (k == 0 and ds is None) else None)     # block input: main path + identity in one launch
+                if ds is not None:
+                    gy, _, gg, gb = _bn_backward(g_idt, ds, want_gz=False)
+                    grads[id(ds.bn.weight)], grads[id(ds.bn.bias)] = gg, gb
+                    grads[id(ds.conv.weight)] = _wgrad(gy, ds)
+                    g_h = _dgrad(gy, ds, residual=g_h)
+                g = g_h
+            # max-pool and stem
+            a0 = ctx.a0
+            B, C, H, W = a0.shape
+            g_a0 = _cl_empty(B, C, H, W, dev)
+            _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(a0.data_ptr(), g.data_ptr(), g_a0.data_ptr(), B, H, W, C, _lib.current_stream()),
+                       'hmf_maxpool3x3s2_nhwc_backward')
+            s = saved[0]
+            gy, _, gg, gb = _bn_backward(g_a0, s, want_gz=False)
+            grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
+            grads[id(s.conv.weight)] = _wgrad(gy, s)
+        ctx.saved = None
+        return (None, None) + tuple(grads.get(i) for i in ctx.param_ids)

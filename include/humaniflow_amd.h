@@ -283,7 +283,7 @@ int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, 
  * hmf_maxpool3x3s2_nhwc: the 3x3 / stride 2 / pad 1 max-pool that follows, NHWC (B,H,W,C) -> (B,(H-1)/2+1,(W-1)/2+1,C), C % 4 == 0. */
 long long hmf_stem_packed_floats(void);
 int hmf_stem_pack_host(const float* w, float* packed);
-int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, void* stream);
+int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, void* stream);
 int hmf_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -297,6 +297,35 @@ int hmf_pointset_errors(const float* P, const float* T, int npairs, int group, i
 /* Sample diversity (eval_metrics_tracker.py:398-410): S (B, N, npts, 3) -> partial (B, ceil(npts/256)) partial sums over n and points
  * of |S - mean_n S|; the caller adds the chunks (deterministic) and divides by N * npts. */
 int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Encoder, training mode (models/resnet.py under train(): nn.BatchNorm2d batch statistics) and its backward                 */
+/* ------------------------------------------------------------------------------------------ */
+/* All tensors NHWC rows [M][C], M = B*H*W, C % 64 == 0.  Forward of one conv+BN(+ReLU)(+residual) unit:
+ *   y = hmf_conv2d_nhwc(x, w, bias = NULL, relu = 0)   (or hmf_stem_conv with relu = 0)
+ *   hmf_bn_stats(y) -> acc[2][C] (double, zeroed by the caller); hmf_bn_finalize -> mean, rstd, scale = gamma rstd, shift = beta - mean scale,
+ *       and the running statistics updated as torch does (momentum, unbiased variance);
+ *   out = hmf_bn_apply(y, scale, shift, residual, relu).
+ * Backward, given g = dL/d out:  gz = g * (out > 0)  [relu];  hmf_bn_bwd_reduce -> acc = (sum gz, sum gz xhat);  hmf_bn_bwd_finalize ->
+ * g_gamma, g_beta and the per-channel coefficients of  gy = a gz + b y + c  (= gamma rstd (gz - mean(gz) - xhat mean(gz xhat)));
+ * hmf_bn_bwd_apply writes gy (and optionally gz, the identity branch's gradient).                                                      */
+int hmf_bn_stats(const float* y, int M, int C, double* acc, void* stream);
+int hmf_bn_finalize(const double* acc, int M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
+int hmf_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, int M, int C, int relu, void* stream);
+int hmf_bn_bwd_reduce(const float* g, const float* out, const float* y, const float* mean, const float* rstd, int M, int C, int relu, double* acc,
+                      void* stream);
+int hmf_bn_bwd_finalize(const double* acc, int M, int C, const float* gamma, const float* mean, const float* rstd, float* g_gamma, float* g_beta,
+                        float* ca, float* cb, float* cc, void* stream);
+int hmf_bn_bwd_apply(const float* g, const float* out, const float* y, const float* ca, const float* cb, const float* cc, float* gy, float* gz_out,
+                     int M, int C, int relu, void* stream);
+/* Backward of hmf_maxpool3x3s2_nhwc: x (B,H,W,C) the pooled tensor's input, g_out (B,OH,OW,C) -> g_x; ties go to the first maximum in
+ * (kh, kw) scan order, as torch's forward records them.                                                                               */
+int hmf_maxpool3x3s2_nhwc_backward(const float* x, const float* g_out, float* g_x, int B, int H, int W, int C, void* stream);
+/* Weight gradient of a convolution: gy (B,OH,OW,Cout), x (B,H,W,Cin) NHWC -> dw [Cout][ks][ks][Cin] (channels_last filter layout), padding ks/2.
+ * stem_nchw = 1: x is the NCHW proxy input (B,Cin,H,W) and dw comes out as [Cout][Cin][ks][ks] (torch's native layout).
+ * dw is zeroed, then accumulated with float atomics over slices of the pixel axis (run-to-run differences at rounding level).            */
+int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int ks, int stride, int stem_nchw, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */

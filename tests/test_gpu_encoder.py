@@ -171,7 +171,7 @@ def test_stem_conv_and_maxpool_match_float64_reference(B, H, W):
     OH, OW = ref.shape[2:]
     y = torch.full((B, 64, OH, OW), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
     st = _lib.current_stream()
-    _lib.check(lib.hmf_stem_conv(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, 18, H, W, st), 'hmf_stem_conv')
+    _lib.check(lib.hmf_stem_conv(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'hmf_stem_conv')
     z = torch.full(tuple(refp.shape), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
     _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
     torch.cuda.synchronize()

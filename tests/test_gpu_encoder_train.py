@@ -1,0 +1,134 @@
+"""GPU parity of the encoder's training graph (humaniflow_amd/encoder_train.py + csrc/encoder_train.hip) vs torch autograd through the plain
+module graph (`ResNetEncoder.forward_module`, nn.Conv2d / nn.BatchNorm2d in train mode) in float64: features, every parameter gradient,
+the running statistics; and each new kernel against its torch operator."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from humaniflow_amd import _lib
+from humaniflow_amd.encoder import ResNetEncoder
+from humaniflow_amd import encoder_train as et
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30)).item()
+
+
+def test_batchnorm_training_kernels_match_torch():
+    torch.manual_seed(0)
+    B, C, H, W = 6, 128, 12, 10
+    y = (torch.randn(B, C, H, W, device='cuda') * 2 + 0.5).contiguous(memory_format=CL)
+    res = torch.randn(B, C, H, W, device='cuda').contiguous(memory_format=CL)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 2)
+    ref_bn = copy.deepcopy(bn).double()
+    yr = y.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True)
+    out_ref = F.relu(ref_bn(yr) + rr)
+    g = torch.randn(B, C, H, W, device='cuda').contiguous(memory_format=CL)
+    out_ref.backward(g.double())
+    with torch.no_grad():
+        out, mean, rstd = et._bn_forward(y, bn, res, True)
+        s = et._Saved()
+        s.bn, s.y, s.out, s.mean, s.rstd, s.relu = bn, y, out, mean, rstd, True
+        gy, gz, gg, gb = et._bn_backward(g, s, want_gz=True)
+    assert _rel(out, out_ref.detach()) < 1e-5
+    assert _rel(bn.running_mean, ref_bn.running_mean) < 1e-5 and _rel(bn.running_var, ref_bn.running_var) < 1e-5 and int(bn.num_batches_tracked) == 1
+    assert _rel(gy, yr.grad) < 2e-5 and _rel(gz, rr.grad) < 1e-6
+    assert _rel(gg, ref_bn.weight.grad) < 2e-5 and _rel(gb, ref_bn.bias.grad) < 2e-5
+
+
+@pytest.mark.parametrize('cin,cout,ks,stride,hw', [(64, 64, 3, 1, 16), (64, 128, 3, 2, 16), (256, 64, 1, 1, 8), (64, 256, 1, 1, 12), (256, 512, 1, 2, 8),
+                                                    (128, 128, 3, 1, 6), (512, 2048, 1, 1, 4)])
+def test_conv_weight_and_input_gradients_match_torch(cin, cout, ks, stride, hw):
+    torch.manual_seed(cin + cout + ks)
+    B = 5
+    x = torch.randn(B, cin, hw, hw, device='cuda').contiguous(memory_format=CL)
+    conv = torch.nn.Conv2d(cin, cout, ks, stride, ks // 2, bias=False).cuda()
+    xr = x.double().requires_grad_(True)
+    cr = copy.deepcopy(conv).double()
+    yr = cr(xr)
+    gy = torch.randn_like(yr).float().contiguous(memory_format=CL)
+    yr.backward(gy.double())
+    res = torch.randn(B, cin, hw, hw, device='cuda').contiguous(memory_format=CL)
+    s = et._Saved()
+    s.conv, s.x, s.stride, s.stem = conv, x, stride, False
+    with torch.no_grad():
+        y = et._conv_raw(x, conv.weight.detach().contiguous(memory_format=CL), stride)
+        dw = et._wgrad(gy, s)
+        dx = et._dgrad(gy, s)
+        dx_res = et._dgrad(gy, s, residual=res)
+    assert _rel(y, yr.detach()) < 2e-5
+    assert _rel(dw, cr.weight.grad) < 5e-5, _rel(dw, cr.weight.grad)
+    assert _rel(dx, xr.grad) < 5e-5
+    assert _rel(dx_res - res, xr.grad) < 5e-5
+
+
+def test_stem_weight_gradient_and_maxpool_backward_match_torch():
+    torch.manual_seed(3)
+    B, H = 3, 64
+    x = torch.randn(B, 18, H, H, device='cuda')
+    conv = torch.nn.Conv2d(18, 64, 7, 2, 3, bias=False).cuda()
+    cr = copy.deepcopy(conv).double()
+    yr = cr(x.double())
+    gy = torch.randn_like(yr).float().contiguous(memory_format=CL)
+    yr.backward(gy.double())
+    s = et._Saved()
+    s.conv, s.x, s.stride, s.stem = conv, x, 2, True
+    with torch.no_grad():
+        dw = et._wgrad(gy, s)
+    assert dw.shape == (64, 18, 7, 7) and _rel(dw, cr.weight.grad) < 5e-5
+    # max-pool backward incl. ties (post-ReLU zeros): the first maximum of a window receives the gradient, as in torch
+    a = F.relu(torch.randn(B, 64, 32, 32, device='cuda')).contiguous(memory_format=CL)
+    ar = a.double().requires_grad_(True)
+    pr = F.max_pool2d(ar, 3, 2, 1)
+    gp = torch.randn_like(pr).float().contiguous(memory_format=CL)
+    pr.backward(gp.double())
+    lib = _lib.load()
+    ga = torch.empty_like(a)
+    _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(a.data_ptr(), gp.data_ptr(), ga.data_ptr(), B, 32, 32, 64, _lib.current_stream()), 'maxpool bwd')
+    assert _rel(ga, ar.grad) < 1e-6
+
+
+@pytest.mark.parametrize('layers,B,size', [(18, 4, 64), (50, 3, 64), (18, 6, 128)])
+def test_whole_encoder_training_graph_matches_module_autograd(layers, B, size):
+    torch.manual_seed(layers)
+    enc = ResNetEncoder(layers, 18).cuda().train()
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    ref = copy.deepcopy(enc).double()
+    x = torch.randn(B, 18, size, size, device='cuda')
+    w = torch.randn(B, enc.out_dim, device='cuda')
+    f_ref = ref.forward_module(x.double())
+    (f_ref * w.double()).sum().backward()
+    feats = enc(x)                                                   # train() + grad: the HIP training graph
+    assert feats.grad_fn is not None and 'EncoderTrainFn' in type(feats.grad_fn).__name__
+    (feats * w).sum().backward()
+    assert _rel(feats.detach(), f_ref.detach()) < 1e-4
+    worst = 0.0
+    for (n, p), (_, pr) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and p.grad.shape == p.shape, n
+        r = _rel(p.grad, pr.grad)
+        worst = max(worst, r)
+        assert r < 2e-3, (n, r)                                      # fp32 through up to 53 layers of batch-statistics BN vs float64
+    for (n, b), (_, br) in zip(enc.named_buffers(), ref.named_buffers()):
+        if n.endswith('num_batches_tracked'):
+            assert int(b) == int(br) == 1
+        else:
+            assert _rel(b, br) < 1e-4, n
+    # eval() without grad still takes the folded inference plan; the plan sees the parameter update of an optimiser step
+    opt = torch.optim.SGD(enc.parameters(), lr=1e-3)
+    opt.step()
+    enc.eval()
+    with torch.no_grad():
+        a = enc(x)
+        b = enc.forward_module(x)
+    assert _rel(a, b) < 1e-4

@@ -37,7 +37,7 @@ for it in range(cases):
         _lib.check(lib.hmf_stem_pack_host(w.contiguous().data_ptr(), pk.data_ptr()), 'pack')
         y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
         xd, pd, bd = x.cuda(), pk.cuda(), b.cuda()
-        _lib.check(lib.hmf_stem_conv(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, 18, H, W, st), 'stem')
+        _lib.check(lib.hmf_stem_conv(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'stem')
         check('stem B%d %dx%d' % (B, H, W), y, ref)
         z = torch.full(F.max_pool2d(ref, 3, 2, 1).shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
         _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, ref.shape[2], ref.shape[3], 64, st), 'pool')
