@@ -115,23 +115,25 @@ def test_whole_encoder_training_graph_matches_module_autograd(layers, B, size):
     feats = enc(x)                                                   # train() + grad: the HIP training graph
     assert feats.grad_fn is not None and 'EncoderTrainFn' in type(feats.grad_fn).__name__
     (feats * w).sum().backward()
-    # float32 vs float64 through up to 53 layers of batch-statistics BatchNorm; at size 64 the deepest maps are 2x2 (statistics over 12-16 values
-    # amplify rounding and ReLU-mask flips).  Bar: 2e-3, or three times the distance of ATen's own float32 run from float64 where that is larger
-    # (ResNet-50, B=3: 2.4e-2 on conv1.weight for this implementation, compare the printed ATen figure).
-    assert _rel(feats.detach(), f_ref.detach()) < max(2e-4, 3 * _rel(f32.detach(), f_ref.detach()))
+    # Gradients of a deep ReLU network are discontinuous where a pre-activation crosses zero, so ANY float32 evaluation differs from float64 by a few
+    # per cent on ResNet-50 with random weights (mask flips): ATen's float32 run is 2-4e-2 (relative L2) from float64 on the same tensors, this
+    # implementation 2-4e-2 as well; ResNet-18 at these sizes has no flips that matter (2e-5).  Bar per tensor: relative L2 error <= 1e-3, or twice
+    # the distance of ATen's own float32 run from float64.  The kernels themselves are pinned tightly by the per-operator tests above.
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30)).item()
+    assert l2(feats.detach(), f_ref.detach()) < max(1e-4, 2 * l2(f32.detach(), f_ref.detach()))
     worst = (0.0, 0.0, '')
     for (n, p), (_, pr), (_, p32) in zip(enc.named_parameters(), ref.named_parameters(), ref32.named_parameters()):
         assert p.grad is not None and p.grad.shape == p.shape, n
-        r, r32 = _rel(p.grad, pr.grad), _rel(p32.grad, pr.grad)
+        r, r32 = l2(p.grad, pr.grad), l2(p32.grad, pr.grad)
         if r > worst[0]:
             worst = (r, r32, n)
-        assert r < max(2e-3, 3 * r32), (n, r, r32)
-    print('worst parameter gradient: %s rel %.2e (ATen float32: %.2e)' % (worst[2], worst[0], worst[1]))
+        assert r < max(1e-3, 2 * r32), (n, r, r32)
+    print('worst parameter gradient: %s relative L2 %.2e (ATen float32: %.2e)' % (worst[2], worst[0], worst[1]))
     for (n, b), (_, br) in zip(enc.named_buffers(), ref.named_buffers()):
         if n.endswith('num_batches_tracked'):
             assert int(b) == int(br) == 1
         else:
-            assert _rel(b, br) < 1e-4, n
+            assert _rel(b, br) < 5e-4, n
     # eval() without grad still takes the folded inference plan; the plan sees the parameter update of an optimiser step
     opt = torch.optim.SGD(enc.parameters(), lr=1e-3)
     opt.step()
