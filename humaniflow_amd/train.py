@@ -3,7 +3,7 @@
   forward    HumaniflowModel(proxy, compute_point_est=True, num_samples=LOSS.NUM_J2D_SAMPLES, compute_for_loglik=True, targets...)   :250-256
   SMPL       joints of the point estimate and of the samples in ONE launch, flip about x, orthographic projection                     :283-318
   loss       HumaniflowLoss: pose NLL + shape NLL + visible-2D-joint MSE + global-rotation MSE                                        :323-343
-  backward   HIP reverse sweeps of the flow / SMPL (autograd.py), torch autograd for the heads and -- for now -- the encoder
+  backward   HIP reverse sweeps of the flow / SMPL (autograd.py) and of the encoder (encoder_train.py), torch autograd for the four head GEMMs
   exchange   gradients bucketed (25 MB) and all-reduced over RCCL while the rest of the backward still runs (xGMI rings are per-link bound)
   update     Adam; a non-finite loss or gradient skips the update instead of the reference's deep-copy / reload roll-back (:264-278, :345-347)
 
@@ -202,9 +202,11 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     stages['forward+loss_ms'], (loss, _) = tm(lambda: train_forward_loss(model, smpl, criterion, *batches[0], N))
     stages['backward_ms'], _ = tm(lambda: loss.backward())
     stages['exchange+update_ms'], _ = tm(lambda: (reducer.finish(), optimiser.step()))
-    with torch.no_grad():
-        feats_ms, feats = tm(lambda: model.image_encoder.forward_module(batches[0][0]))
-    stages['of_forward: encoder (ATen, train-mode BatchNorm)_ms'] = feats_ms
+    enc_ms, feats = tm(lambda: model.image_encoder(batches[0][0]))
+    stages['of_forward: encoder training graph (batch-statistics BN)_ms'] = enc_ms
+    w_ = torch.randn_like(feats)
+    stages['of_backward: encoder_ms'], _ = tm(lambda: (feats * w_).sum().backward())
+    optimiser.zero_grad(set_to_none=True)
     if rank == 0:
         value = world * B * N * args.steps / elapsed
         print(json.dumps({
@@ -218,8 +220,9 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
                        if world > 1 else 'none'},
             'rccl_ranks_seen': int(gathered.shape[0]), 'mean_loss': float(gathered[:, 0].mean()), 'skipped_steps': int(gathered[:, 1].sum()),
             'train_images_per_s': round(world * B * args.steps / elapsed, 1), 'stages_ms': {k: round(v, 3) for k, v in stages.items()},
-            'hand_written': 'flow forward/backward (hmf_flow_forward, hmf_flow_log_prob_SO3[_backward], hmf_flow_sample_backward), SMPL forward + joints '
-                            'backward, proxy front end; encoder training graph on ATen autograd (DESIGN.md section 7)',
+            'hand_written': 'encoder training graph (conv kernels + hmf_bn_* + hmf_conv_wgrad + dgrad through hmf_conv2d_nhwc), flow forward/backward '
+                            '(hmf_flow_forward, hmf_flow_log_prob_SO3[_backward], hmf_flow_sample_backward), SMPL forward + joints backward, proxy front end; '
+                            'library GEMMs (torch) for the heads and the dense weight-gradient reductions of the flow',
             'roofline': None, 'cpu_baseline': None}))
     if dist is not None:
         dist.destroy_process_group()
