@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const f32x4* __restrict__ x
 // ---------------------------------------------------------------------------------------------------
 // weight gradient.  gy [M][Cout] (M = B OH OW), x NHWC [B][H][W][Cin] (STEM: the NCHW proxy input [B][Cin][H][W]),
 // dw [Cout][K]: K = KS*KS*Cin in (kh, kw, ci) order = channels_last filter layout (STEM: (ci, kh, kw) order = torch's native layout).
-// One wave per (64 x 64 tile of dw, slice of the pixel axis); grid = (tiles, slices), 64 threads.
+// One work-group of 4 waves per (64 x 64 tile of dw, slice of the pixel axis): each wave multiplies a quarter of the slice into its own
+// accumulators, the four partial tiles are summed through LDS and added to dw with one atomic pass; grid = (tiles, slices).
 // ---------------------------------------------------------------------------------------------------
 struct WgradArgs {
     const float* gy;
@@ -206,12 +207,14 @@ struct WgradArgs {
 };
 
 template <bool STEM>
-__global__ __launch_bounds__(64) void k_conv_wgrad(const WgradArgs a) {
-    const int lane = threadIdx.x, li = lane & 31, lq = lane >> 5;
+__global__ __launch_bounds__(256) void k_conv_wgrad(const WgradArgs a) {
+    __shared__ float part[3][64 * 64];                       // partial tiles of waves 1..3 (wave 0 keeps its own in registers)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lq = lane >> 5;
     const int ct = blockIdx.x / a.ktiles, kt = blockIdx.x - ct * a.ktiles;
     const int co0 = ct * 64, k0 = kt * 64;
-    const int m_begin = blockIdx.y * a.rows_per_slice, m_end = min(m_begin + a.rows_per_slice, a.M);
-    if (m_begin >= m_end) return;
+    // the block owns rows_per_slice pixels, each of its 4 waves a quarter of them (multiples of 8 pixels)
+    const int q4 = a.rows_per_slice / 4;
+    const int m_begin = blockIdx.y * a.rows_per_slice + wave * q4, m_end = min(m_begin + q4, a.M);
     // ---- per-lane description of its two B-operand columns (kcol = k0 + 32 tb + li) ----
     int kh[2], kw[2], cbase[2];          // filter tap and the float offset of the channel inside a pixel (NHWC) / plane (STEM)
     bool kvalid[2];
@@ -270,8 +273,8 @@ __global__ __launch_bounds__(64) void k_conv_wgrad(const WgradArgs a) {
             }
         }
     };
-    const int ngroups = (m_end - m_begin + 2 * U - 1) / (2 * U);
-    load_group(0);
+    const int ngroups = m_end > m_begin ? (m_end - m_begin + 2 * U - 1) / (2 * U) : 0;
+    if (ngroups > 0) load_group(0);
     for (int g = 0; g < ngroups; ++g) {
         const int slot = g & 1;
         if (g + 1 < ngroups) load_group(slot ^ 1);
@@ -283,19 +286,32 @@ __global__ __launch_bounds__(64) void k_conv_wgrad(const WgradArgs a) {
                 for (int tb = 0; tb < 2; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][u][ta], fb[slot][u][tb], acc[ta][tb], 0, 0, 0);
     }
-    // ---- combine the pixel slices: float atomics, 128-byte runs per instruction ----
+    // ---- combine: the four waves of the block through LDS, then ONE atomic pass per block over the pixel slices (128-byte runs) ----
+    // tile element (ta, tb, r) of lane (li, lq) lives at part[..][((ta*2 + tb)*16 + r)*64 + lane]
+    if (wave > 0) {
 #pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
+        for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            const int kcol = k0 + 32 * tb + li;
-            if (kcol >= a.K) continue;
+            for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + 32 * ta + (r & 3) + 8 * (r >> 2) + 4 * lq;
-                if (co < a.Cout) atomicAdd(a.dw + (size_t)co * a.K + kcol, acc[ta][tb][r]);
+                for (int r = 0; r < 16; ++r) part[wave - 1][((ta * 2 + tb) * 16 + r) * 64 + lane] = acc[ta][tb][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int kcol = k0 + 32 * tb + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = ((ta * 2 + tb) * 16 + r) * 64 + lane;
+                    const float v = acc[ta][tb][r] + part[0][e] + part[1][e] + part[2][e];
+                    const int co = co0 + 32 * ta + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                    if (kcol < a.K && co < a.Cout) atomicAdd(a.dw + (size_t)co * a.K + kcol, v);
+                }
             }
-        }
+    }
 }
 
 }  // namespace hmf
@@ -382,14 +398,14 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
     a.K = ks * ks * Cin;
     a.ktiles = (a.K + 63) / 64;
     const int tiles = a.ktiles * ((Cout + 63) / 64);
-    // enough waves to fill the chip (~8 per SIMD), slices a multiple of 8 pixels
-    int slices = std::max(1, std::min((int)((M + 63) / 64), (256 * 4 * 8 + tiles - 1) / tiles));
-    a.rows_per_slice = (int)(((M + slices - 1) / slices + 7) / 8 * 8);
+    // ~6 work-groups (4 waves each, 48 KB of LDS) per CU; a block's pixel slice is 4 wave quarters of a multiple of 8 pixels
+    int slices = std::max(1, std::min((int)((M + 255) / 256), (256 * 6 + tiles - 1) / tiles));
+    a.rows_per_slice = (int)(((M + slices - 1) / slices + 31) / 32 * 32);
     slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
     hipStream_t st = (hipStream_t)stream;
     HMF_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * a.K * sizeof(float), st));
-    if (stem_nchw) hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(tiles, slices), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(tiles, slices), dim3(64), 0, st, a);
+    if (stem_nchw) hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(tiles, slices), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(tiles, slices), dim3(256), 0, st, a);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -40,6 +40,46 @@ def _conv_raw(x, w_cl, stride, residual=None):
     return y
 
 
+_PATCH_MAPS = {}
+
+
+def _patch_packed(w4, cfg):
+    """Packed B operand of hmf_conv_patch for a (Cout, Cin, 3, 3) filter, built on the device: the host packer only permutes, so packing an
+    index-valued array once per (shape, cfg, device) gives a gather map (the filters change every optimiser step)."""
+    lib = _lib.load()
+    Cout, Cin = w4.shape[:2]
+    key = (Cin, Cout, cfg, str(w4.device))
+    m = _PATCH_MAPS.get(key)
+    if m is None:
+        n = Cout * 9 * Cin
+        idx = torch.arange(n, dtype=torch.float32)
+        packed = torch.empty(int(lib.hmf_conv_patch_packed_floats(Cin, Cout, 3)), dtype=torch.float32)
+        _lib.check(lib.hmf_conv_patch_pack_host(idx.data_ptr(), packed.data_ptr(), Cin, Cout, 3, cfg), 'hmf_conv_patch_pack_host')
+        m = _PATCH_MAPS[key] = packed.long().to(w4.device)
+    return w4.permute(0, 2, 3, 1).reshape(-1)[m]                      # (Cout, kh, kw, Cin) order, gathered into MFMA lane order
+
+
+def _conv3x3_patch(x, w4, stride, residual=None):
+    """Bias-free 3x3 convolution on the patch-resident kernel (2x the implicit-GEMM rate on these shapes): w4 (Cout, Cin, 3, 3), any memory format."""
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    Cout = w4.shape[0]
+    cfg = 8210 if (stride == 2 or Cin != 64) else 16410
+    packed = _patch_packed(w4, cfg)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = _cl_empty(B, Cout, OH, OW, x.device)
+    _lib.check(lib.hmf_conv_patch(x.data_ptr(), packed.data_ptr(), None, None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W,
+                                  Cin, Cout, 3, stride, 0, cfg, _lib.current_stream()), 'hmf_conv_patch')
+    return y
+
+
+def _conv_any(x, w4, stride, residual=None):
+    """Bias-free convolution, filter given in the parameter's (Cout, Cin, k, k) shape (any strides)."""
+    if w4.shape[2] == 3 and x.shape[1] % 64 == 0 and w4.shape[0] % 64 == 0:
+        return _conv3x3_patch(x, w4, stride, residual)
+    return _conv_raw(x, w4.contiguous(memory_format=CL), stride, residual)
+
+
 class _Saved:
     __slots__ = ('conv', 'bn', 'x', 'y', 'out', 'mean', 'rstd', 'relu', 'stride', 'stem')
 
@@ -107,18 +147,18 @@ def _dgrad(gy, s, residual=None):
     """dL/dx of unit s (+ residual): a convolution of gy with the flipped, in/out-transposed filter."""
     w = s.conv.weight.detach()
     ks = w.shape[2]
-    wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=CL) if ks > 1 else w.transpose(0, 1).contiguous(memory_format=CL)      # (Cin, Cout, k, k)
+    wt = w.flip(2, 3).transpose(0, 1) if ks > 1 else w.transpose(0, 1)          # (Cin, Cout, k, k) view: flipped, in/out swapped
     B, Cin, H, W = s.x.shape
     if s.stride == 1:
-        return _conv_raw(gy, wt, 1, residual)
+        return _conv_any(gy, wt, 1, residual)
     if ks == 1:                                                       # strided 1x1 (downsample branch): only the sampled pixels receive gradient
         gx = torch.zeros((B, Cin, H, W), device=gy.device, dtype=torch.float32).contiguous(memory_format=CL) if residual is None else residual.clone()
-        c = _conv_raw(gy, wt, 1)
+        c = _conv_any(gy, wt, 1)
         gx[:, :, ::s.stride, ::s.stride] += c
         return gx
     gd = torch.zeros((B, gy.shape[1], H, W), device=gy.device, dtype=torch.float32).contiguous(memory_format=CL)    # zero-inserted gradient map
     gd[:, :, ::s.stride, ::s.stride] = gy
-    return _conv_raw(gd, wt, 1, residual)
+    return _conv_any(gd, wt, 1, residual)
 
 
 class EncoderTrainFn(torch.autograd.Function):
@@ -138,7 +178,7 @@ class EncoderTrainFn(torch.autograd.Function):
                 s.y = _cl_empty(B, 64, OH, OW, dev)
                 _lib.check(lib.hmf_stem_conv(xin.data_ptr(), packed.data_ptr(), None, s.y.data_ptr(), B, C, H, W, 0, _lib.current_stream()), 'hmf_stem_conv')
             else:
-                s.y = _conv_raw(xin, conv.weight.detach().contiguous(memory_format=CL), s.stride)
+                s.y = _conv_any(xin, conv.weight.detach(), s.stride)
             s.out, s.mean, s.rstd = _bn_forward(s.y, bn, residual, relu)
             saved.append(s)
             return s.out

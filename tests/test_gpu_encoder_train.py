@@ -60,7 +60,7 @@ def test_conv_weight_and_input_gradients_match_torch(cin, cout, ks, stride, hw):
     s = et._Saved()
     s.conv, s.x, s.stride, s.stem = conv, x, stride, False
     with torch.no_grad():
-        y = et._conv_raw(x, conv.weight.detach().contiguous(memory_format=CL), stride)
+        y = et._conv_any(x, conv.weight.detach(), stride)
         dw = et._wgrad(gy, s)
         dx = et._dgrad(gy, s)
         dx_res = et._dgrad(gy, s, residual=res)
