@@ -200,19 +200,23 @@ struct NetAct {
 __device__ __forceinline__ float hypernet_fwd(const FlowDev& d, const PartTab& pt, int c, int lane, float ctx_lane, float x1, NetAct& A) {
     const float* W = d.arena + pt.o_nnT[c][0];
     float a = d.arena[pt.o_nnb[c][0] + lane];
-    for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(ctx_lane, k), a);
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(ctx_lane, k), a);      // unrolled: the weight loads of 16 steps in flight together
     a = fmaf(W[64 * 64 + lane], x1, a);
     A.h1 = fmaxf(a, 0.f);
     W = d.arena + pt.o_nnT[c][1];
     a = d.arena[pt.o_nnb[c][1] + lane];
+#pragma unroll 16
     for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h1, k), a);
     A.h2 = lane < 32 ? fmaxf(a, 0.f) : 0.f;
     W = d.arena + pt.o_nnT[c][2];
     a = d.arena[pt.o_nnb[c][2] + lane];
+#pragma unroll 16
     for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h2, k), a);
     A.h3 = lane < 32 ? fmaxf(a, 0.f) : 0.f;
     W = d.arena + pt.o_nnT[c][3];
     a = d.arena[pt.o_nnb[c][3] + lane];
+#pragma unroll 16
     for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h3, k), a);
     return a;
 }
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(256) void k_flow_chain_bwd(FlowDev d, int lev, cons
     float pre = d.arena[pt.o_bctx + lane];
     {
         const float* h = H + (size_t)row * kIsgc;
+#pragma unroll 16
         for (int k = 0; k < kIsgc; ++k) pre = fmaf(WT[(size_t)k * kCtx + lane], h[k], pre);
         for (int a = 0; a < pt.n_anc; ++a) {
             const float* ra = rot + ((size_t)row * kP + pt.anc[a]) * 9;
