@@ -250,7 +250,9 @@ __device__ __forceinline__ void skin_element(const SmplDev& d, const char* __res
     asm volatile("" : "+v"(x), "+v"(y), "+v"(z));        // keep the body OUT of the exec-masked store block (otherwise the compiler sinks each body into its own exec-masked block and serialises 32 x 4 LDS round trips per tile)
     if (e.ok_v && (e.full_rows || rc < e.row_lim)) {
         float* o = e.obase + rc * (kV * 3);
-        o[0] = x; o[1] = y; o[2] = z;
+        // streaming stores: the 267 MB of vertices are written once and never re-read by this kernel; keeping them out of the way of the
+        // 2.3 MB operand range that each XCD's L2 is supposed to hold (r01 PMC: the operand was re-fetched ~9x)
+        __builtin_nontemporal_store(x, o); __builtin_nontemporal_store(y, o + 1); __builtin_nontemporal_store(z, o + 2);
     }
 }
 

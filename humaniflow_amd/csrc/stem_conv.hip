@@ -16,15 +16,21 @@ namespace hmf {
 
 constexpr int kStemC = 18, kStemK = 7, kStemN = 64;
 constexpr int kStemTH = 8, kStemTW = 16;                                  // output tile
-constexpr int kStemPH = 2 * kStemTH + 5, kStemPW = 2 * kStemTW + 5;       // 21 x 37 input patch (odd row stride: conflict-free)
-constexpr int kStemPlane = kStemPH * kStemPW;                             // 777 floats per channel
+constexpr int kStemPH = 2 * kStemTH + 5, kStemPW = 2 * kStemTW + 5;       // 21 x 37 input patch
+// LDS image of the patch: columns de-interleaved by parity (even columns in slots 0..18, odd ones in 20..37) with a row pitch of 40 floats.
+// A k-step reads column 2 px + kw for the 16 px of a row: one parity, consecutive slots -> consecutive banks; the lanes' second pixel row
+// is two patch rows = 80 floats further = the other 16 banks.  (Round 1 stored rows linearly with pitch 37: stride-2 columns put the 32
+// lanes of a half-wave on 16 banks, 47 % of the LDS cycles were bank conflicts.)
+constexpr int kStemPitch = 40, kStemOdd = 20;
+constexpr int kStemPlane = kStemPH * kStemPitch;                          // 840 floats per channel
+__device__ __forceinline__ constexpr int stem_slot(int col) { return (col & 1) * kStemOdd + (col >> 1); }
 constexpr int kStemSteps = (kStemC / 2) * kStemK * kStemK;                // 441 k-steps
 constexpr int kStemGroups = (kStemSteps + 3) / 4;                         // 111 groups of 4
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_conv(
     const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
     int OH, int OW, int tiles_w, int tiles_hw, int relu) {
-    __shared__ float patch[kStemC * kStemPlane + 8];
+    __shared__ float patch[kStemC * kStemPlane + 8];            // 60.5 KB: two work-groups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
     const int b = blockIdx.x / tiles_hw, trem = blockIdx.x - b * tiles_hw;
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // ---- input patch -> LDS (NCHW source: 37-float runs per (channel, row)).  Raw buffer loads: an element outside the image gets an
     // out-of-range offset and comes back as zero, so all 55 loads of a thread are in flight together (no branch, no select). ----
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * kStemC * H * W), 0, kStemC * H * W * 4, 0x00020000);
-    constexpr int kPatch = kStemC * kStemPlane, kIter = (kPatch + 255) / 256;
+    constexpr int kPatch = kStemC * kStemPH * kStemPW, kIter = (kPatch + 255) / 256;          // patch elements in (channel, row, column) order
     float pv[kIter];
 #pragma unroll
     for (int k = 0; k < kIter; ++k) {
@@ -47,13 +53,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < kIter - 1; ++k) patch[tid + 256 * k] = pv[k];
-    if (tid + 256 * (kIter - 1) < kPatch + 8) patch[tid + 256 * (kIter - 1)] = pv[kIter - 1];
+    for (int k = 0; k < kIter; ++k) {
+        const int e = tid + 256 * k;
+        const int c = e / (kStemPH * kStemPW), rem = e - c * (kStemPH * kStemPW), r = rem / kStemPW, col = rem - r * kStemPW;
+        patch[e < kPatch ? c * kStemPlane + r * kStemPitch + stem_slot(col) : kStemC * kStemPlane] = pv[k];      // beyond the patch: the pad word
+    }
     __syncthreads();
 
     // ---- 441 k-steps ----
     const int py = 2 * wave + (li >> 4), px = li & 15;
-    const float* pa = patch + (2 * py) * kStemPW + 2 * px + lq * kStemPlane;
+    const float* pa = patch + (2 * py) * kStemPitch + px + lq * kStemPlane;
     const f32x4* pw = wp + lane;
     f32x16 acc[2];
 #pragma unroll
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int u = 0; u < 4; ++u) {
             const int s = 4 * g + u < kStemSteps ? 4 * g + u : kStemSteps - 1;
             const int cp = s / 49, kk = s - cp * 49, kh = kk / 7, kw = kk - kh * 7;
-            av[slot][u] = pa[cp * 2 * kStemPlane + kh * kStemPW + kw];
+            av[slot][u] = pa[cp * 2 * kStemPlane + kh * kStemPitch + stem_slot(kw)];
         }
     };
 #pragma unroll
