@@ -248,10 +248,10 @@ def conv_families(ms_, tag_, reps, conv_flops):
     return fam
 
 
-def load_pmc_traffic(source_hash):
+def load_pmc_traffic(source_hash, workload):
     """HBM bytes per launch from the separate `rocprofv3 --pmc` passes summarised by tools/pmc_summary.py.  PMC counters cannot be read
     from inside the process; the file is stamped with the library source hash it was profiled at and is IGNORED when that differs from
-    the library being benchmarked (no silent stale figure)."""
+    the library being benchmarked, or when it was collected on another workload (batch, samples, blend dtype): no silent stale figure."""
     best = None
     pdir = os.path.join(ROOT, 'profiles')
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -260,7 +260,7 @@ def load_pmc_traffic(source_hash):
                 d = json.load(open(os.path.join(pdir, f)))
             except Exception:
                 continue
-            if isinstance(d, dict) and d.get('lib_source_hash') == source_hash:
+            if isinstance(d, dict) and d.get('lib_source_hash') == source_hash and d.get('workload', 'B=32,N=100,fp32') == workload:
                 best = (f, d)
     return best
 
@@ -428,7 +428,7 @@ def main():
         }
         step_flops = sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)
         agg = step_flops / (elapsed / args.steps) / 1e12
-        pmc = load_pmc_traffic(source_hash())
+        pmc = load_pmc_traffic(source_hash(), 'B=%d,N=%d,%s' % (args.batch, args.samples, args.blend_dtype))
 
         def traffic_of(key):
             if pmc is None:
@@ -449,7 +449,7 @@ def main():
                 'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4),
                 'traffic': traffic_of(key),
                 'traffic_note': ('mean HBM bytes/launch over this family from separate rocprofv3 --pmc passes (profiles/%s, same library source hash)' % pmc[0]) if pmc
-                                else 'null: no profiles/*_pmc.json was collected at this library source hash',
+                                else 'null: no profiles/*_pmc.json was collected at this library source hash on this workload',
                 'avg_launch_us': round(dom['us_per_step'] / dom['launches_per_step'], 2), 'launches_measured': dom['launches_per_step'] * P,
                 'algorithmic_flop_per_launch': per_launch_flop,
                 'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (measurement pass: HIP events on the launch stream, one stream)',

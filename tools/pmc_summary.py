@@ -41,6 +41,6 @@ try:
     head = subprocess.run(['git', 'rev-parse', 'HEAD'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.decode().strip() or None
 except Exception:
     head = None
-json.dump({'lib_source_hash': source_hash(), 'git_head': head,
+json.dump({'lib_source_hash': source_hash(), 'git_head': head, 'workload': os.environ.get('HMF_PMC_WORKLOAD', 'B=32,N=100,fp32'),
            'how': 'two separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --no-cpu-baseline`; KiB units; FETCH x2 on gfx950 for 16 B/lane reads',
            'kernels': out}, sys.stdout, indent=1)
