@@ -41,9 +41,11 @@ WINOGRAD_MFMA_FRACTION = 4.0 / 9.0     # F(2x2,3x3): 16 multiplies per 2x2 outpu
 
 
 def encoder_conv_flops(enc, B, size):
-    """Algorithmic FLOPs (2*M*N*K, no padding taps removed) of every convolution of the encoder in launch order."""
-    flops, kind = [2.0 * B * (size // 2) ** 2 * 64 * enc.conv1.in_channels * 49], ['7x7/2']
+    """Algorithmic FLOPs (2*M*N*K, no padding taps removed) of every convolution launch of the encoder's inference plan, in launch order.
+    A fused seam (hmf_conv_pair: block i's last 1x1 + block i+1's first 1x1, `enc._plan['pair']`) is one launch carrying both layers' FLOPs."""
+    flops, kind, role = [2.0 * B * (size // 2) ** 2 * 64 * enc.conv1.in_channels * 49], ['7x7/2'], [None]
     hw = size // 4
+    bi = 0
     for li in range(1, 5):
         for blk in getattr(enc, 'layer%d' % li):
             stages = [c for c, _ in blk.stages()]
@@ -59,10 +61,23 @@ def encoder_conv_flops(enc, B, size):
                     f += 2.0 * B * oh * oh * c.out_channels * blk.downsample[0].in_channels
                 flops.append(f)
                 kind.append('%dx%d' % (c.kernel_size[0], c.kernel_size[0]))
+                role.append((bi, 'first' if c is stages[0] else ('last' if c is stages[-1] else 'mid')))
                 if not is_ds:
                     cur = oh
             hw = cur
-    return flops, kind
+            bi += 1
+    plan = getattr(enc, '_plan', None)
+    pairs = set(plan['pair']) if plan and plan.get('pair') and B * (size // 4) ** 2 % 64 == 0 else set()
+    out_f, out_k = [], []
+    for f, k, r in zip(flops, kind, role):
+        if r is not None and r[1] == 'first' and (r[0] - 1) in pairs:
+            li_ = max(i for i in range(len(out_f)) if out_k[i].startswith('1x1'))          # the seam launch = the previous block's last 1x1
+            out_f[li_] += f
+            out_k[li_] = '1x1+1x1 (seam)'
+            continue
+        out_f.append(f)
+        out_k.append(k)
+    return out_f, out_k
 
 
 def parse():
@@ -215,7 +230,7 @@ def dry_run_cpu(args):
 
 
 KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
-CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_igemm (1x1)', 11: 'k_conv_winograd (3x3)'}
+CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_igemm + k_conv_pair (1x1)', 11: 'k_conv_winograd (3x3)'}
 
 
 def collect_profile(lib, _lib, cap=65536):
@@ -433,7 +448,8 @@ def main():
         def traffic_of(key):
             if pmc is None:
                 return None
-            cand = [v for k, v in pmc[1].get('kernels', {}).items() if key in k]
+            keys = key if isinstance(key, tuple) else (key,)
+            cand = [v for k, v in pmc[1].get('kernels', {}).items() if any(kk in k for kk in keys)]
             if not cand:
                 return None
             return int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
@@ -441,7 +457,7 @@ def main():
             dom_name = max(conv, key=lambda k: conv[k]['us_per_step'])
             dom = conv[dom_name]
             per_launch_flop = dom['gflop_per_step'] * 1e9 / dom['launches_per_step']
-            key = {'k_conv_igemm (1x1)': 'k_conv_igemm', 'k_conv_patch (3x3)': 'k_conv_patch', 'k_conv_winograd (3x3)': 'k_conv_winograd',
+            key = {'k_conv_igemm + k_conv_pair (1x1)': ('k_conv_igemm', 'k_conv_pair'), 'k_conv_patch (3x3)': 'k_conv_patch', 'k_conv_winograd (3x3)': 'k_conv_winograd',
                    'k_stem_conv (7x7/2)': 'k_stem_conv'}[dom_name]
             res['roofline'] = {
                 'kernel': '%s convolutions of the encoder: %d launches/step, the kernel family with the largest share of the step' % (dom_name, dom['launches_per_step']),

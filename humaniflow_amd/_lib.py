@@ -91,9 +91,12 @@ _SIGS = {
     'hmf_conv_patch': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
     'hmf_pointset_errors': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP, _VP]),
     'hmf_sample_diversity': (C.c_int, [_VP] + [C.c_int] * 3 + [_VP, _VP]),
+    'hmf_conv_pair_pack_host': (C.c_int, [_VP] * 4 + [C.c_int] * 3),
+    'hmf_conv_pair': (C.c_int, [_VP] * 9 + [C.c_int] * 11 + [_VP]),
     'hmf_conv_winograd_packed_floats': (C.c_longlong, [C.c_int] * 2),
     'hmf_conv_winograd_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 2),
     'hmf_conv_winograd': (C.c_int, [_VP] * 5 + [C.c_int] * 6 + [_VP]),
+    'hmf_conv_winograd_variant': (C.c_int, [_VP] * 5 + [C.c_int] * 7 + [_VP]),      # tools/winograd_ablate.py
     'hmf_conv1x1_dual_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 10 + [_VP]),
     'hmf_conv2d_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
     'hmf_profile_enable': (C.c_int, [C.c_int]),

@@ -1,0 +1,263 @@
+// The seam between two ResNet bottlenecks as ONE launch (models/resnet.py:102-127 -- block i's `conv3 + bn3 (+ downsample) + identity + ReLU`
+// followed by block i+1's `conv1 + bn1 + ReLU`):
+//
+//   Y[m][:]  = relu( [X1[m] | X2[m']] . W3^T + bias3 (+ R[m]) )        C channels   (written: it is the next block's identity branch)
+//   Z[m][:]  = relu( Y[m] . W1^T + bias1 )                              N2 channels
+//
+// In layer1 / layer2 the C = 256 / 512-channel fp32 tensor Y is what bounds the two 1x1 layers (HBM: 134 MB per pass at B = 32, 64x64): as two
+// launches Y is written once and read back; here the 64-pixel x 64-channel chunks of Y go to HBM and, through LDS, straight into the second GEMM,
+// so Y is never re-read (470 -> 335 MB per seam in layer1).
+//
+// Work-group = 64 pixels, 4 waves (2 x 2).  The [64 x Kt] input panel stays in LDS.  For each chunk c of 64 mid channels:
+//   phase 1   every wave: one 32 x 32 tile of Y (K = Kt), + bias + residual, ReLU -> global, and -> LDS chunk buffer (double-buffered)
+//   barrier
+//   phase 2   every wave: its 32 x 32 tile(s) of Z += chunk[64 x 64] . W1[:, chunk]^T
+// Both weight matrices are pre-packed in MFMA B-operand lane order per (chunk, n-tile, k-group) and stream L2 -> VGPR (1 KiB per wave-level load):
+// W1's fragments of chunk c are requested before phase 1 of c, W3's fragments and the residual of chunk c + 1 before phase 2 of c.
+#include "hmf_common.h"
+
+namespace hmf {
+
+struct PairArgs {
+    const float* x1;      // [M][K1]
+    const float* x2;      // [B][H2][W2][K2] (pixel (oh * stride2, ow * stride2)) or null
+    const f32x4* w3p;     // packed [C/64][2][Kt/8][64 lanes]
+    const float* bias3;   // [C]
+    const float* res;     // [M][C] or null
+    float* y;             // [M][C]
+    const f32x4* w1p;     // packed [C/64][N2/32][8][64 lanes]
+    const float* bias1;   // [N2]
+    float* z;             // [M][N2]
+    int M, K1, K2, C, B, OH, OW, H2, W2, stride2;
+    int y_nt;             // y does not fit the L2s anyway: store it non-temporal (measured on layer1: 102 -> 84 us per seam)
+};
+
+constexpr int kPairYS = 64 + 4;          // LDS row stride of a Y chunk
+
+// ABL (tools/pair_probe.py, timing only; & 7 give wrong results): & 1 = y is not stored, & 2 = the residual is not loaded, & 4 = no chunk barrier,
+// & 8 = residual loads streaming (nt), & 16 = y stores NOT non-temporal.
+template <int KT, int N2, int OCC, int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_pair(const PairArgs a) {
+    constexpr int XS = KT + 4, G3 = KT / 8, TN2 = N2 / 64, NT2 = N2 / 32, V4 = KT / 4, NX = 64 * V4 / 256;
+    __shared__ float sX[64 * XS];
+    __shared__ float sY[2][64 * kPairYS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: scalar offsets below
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lq = lane >> 5;
+    const int m0 = blockIdx.x * 64;
+    constexpr int kOOB = (int)0x80000000;
+
+    // ---- input panel -> LDS ----
+    {
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.M * a.K1 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0, a.x2 ? a.B * a.H2 * a.W2 * a.K2 * 4 : 0, 0x00020000);
+        f32x4 pv[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i, row = e / V4, c4 = (e - row * V4) * 4;
+            const int m = m0 + row;
+            if (c4 < a.K1) {
+                pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, m < a.M ? (m * a.K1 + c4) * 4 : kOOB, 0, 0));
+            } else {
+                int off = kOOB;
+                if (m < a.M) {
+                    const int b = m / (a.OH * a.OW), r = m - b * a.OH * a.OW, oh = r / a.OW, ow = r - oh * a.OW;
+                    off = (((b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.K2 + (c4 - a.K1)) * 4;
+                }
+                pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, off, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i, row = e / V4, c4 = (e - row * V4) * 4;
+            *(f32x4*)&sX[row * XS + c4] = pv[i];
+        }
+    }
+
+    const int nchunk = a.C / 64;
+    const int pxb = 32 * wm + 4 * lq;                       // accumulator register r of this lane: pixel pxb + (r & 3) + 8 (r >> 2), channel li of the tile
+    const float* pa1 = sX + (32 * wm + li) * XS + 4 * lq;
+    const int ya = (32 * wm + li) * kPairYS + 4 * lq;
+
+    // Every global access below is a raw buffer access: one per-lane 32-bit offset + a scalar offset (chunk, k-group, accumulator row), so no
+    // 64-bit per-row address lives in registers across the chunk loop.  M is a multiple of 64 (checked by the host wrapper): no row tails.
+    const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3p, 0, nchunk * 2 * G3 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1p, 0, nchunk * NT2 * 8 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.y), 0, a.M * a.C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.M * a.C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.z, 0, a.M * N2 * 4, 0x00020000);
+    const int vlane = lane * 16;
+    const int vy = ((m0 + 4 * lq) * a.C + li) * 4;          // + scalar ((32 wm + row(r)) C + 64 c + 32 wn) * 4
+    const int vz = ((m0 + 4 * lq) * N2 + li) * 4;
+    const int rowC = a.C * 4;
+
+    f32x4 b3[G3], b1[TN2][8];
+    float rva[16], rvb[16];
+    auto load_b3 = [&](int c) {
+        const int so = (c * 2 + wn) * G3 * 1024;
+#pragma unroll
+        for (int g = 0; g < G3; ++g) b3[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw3, vlane, so + g * 1024, 0));
+    };
+    auto load_b1 = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < TN2; ++j) {
+            const int so = (c * NT2 + wn * TN2 + j) * 8 * 1024;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) b1[j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw1, vlane, so + g * 1024, 0));
+        }
+    };
+    auto load_res = [&](int c, float (&rv)[16]) {
+        if (a.res && !(ABL & 2)) {
+            const int so = 32 * wm * rowC + (64 * c + 32 * wn) * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vy, so + ((r & 3) + 8 * (r >> 2)) * rowC, (ABL & 8) ? 2 : 0));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        }
+    };
+
+    f32x16 accz[TN2];
+#pragma unroll
+    for (int j = 0; j < TN2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accz[j][r] = 0.f;
+
+    load_res(0, rva);
+    load_b3(0);
+    __syncthreads();                                        // the input panel is in LDS
+
+    // One chunk.  Order of the memory operations: vmcnt retires in order, so everything a later MFMA phase waits for is requested BEFORE the y stores of
+    // this chunk (a store is acknowledged late): W3 fragments + residual of chunk c + 1 right after phase 1, W1 fragments of c at the top.
+    auto chunk = [&](int c, float (&rv)[16], float (&rvn)[16]) {
+        load_b1(c);
+        // ---- phase 1: a 32 x 32 tile of Y, K = KT ----
+        f32x16 accy;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accy[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < G3; ++g) {
+            const f32x4 fa = *(const f32x4*)(pa1 + 8 * g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accy = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], b3[g][u], accy, 0, 0, 0);
+        }
+        if (c + 1 < nchunk) {
+            load_b3(c + 1);
+            load_res(c + 1, rvn);
+        }
+        {
+            const float bv = a.bias3[64 * c + 32 * wn + li];
+            float* ys = sY[c & 1] + pxb * kPairYS + 32 * wn + li;
+            const int so = 32 * wm * rowC + (64 * c + 32 * wn) * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                const float v = fmaxf(accy[r] + bv + rv[r], 0.f);
+                if (ABL & 1) {
+                } else if (a.y_nt && !(ABL & 16)) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, vy, so + row * rowC, 2);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, vy, so + row * rowC, 0);
+                }
+                ys[row * kPairYS] = v;
+            }
+        }
+        if (!(ABL & 4)) __syncthreads();
+        // ---- phase 2: Z += chunk . W1[:, chunk]^T ----
+        const float* pa2 = sY[c & 1] + ya;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 fa = *(const f32x4*)(pa2 + 8 * g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < TN2; ++j) accz[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], b1[j][g][u], accz[j], 0, 0, 0);
+        }
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(c, rva, rvb);
+        if (c + 1 < nchunk) chunk(c + 1, rvb, rva);
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN2; ++j) {
+        const float bv = a.bias1[(wn * TN2 + j) * 32 + li];
+        const int so = (32 * wm * N2 + (wn * TN2 + j) * 32) * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fmaxf(accz[j][r] + bv, 0.f)), rz, vz, so + ((r & 3) + 8 * (r >> 2)) * N2 * 4, 0);
+    }
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+// w3 [C][Kt] row-major (Kt = K1 + K2: the concatenated filters of conv3 and the downsample branch), w1 [N2][C] row-major ->
+//   w3p[((c * 2 + wn) * Kt/8 + g) * 64 + lane][u] = w3[64 c + 32 wn + (lane & 31)][8 g + 4 (lane >> 5) + u]
+//   w1p[((c * N2/32 + t) * 8 + g) * 64 + lane][u] = w1[32 t + (lane & 31)][64 c + 8 g + 4 (lane >> 5) + u]
+extern "C" int hmf_conv_pair_pack_host(const float* w3, const float* w1, float* w3p, float* w1p, int Kt, int C, int N2) {
+    if (!w3 || !w1 || !w3p || !w1p) return fail(HMF_ERR_INVALID, "hmf_conv_pair_pack_host: null pointer");
+    if ((Kt != 64 && Kt != 128) || C % 64 || (N2 != 64 && N2 != 128)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair_pack_host: Kt=%d C=%d N2=%d", Kt, C, N2);
+    long long o = 0;
+    for (int c = 0; c < C / 64; ++c)
+        for (int wn = 0; wn < 2; ++wn)
+            for (int g = 0; g < Kt / 8; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int u = 0; u < 4; ++u) w3p[o++] = w3[(long long)(64 * c + 32 * wn + (l & 31)) * Kt + 8 * g + 4 * (l >> 5) + u];
+    o = 0;
+    for (int c = 0; c < C / 64; ++c)
+        for (int t = 0; t < N2 / 32; ++t)
+            for (int g = 0; g < 8; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int u = 0; u < 4; ++u) w1p[o++] = w1[(long long)(32 * t + (l & 31)) * C + 64 * c + 8 * g + 4 * (l >> 5) + u];
+    return HMF_OK;
+}
+
+extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_packed, const float* bias3, const float* residual, float* y,
+                             const float* w1_packed, const float* bias1, float* z, int B, int OH, int OW, int K1, int H2, int W2, int K2, int stride2,
+                             int C, int N2, int variant, void* stream) {
+    if (!x1 || !w3_packed || !bias3 || !y || !w1_packed || !bias1 || !z || B <= 0 || OH <= 0 || OW <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_pair: bad args");
+    if (!x2) K2 = 0;
+    const int Kt = K1 + K2;
+    if ((Kt != 64 && Kt != 128) || K1 % 4 || C % 64 || (N2 != 64 && N2 != 128))
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair: K1+K2=%d must be 64 or 128, C=%d a multiple of 64, N2=%d 64 or 128", Kt, C, N2);
+    if (x2 && (stride2 < 1 || (H2 - 1) / stride2 + 1 != OH || (W2 - 1) / stride2 + 1 != OW))
+        return fail(HMF_ERR_INVALID, "hmf_conv_pair: x2 %dx%d / %d does not give %dx%d", H2, W2, stride2, OH, OW);
+    if (((uintptr_t)x1 & 15) || ((uintptr_t)x2 & 15) || ((uintptr_t)w3_packed & 15) || ((uintptr_t)w1_packed & 15))
+        return fail(HMF_ERR_INVALID, "hmf_conv_pair: x1, x2 and the packed filters must be 16-byte aligned");
+    const long long M = (long long)B * OH * OW;
+    if (M % 64) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair: B*OH*OW=%lld must be a multiple of 64", M);
+    if (M * C >= (1LL << 29) || (x2 && (long long)B * H2 * W2 * K2 >= (1LL << 29))) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair: tensor exceeds 2^29 elements");
+    PairArgs a;
+    a.x1 = x1; a.x2 = x2; a.w3p = (const f32x4*)w3_packed; a.bias3 = bias3; a.res = residual; a.y = y;
+    a.w1p = (const f32x4*)w1_packed; a.bias1 = bias1; a.z = z;
+    a.M = (int)M; a.K1 = K1; a.K2 = K2; a.C = C; a.B = B; a.OH = OH; a.OW = OW; a.H2 = H2; a.W2 = W2; a.stride2 = stride2;
+    a.y_nt = (M * C * 4 >= (48LL << 20)) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((M + 63) / 64);
+    ProfScope ps(8, (int)M, st);               // booked with the 1x1 family (it replaces two of its launches)
+    if (variant == 0) {
+        if (Kt == 64 && N2 == 64) hipLaunchKernelGGL((k_conv_pair<64, 64, 3>), dim3(grid), dim3(256), 0, st, a);
+        else if (Kt == 64 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<64, 128, 2>), dim3(grid), dim3(256), 0, st, a);
+        else if (Kt == 128 && N2 == 64) hipLaunchKernelGGL((k_conv_pair<128, 64, 2>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_pair<128, 128, 2>), dim3(grid), dim3(256), 0, st, a);
+    } else if (Kt == 64 && N2 == 64) {           // timing experiments on the layer1 shape (tools/pair_probe.py)
+        switch (variant) {
+            case 1: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 1>), dim3(grid), dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 2>), dim3(grid), dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 3>), dim3(grid), dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 4>), dim3(grid), dim3(256), 0, st, a); break;
+            case 7: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 7>), dim3(grid), dim3(256), 0, st, a); break;
+            case 8: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 8>), dim3(grid), dim3(256), 0, st, a); break;
+            case 16: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 16>), dim3(grid), dim3(256), 0, st, a); break;
+            case 24: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 24>), dim3(grid), dim3(256), 0, st, a); break;
+            case 20: hipLaunchKernelGGL((k_conv_pair<64, 64, 2, 0>), dim3(grid), dim3(256), 0, st, a); break;
+            case 27: hipLaunchKernelGGL((k_conv_pair<64, 64, 2, 7>), dim3(grid), dim3(256), 0, st, a); break;
+            default: return fail(HMF_ERR_INVALID, "hmf_conv_pair: unknown variant %d", variant);
+        }
+    } else {
+        return fail(HMF_ERR_INVALID, "hmf_conv_pair: variants are built for K = 64, N2 = 64 only");
+    }
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}

@@ -32,8 +32,11 @@ constexpr int kWNG = kWSC / 8;                       // k-groups per slab
 // NIMG = 1: the 8 x 16 tile lies in one image (patch 10 x 18).  NIMG = 2: maps at most 8 pixels wide (layer4 at 256x256 input) -- the tile
 // is 8 x 8 pixels of TWO consecutive images side by side (patch 10 x (10 + 10)), so the MFMA still sees 32 Winograd tiles.
 
-template <int TN, int NIMG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_winograd(const WinoArgs a) {
+// MODE (tools/winograd_ablate.py, results wrong when != 0): & 1 = no patch fetch after the first slab, & 2 = no output transform / stores.
+// PIPE: 0 = transform of group g, then its MFMAs, fenced (round 1); 1 = the transform of group g + 1 is issued with the MFMAs of group g;
+// 2 = the same with an explicit 1 MFMA : 1 ds_read : 3 VALU interleave.
+template <int TN, int NIMG, int MODE = 0, int PIPE = 1, int OCC = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_winograd(const WinoArgs a) {
     // LDS image of the patch.  NIMG = 1: columns de-interleaved by parity (pixel (r, c) at slot (c & 1) * 9 + (c >> 1) of row r): the four patch
     // columns 2 tj + {0,1,2,3} of tile tj are then slots {tj, 9 + tj, tj + 1, 9 + tj + 1}, i.e. consecutive lanes read consecutive pixels (17 x 16 B
     // apart), and with a row pitch of 4 (mod 8) slots the four 16-lane groups of ds_read_b128 each cover 16 distinct bank slots: conflict-free.
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int off = goff[k] == kOOB ? kOOB : goff[k] + s * kWSC * 4;
-            pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            if (MODE & 1) pv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            else pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s) __syncthreads();
@@ -108,14 +112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         __syncthreads();
 
         const bool last = (s + 1 == nslab);
-#pragma clang loop unroll(full)
-        for (int g = 0; g < kWNG; ++g) {
-            if (!(last && g + 1 == kWNG)) {
-#pragma unroll
-                for (int t = 0; t < TN; ++t)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) bw[(g + 1) & 1][t][n] = pw[t][((g + 1) * 4 + n) * 64];
-            }
+        auto xform = [&](int g, f32x4 (&v)[4]) {
             f32x4 t[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -125,19 +122,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const f32x4 d2 = *(const f32x4*)(p2 + co + 8 * g);
                 t[c] = s1 * d1 + s2 * d2;
             }
-            f32x4 v[4];
             v[0] = t[0] - t[2];
             v[1] = t[1] + t[2];
             v[2] = t[2] - t[1];
             v[3] = t[1] - t[3];
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        f32x4 v[2][4];
+        if (PIPE) xform(0, v[0]);
+#pragma clang loop unroll(full)
+        for (int g = 0; g < kWNG; ++g) {
+            if (!(last && g + 1 == kWNG)) {
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bw[(g + 1) & 1][t][n] = pw[t][((g + 1) * 4 + n) * 64];
+            }
+            if (PIPE) {
+                if (g + 1 < kWNG) xform(g + 1, v[(g + 1) & 1]);
+            } else {
+                xform(g, v[g & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[n][u], bw[g & 1][t][n][u], acc[t][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int t = 0; t < TN; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[g & 1][n][u], bw[g & 1][t][n][u], acc[t][n], 0, 0, 0);
+            if (PIPE == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            }
+            if (!PIPE) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int t = 0; t < TN; ++t) pw[t] += kWNG * 4 * 64;
@@ -146,6 +166,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // ---- output transform: exchange the 16 position accumulators through LDS, 16 tiles at a time ----
     // M[pos][tile16][ch32]: pos = 4 * wave + nu; accumulator register r of lane (j = li, q) holds tile (r & 3) + 8 (r >> 2) + 4 q, channel j
     const int ch = tid & 31;
+    if (MODE & 2) {
+        if (acc[0][0][0] + acc[0][1][1] + acc[0][2][2] + acc[0][3][3] == 12345.678f) a.y[tid] = 1.f;      // keep the accumulators alive
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int n_out = (nt * TN + t) * 32 + ch;
@@ -225,8 +249,8 @@ extern "C" int hmf_conv_winograd_pack_host(const float* w /*[Cout][3][3][Cin]*/,
 
 extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }
 
-extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
-                                 int Cin, int Cout, int relu, void* stream) {
+static int conv_winograd_impl(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                              int Cin, int Cout, int relu, int variant, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: bad args");
     if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: Cin=%d must be a multiple of 64 and Cout=%d of 32", Cin, Cout);
     if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: x and w_packed must be 16-byte aligned");
@@ -245,8 +269,33 @@ extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const fl
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, B * H * W, st);
-    if (pair) hipLaunchKernelGGL((k_conv_winograd<1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_conv_winograd<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+#define HMF_WINO_LAUNCH(MODE, PIPE, OCC)                                                                                   \
+    do {                                                                                                                   \
+        if (pair) hipLaunchKernelGGL((k_conv_winograd<1, 2, MODE, PIPE, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((k_conv_winograd<1, 1, MODE, PIPE, OCC>), dim3((unsigned)blocks), dim3(256), 0, st, a);    \
+    } while (0)
+    switch (variant) {
+        case 0: HMF_WINO_LAUNCH(0, 0, 2); break;
+        case 1: HMF_WINO_LAUNCH(1, 0, 2); break;       // 1..3, 10.., 20..: tools/winograd_ablate.py only
+        case 2: HMF_WINO_LAUNCH(2, 0, 2); break;
+        case 3: HMF_WINO_LAUNCH(3, 0, 2); break;
+        case 10: HMF_WINO_LAUNCH(0, 0, 3); break;
+        case 13: HMF_WINO_LAUNCH(3, 0, 3); break;
+        case 20: HMF_WINO_LAUNCH(0, 1, 2); break;
+        default: return fail(HMF_ERR_INVALID, "hmf_conv_winograd_variant: unknown variant %d", variant);
+    }
+#undef HMF_WINO_LAUNCH
     HMF_LAUNCH_CHECK();
     return HMF_OK;
+}
+
+extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                                 int Cin, int Cout, int relu, void* stream) {
+    return conv_winograd_impl(x, w_packed, bias, residual, y, B, H, W, Cin, Cout, relu, 0, stream);
+}
+
+// timing experiments (tools/winograd_ablate.py); a variant other than 0 / 10 / 20 computes wrong results
+extern "C" int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                                         int Cin, int Cout, int relu, int variant, void* stream) {
+    return conv_winograd_impl(x, w_packed, bias, residual, y, B, H, W, Cin, Cout, relu, variant, stream);
 }

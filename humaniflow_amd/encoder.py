@@ -96,6 +96,7 @@ class ResNetEncoder(nn.Module):
     # ---- folded inference plan ----------------------------------------------------------
     # eval-mode BatchNorm folded into the conv weight + a per-channel bias that the convolution kernel adds in its epilogue; a
     # downsample branch's bias is added to the block's last bias so that branch needs no pass of its own.
+    fuse_pairs = True        # a bottleneck's last 1x1 + the next bottleneck's first 1x1 as one launch where built (hmf_conv_pair: layer1 / layer2)
     fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_dual_nhwc)
 
     def _fold(self, conv, bn):
@@ -166,7 +167,22 @@ class ResNetEncoder(nn.Module):
                     wcat = torch.cat([w3.reshape(w3.shape[0], -1), wd.reshape(wd.shape[0], -1)], dim=1).contiguous()
                     dual = (wcat, stages[-1][1], ds[2][0])
                 plan['blocks'].append((stages, ds, dual))
-        plan['packed'], plan['wino'] = {}, {}
+        plan['packed'], plan['wino'], plan['pair'] = {}, {}, {}
+        if self.conv1.weight.is_cuda and self.fuse_pairs:
+            # block i's last 1x1 (+ downsample branch) and block i+1's first 1x1 as one launch where the kernel is built for the shapes
+            # (layer1 and layer2 of ResNet-50: the 256 / 512-channel tensor between them is what bounds both layers)
+            blocks = plan['blocks']
+            for i in range(len(blocks) - 1):
+                stages, ds, dual = blocks[i]
+                w3, b3, s3, _ = stages[-1]
+                w1, b1, s1, _ = blocks[i + 1][0][0]
+                if len(stages) != 3 or w3.shape[2] != 1 or w1.shape[2] != 1 or s3[0] != 1 or s1[0] != 1 or (ds is not None and dual is None):
+                    continue
+                wk = dual[0] if dual is not None else w3.reshape(w3.shape[0], -1)
+                C, Kt, N2 = wk.shape[0], wk.shape[1], w1.shape[0]
+                if Kt not in (64, 128) or C % 64 or N2 not in (64, 128) or C > 512 or (dual is not None and dual[2] != 1):
+                    continue
+                plan['pair'][i] = self._pack_pair(wk, w1.reshape(N2, C)) + (N2,)
         if self.conv1.weight.is_cuda:
             for stages, ds, dual in plan['blocks']:
                 for w, b, s, p in stages:
@@ -197,6 +213,31 @@ class ResNetEncoder(nn.Module):
         packed = torch.empty(int(lib.hmf_conv_patch_packed_floats(cin, cout, ks)), dtype=torch.float32)
         _lib.check(lib.hmf_conv_patch_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout, ks, cfg), 'hmf_conv_patch_pack_host')
         return packed.to(w.device)
+
+    def _pack_pair(self, w3, w1):
+        from . import _lib
+        lib = _lib.load()
+        dev = w3.device
+        w3, w1 = w3.detach().cpu().contiguous(), w1.detach().cpu().contiguous()
+        p3, p1 = torch.empty_like(w3), torch.empty_like(w1)
+        _lib.check(lib.hmf_conv_pair_pack_host(w3.data_ptr(), w1.data_ptr(), p3.data_ptr(), p1.data_ptr(), w3.shape[1], w3.shape[0], w1.shape[0]),
+                   'hmf_conv_pair_pack_host')
+        return p3.to(dev), p1.to(dev)
+
+    def _conv_pair(self, h, x2, residual, pk, bias3, bias1):
+        """(y, z): y = relu([h | x2] . W3 + bias3 (+ residual)), z = relu(y . W1 + bias1) in one launch (csrc/conv_pair.hip)."""
+        from . import _lib
+        lib = _lib.load()
+        B, K1, OH, OW = h.shape
+        p3, p1, N2 = pk
+        C = p1.numel() // N2
+        y = torch.empty((B, C, OH, OW), device=h.device, dtype=torch.float32, memory_format=torch.channels_last)
+        z = torch.empty((B, N2, OH, OW), device=h.device, dtype=torch.float32, memory_format=torch.channels_last)
+        K2, H2, W2 = (x2.shape[1], x2.shape[2], x2.shape[3]) if x2 is not None else (0, 0, 0)
+        _lib.check(lib.hmf_conv_pair(h.data_ptr(), None if x2 is None else x2.data_ptr(), p3.data_ptr(), bias3.data_ptr(),
+                                     None if residual is None else residual.data_ptr(), y.data_ptr(), p1.data_ptr(), bias1.data_ptr(), z.data_ptr(),
+                                     B, OH, OW, K1, H2, W2, K2, 1, C, N2, 0, _lib.current_stream()), 'hmf_conv_pair')
+        return y, z
 
     def _conv_dual(self, h, x, wcat, bias, stride):
         """relu(conv1x1(h) + conv1x1(x, stride) + bias) in one launch (bias = both folded-BN shifts)."""
@@ -271,18 +312,22 @@ class ResNetEncoder(nn.Module):
         p = self._plan
         with torch.cuda.device(x.device):
             x = self._stem_hip(x.float().contiguous(), p['stem_packed'], p['stem'][1])
-            for stages, ds, dual in p['blocks']:
-                if dual is not None:
-                    h = x
-                    for w, b, s, pad in stages[:-1]:
-                        h = self._conv_hip(h, w, b, s[0], None, True)
+            pre = None                                   # the block's first 1x1 stage, when the previous seam launch already produced it
+            for i, (stages, ds, dual) in enumerate(p['blocks']):
+                h = x if pre is None else pre
+                for w, b, s, pad in stages[(0 if pre is None else 1):-1]:
+                    h = self._conv_hip(h, w, b, s[0], None, True)
+                pre = None
+                pk = p['pair'].get(i)
+                if pk is not None and (h.shape[0] * h.shape[2] * h.shape[3]) % 64 == 0:
+                    nb1 = p['blocks'][i + 1][0][0][1]
+                    x, pre = self._conv_pair(h, x if dual is not None else None, None if dual is not None else x, pk, stages[-1][1], nb1)
+                elif dual is not None:
                     x = self._conv_dual(h, x, dual[0], dual[1], dual[2])
-                    continue
-                idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
-                for w, b, s, pad in stages[:-1]:
-                    x = self._conv_hip(x, w, b, s[0], None, True)
-                w, b, s, pad = stages[-1]
-                x = self._conv_hip(x, w, b, s[0], idt, True)
+                else:
+                    idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
+                    w, b, s, pad = stages[-1]
+                    x = self._conv_hip(h, w, b, s[0], idt, True)
             return x.mean(dim=(2, 3))
 
     _warned_autograd = False

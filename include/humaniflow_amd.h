@@ -257,6 +257,18 @@ int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const flo
 int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const float* bias, float* y, int B, int OH, int OW, int Cin,
                           int H2, int W2, int Cin2, int stride2, int Cout, int relu, void* stream);
 
+/* The seam between two bottlenecks (models/resnet.py:102-127: block i's conv3 + bn3 (+ downsample branch) + identity + ReLU, then block
+ * i+1's conv1 + bn1 + ReLU) as ONE launch: y = relu([x1 | x2(strided)] . W3^T + bias3 (+ residual)) is written (the next identity branch) and
+ * its 64-channel chunks feed z = relu(y . W1^T + bias1) through LDS, so the C-channel tensor y is not read back from HBM.
+ * x1 (B,OH,OW,K1); x2 (B,H2,W2,K2) or NULL (then K2 is ignored); K1 + K2 in {64, 128}; y/residual (B,OH,OW,C), C % 64 == 0; z (B,OH,OW,N2),
+ * N2 in {64, 128}; B*OH*OW % 64 == 0.  Filters packed by hmf_conv_pair_pack_host (w3 (C, K1+K2) and w1 (N2, C) row-major, BN folded) into
+ * C*(K1+K2) and N2*C floats of MFMA lane order.  variant: 0 (others are timing experiments of tools/pair_probe.py that compute wrong results).
+ * Profiler tag 8. */
+int hmf_conv_pair_pack_host(const float* w3, const float* w1, float* w3_packed, float* w1_packed, int Kt, int C, int N2);
+int hmf_conv_pair(const float* x1, const float* x2, const float* w3_packed, const float* bias3, const float* residual, float* y,
+                  const float* w1_packed, const float* bias1, float* z, int B, int OH, int OW, int K1, int H2, int W2, int K2, int stride2,
+                  int C, int N2, int variant, void* stream);
+
 /* Patch-resident direct 3x3 convolution (stride 1 or 2; the encoder uses it where the Winograd kernel does not apply): the input patch of a
  * pixel tile lives in LDS for a whole slab of 64 input channels and the weights stream from L2 in MFMA lane order (no barrier inside a slab).
  * w_packed = hmf_conv_patch_pack_host(w (Cout,3,3,Cin) channels_last, ..., cfg) uploaded to the device (hmf_conv_patch_packed_floats floats).
@@ -275,6 +287,12 @@ long long hmf_conv_winograd_packed_floats(int Cin, int Cout);
 int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout);
 int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                       int Cin, int Cout, int relu, void* stream);
+
+/* Timing experiments on the same kernel (tools/winograd_ablate.py): variant 0 = hmf_conv_winograd; 10 = three waves per SIMD; 20 = the input
+ * transform of k-group g+1 issued with the MFMAs of group g; 1 / 2 / 3 / 13 drop the patch fetch and / or the output transform and compute
+ * WRONG results.  Not used by the product path. */
+int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                              int Cin, int Cout, int relu, int variant, void* stream);
 
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
  * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.

@@ -1,0 +1,43 @@
+"""Timing experiments on k_conv_winograd over the ResNet-50 stride-1 3x3 shapes (variants other than 0 may compute wrong results):
+where does a launch spend its time -- patch fetch, output transform, or the LDS + transform + MFMA loop?
+    python tools/winograd_ablate.py [B]"""
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from humaniflow_amd import _lib
+lib = _lib.load()
+dev = 'cuda:0'
+
+
+def timeit(fn, iters=100):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+VARIANTS = ((0, 'product'), (10, '3 waves/SIMD'), (20, 'pipelined transform'), (1, 'no-fetch'), (2, 'no-epilogue'), (3, 'bare loop'), (13, 'bare 3 waves/SIMD'))
+for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256), ('layer4', 8, 512)):
+    x = torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(c, 3, 3, c) / (3 * c ** 0.5)).contiguous()
+    packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(c, c)), dtype=torch.float32)
+    _lib.check(lib.hmf_conv_winograd_pack_host(w.data_ptr(), packed.data_ptr(), c, c), 'pack')
+    wk = packed.to(dev)
+    bias = torch.randn(c, device=dev)
+    y = torch.empty(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    st = _lib.current_stream()
+    fl = 2.0 * B * hw * hw * c * c * 9
+    line = '%-6s %5.2f GF direct (%.2f executed)' % (name, fl / 1e9, fl / 1e9 * 4 / 9)
+    for var, lab in VARIANTS:
+        fn = lambda: _lib.check(lib.hmf_conv_winograd_variant(x.data_ptr(), wk.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, hw, hw, c, c, 1, var, st), 'wino')
+        t = timeit(fn)
+        line += ' | %s %5.1f us' % (lab, t)
+    print(line, flush=True)
