@@ -33,10 +33,8 @@ struct ConvArgs {
     // 1x1 convolution and its downsample branch (models/resnet.py:111-127) as ONE GEMM, so the identity tensor is never written or re-read
     const float* x2;     // [B][H2][W2][Cin2]
     int H2, W2, Cin2, stride2;
-    int y_nt;            // output larger than the L2s: non-temporal stores (they would only evict operands that are still needed)
 };
 
-constexpr long long kNtBytes = 48LL << 20;   // outputs from this size on are stored non-temporal (8 x 4 MB of L2 on the device)
 constexpr int kConvKC = 32;             // channels per k-chunk
 constexpr int kConvS = kConvKC + 4;     // LDS row stride in floats
 
@@ -235,11 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] + bv + rv[i][r];
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (full || m < a.M) {
-                    float* p = a.y + (long long)m * a.Cout + n;
-                    if (a.y_nt) __builtin_nontemporal_store(v, p);
-                    else *p = v;
-                }
+                if (full || m < a.M) a.y[(long long)m * a.Cout + n] = v;     // (non-temporal stores measured: no gain here, and the training graph re-reads y at once)
             }
         }
     }
@@ -282,7 +276,6 @@ extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias
     if (M * (long long)Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29))
         return fail(HMF_ERR_UNSUPPORTED, "hmf_conv2d_nhwc: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
     a.M = (int)M;
-    a.y_nt = (M * Cout * 4 >= kNtBytes) ? 1 : 0;
     if (tile == 0) {
         // measured on MI355X (tools/conv_probe.py, B=32): the 64x64 tile (36 KB LDS -> 4 work-groups = 16 waves per CU) wins or ties on
         // every ResNet layer; 64x128 is ahead by 2-3 % on the 3x3 layers with Cout >= 128 and many rows.
@@ -324,7 +317,6 @@ extern "C" int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const floa
     a.x = x; a.w = w; a.bias = bias; a.res = nullptr; a.y = y;
     a.B = B; a.H = OH; a.W = OW; a.Cin = Cin; a.Cout = Cout; a.stride = 1; a.pad = 0; a.relu = relu; a.OH = OH; a.OW = OW; a.M = (int)M;
     a.x2 = x2; a.H2 = H2; a.W2 = W2; a.Cin2 = Cin2; a.stride2 = stride2;
-    a.y_nt = (M * Cout * 4 >= kNtBytes) ? 1 : 0;
     launch_conv<64, 64, 1, true>(a, (hipStream_t)stream);
     HMF_LAUNCH_CHECK();
     return HMF_OK;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     // weight stream of this wave: [n-tile][wave xi][slab][g][nu][lane][4]
     const f32x4* pw[TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((long long)((nt * TN + t) * 4 + wave) * nslab * kWNG * 4) * 64 + lane;
+    for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((MODE & 8) ? 0LL : (long long)((nt * TN + t) * 4 + wave) * nslab * kWNG * 4) * 64 + lane;   // MODE & 8: every wave streams the SAME weights (L1 hits)
 
     // row transform of this wave: t[b] = s1 * d[a1][b] + s2 * d[a2][b]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
     const int a1 = wave == 0 ? 0 : 1, a2 = wave == 3 ? 3 : 2;
@@ -163,8 +163,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         for (int t = 0; t < TN; ++t) pw[t] += kWNG * 4 * 64;
     }
 
-    // ---- output transform: exchange the 16 position accumulators through LDS, 16 tiles at a time ----
-    // M[pos][tile16][ch32]: pos = 4 * wave + nu; accumulator register r of lane (j = li, q) holds tile (r & 3) + 8 (r >> 2) + 4 q, channel j
+    // ---- output transform Y = A^T M A.  The nu direction is applied in registers (a wave owns all four nu of its row xi): per (tile, channel) the
+    // wave keeps P[xi][dx] = (m0 + m1 + m2, m1 - m2 - m3); the 4 x 2 values are exchanged through LDS in one pass (32 KB, the patch buffer) and every
+    // thread finishes (tile, channel) pairs along xi.  (Round 1 exchanged all 16 positions in two half passes: twice the LDS traffic and barriers;
+    // the output transform was 5-20 us of a 50-65 us launch, tools/winograd_ablate.py.)
+    // accumulator register r of lane (j = li, q) holds tile (r & 3) + 8 (r >> 2) + 4 q, channel j
     const int ch = tid & 31;
     if (MODE & 2) {
         if (acc[0][0][0] + acc[0][1][1] + acc[0][2][2] + acc[0][3][3] == 12345.678f) a.y[tid] = 1.f;      // keep the accumulators alive
@@ -174,48 +177,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     for (int t = 0; t < TN; ++t) {
         const int n_out = (nt * TN + t) * 32 + ch;
         const float bv = a.bias ? a.bias[n_out] : 0.f;
+        __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            __syncthreads();
+        for (int r = 0; r < 16; ++r) {
+            const int tile = (r & 3) + 8 * (r >> 2) + 4 * lq;
+            const float m0 = acc[t][0][r], m1 = acc[t][1][r], m2 = acc[t][2][r], m3 = acc[t][3][r];
+            lds[((wave * 2 + 0) * 32 + tile) * 32 + li] = m0 + m1 + m2;
+            lds[((wave * 2 + 1) * 32 + tile) * 32 + li] = m1 - m2 - m3;
+        }
+        __syncthreads();
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+        for (int k = 0; k < 4; ++k) {
+            const int tile = (tid >> 5) + 8 * k;
+            float pm[4][2];
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = 8 * h + rr;                                  // registers with (r >> 2) in {2h, 2h+1}: tiles 16h .. 16h+15
-                    const int tl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lq;      // tile within the half
-                    lds[((4 * wave + n) * 16 + tl) * 32 + li] = acc[t][n][r];
-                }
-            __syncthreads();
+            for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int tl = (tid >> 5) + 8 * k, tile = 16 * h + tl;
-                float m[4][4];
+                for (int dx = 0; dx < 2; ++dx) pm[xi][dx] = lds[((xi * 2 + dx) * 32 + tile) * 32 + ch];
+            const float yv[2][2] = {{pm[0][0] + pm[1][0] + pm[2][0], pm[0][1] + pm[1][1] + pm[2][1]},
+                                    {pm[1][0] - pm[2][0] - pm[3][0], pm[1][1] - pm[2][1] - pm[3][1]}};
+            const int oh = oh0 + 2 * (tile >> 3), ow = NIMG == 1 ? ow0 + 2 * (tile & 7) : 2 * (tile & 3);
+            const int bi = b + (NIMG == 1 ? 0 : (tile >> 2) & 1);
 #pragma unroll
-                for (int xi = 0; xi < 4; ++xi)
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int nu = 0; nu < 4; ++nu) m[xi][nu] = lds[((4 * xi + nu) * 16 + tl) * 32 + ch];
-                float s0[4], s1v[4];
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) {
-                    s0[nu] = m[0][nu] + m[1][nu] + m[2][nu];
-                    s1v[nu] = m[1][nu] - m[2][nu] - m[3][nu];
-                }
-                const float yv[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1v[0] + s1v[1] + s1v[2], s1v[1] - s1v[2] - s1v[3]}};
-                const int oh = oh0 + 2 * (tile >> 3), ow = NIMG == 1 ? ow0 + 2 * (tile & 7) : 2 * (tile & 3);
-                const int bi = b + (NIMG == 1 ? 0 : (tile >> 2) & 1);
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        if (oh + dy < a.H && ow + dx < a.W && bi < a.B) {
-                            const long long o = (((long long)bi * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
-                            float v = yv[dy][dx] + bv;
-                            if (a.res) v += a.res[o];
-                            if (a.relu) v = fmaxf(v, 0.f);
-                            a.y[o] = v;
-                        }
+                for (int dx = 0; dx < 2; ++dx) {
+                    if (oh + dy < a.H && ow + dx < a.W && bi < a.B) {
+                        const long long o = (((long long)bi * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
+                        float v = yv[dy][dx] + bv;
+                        if (a.res) v += a.res[o];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (!(MODE & 4) || v == 12345.678f) a.y[o] = v;
                     }
-            }
+                }
         }
     }
 }
@@ -282,6 +276,9 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
         case 10: HMF_WINO_LAUNCH(0, 0, 3); break;
         case 13: HMF_WINO_LAUNCH(3, 0, 3); break;
         case 20: HMF_WINO_LAUNCH(0, 1, 2); break;
+        case 4: HMF_WINO_LAUNCH(4, 0, 2); break;
+        case 8: HMF_WINO_LAUNCH(8, 0, 2); break;
+        case 11: HMF_WINO_LAUNCH(11, 0, 2); break;
         default: return fail(HMF_ERR_INVALID, "hmf_conv_winograd_variant: unknown variant %d", variant);
     }
 #undef HMF_WINO_LAUNCH

@@ -29,7 +29,7 @@ constexpr int kStemGroups = (kStemSteps + 3) / 4;                         // 111
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_conv(
     const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
-    int OH, int OW, int tiles_w, int tiles_hw, int relu, int nt) {
+    int OH, int OW, int tiles_w, int tiles_hw, int relu) {
     __shared__ float patch[kStemC * kStemPlane + 8];            // 60.5 KB: two work-groups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
@@ -113,12 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * lq;
             const int oh = oh0 + 2 * wave + (i >> 4), ow = ow0 + (i & 15);
-            if (oh < OH && ow < OW) {
-                float* p = y + (((long long)b * OH + oh) * OW + ow) * kStemN + n;
-                const float v = relu ? fmaxf(acc[t][r] + bv, 0.f) : acc[t][r] + bv;
-                if (nt) __builtin_nontemporal_store(v, p);          // a map larger than the L2s (134 MB at B = 32): do not let it evict the filters
-                else *p = v;
-            }
+            if (oh < OH && ow < OW) y[(((long long)b * OH + oh) * OW + ow) * kStemN + n] = relu ? fmaxf(acc[t][r] + bv, 0.f) : acc[t][r] + bv;
         }
     }
 }
@@ -183,8 +178,7 @@ extern "C" int hmf_stem_conv(const float* x, const float* w_packed, const float*
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(9, B, st);
-    hipLaunchKernelGGL(k_stem_conv, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw, relu,
-                       ((long long)B * OH * OW * kStemN * 4 >= (48LL << 20)) ? 1 : 0);
+    hipLaunchKernelGGL(k_stem_conv, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw, relu);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -24,7 +24,7 @@ def timeit(fn, iters=100):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-VARIANTS = ((0, 'product'), (10, '3 waves/SIMD'), (20, 'pipelined transform'), (1, 'no-fetch'), (2, 'no-epilogue'), (3, 'bare loop'), (13, 'bare 3 waves/SIMD'))
+VARIANTS = ((0, 'product'), (10, '3 waves/SIMD'), (20, 'pipelined transform'), (1, 'no-fetch'), (4, 'no-stores'), (8, 'one weight stream for all waves'), (11, 'bare + one weight stream'), (2, 'no-epilogue'), (3, 'bare loop'), (13, 'bare 3 waves/SIMD'))
 for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256), ('layer4', 8, 512)):
     x = torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(c, 3, 3, c) / (3 * c ** 0.5)).contiguous()
