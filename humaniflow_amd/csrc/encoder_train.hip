@@ -314,6 +314,254 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// weight gradient of a 3x3 layer, all nine taps resident (round 2).  The kernel above streams gy and x once per 64 x 64 tile of dw: a 3x3
+// layer re-reads both tensors 9 x Cin/64 times (16 flop per byte: it ran at 45-59 TFLOP/s, memory-bound).  Here a work-group owns
+// 64 output channels x (9 taps x 32 input channels) of dw and walks chunks of <= 64 output pixels (whole rows of one image): the chunk of gy
+// [64 px][64 co] and the input patch [(rows-1) s + 3][(OW-1) s + 3][32 ci] are copied to LDS once and serve all nine taps (87 flop per byte).
+// Wave (h, tg) owns output-channel half h and taps {0..4} or {5..8} (alternating per work-group so the SIMDs balance): 5 (4) accumulator
+// tiles, per k-step (2 pixels) one A operand (gy) and one B operand per tap, ds_read_b32 with lane = channel (conflict-free).  No
+// cross-wave reduction; one atomic pass per work-group (pixel slices).
+// ---------------------------------------------------------------------------------------------------
+struct Wgrad3Args {
+    const float* gy;      // [B][OH][OW][Cout]
+    const float* x;       // [B][H][W][Cin]
+    float* dw;            // [Cout][3][3][Cin], zeroed
+    int B, H, W, Cin, OH, OW, Cout, rows, chunks_per_img, nchunks, chunks_per_slice, ci_tiles;
+};
+
+template <int ST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ST == 1 ? 3 : 2))) void k_conv_wgrad3(const Wgrad3Args a) {
+    constexpr int kMaxPatch = ST == 1 ? 200 : 328;           // patch pixels: 3 x 66 (one 64-pixel row), 5 x 65 (two 32-pixel rows, stride 2)
+    constexpr int NX = (kMaxPatch * 8 + 255) / 256;
+    __shared__ float gyP[64 * 64];
+    __shared__ float xP[kMaxPatch * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lq = lane >> 5;
+    const int h = wave & 1, tg = ((wave >> 1) ^ (int)(blockIdx.x + blockIdx.y)) & 1;
+    const int tap0 = tg ? 5 : 0, ntap = tg ? 4 : 5;
+    const int ct = blockIdx.x / a.ci_tiles, it = blockIdx.x - ct * a.ci_tiles;
+    const int co0 = ct * 64, ci0 = it * 32;
+    const int PH = (a.rows - 1) * ST + 3, PW = (a.OW - 1) * ST + 3, NP = PH * PW;
+    const int P = a.rows * a.OW, nsteps = (P + 1) / 2;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.H * a.W * a.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, 0, a.B * a.OH * a.OW * a.Cout * 4, 0x00020000);
+    constexpr int kOOB = (int)0x80000000;
+    // patch element e = tid + 256 i: pixel (pa, pb) of the patch, 16-byte channel group e & 7 (chunk-invariant: decoded once)
+    int pab[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int pix = (tid + 256 * i) >> 3;
+        const int pa = pix / PW;
+        pab[i] = pix < NP ? (pa << 16) | (pix - pa * PW) : -1;
+    }
+    f32x4 pg[4], px[NX];
+    auto fetch = [&](int chunk) {
+        const int b = chunk / a.chunks_per_img, oh0 = (chunk - b * a.chunks_per_img) * a.rows;
+        const int pvalid = min(a.rows, a.OH - oh0) * a.OW;
+        const int m0 = (b * a.OH + oh0) * a.OW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, p = e >> 4, c4 = e & 15;
+            pg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, p < pvalid ? ((m0 + p) * a.Cout + co0 + 4 * c4) * 4 : kOOB, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int ih = oh0 * ST - 1 + (pab[i] >> 16), iw = (pab[i] & 0xffff) - 1;
+            const bool ok = (pab[i] >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            px[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (((b * a.H + ih) * a.W + iw) * a.Cin + ci0 + 4 * ((tid + 256 * i) & 7)) * 4 : kOOB, 0, 0));
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)&gyP[(tid + 256 * i) * 4] = pg[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (pab[i] >= 0) *(f32x4*)&xP[(tid + 256 * i) * 4] = px[i];
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int toff[5];                                             // float offset of the wave's taps inside the patch
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int tap = min(tap0 + t, 8);
+        toff[t] = ((tap / 3) * PW + (tap % 3)) * 32;
+    }
+    const float* ga = gyP + lq * 64 + 32 * h + li;
+
+    const int c_begin = blockIdx.y * a.chunks_per_slice, c_end = min(c_begin + a.chunks_per_slice, a.nchunks);
+    if (c_begin < c_end) fetch(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        if (c > c_begin) __syncthreads();                    // the previous chunk's operands have been read
+        stash();
+        __syncthreads();
+        if (c + 1 < c_end) fetch(c + 1);
+        int pr = 0, pc = lq;                                 // this lane's pixel of the k-step: (row, column) inside the chunk
+        float fa = ga[0], fb[5];
+        {
+            const float* xb = xP + (pr * ST * PW + pc * ST) * 32 + li;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) fb[t] = xb[toff[t]];
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            pc += 2;
+            if (pc >= a.OW) { pc -= a.OW; ++pr; }
+            const int sn = min(s + 1, nsteps - 1);
+            const bool live = 2 * (s + 1) + lq < P;          // a pixel beyond the chunk has a zero gy row: point it at patch pixel (0, 0), never at unwritten LDS
+            const int prn = live ? pr : 0, pcn = live ? pc : 0;
+            const float fan = ga[sn * 128];
+            float fbn[5];
+            const float* xb = xP + (prn * ST * PW + pcn * ST) * 32 + li;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) fbn[t] = xb[toff[t]];
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < ntap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[t], acc[t], 0, 0, 0);
+            fa = fan;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) fb[t] = fbn[t];
+        }
+    }
+    // ---- one atomic pass: dw[co][tap][ci0 + li] (128-byte runs) ----
+    const int K = 9 * a.Cin;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        if (t < ntap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                atomicAdd(a.dw + (size_t)co * K + (tap0 + t) * a.Cin + ci0 + li, acc[t][r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight gradient of the 7x7/2 stem (NCHW input, dw in torch's native (co, ci, kh, kw) order; 133 GFLOP at B = 72, the largest single kernel
+// of the training step).  The generic kernel gathers x per lane from global memory (a wave-level load touches ~18 short runs: texture-address
+// bound, 46 TFLOP/s).  Here a work-group owns 64 output channels x 224 consecutive k = (ci, kh, kw) (7 MFMA tiles: 28 tiles = 896 >= 882 in
+// total, 4 k-blocks) and walks chunks of <= 64 output pixels of one output row: gy [64 px][64 co] and the <= 6 input channels x 7 rows x 133
+// columns the chunk touches are copied to LDS with coalesced loads; the B operand of lane k is patch[koff(k) + 2 p] -- with a row pitch of
+// 7 (mod 32) floats and a channel pitch of 17 (mod 32) the bank of lane k is k mod 32: conflict-free.  Wave (h, kg): channel half h, 4 or 3 k-tiles.
+// ---------------------------------------------------------------------------------------------------
+struct StemWgradArgs {
+    const float* gy;      // [B][OH][OW][64]
+    const float* x;       // [B][Cin][H][W]
+    float* dw;            // [64][Cin * 49], zeroed
+    int B, Cin, H, W, OH, OW, K, segs_per_row, nchunks, chunks_per_slice;
+};
+
+constexpr int kSwRP = 135, kSwCP = 7 * kSwRP, kSwCols = 133, kSwCh = 6;      // 135 = 7 (mod 32), 945 = 17 (mod 32)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_wgrad(const StemWgradArgs a) {
+    constexpr int NE = kSwCh * 7 * kSwCols, NX = (NE + 255) / 256;          // 5586 patch floats, 22 per thread
+    __shared__ float gyP[64 * 64];
+    __shared__ float xP[kSwCh * kSwCP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lq = lane >> 5;
+    const int h = wave & 1, kg = ((wave >> 1) ^ (int)blockIdx.y) & 1;
+    const int kb = blockIdx.x, t0 = kg ? 4 : 0, nt = kg ? 3 : 4;
+    const int ci_base = (224 * kb) / 49;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.Cin * a.H * a.W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, 0, a.B * a.OH * a.OW * 64 * 4, 0x00020000);
+    constexpr int kOOB = (int)0x80000000;
+    int koff[4];
+    bool kval[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = 224 * kb + 32 * (t0 + t) + li;
+        kval[t] = (t < nt) & (k < a.K);
+        const int kc = kval[t] ? k : 224 * kb;
+        const int ci = kc / 49, r = kc - ci * 49, kh = r / 7, kw = r - kh * 7;
+        koff[t] = (ci - ci_base) * kSwCP + kh * kSwRP + kw + 2 * lq;
+    }
+    // Patch walk: the 42 (channel, row) lines of 133 floats.  Waves 0-1 take the even lines, waves 2-3 the odd ones, lane = column 0..127 (coalesced
+    // 256-byte runs; the line index is wave-uniform: scalar address arithmetic); the last 5 columns of all lines are one extra load of threads 0..209.
+    static_assert(NX == 22 && kSwCols == 133, "patch walk");
+    const int half = wave >> 1, colA = tid & 127;
+    const int tl = tid / 5, tc = 128 + (tid - tl * 5), tlc = tl / 7, tlr = tl - tlc * 7;       // tail element: line tl (< 42), column tc
+    f32x4 pg[4];
+    float px[NX];
+    auto fetch = [&](int chunk) {
+        const int seg = chunk % a.segs_per_row, row = chunk / a.segs_per_row;          // row = b * OH + oh
+        const int b = row / a.OH, oh = row - b * a.OH, ow0 = seg * 64;
+        const int pvalid = min(64, a.OW - ow0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, p = e >> 4, c4 = e & 15;
+            pg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, p < pvalid ? ((row * a.OW + ow0 + p) * 64 + 4 * c4) * 4 : kOOB, 0, 0));
+        }
+        const int iwA = 2 * ow0 - 3 + colA;
+        const int vA = (unsigned)iwA < (unsigned)a.W ? iwA * 4 : kOOB;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const int line = 2 * i + half, c = line / 7, r = line - c * 7;              // wave-uniform
+            const int ci = ci_base + c, ih = 2 * oh - 3 + r;
+            const bool ok = (ci < a.Cin) & ((unsigned)ih < (unsigned)a.H);
+            px[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (ok && vA != kOOB) ? vA + (((b * a.Cin + ci) * a.H + ih) * a.W) * 4 : kOOB, 0, 0));
+        }
+        {
+            const int ci = ci_base + tlc, ih = 2 * oh - 3 + tlr, iw = 2 * ow0 - 3 + tc;
+            const bool ok = (tid < 210) & (ci < a.Cin) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            px[21] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (((b * a.Cin + ci) * a.H + ih) * a.W + iw) * 4 : kOOB, 0, 0));
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)&gyP[(tid + 256 * i) * 4] = pg[i];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const int line = 2 * i + half, c = line / 7, r = line - c * 7;
+            xP[c * kSwCP + r * kSwRP + colA] = px[i];
+        }
+        if (tid < 210) xP[tlc * kSwCP + tlr * kSwRP + tc] = px[21];
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* ga = gyP + lq * 64 + 32 * h + li;
+    const int nsteps = (min(64, a.OW) + 1) / 2;
+    const int c_begin = blockIdx.y * a.chunks_per_slice, c_end = min(c_begin + a.chunks_per_slice, a.nchunks);
+    if (c_begin < c_end) fetch(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        if (c > c_begin) __syncthreads();
+        stash();
+        __syncthreads();
+        if (c + 1 < c_end) fetch(c + 1);
+        float fa = ga[0], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb[t] = xP[koff[t]];
+        for (int s = 0; s < nsteps; ++s) {
+            const int sn = min(s + 1, nsteps - 1);
+            const float fan = ga[sn * 128];
+            float fbn[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fbn[t] = xP[koff[t] + 4 * sn];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[t], acc[t], 0, 0, 0);
+            fa = fan;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[t] = fbn[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (kval[t]) {
+            const int k = 224 * kb + 32 * (t0 + t) + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * h + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                atomicAdd(a.dw + (size_t)co * a.K + k, acc[t][r]);
+            }
+        }
+    }
+}
+
 }  // namespace hmf
 
 using namespace hmf;
@@ -395,6 +643,42 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
     const long long M = (long long)B * a.OH * a.OW;
     if (M * Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad: tensor exceeds 2^29 elements");
     a.M = (int)M;
+    hipStream_t st = (hipStream_t)stream;
+    if (stem_nchw && ks == 7 && stride == 2 && Cout == 64 && (a.OW % 2) == 0) {
+        StemWgradArgs w;
+        w.gy = gy; w.x = x; w.dw = dw; w.B = B; w.Cin = Cin; w.H = H; w.W = W; w.OH = a.OH; w.OW = a.OW; w.K = Cin * 49;
+        w.segs_per_row = (a.OW + 63) / 64;
+        w.nchunks = B * a.OH * w.segs_per_row;
+        const int kblocks = (w.K + 223) / 224;
+        int slices = std::max(1, std::min(w.nchunks, (256 * 3 + kblocks - 1) / kblocks));
+        w.chunks_per_slice = (w.nchunks + slices - 1) / slices;
+        slices = (w.nchunks + w.chunks_per_slice - 1) / w.chunks_per_slice;
+        HMF_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * w.K * sizeof(float), st));
+        hipLaunchKernelGGL(k_stem_wgrad, dim3(kblocks, slices), dim3(256), 0, st, w);
+        HMF_LAUNCH_CHECK();
+        return HMF_OK;
+    }
+    if (!stem_nchw && ks == 3 && Cout % 64 == 0 && a.OW >= 2 && a.OW <= 64) {
+        // all nine taps resident: chunks of whole output rows, <= 64 pixels
+        Wgrad3Args w;
+        w.gy = gy; w.x = x; w.dw = dw; w.B = B; w.H = H; w.W = W; w.Cin = Cin; w.OH = a.OH; w.OW = a.OW; w.Cout = Cout;
+        w.rows = std::max(1, std::min(64 / a.OW, a.OH));
+        const int PH = (w.rows - 1) * stride + 3, PW = (a.OW - 1) * stride + 3;
+        if (PH * PW <= (stride == 1 ? 200 : 328)) {
+            w.chunks_per_img = (a.OH + w.rows - 1) / w.rows;
+            w.nchunks = B * w.chunks_per_img;
+            w.ci_tiles = Cin / 32;
+            const int tiles = (Cout / 64) * w.ci_tiles;
+            int slices = std::max(1, std::min(w.nchunks, (256 * 3 + tiles - 1) / tiles));
+            w.chunks_per_slice = (w.nchunks + slices - 1) / slices;
+            slices = (w.nchunks + w.chunks_per_slice - 1) / w.chunks_per_slice;
+            HMF_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * 9 * Cin * sizeof(float), st));
+            if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad3<1>, dim3(tiles, slices), dim3(256), 0, st, w);
+            else hipLaunchKernelGGL(k_conv_wgrad3<2>, dim3(tiles, slices), dim3(256), 0, st, w);
+            HMF_LAUNCH_CHECK();
+            return HMF_OK;
+        }
+    }
     a.K = ks * ks * Cin;
     a.ktiles = (a.K + 63) / 64;
     const int tiles = a.ktiles * ((Cout + 63) / 64);
@@ -402,7 +686,6 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
     int slices = std::max(1, std::min((int)((M + 255) / 256), (256 * 6 + tiles - 1) / tiles));
     a.rows_per_slice = (int)(((M + slices - 1) / slices + 31) / 32 * 32);
     slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
-    hipStream_t st = (hipStream_t)stream;
     HMF_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * a.K * sizeof(float), st));
     if (stem_nchw) hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(tiles, slices), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(tiles, slices), dim3(256), 0, st, a);

@@ -45,7 +45,8 @@ def test_batchnorm_training_kernels_match_torch():
 
 
 @pytest.mark.parametrize('cin,cout,ks,stride,hw', [(64, 64, 3, 1, 16), (64, 128, 3, 2, 16), (256, 64, 1, 1, 8), (64, 256, 1, 1, 12), (256, 512, 1, 2, 8),
-                                                    (128, 128, 3, 1, 6), (512, 2048, 1, 1, 4)])
+                                                    (128, 128, 3, 1, 6), (512, 2048, 1, 1, 4), (64, 64, 3, 1, 64), (64, 128, 3, 2, 64), (128, 64, 3, 1, 7),
+                                                    (64, 64, 3, 2, 13), (64, 192, 3, 1, 32), (64, 64, 3, 1, 66)])
 def test_conv_weight_and_input_gradients_match_torch(cin, cout, ks, stride, hw):
     torch.manual_seed(cin + cout + ks)
     B = 5
@@ -68,6 +69,23 @@ def test_conv_weight_and_input_gradients_match_torch(cin, cout, ks, stride, hw):
     assert _rel(dw, cr.weight.grad) < 5e-5, _rel(dw, cr.weight.grad)
     assert _rel(dx, xr.grad) < 5e-5
     assert _rel(dx_res - res, xr.grad) < 5e-5
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 256, 256), (2, 160, 200), (1, 32, 36)])
+def test_stem_weight_gradient_row_segments(B, H, W):
+    """Stem weight gradient on maps wider than one 64-pixel chunk (two full segments per row; a full + a partial one; a single short one)."""
+    torch.manual_seed(H + W)
+    x = torch.randn(B, 18, H, W, device='cuda')
+    conv = torch.nn.Conv2d(18, 64, 7, 2, 3, bias=False).cuda()
+    cr = copy.deepcopy(conv).double()
+    yr = cr(x.double())
+    gy = torch.randn_like(yr).float().contiguous(memory_format=CL)
+    yr.backward(gy.double())
+    s = et._Saved()
+    s.conv, s.x, s.stride, s.stem = conv, x, 2, True
+    with torch.no_grad():
+        dw = et._wgrad(gy, s)
+    assert _rel(dw, cr.weight.grad) < 5e-5, _rel(dw, cr.weight.grad)
 
 
 def test_stem_weight_gradient_and_maxpool_backward_match_torch():
