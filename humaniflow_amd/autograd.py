@@ -4,6 +4,7 @@ What the reference differentiates in train/train_humaniflow.py:248-330 and where
 
   teacher-forced pose NLL   conditioned_pose_SO3flow_dists_for_loglik[j].log_prob(R_j)     FlowLogProbSO3   (k_flow_logprob_bwd)
   teacher-forced contexts   compute_flow_context on the target rotations                     FlowContext      (dense reductions)
+  (all flow parameters enter the graph once, through FlowParamAnchor: one gradient per tensor per pass)
   reparameterised samples   pose_SO3_samples, ancestors feeding descendants (:302-311)       FlowSampleChain  (k_flow_chain_bwd, 8 rounds reversed)
   2D reprojection           SMPL joints of the samples / point estimate                      SmplJoints       (k_smpl_joints_bwd)
   6D -> R of the global rotation                                                              Rot6dToRotmat
@@ -61,17 +62,6 @@ def _hypernet_params(model, part0, P):
     return out
 
 
-def _hypernet_grad_list(rec, P, needs):
-    """Gradients in the order of _hypernet_params; `needs` = ctx.needs_input_grad slice for those tensors."""
-    grads = rec.hypernet_grads()
-    out = []
-    for p in range(P):
-        for c in range(2):
-            for l in range(4):
-                out += [grads[l][0][p, c], grads[l][1][p, c]]
-    return [g if n else None for g, n in zip(out, needs)]
-
-
 # ---- context layers: shared dense pull-back ---------------------------------------------------------------------------------
 def _anc_index(model, device):
     """Per part: column indices of its ancestors' flattened rotations inside a (rows, 23*9) rotation matrix block."""
@@ -83,19 +73,22 @@ def _anc_index(model, device):
     return cache[key]
 
 
-def _context_layer_grads(model, delta, isgc_rows, rot_rows):
+def _context_pullback(model, delta, isgc_rows, rot_rows):
     """delta (P, rows, 64) = d L / d (pre-activation of fc_flow_context[j]); isgc_rows (rows, 256); rot_rows (rows, 23, 9).
-    Returns ([dW_j (64, 256 + 9 a_j)], [db_j], g_isgc (rows, 256))."""
-    P = delta.shape[0]
+    Returns (g_full (P, 64, 256 + 207) = delta^T . [isgc | all rotations], db (P, 64), g_isgc (rows, 256)); the per-part weight gradient is a
+    column selection of g_full (`_context_weight_grads`), done once per backward pass in FlowParamAnchor."""
     x_full = torch.cat([isgc_rows, rot_rows.reshape(rot_rows.shape[0], -1)], dim=1)                       # (rows, 256 + 207)
     g_full = torch.matmul(delta.transpose(1, 2), x_full)                                                   # (P, 64, 463)
-    idx = _anc_index(model, delta.device)
     nin = isgc_rows.shape[1]
-    dW = [torch.cat([g_full[j, :, :nin], g_full[j].index_select(1, idx[j] + nin)], dim=1) for j in range(P)]
-    db = list(delta.sum(1))
     w0 = torch.stack([m.weight.detach()[:, :nin] for m in model.fc_flow_context])                           # (P, 64, 256)
     g_isgc = torch.einsum('pro,pok->rk', delta, w0)
-    return dW, db, g_isgc
+    return g_full, delta.sum(1), g_isgc
+
+
+def _context_weight_grads(model, g_full, nin=256):
+    """[dW_j (64, nin + 9 a_j)] from g_full (P, 64, nin + 207): the columns of part j's ancestors."""
+    idx = _anc_index(model, g_full.device)
+    return [torch.cat([g_full[j, :, :nin], g_full[j].index_select(1, idx[j] + nin)], dim=1) for j in range(g_full.shape[0])]
 
 
 def _ctx_params(model):
@@ -105,13 +98,71 @@ def _ctx_params(model):
     return out
 
 
+class FlowParamAnchor(torch.autograd.Function):
+    """One gradient per flow parameter per backward pass.  The three consumers below (context layers on the targets, SO(3) log-density, sample
+    chain) all differentiate w.r.t. the same ~420 parameter tensors; as independent autograd nodes each would hand autograd its own per-tensor
+    gradients and autograd would add them tensor by tensor (~830 tiny launches per step).  Instead the parameters enter the graph ONCE, here;
+    the node's output is a scalar token the consumers take as an input.  In backward a consumer leaves its STACKED gradients (all parts in
+    one tensor) in `stash` and returns a zero for the token; this node runs after all of them (autograd's dependency order), sums the stacked
+    tensors (a dozen launches) and returns per-parameter views."""
+
+    @staticmethod
+    def forward(ctx, model, stash, *params):
+        ctx.model, ctx.stash = model, stash
+        return torch.zeros((), dtype=torch.float32, device=params[0].device)
+
+    @staticmethod
+    def backward(ctx, g):
+        model, entries = ctx.model, list(ctx.stash)
+        ctx.stash.clear()
+        P = model.num_bodyparts
+        needs = ctx.needs_input_grad[2:]
+        g_full, g_db, hyper = None, None, None
+        for e in entries:
+            if e[0] == 'ctx':
+                g_full = e[1] if g_full is None else g_full + e[1]
+                g_db = e[2] if g_db is None else g_db + e[2]
+            else:
+                _, part0, n, grads = e
+                if n != P:                                       # a sub-range of parts (per-part log_prob calls): embed into the full stack
+                    full = []
+                    for dW, db in grads:
+                        fW, fb = dW.new_zeros((P,) + dW.shape[1:]), db.new_zeros((P,) + db.shape[1:])
+                        fW[part0:part0 + n], fb[part0:part0 + n] = dW, db
+                        full.append((fW, fb))
+                    grads = full
+                hyper = list(grads) if hyper is None else [(a[0] + b[0], a[1] + b[1]) for a, b in zip(hyper, grads)]
+        out = []
+        if g_full is not None:
+            dW = _context_weight_grads(model, g_full)
+            for j in range(P):
+                out += [dW[j], g_db[j]]
+        else:
+            out += [None] * (2 * P)
+        if hyper is not None:
+            for p in range(P):
+                for c in range(2):
+                    for l in range(4):
+                        out += [hyper[l][0][p, c], hyper[l][1][p, c]]
+        else:
+            out += [None] * (16 * P)
+        return (None, None) + tuple(gr if n else None for gr, n in zip(out, needs))
+
+
+def new_flow_anchor(model):
+    """(token, stash) for one forward pass: pass both to every consumer of that pass."""
+    stash = []
+    token = FlowParamAnchor.apply(model, stash, *(_ctx_params(model) + _hypernet_params(model, 0, model.num_bodyparts)))
+    return token, stash
+
+
 class FlowContext(torch.autograd.Function):
     """compute_flow_context for all 23 parts from GIVEN (teacher-forced) rotations: (B,256), (B,23,3,3) -> (B,23,64)."""
 
     @staticmethod
-    def forward(ctx, model, isgc, pose_R, *params):
+    def forward(ctx, model, isgc, pose_R, token, stash):
         out = model._flow_context_kernel(isgc.detach(), pose_R.detach())
-        ctx.model = model
+        ctx.model, ctx.stash = model, stash
         ctx.save_for_backward(isgc.detach(), pose_R.detach().float().reshape(pose_R.shape[0], 23, 9), out)
         ctx.r_needs_grad = pose_R.requires_grad
         return out
@@ -122,20 +173,18 @@ class FlowContext(torch.autograd.Function):
             raise NotImplementedError('humaniflow_amd: gradient w.r.t. the teacher-forced rotations (pose_R_for_loglik) is not built')
         isgc, rot, out = ctx.saved_tensors
         delta = (g * torch.where(out > 0, torch.ones_like(out), out + 1.0)).transpose(0, 1).contiguous()   # ELU', (P, B, 64)
-        dW, db, g_isgc = _context_layer_grads(ctx.model, delta, isgc, rot)
-        grads = []
-        for j in range(len(dW)):
-            grads += [dW[j], db[j]]
-        return (None, g_isgc, None) + tuple(grads)
+        g_full, db, g_isgc = _context_pullback(ctx.model, delta, isgc, rot)
+        ctx.stash.append(('ctx', g_full, db))
+        return None, g_isgc, None, g.new_zeros(()), None
 
 
 class FlowLogProbSO3(torch.autograd.Function):
     """log p(R_j | ctx_j) for parts part0 .. part0+P-1: ctx (B,P,64) fp32, R (B,P,3,3) fp64 -> (B,P) fp32."""
 
     @staticmethod
-    def forward(ctx, model, part0, P, cvec, R64, *params):
+    def forward(ctx, model, part0, P, cvec, R64, token, stash):
         out = model._log_prob_kernel(cvec.detach(), R64, part0, P, group=True)
-        ctx.model, ctx.part0, ctx.P = model, part0, P
+        ctx.model, ctx.part0, ctx.P, ctx.stash = model, part0, P, stash
         ctx.save_for_backward(cvec.detach().contiguous(), R64)
         return out
 
@@ -154,8 +203,8 @@ class FlowLogProbSO3(torch.autograd.Function):
             _lib.check(lib.hmf_flow_log_prob_SO3_backward(model._flow_handle(cvec.device), _lib.dptr(cvec), ids, P, _lib.dptr(R64), B,
                                                           _lib.dptr(gc), _lib.dptr(g_ctx), C.byref(st), _lib.current_stream()),
                        'hmf_flow_log_prob_SO3_backward')
-        pg = _hypernet_grad_list(rec, P, ctx.needs_input_grad[5:])
-        return (None, None, None, g_ctx if ctx.needs_input_grad[3] else None, None) + tuple(pg)
+        ctx.stash.append(('hyper', part0, P, rec.hypernet_grads()))
+        return None, None, None, g_ctx if ctx.needs_input_grad[3] else None, None, g.new_zeros(()), None
 
 
 class FlowSampleChain(torch.autograd.Function):
@@ -164,9 +213,9 @@ class FlowSampleChain(torch.autograd.Function):
     H, the 23 context layers and the 46 hyper-networks (ancestor recursion included)."""
 
     @staticmethod
-    def forward(ctx, model, H, rot_samples, eps_pose, *params):
+    def forward(ctx, model, H, rot_samples, eps_pose, token, stash):
         B, N = rot_samples.shape[:2]
-        ctx.model, ctx.B, ctx.N = model, B, N
+        ctx.model, ctx.B, ctx.N, ctx.stash = model, B, N, stash
         ctx.save_for_backward(H.detach().contiguous(), rot_samples.detach().contiguous(), eps_pose.detach().contiguous())
         return rot_samples.detach().clone()
 
@@ -182,13 +231,10 @@ class FlowSampleChain(torch.autograd.Function):
         with torch.cuda.device(H.device):
             _lib.check(lib.hmf_flow_sample_backward(model._flow_handle(H.device), _lib.dptr(H), _lib.dptr(rot), _lib.dptr(eps), B, N,
                                                     _lib.dptr(g_rot), C.byref(st), _lib.current_stream()), 'hmf_flow_sample_backward')
-        dW, db, g_H = _context_layer_grads(model, rec.DCTX, H, rot.reshape(B * N, P, 9))
-        grads = []
-        for j in range(P):
-            grads += [dW[j], db[j]]
-        grads += _hypernet_grad_list(rec, P, [True] * (16 * P))
-        needs = ctx.needs_input_grad[4:]
-        return (None, g_H, None, None) + tuple(gr if n else None for gr, n in zip(grads, needs))
+        g_full, db, g_H = _context_pullback(model, rec.DCTX, H, rot.reshape(B * N, P, 9))
+        ctx.stash.append(('ctx', g_full, db))
+        ctx.stash.append(('hyper', 0, P, rec.hypernet_grads()))
+        return None, g_H, None, None, g_rot.new_zeros(()), None
 
 
 class SmplJoints(torch.autograd.Function):

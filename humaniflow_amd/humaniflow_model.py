@@ -432,11 +432,16 @@ class HumaniflowModel(nn.Module):
                                             _lib.current_stream()), 'hmf_flow_context')
         return ctx
 
-    def compute_flow_context_all(self, input_shape_glob_cam_feats, pose_SO3):
-        """models/humaniflow_model.py:152-186 for all 23 parts at once from GIVEN rotations: (B,256),(B,23,3,3) -> (B,23,64)."""
+    def compute_flow_context_all(self, input_shape_glob_cam_feats, pose_SO3, anchor=None):
+        """models/humaniflow_model.py:152-186 for all 23 parts at once from GIVEN rotations: (B,256),(B,23,3,3) -> (B,23,64).
+        `anchor`: the (token, stash) of autograd.new_flow_anchor shared by the consumers of one forward pass (made here when absent); it rides
+        on the returned tensor so that log_prob_parts(ctx, ...) joins the same pass."""
         if self._needs_grad(input_shape_glob_cam_feats, pose_SO3):
-            from .autograd import FlowContext, _ctx_params
-            return FlowContext.apply(self, input_shape_glob_cam_feats, pose_SO3, *_ctx_params(self))
+            from .autograd import FlowContext, new_flow_anchor
+            anchor = anchor or new_flow_anchor(self)
+            out = FlowContext.apply(self, input_shape_glob_cam_feats, pose_SO3, *anchor)
+            out._hmf_flow_anchor = anchor
+            return out
         return self._flow_context_kernel(input_shape_glob_cam_feats, pose_SO3)
 
     def _log_prob_kernel(self, ctx, value, part0, P, group):
@@ -465,8 +470,9 @@ class HumaniflowModel(nn.Module):
             raise NotImplementedError('humaniflow_amd: gradients w.r.t. the rotation a flow density is evaluated AT are not built (the optimise driver, '
                                       'optimise/optimise_humaniflow.py:96-109); training differentiates w.r.t. the context and the weights')
         if self._needs_grad(ctx):
-            from .autograd import FlowLogProbSO3, _hypernet_params
-            return FlowLogProbSO3.apply(self, part0, P, ctx, R.detach().to(torch.float64).contiguous(), *_hypernet_params(self, part0, P))
+            from .autograd import FlowLogProbSO3, new_flow_anchor
+            anchor = getattr(ctx, '_hmf_flow_anchor', None) or new_flow_anchor(self)
+            return FlowLogProbSO3.apply(self, part0, P, ctx, R.detach().to(torch.float64).contiguous(), *anchor)
         return self._log_prob_kernel(ctx, R, part0, P, group=True)
 
     def log_prob_all_parts(self, ctx, R):
@@ -498,6 +504,7 @@ class HumaniflowModel(nn.Module):
         if grad_for_pose_point_est:
             raise NotImplementedError('humaniflow_amd: grad_for_pose_point_est=True (gradients through the z = 0 point-estimate chain) is not built')
         grad = torch.is_grad_enabled() and (input_feats.requires_grad or any(p.requires_grad for p in self.parameters()))
+        flow_anchor = None                      # autograd.new_flow_anchor of this pass (made by the first differentiable flow consumer)
         if grad and not self.default_flow:
             raise NotImplementedError('humaniflow_amd: gradients are built for the default flow configuration (spline_coupling + permute); call the '
                                       'variants under torch.no_grad()')
@@ -554,13 +561,14 @@ class HumaniflowModel(nn.Module):
             if grad and N > 0:
                 # Training: attach the reparameterised-sample graph to the kernel's results (:255-258, :302-311).  The shape samples and the
                 # per-row isgc features are re-expressed in torch ops (tiny), the kinematic chain's backward is the HIP reverse sweep.
-                from .autograd import FlowSampleChain, _ctx_params, _hypernet_params
+                from .autograd import FlowSampleChain, new_flow_anchor
+                flow_anchor = new_flow_anchor(self)
                 if use_shape_mode_for_samples:
                     shape_samples = shape_mode[:, None, :].expand(-1, N, -1)
                 else:
                     shape_samples = (shape_mode + eps_shape * torch.exp(shape_log_std)).transpose(0, 1)        # (B,N,nb), = the kernel's values
                 H = self._isgc_autograd(input_feats, shape_samples, glob_R, cam).reshape(BN, -1)
-                rot_s = FlowSampleChain.apply(self, H, rot_s, eps_pose, *(_ctx_params(self) + _hypernet_params(self, 0, P)))
+                rot_s = FlowSampleChain.apply(self, H, rot_s, eps_pose, *flow_anchor)
                 if packed:
                     rot_all = torch.cat([rot_s.reshape(BN, P, 3, 3), rot_p], dim=0)
                     shape_all = torch.cat([shape_samples.reshape(BN, nb), shape_mode], dim=0)
@@ -576,7 +584,7 @@ class HumaniflowModel(nn.Module):
 
         if compute_for_loglik:
             isgc = self.compute_input_shape_glob_cam_feats(input_feats, shape_for_loglik, glob_R_for_loglik, cam)    # :279-283
-            ctx = self.compute_flow_context_all(isgc, pose_R_for_loglik)                                              # :315-318
+            ctx = self.compute_flow_context_all(isgc, pose_R_for_loglik, anchor=flow_anchor)                          # :315-318
             return_dict['conditioned_pose_so3flow_dists_for_loglik'] = [
                 self.pose_so3flow_dists[j].condition(ctx[:, j], parent=(ctx, j)) for j in range(P)]
             return_dict['conditioned_pose_SO3flow_dists_for_loglik'] = [
