@@ -644,6 +644,7 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
     if (M * Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad: tensor exceeds 2^29 elements");
     a.M = (int)M;
     hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(13, a.M, st);                  // weight-gradient family (bench.py --train)
     if (stem_nchw && ks == 7 && stride == 2 && Cout == 64 && (a.OW % 2) == 0) {
         StemWgradArgs w;
         w.gy = gy; w.x = x; w.dw = dw; w.B = B; w.Cin = Cin; w.H = H; w.W = W; w.OH = a.OH; w.OW = a.OW; w.K = Cin * 49;

@@ -207,6 +207,52 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     w_ = torch.randn_like(feats)
     stages['of_backward: encoder_ms'], _ = tm(lambda: (feats * w_).sum().backward())
     optimiser.zero_grad(set_to_none=True)
+    # ---- per-kernel-family measurement pass: HIP event pair around every convolution / weight-gradient launch of 2 more steps ----
+    roof = None
+    try:
+        import numpy as np
+        enc = model.image_encoder
+        convs = [m for m in enc.modules() if isinstance(m, torch.nn.Conv2d)]
+        shapes = {}
+        hooks = [m.register_forward_hook(lambda mod, i, o: shapes.__setitem__(mod, o.shape)) for m in convs]
+        lib = _lib.load()
+        was_training = enc.training
+        enc.eval()                                                      # shapes only: do not touch the running statistics
+        with torch.no_grad():
+            enc.forward_module(batches[0][0][:1])
+        enc.train(was_training)
+        for h in hooks:
+            h.remove()
+        per_img = {m: 2.0 * shapes[m][2] * shapes[m][3] * m.out_channels * m.in_channels * m.kernel_size[0] ** 2 for m in convs}
+        f_all = B * sum(per_img.values())
+        f_dgrad = f_all - B * per_img[enc.conv1]                       # the proxy input needs no gradient
+        P = 2
+        lib.hmf_profile_enable(1)
+        for k in range(P):
+            optimiser.zero_grad(set_to_none=True)
+            loss, _ = train_forward_loss(model, smpl, criterion, *batches[k % len(batches)], N)
+            loss.backward()
+        torch.cuda.synchronize()
+        cap = 65536
+        ms, tag, rows = np.zeros(cap), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), cap)
+        lib.hmf_profile_enable(0)
+        ms, tag = ms[:n], tag[:n]
+        t_w = float(ms[tag == 13].sum()) / P * 1e-3
+        t_c = float(ms[(tag >= 8) & (tag <= 11)].sum()) / P * 1e-3
+        fam = {'weight gradients (k_stem_wgrad, k_conv_wgrad3, k_conv_wgrad)': (f_all, t_w, int((tag == 13).sum()) // P),
+               'forward + input-gradient convolutions (k_stem_conv, k_conv_patch, k_conv_igemm)': (f_all + f_dgrad, t_c, int(((tag >= 8) & (tag <= 11)).sum()) // P)}
+        name = max(fam, key=lambda k: fam[k][1])
+        f, t, nl = fam[name]
+        roof = {'kernel': name + ': the kernel family with the largest share of the training step (%d launches/step)' % nl, 'bound': 'mfma',
+                'achieved': round(f / t / 1e12, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(f / t / 1e12 / 157.3, 4), 'traffic': None,
+                'ms_per_step': round(t * 1e3, 3), 'algorithmic_gflop_per_step': round(f / 1e9, 1),
+                'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (HIP event pair around every launch of %d extra steps)' % P,
+                'families': {k: {'gflop_per_step': round(v[0] / 1e9, 1), 'ms_per_step': round(v[1] * 1e3, 3), 'tflops': round(v[0] / v[1] / 1e12, 2),
+                                 'launches_per_step': v[2]} for k, v in fam.items()}}
+    except Exception as e:                                              # the measurement pass must not cost the bench line
+        log('train roofline pass failed: %r' % (e,))
+    optimiser.zero_grad(set_to_none=True)
     if rank == 0:
         value = world * B * N * args.steps / elapsed
         print(json.dumps({
@@ -223,6 +269,6 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
             'hand_written': 'encoder training graph (conv kernels + hmf_bn_* + hmf_conv_wgrad + dgrad through hmf_conv2d_nhwc), flow forward/backward '
                             '(hmf_flow_forward, hmf_flow_log_prob_SO3[_backward], hmf_flow_sample_backward), SMPL forward + joints backward, proxy front end; '
                             'library GEMMs (torch) for the heads and the dense weight-gradient reductions of the flow',
-            'roofline': None, 'cpu_baseline': None}))
+            'roofline': roof, 'cpu_baseline': None}))
     if dist is not None:
         dist.destroy_process_group()
