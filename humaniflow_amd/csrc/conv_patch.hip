@@ -40,9 +40,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr int NIT = (NV + 255) / 256;
     // LDS row pitch (floats): ds_read_b128 is served in four 16-lane groups ({0-3,12-15,20-27}, ...) over 64 banks, so the 16-byte slots
     // of a group must be distinct mod 16.  Pixel stride CS = 17 slots; a 16-wide tile needs the row pitch = 0 (mod 16 slots), an 8-wide
-    // tile = 8 (mod 16 slots); the stride-2 variant cannot be made conflict-free with 16-byte reads (2-way) and keeps the dense pitch.
+    // tile = 8 (mod 16 slots); the stride-2 variant stores the columns split by parity (below).
     constexpr int kDense = PW * CS;
-    constexpr int RPF = ST == 2 ? kDense : (TW == 16 ? (kDense + 63) / 64 * 64 : ((kDense - 32 + 63) / 64 * 64 + 32));
+    // Stride 2 (round 2): patch columns de-interleaved by parity (column c at slot (c & 1) * kHalf + (c >> 1)), so the lanes' columns 2 px + kw are
+    // consecutive slots; two tile rows of a 16-lane group are 2 patch rows apart: row pitch = 4 (mod 8) slots (as k_conv_winograd's patch image).
+    constexpr int kHalf = (PW + 1) / 2;
+    constexpr int RPF = ST == 2 ? ((kDense / 4 + 3) / 8 * 8 + 4) * 4 : (TW == 16 ? (kDense + 63) / 64 * 64 : ((kDense - 32 + 63) / 64 * 64 + 32));
+    static_assert(ST != 2 || (RPF >= kDense && (RPF / 4) % 8 == 4), "stride-2 row pitch");
     // weight ring: slot = group % kRing must stay in phase over slabs -> kRing divides GPS (8, 16 or 72 groups per slab)
     constexpr int kRing = 8, kPF = kRing - 2;
     __shared__ float patch[PH * RPF];
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int ih = KS == 1 ? (oh0 + r) * a.stride : oh0 * ST + r - 1, iw = KS == 1 ? (ow0 + col) * a.stride : ow0 * ST + col - 1;
         const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
         goff[k] = ok ? (((b * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
-        loff[k] = r * RPF + col * CS + 4 * c4;
+        loff[k] = r * RPF + (ST == 2 ? (col & 1) * kHalf + (col >> 1) : col) * CS + 4 * c4;
     }
     const int nslab = a.Cin / SC;
     constexpr int GPS = KS * KS * NG;               // groups per slab
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((long long)((nt * CG + cg) * TN + t) * nslab * GPS) * 64 + lane;
 
     const int prow = pg * RPG + li / TW, pcol = li % TW;
-    const float* pa = patch + prow * ST * RPF + pcol * ST * CS + 4 * lq;
+    const float* pa = patch + prow * ST * RPF + pcol * (ST == 2 ? 1 : ST) * CS + 4 * lq;
 
     f32x16 acc[TN];
 #pragma unroll
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
             if (gi + 1 < GPS) {
                 const int tap = (gi + 1) / NG, g = (gi + 1) - tap * NG;
-                fa[(gi + 1) & 1] = *(const f32x4*)(pa + (tap / KS) * RPF + (tap % KS) * CS + 8 * g);
+                const int kw = tap % KS, cslot = ST == 2 ? (kw & 1) * kHalf + (kw >> 1) : kw;
+                fa[(gi + 1) & 1] = *(const f32x4*)(pa + (tap / KS) * RPF + cslot * CS + 8 * g);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

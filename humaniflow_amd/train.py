@@ -212,20 +212,19 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     try:
         import numpy as np
         enc = model.image_encoder
-        convs = [m for m in enc.modules() if isinstance(m, torch.nn.Conv2d)]
+        import copy
+        lib = _lib.load()
+        menc = copy.deepcopy(enc).to('meta')                            # shapes only: a meta copy, no kernel runs
+        convs = [m for m in menc.modules() if isinstance(m, torch.nn.Conv2d)]
         shapes = {}
         hooks = [m.register_forward_hook(lambda mod, i, o: shapes.__setitem__(mod, o.shape)) for m in convs]
-        lib = _lib.load()
-        was_training = enc.training
-        enc.eval()                                                      # shapes only: do not touch the running statistics
         with torch.no_grad():
-            enc.forward_module(batches[0][0][:1])
-        enc.train(was_training)
+            menc.forward_module(torch.empty((1,) + tuple(batches[0][0].shape[1:]), device='meta'))
         for h in hooks:
             h.remove()
         per_img = {m: 2.0 * shapes[m][2] * shapes[m][3] * m.out_channels * m.in_channels * m.kernel_size[0] ** 2 for m in convs}
         f_all = B * sum(per_img.values())
-        f_dgrad = f_all - B * per_img[enc.conv1]                       # the proxy input needs no gradient
+        f_dgrad = f_all - B * per_img[menc.conv1]                      # the proxy input needs no gradient
         P = 2
         lib.hmf_profile_enable(1)
         for k in range(P):
