@@ -172,26 +172,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// "transpose-reduce": lane l ends with sum over all lanes of v[l % K] (63 shuffles for K = 64 instead of K full reductions)
-template <int K>
-__device__ __forceinline__ float xreduce(float (&v)[K], int lane) {
-    if (K == 32) {
-#pragma unroll
-        for (int i = 0; i < K; ++i) v[i] += __shfl_xor(v[i], 32);
-    }
-#pragma unroll
-    for (int s = (K == 64 ? 32 : 16); s >= 1; s >>= 1) {
-        const bool up = (lane & s) != 0;
-#pragma unroll
-        for (int i = 0; i < s; ++i) {
-            const float send = up ? v[i] : v[i + s];
-            const float keep = up ? v[i + s] : v[i];
-            v[i] = keep + __shfl_xor(send, s);
-        }
-    }
-    return v[0];
-}
-
 struct NetAct {
     float h1, h2, h3;          // post-ReLU activations of this lane's channel (h2, h3: lanes < 32, else 0)
 };
@@ -200,23 +180,23 @@ struct NetAct {
 __device__ __forceinline__ float hypernet_fwd(const FlowDev& d, const PartTab& pt, int c, int lane, float ctx_lane, float x1, NetAct& A) {
     const float* W = d.arena + pt.o_nnT[c][0];
     float a = d.arena[pt.o_nnb[c][0] + lane];
-#pragma unroll 16
+#pragma unroll 32
     for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(ctx_lane, k), a);      // unrolled: the weight loads of 16 steps in flight together
     a = fmaf(W[64 * 64 + lane], x1, a);
     A.h1 = fmaxf(a, 0.f);
     W = d.arena + pt.o_nnT[c][1];
     a = d.arena[pt.o_nnb[c][1] + lane];
-#pragma unroll 16
+#pragma unroll 32
     for (int k = 0; k < 64; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h1, k), a);
     A.h2 = lane < 32 ? fmaxf(a, 0.f) : 0.f;
     W = d.arena + pt.o_nnT[c][2];
     a = d.arena[pt.o_nnb[c][2] + lane];
-#pragma unroll 16
+#pragma unroll 32
     for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h2, k), a);
     A.h3 = lane < 32 ? fmaxf(a, 0.f) : 0.f;
     W = d.arena + pt.o_nnT[c][3];
     a = d.arena[pt.o_nnb[c][3] + lane];
-#pragma unroll 16
+#pragma unroll 32
     for (int k = 0; k < 32; ++k) a = fmaf(W[k * 64 + lane], __shfl(A.h3, k), a);
     return a;
 }
@@ -225,41 +205,41 @@ struct NetDelta {
     float d1, d2, d3, d4;      // pre-activation gradients of the four layers, this lane's channel
 };
 
-// reverse sweep of the hyper-network: g_raw (lane < 62) -> deltas, d L / d context (lane = context channel), d L / d x1 (wave-uniform)
+// reverse sweep of the hyper-network: g_raw (lane < 62) -> deltas, d L / d context (lane = context channel), d L / d x1 (wave-uniform).
+// g_in[k] = sum_o W[o][k] delta[o] runs on the NATURAL copy of each layer (row o, lane = input k: flow_pack.hip places it behind the transposed
+// copy): a lane-parallel walk over the outputs with delta[o] broadcast by a lane read -- the same shape as the forward sweep.  (The first version
+// reduced W^T[k][lane] delta[lane] across lanes with a 63-shuffle transpose-reduce per layer: 2.3 of the 3.2 ms of the sample-chain backward.)
 __device__ __forceinline__ void hypernet_bwd(const FlowDev& d, const PartTab& pt, int c, int lane, const NetAct& A, float g_raw, NetDelta& D,
                                              float& g_ctx, float& g_x1) {
     D.d4 = lane < 62 ? g_raw : 0.f;
     {
-        const float* W = d.arena + pt.o_nnT[c][3];
-        float p[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) p[k] = W[k * 64 + lane] * D.d4;
-        const float g = xreduce<32>(p, lane);
-        D.d3 = (lane < 32 && A.h3 > 0.f) ? g : 0.f;
+        const float* Wn = d.arena + pt.o_nnT[c][3] + 32 * 64;
+        float a = 0.f;
+#pragma unroll 31
+        for (int o = 0; o < 62; ++o) a = fmaf(Wn[o * 64 + lane], __shfl(D.d4, o), a);
+        D.d3 = (lane < 32 && A.h3 > 0.f) ? a : 0.f;
     }
     {
-        const float* W = d.arena + pt.o_nnT[c][2];
-        float p[32];
+        const float* Wn = d.arena + pt.o_nnT[c][2] + 32 * 64;
+        float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) p[k] = W[k * 64 + lane] * D.d3;
-        const float g = xreduce<32>(p, lane);
-        D.d2 = (lane < 32 && A.h2 > 0.f) ? g : 0.f;
+        for (int o = 0; o < 32; ++o) a = fmaf(Wn[o * 64 + lane], __shfl(D.d3, o), a);
+        D.d2 = (lane < 32 && A.h2 > 0.f) ? a : 0.f;
     }
     {
-        const float* W = d.arena + pt.o_nnT[c][1];
-        float p[64];
+        const float* Wn = d.arena + pt.o_nnT[c][1] + 64 * 64;
+        float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < 64; ++k) p[k] = W[k * 64 + lane] * D.d2;
-        const float g = xreduce<64>(p, lane);
-        D.d1 = A.h1 > 0.f ? g : 0.f;
+        for (int o = 0; o < 32; ++o) a = fmaf(Wn[o * 64 + lane], __shfl(D.d2, o), a);
+        D.d1 = A.h1 > 0.f ? a : 0.f;
     }
     {
-        const float* W = d.arena + pt.o_nnT[c][0];
-        float p[64];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) p[k] = W[k * 64 + lane] * D.d1;
-        g_ctx = xreduce<64>(p, lane);
-        g_x1 = wave_sum(W[64 * 64 + lane] * D.d1);
+        const float* Wn = d.arena + pt.o_nnT[c][0] + 65 * 64;
+        float a = 0.f;
+#pragma unroll 32
+        for (int o = 0; o < 64; ++o) a = fmaf(Wn[o * 64 + lane], __shfl(D.d1, o), a);
+        g_ctx = a;
+        g_x1 = wave_sum(d.arena[pt.o_nnT[c][0] + 64 * 64 + lane] * D.d1);
     }
 }
 
@@ -470,11 +450,18 @@ __global__ __launch_bounds__(256) void k_flow_chain_bwd(FlowDev d, int lev, cons
     float pre = d.arena[pt.o_bctx + lane];
     {
         const float* h = H + (size_t)row * kIsgc;
-#pragma unroll 16
+#pragma unroll 32
         for (int k = 0; k < kIsgc; ++k) pre = fmaf(WT[(size_t)k * kCtx + lane], h[k], pre);
-        for (int a = 0; a < pt.n_anc; ++a) {
-            const float* ra = rot + ((size_t)row * kP + pt.anc[a]) * 9;
-            for (int e = 0; e < 9; ++e) pre = fmaf(WT[(size_t)(kIsgc + a * 9 + e) * kCtx + lane], ra[e], pre);
+        // ancestors: a fixed, fully unrolled walk over the (at most 7 x 9) rotation entries with the loads predicated, so that all of them are in
+        // flight together (a runtime-bounded loop waited for one L2 round trip per entry: up to 63 dependent round trips per wave)
+        const int ka = 9 * pt.n_anc;
+        const float* rr = rot + (size_t)row * kP * 9;
+#pragma unroll
+        for (int k = 0; k < 63; ++k) {
+            const int kc = k < ka ? k : 0;
+            const float w = WT[(size_t)(kIsgc + kc) * kCtx + lane];
+            const float r = rr[(k < ka ? pt.anc[kc / 9] : 0) * 9 + kc % 9];          // (a root part has no valid anc[] entry at all)
+            pre = fmaf(k < ka ? w : 0.f, r, pre);
         }
     }
     const float ctx = elu1(pre);
@@ -567,13 +554,13 @@ __global__ __launch_bounds__(256) void k_flow_chain_bwd(FlowDev d, int lev, cons
     float g_ctx0, g_z0;
     hypernet_bwd(d, pt, 0, lane, A0, scatter_raw_grad(S0, lane), D0, g_ctx0, g_z0);
     const float dctx = (g_ctx0 + g_ctx1) * (pre > 0.f ? 1.f : ctx + 1.f);          // ELU'
-    // ---- ancestors: d L / d R_anc += W_ctx[:, 256 + k]^T . delta ----
+    // ---- ancestors: d L / d R_anc += W_ctx[:, 256 + k]^T . delta (natural copy of the ancestor columns, lane = entry k) ----
     {
-        float p[64];
         const int ka = 9 * pt.n_anc;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) p[k] = k < ka ? WT[(size_t)(kIsgc + k) * kCtx + lane] * dctx : 0.f;
-        const float ga = xreduce<64>(p, lane);
+        const float* Wn = WT + (size_t)(kIsgc + ka) * kCtx;
+        float ga = 0.f;
+#pragma unroll 32
+        for (int o = 0; o < 64; ++o) ga = fmaf(Wn[o * 64 + lane], __shfl(dctx, o), ga);
         if (lane < ka) atomicAdd(g_rot + ((size_t)row * kP + pt.anc[lane / 9]) * 9 + lane % 9, ga);
     }
     store_net(G, j, 0, row, lane, D0, A0, z0);

@@ -132,9 +132,13 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
         t.o_bctx = (int)P.place(kCtx);
         std::copy(w->b_ctx_host[j], w->b_ctx_host[j] + kCtx, P.buf.begin() + t.o_bctx);
         // natural transposed copy of the context layer (lane = output channel): teacher-forced kernels, backward, generic variants
-        t.o_wctxT = (int)P.place((size_t)kin * kCtx);
+        // ... followed by the NATURAL copy of its ancestor columns [64 out][64: lane = ancestor entry k < 9a, zero beyond] for the backward sweep
+        // (d L / d ancestors = W_anc^T . delta as a lane-parallel sum over outputs: no cross-lane reduction); offset = o_wctxT + kin * 64
+        t.o_wctxT = (int)P.place((size_t)kin * kCtx + (size_t)kCtx * 64);
         for (int k = 0; k < kin; ++k)
             for (int n = 0; n < kCtx; ++n) P.buf[t.o_wctxT + (size_t)k * kCtx + n] = wc[(size_t)n * kin + k];
+        for (int n = 0; n < kCtx; ++n)
+            for (int k = 0; k < ka; ++k) P.buf[t.o_wctxT + (size_t)kin * kCtx + (size_t)n * 64 + k] = wc[(size_t)n * kin + kIsgc + k];
         if (fp.generic) continue;
         // context layer, isgc half: 2 tiles x 128 k-steps over the 256 isgc channels held in ARL (8 tiles)
         t.o_wc0 = (int)pack_a(P, 2, 128, [&](int tl, int s, int lane) {
@@ -185,9 +189,12 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
         static const int Kd[4] = {65, 64, 32, 32}, Nd[4] = {64, 32, 32, 62};
         for (int c = 0; c < 2; ++c)
             for (int l = 0; l < 4; ++l) {
-                t.o_nnT[c][l] = (int)P.place((size_t)Kd[l] * 64);      // padded to 64 columns
+                // [Kd][64] transposed (lane = output), then the natural copy [64 rows = output][64: lane = input k < min(Kd, 64)] at + Kd * 64
+                t.o_nnT[c][l] = (int)P.place((size_t)Kd[l] * 64 + 64 * 64);
                 for (int k = 0; k < Kd[l]; ++k)
                     for (int n = 0; n < Nd[l]; ++n) P.buf[t.o_nnT[c][l] + (size_t)k * 64 + n] = wn[c * 4 + l][(size_t)n * Kd[l] + k];
+                for (int n = 0; n < Nd[l]; ++n)
+                    for (int k = 0; k < std::min(Kd[l], 64); ++k) P.buf[t.o_nnT[c][l] + (size_t)Kd[l] * 64 + (size_t)n * 64 + k] = wn[c * 4 + l][(size_t)n * Kd[l] + k];
                 t.o_nnb[c][l] = (int)P.place(64);
                 std::copy(bn[c * 4 + l], bn[c * 4 + l] + Nd[l], P.buf.begin() + t.o_nnb[c][l]);
             }

@@ -137,19 +137,32 @@ def grads_finite(params):
 
 
 def train_step(model, smpl, criterion, optimiser, reducer, proxy_input, targets, num_samples, noise=None):
-    """One optimisation step.  Returns (loss tensor, skipped flag)."""
+    """One optimisation step.  Returns (loss tensor, skipped): a non-finite loss or gradient skips the update (the reference reloads the previous
+    state dicts, train/train_humaniflow.py:264-278).  With a fused Adam on the device the decision never leaves the device: the finite flag is
+    handed to the optimiser as `found_inf` (the fused kernel then leaves parameters, moments and step counts untouched), `skipped` is a 0-dim
+    tensor and the host never waits for the step -- consecutive steps overlap launch with execution.  Other optimisers: one host read."""
     optimiser.zero_grad(set_to_none=True)
     loss, _ = train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=noise)
     loss.backward()
     reducer.finish()
     params = [p for g in optimiser.param_groups for p in g['params']]
-    if not (bool(torch.isfinite(loss)) and grads_finite(params)):       # the reference reloads the previous state dicts (:264-278)
-        optimiser.zero_grad(set_to_none=True)
-        return loss.detach(), True
-    optimiser.step()
+    on_device = isinstance(optimiser, torch.optim.Adam) and loss.is_cuda and all(g.get('fused') for g in optimiser.param_groups)
+    if on_device:
+        norms = torch._foreach_norm([p.grad for p in params if p.grad is not None])
+        bad = (~(torch.isfinite(loss.detach()) & torch.isfinite(torch.stack(norms)).all())).to(torch.float32)
+        optimiser.grad_scale, optimiser.found_inf = None, bad
+        optimiser.step()
+        optimiser.found_inf = None
+        skipped = bad
+    else:
+        if not (bool(torch.isfinite(loss)) and grads_finite(params)):
+            optimiser.zero_grad(set_to_none=True)
+            return loss.detach(), True
+        optimiser.step()
+        skipped = False
     for d in model.pose_SO3flow_dists:                                  # :353-354 (no caches here; kept for call parity)
         d.clear_cache()
-    return loss.detach(), False
+    return loss.detach(), skipped
 
 
 def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist_gather_metrics):
@@ -175,7 +188,7 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     NB = max(1, args.batches)
     batches = [synthetic_train_batch(smpl, B, cfg.DATA.PROXY_REP_SIZE, dev, seed=1000 + rank * NB + i, data_cfg=cfg.DATA) for i in range(NB)]
     torch.manual_seed(1234 + rank)
-    losses, skipped = [], 0
+    losses, skipped = [], torch.zeros((), device=dev)
     log('train flavour: B=%d, N=%d, ResNet-%d, %d parameters (%.1f MB of gradients per step), %d ranks'
         % (B, N, args.layers, sum(p.numel() for p in params), sum(p.numel() for p in params) * 4 / 2 ** 20, world))
     for k in range(args.warmup):
@@ -185,8 +198,8 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     for k in range(args.steps):
         loss, sk = train_step(model, smpl, criterion, optimiser, reducer, *batches[(args.warmup + k) % NB], N)
         losses.append(loss)
-        skipped += int(sk)
-    metric_vec = torch.stack([torch.stack(losses).double().mean(), torch.tensor(float(skipped), dtype=torch.float64, device=dev)])
+        skipped = skipped + sk
+    metric_vec = torch.stack([torch.stack(losses).double().mean(), skipped.double().reshape(())])
     gathered = dist_gather_metrics(metric_vec, dist, world)
     elapsed = dist_elapsed(t0, dist, dev)
     # stage split of one step (separate, untimed): forward+loss / backward / exchange+update

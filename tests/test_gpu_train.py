@@ -228,3 +228,35 @@ def test_full_train_step_loss_and_gradients_at_batch_72():
         close(name, p.grad, g64[name], g32[name])
         n += 1
     assert n == 424                                                              # every non-encoder parameter of the checkpoint layout
+
+
+def test_train_step_skips_non_finite_updates_on_the_device():
+    """train/train_humaniflow.py:264-278 (NaN roll-back): with the fused Adam the skip is decided on the device -- parameters, moments and step
+    counts stay untouched when a gradient is non-finite, and a clean step afterwards updates as usual."""
+    import humaniflow_amd as H
+    from humaniflow_amd import train as T
+    from humaniflow_amd.losses import HumaniflowLoss
+    from humaniflow_amd.synthetic import init_benchmark_weights
+    dev = torch.device('cuda')
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_RESNET_LAYERS = 18
+    torch.manual_seed(0)
+    model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).to(dev).train()
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=4, create_transl=False).to(dev)
+    crit = HumaniflowLoss(cfg.LOSS, cfg.DATA.PROXY_REP_SIZE)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    red = T.GradBucketReducer(params, None)
+    batch = T.synthetic_train_batch(smpl, 4, cfg.DATA.PROXY_REP_SIZE, dev, seed=5, data_cfg=cfg.DATA)
+    loss, sk = T.train_step(model, smpl, crit, opt, red, *batch, 2)
+    assert float(sk) == 0.0 and torch.isfinite(loss)
+    before = [p.detach().clone() for p in params]
+    steps_before = [float(opt.state[p]['step']) for p in params if p in opt.state]
+    poison = params[-1].register_hook(lambda g: g * float('nan'))
+    loss, sk = T.train_step(model, smpl, crit, opt, red, *batch, 2)
+    poison.remove()
+    assert float(sk) == 1.0
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, params))
+    assert steps_before == [float(opt.state[p]['step']) for p in params if p in opt.state]
+    loss, sk = T.train_step(model, smpl, crit, opt, red, *batch, 2)
+    assert float(sk) == 0.0 and not all(torch.equal(a, b.detach()) for a, b in zip(before, params))
