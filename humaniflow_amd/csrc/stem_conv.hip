@@ -27,6 +27,11 @@ __device__ __forceinline__ constexpr int stem_slot(int col) { return (col & 1) *
 constexpr int kStemSteps = (kStemC / 2) * kStemK * kStemK;                // 441 k-steps
 constexpr int kStemGroups = (kStemSteps + 3) / 4;                         // 111 groups of 4
 
+// POOL: the 3x3 / stride-2 max-pool that follows the stem (models/resnet.py:144,206) is applied to the work-group's 8 x 16 tile before it leaves
+// the CU: y is then the POOLED map (B, PH, PW, 64), zeroed by the caller.  Pool windows that lie inside the tile (3 x 7 of the 5 x 9 the tile
+// touches) are stored; windows shared with a neighbouring tile are combined with an integer atomic max (post-ReLU values are >= +0, so the
+// float order is the unsigned order).  The 134 MB conv map (B = 32) is never written or re-read and the pool launch disappears.
+template <bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_conv(
     const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
     int OH, int OW, int tiles_w, int tiles_hw, int relu) {
@@ -104,6 +109,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (POOL) {
+        // ---- epilogue with the max-pool: tile [8][16][64] -> LDS (the patch is dead), pooled windows from LDS ----
+        __syncthreads();
+        float* tl = patch;                                       // [row 8][col 16][ch 64]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n = 32 * t + li;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lq;
+                const int row = 2 * wave + (i >> 4), col = i & 15;
+                const bool in = (oh0 + row < OH) & (ow0 + col < OW);
+                tl[(row * 16 + col) * 64 + n] = in ? fmaxf(acc[t][r] + bv, 0.f) + 0.f : 0.f;       // + 0.f: never -0 (its bit pattern would win the max)
+            }
+        }
+        __syncthreads();
+        const int PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;
+        const int ch = tid & 63, q = tid >> 6;
+        const int pr0 = oh0 >> 1, pc0 = ow0 >> 1;
+        for (int p = q; p < 45; p += 4) {
+            const int a = p / 9, c = p - a * 9;                   // pooled position (pr0 + a, pc0 + c): conv rows 2a-1 .. 2a+1 of the tile
+            if (pr0 + a >= PH || pc0 + c >= PW) continue;
+            float m = 0.f;
+#pragma unroll
+            for (int dr = -1; dr <= 1; ++dr) {
+                const int rr = 2 * a + dr;
+                if ((unsigned)rr >= 8u) continue;
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int cc = 2 * c + dc;
+                    if ((unsigned)cc < 16u) m = fmaxf(m, tl[(rr * 16 + cc) * 64 + ch]);
+                }
+            }
+            float* dst = y + (((long long)b * PH + pr0 + a) * PW + pc0 + c) * kStemN + ch;
+            const bool whole = (a >= 1) & (a <= 3) & (c >= 1) & (c <= 7);
+            if (whole) *dst = m;
+            else atomicMax((unsigned int*)dst, __float_as_uint(m));
+        }
+        return;
+    }
     // ---- epilogue: + bias, ReLU, NHWC stores (lane = channel, 128-byte runs) ----
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -178,7 +224,24 @@ extern "C" int hmf_stem_conv(const float* x, const float* w_packed, const float*
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(9, B, st);
-    hipLaunchKernelGGL(k_stem_conv, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw, relu);
+    hipLaunchKernelGGL(k_stem_conv<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw, relu);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+// conv 7x7/2 + bias + ReLU + max-pool 3x3/2 in one launch: y_pooled (B, PH, PW, 64), PH = ((H-1)/2)/2 + 1 (the inference plan's stem)
+extern "C" int hmf_stem_conv_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* stream) {
+    if (!x || !w_packed || !y_pooled || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_stem_conv_pool: bad args");
+    if (C != kStemC) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv_pool: %d input channels (the 18-channel proxy representation is built)", C);
+    if ((uintptr_t)w_packed & 15) return fail(HMF_ERR_INVALID, "hmf_stem_conv_pool: packed weights must be 16-byte aligned");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1, PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;
+    const int th = (OH + kStemTH - 1) / kStemTH, tw = (OW + kStemTW - 1) / kStemTW;
+    const long long blocks = (long long)B * th * tw;
+    if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv_pool: too many tiles");
+    hipStream_t st = (hipStream_t)stream;
+    HMF_HIP(hipMemsetAsync(y_pooled, 0, (size_t)B * PH * PW * kStemN * sizeof(float), st));       // the identity of the max over post-ReLU values
+    ProfScope ps(9, B, st);
+    hipLaunchKernelGGL(k_stem_conv<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y_pooled, B, H, W, OH, OW, tw, th * tw, 1);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

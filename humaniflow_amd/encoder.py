@@ -96,6 +96,7 @@ class ResNetEncoder(nn.Module):
     # ---- folded inference plan ----------------------------------------------------------
     # eval-mode BatchNorm folded into the conv weight + a per-channel bias that the convolution kernel adds in its epilogue; a
     # downsample branch's bias is added to the block's last bias so that branch needs no pass of its own.
+    fuse_stem_pool = True    # stem convolution + max-pool as one launch (hmf_stem_conv_pool)
     fuse_pairs = True        # a bottleneck's last 1x1 + the next bottleneck's first 1x1 as one launch where built (hmf_conv_pair: layer1 / layer2)
     fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_dual_nhwc)
 
@@ -288,16 +289,20 @@ class ResNetEncoder(nn.Module):
         return y
 
     def _stem_hip(self, x, w_packed, bias):
-        """NCHW proxy input -> conv7x7/2 + bias + ReLU (NHWC) -> max-pool 3x3/2: two launches, no layout-conversion pass."""
+        """NCHW proxy input -> conv7x7/2 + bias + ReLU + max-pool 3x3/2 (NHWC): one launch (the pool is applied to the tiles before they leave
+        the CU; `fuse_stem_pool = False` keeps the two-launch form), no layout-conversion pass."""
         from . import _lib
         lib = _lib.load()
         B, C, H, W = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
         st = _lib.current_stream()
+        z = torch.empty((B, 64, PH, PW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        if self.fuse_stem_pool:
+            _lib.check(lib.hmf_stem_conv_pool(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), z.data_ptr(), B, C, H, W, st), 'hmf_stem_conv_pool')
+            return z
         y = torch.empty((B, 64, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         _lib.check(lib.hmf_stem_conv(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), 'hmf_stem_conv')
-        z = torch.empty((B, 64, PH, PW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
         return z
 

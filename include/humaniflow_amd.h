@@ -302,6 +302,11 @@ int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float
 long long hmf_stem_packed_floats(void);
 int hmf_stem_pack_host(const float* w, float* packed);
 int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, void* stream);
+
+/* The stem as the inference plan runs it: conv 7x7/2 + folded-BN bias + ReLU + max-pool 3x3/2/1 (models/resnet.py:141-144,203-206) in ONE launch --
+ * the pool is applied to each work-group's tile before it leaves the CU, windows shared between tiles are combined with an atomic max.
+ * y_pooled (B, PH, PW, 64) NHWC, PH = ((H-1)/2)/2 + 1; zeroed inside.  Same filters as hmf_stem_conv.  Profiler tag 9. */
+int hmf_stem_conv_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* stream);
 int hmf_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -243,6 +243,32 @@ def test_stem_conv_and_maxpool_match_float64_reference(B, H, W):
     assert torch.equal(z, F.max_pool2d(y, 3, 2, 1))              # the pool itself is exact
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 100, 76), (3, 34, 130), (1, 256, 256)])
+def test_stem_with_fused_maxpool_equals_the_two_launches(B, H, W):
+    """hmf_stem_conv_pool (pool applied per tile, shared windows by atomic max) == hmf_stem_conv + hmf_maxpool3x3s2_nhwc, bit for bit
+    (ragged tiles, odd pooled sizes, several images)."""
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, 18, H, W, generator=g).cuda()
+    w = (torch.randn(64, 18, 7, 7, generator=g) / 30).contiguous()
+    bias = torch.randn(64, generator=g).cuda()
+    packed = torch.empty(int(lib.hmf_stem_packed_floats()))
+    _lib.check(lib.hmf_stem_pack_host(w.data_ptr(), packed.data_ptr()), 'pack')
+    pk = packed.cuda()
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    st = _lib.current_stream()
+    y = torch.empty(B, OH, OW, 64, device='cuda')
+    z = torch.empty(B, PH, PW, 64, device='cuda')
+    zf = torch.full((B, PH, PW, 64), float('nan'), device='cuda')
+    _lib.check(lib.hmf_stem_conv(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'stem')
+    _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'pool')
+    _lib.check(lib.hmf_stem_conv_pool(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), zf.data_ptr(), B, 18, H, W, st), 'stem+pool')
+    torch.cuda.synchronize()
+    assert torch.equal(z, zf)
+
+
 def test_folded_encoder_matches_module_path():
     """The whole inference plan (stem + fused residual stages, ResNet-50 and ResNet-18) vs the plain nn.Module path on the same weights."""
     import humaniflow_amd as H
