@@ -90,19 +90,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     const int vz = ((m0 + 4 * lq) * N2 + li) * 4;
     const int rowC = a.C * 4;
 
-    f32x4 b3[G3], b1[TN2][8];
+    // W1 fragments of a chunk: all 8 k-groups in registers for N2 <= 128; for N2 = 256 (four 32-channel tiles per wave: 64 accumulator registers)
+    // they stream through a two-stage ring, one k-group ahead
+    constexpr bool kRing1 = TN2 > 2;
+    f32x4 b3[G3], b1[TN2][kRing1 ? 2 : 8];
     float rva[16], rvb[16];
     auto load_b3 = [&](int c) {
         const int so = (c * 2 + wn) * G3 * 1024;
 #pragma unroll
         for (int g = 0; g < G3; ++g) b3[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw3, vlane, so + g * 1024, 0));
     };
+    auto load_b1g = [&](int c, int g, int slot) {
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+            b1[j][slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw1, vlane, ((c * NT2 + wn * TN2 + j) * 8 + g) * 1024, 0));
+    };
     auto load_b1 = [&](int c) {
+        if (kRing1) {
+            load_b1g(c, 0, 0);
+        } else {
 #pragma unroll
-        for (int j = 0; j < TN2; ++j) {
-            const int so = (c * NT2 + wn * TN2 + j) * 8 * 1024;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) b1[j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw1, vlane, so + g * 1024, 0));
+            for (int g = 0; g < 8; ++g) load_b1g(c, g, g);
         }
     };
     auto load_res = [&](int c, float (&rv)[16]) {
@@ -166,11 +174,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         const float* pa2 = sY[c & 1] + ya;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
+            if (kRing1 && g + 1 < 8) load_b1g(c, g + 1, (g + 1) & 1);
             const f32x4 fa = *(const f32x4*)(pa2 + 8 * g);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < TN2; ++j) accz[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], b1[j][g][u], accz[j], 0, 0, 0);
+                for (int j = 0; j < TN2; ++j) accz[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], b1[j][kRing1 ? (g & 1) : g][u], accz[j], 0, 0, 0);
         }
     };
     for (int c = 0; c < nchunk; c += 2) {
@@ -197,7 +206,7 @@ using namespace hmf;
 //   w1p[((c * N2/32 + t) * 8 + g) * 64 + lane][u] = w1[32 t + (lane & 31)][64 c + 8 g + 4 (lane >> 5) + u]
 extern "C" int hmf_conv_pair_pack_host(const float* w3, const float* w1, float* w3p, float* w1p, int Kt, int C, int N2) {
     if (!w3 || !w1 || !w3p || !w1p) return fail(HMF_ERR_INVALID, "hmf_conv_pair_pack_host: null pointer");
-    if ((Kt != 64 && Kt != 128) || C % 64 || (N2 != 64 && N2 != 128)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair_pack_host: Kt=%d C=%d N2=%d", Kt, C, N2);
+    if ((Kt != 64 && Kt != 128) || C % 64 || (N2 != 64 && N2 != 128 && N2 != 256)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair_pack_host: Kt=%d C=%d N2=%d", Kt, C, N2);
     long long o = 0;
     for (int c = 0; c < C / 64; ++c)
         for (int wn = 0; wn < 2; ++wn)
@@ -219,8 +228,8 @@ extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_p
     if (!x1 || !w3_packed || !bias3 || !y || !w1_packed || !bias1 || !z || B <= 0 || OH <= 0 || OW <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_pair: bad args");
     if (!x2) K2 = 0;
     const int Kt = K1 + K2;
-    if ((Kt != 64 && Kt != 128) || K1 % 4 || C % 64 || (N2 != 64 && N2 != 128))
-        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair: K1+K2=%d must be 64 or 128, C=%d a multiple of 64, N2=%d 64 or 128", Kt, C, N2);
+    if ((Kt != 64 && Kt != 128) || K1 % 4 || C % 64 || (N2 != 64 && N2 != 128 && N2 != 256))
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_pair: K1+K2=%d must be 64 or 128, C=%d a multiple of 64, N2=%d 64, 128 or 256", Kt, C, N2);
     if (x2 && (stride2 < 1 || (H2 - 1) / stride2 + 1 != OH || (W2 - 1) / stride2 + 1 != OW))
         return fail(HMF_ERR_INVALID, "hmf_conv_pair: x2 %dx%d / %d does not give %dx%d", H2, W2, stride2, OH, OW);
     if (((uintptr_t)x1 & 15) || ((uintptr_t)x2 & 15) || ((uintptr_t)w3_packed & 15) || ((uintptr_t)w1_packed & 15))
@@ -240,7 +249,9 @@ extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_p
         if (Kt == 64 && N2 == 64) hipLaunchKernelGGL((k_conv_pair<64, 64, 3>), dim3(grid), dim3(256), 0, st, a);
         else if (Kt == 64 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<64, 128, 2>), dim3(grid), dim3(256), 0, st, a);
         else if (Kt == 128 && N2 == 64) hipLaunchKernelGGL((k_conv_pair<128, 64, 2>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_conv_pair<128, 128, 2>), dim3(grid), dim3(256), 0, st, a);
+        else if (Kt == 128 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<128, 128, 2>), dim3(grid), dim3(256), 0, st, a);
+        else if (Kt == 64 && N2 == 256) hipLaunchKernelGGL((k_conv_pair<64, 256, 2>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_pair<128, 256, 2>), dim3(grid), dim3(256), 0, st, a);
     } else if (Kt == 64 && N2 == 64) {           // timing experiments on the layer1 shape (tools/pair_probe.py)
         switch (variant) {
             case 1: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 1>), dim3(grid), dim3(256), 0, st, a); break;

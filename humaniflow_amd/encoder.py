@@ -181,7 +181,7 @@ class ResNetEncoder(nn.Module):
                     continue
                 wk = dual[0] if dual is not None else w3.reshape(w3.shape[0], -1)
                 C, Kt, N2 = wk.shape[0], wk.shape[1], w1.shape[0]
-                if Kt not in (64, 128) or C % 64 or N2 not in (64, 128) or C > 512 or (dual is not None and dual[2] != 1):
+                if Kt not in (64, 128) or C % 64 or N2 not in (64, 128, 256) or C > 512 or (dual is not None and dual[2] != 1):
                     continue
                 plan['pair'][i] = self._pack_pair(wk, w1.reshape(N2, C)) + (N2,)
         if self.conv1.weight.is_cuda:

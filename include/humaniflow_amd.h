@@ -261,7 +261,7 @@ int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const
  * i+1's conv1 + bn1 + ReLU) as ONE launch: y = relu([x1 | x2(strided)] . W3^T + bias3 (+ residual)) is written (the next identity branch) and
  * its 64-channel chunks feed z = relu(y . W1^T + bias1) through LDS, so the C-channel tensor y is not read back from HBM.
  * x1 (B,OH,OW,K1); x2 (B,H2,W2,K2) or NULL (then K2 is ignored); K1 + K2 in {64, 128}; y/residual (B,OH,OW,C), C % 64 == 0; z (B,OH,OW,N2),
- * N2 in {64, 128}; B*OH*OW % 64 == 0.  Filters packed by hmf_conv_pair_pack_host (w3 (C, K1+K2) and w1 (N2, C) row-major, BN folded) into
+ * N2 in {64, 128, 256}; B*OH*OW % 64 == 0.  Filters packed by hmf_conv_pair_pack_host (w3 (C, K1+K2) and w1 (N2, C) row-major, BN folded) into
  * C*(K1+K2) and N2*C floats of MFMA lane order.  variant: 0 (others are timing experiments of tools/pair_probe.py that compute wrong results).
  * Profiler tag 8. */
 int hmf_conv_pair_pack_host(const float* w3, const float* w1, float* w3_packed, float* w1_packed, int Kt, int C, int N2);

@@ -39,7 +39,7 @@ def test_seam_pair_pack_is_the_documented_permutation():
     """hmf_conv_pair_pack_host: both filters of a bottleneck seam in B-operand lane order per (64-channel chunk, n-tile, k-group)."""
     lib = _lib.load()
     g = torch.Generator().manual_seed(2)
-    for kt, C, n2 in [(64, 256, 64), (128, 512, 128), (128, 64, 64), (64, 128, 128)]:
+    for kt, C, n2 in [(64, 256, 64), (128, 512, 128), (128, 64, 64), (64, 128, 128), (128, 512, 256)]:
         w3, w1 = torch.randn(C, kt, generator=g), torch.randn(n2, C, generator=g)
         p3, p1 = torch.empty_like(w3), torch.empty_like(w1)
         _lib.check(lib.hmf_conv_pair_pack_host(w3.data_ptr(), w1.data_ptr(), p3.data_ptr(), p1.data_ptr(), kt, C, n2), 'pack')
@@ -48,4 +48,4 @@ def test_seam_pair_pack_is_the_documented_permutation():
         b = p1.reshape(C // 64, n2 // 32, 8, 2, 32, 4)                    # [c][t][g][q][j][u] = w1[32t + j][64c + 8g + 4q + u]
         assert torch.equal(b.permute(1, 4, 0, 2, 3, 5).reshape(n2, C), w1)
     assert lib.hmf_conv_pair_pack_host(w3.data_ptr(), w1.data_ptr(), p3.data_ptr(), p1.data_ptr(), 96, 64, 64) < 0       # K must be 64 or 128
-    assert lib.hmf_conv_pair_pack_host(w3.data_ptr(), w1.data_ptr(), p3.data_ptr(), p1.data_ptr(), 64, 64, 256) < 0      # N2 must be 64 or 128
+    assert lib.hmf_conv_pair_pack_host(w3.data_ptr(), w1.data_ptr(), p3.data_ptr(), p1.data_ptr(), 64, 64, 96) < 0       # N2 must be 64, 128 or 256

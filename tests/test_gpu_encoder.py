@@ -150,7 +150,8 @@ def test_bottleneck_seam_pair_matches_float64_reference():
     lib = _lib.load()
     g = torch.Generator().manual_seed(11)
     for B, OH, OW, k1, k2, s2, C, n2, res in [(2, 8, 8, 64, 0, 1, 256, 64, True), (1, 16, 8, 64, 64, 1, 256, 64, False), (3, 8, 8, 128, 0, 1, 512, 128, True),
-                                              (2, 8, 16, 64, 0, 1, 256, 128, True), (2, 8, 8, 64, 64, 2, 128, 128, False), (1, 8, 8, 128, 0, 1, 64, 64, False)]:
+                                              (2, 8, 16, 64, 0, 1, 256, 128, True), (2, 8, 8, 64, 64, 2, 128, 128, False), (1, 8, 8, 128, 0, 1, 64, 64, False),
+                                              (2, 8, 8, 128, 0, 1, 512, 256, True), (1, 8, 8, 64, 0, 1, 128, 256, False)]:
         H2, W2 = (OH - 1) * s2 + 1 + (s2 - 1), (OW - 1) * s2 + 1 + (s2 - 1)
         h = torch.randn(B, k1, OH, OW, generator=g)
         x2 = torch.randn(B, k2, H2, W2, generator=g) if k2 else None
@@ -197,11 +198,11 @@ def test_encoder_seam_fusion_equals_separate_launches():
     enc._conv_pair = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
     with torch.no_grad():
         a = enc(x)
-        assert len(enc._plan['pair']) == 5 and len(calls) == 5          # layer1: 3 seams (the first with the downsample branch), layer2: 2
+        assert len(enc._plan['pair']) == 6 and len(calls) == 6          # layer1: 3 seams (the first with the downsample branch), layer2: 3
         saved, enc._plan['pair'] = enc._plan['pair'], {}
         b = enc(x)
         enc._plan['pair'] = saved
-        assert len(calls) == 5
+        assert len(calls) == 6
     # (the fused kernel walks K in the same order as the separate launches: the results are usually bitwise equal)
     assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
 

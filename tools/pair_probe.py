@@ -25,7 +25,8 @@ def timeit(fn, iters=50):
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 for name, hw, k1, k2, C, n2, res in (('layer1.0->1 (+downsample)', 64, 64, 64, 256, 64, False), ('layer1.1->2', 64, 64, 0, 256, 64, True),
-                                     ('layer1.2->layer2.0', 64, 64, 0, 256, 128, True), ('layer2.1->2', 32, 128, 0, 512, 128, True)):
+                                     ('layer1.2->layer2.0', 64, 64, 0, 256, 128, True), ('layer2.1->2', 32, 128, 0, 512, 128, True),
+                                     ('layer2.3->layer3.0', 32, 128, 0, 512, 256, True)):
     h = torch.randn(B, k1, hw, hw, device=dev).contiguous(memory_format=CL)
     x2 = torch.randn(B, k2, hw, hw, device=dev).contiguous(memory_format=CL) if k2 else None
     w3 = torch.randn(C, k1 + k2) / (k1 + k2) ** 0.5
