@@ -288,11 +288,6 @@ int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout
 int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                       int Cin, int Cout, int relu, void* stream);
 
-/* Timing experiments on the same kernel (tools/winograd_ablate.py): variant 0 = hmf_conv_winograd; 10 = three waves per SIMD; 20 = the input
- * transform of k-group g+1 issued with the MFMAs of group g; 1 / 2 / 3 / 13 drop the patch fetch and / or the output transform and compute
- * WRONG results.  Not used by the product path. */
-int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
-                              int Cin, int Cout, int relu, int variant, void* stream);
 
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
  * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.
