@@ -43,29 +43,40 @@ def _conv_raw(x, w_cl, stride, residual=None):
 _PATCH_MAPS = {}
 
 
-def _patch_packed(w4, cfg):
+def _patch_packed(w4, cfg, native=None):
     """Packed B operand of hmf_conv_patch for a (Cout, Cin, 3, 3) filter, built on the device: the host packer only permutes, so packing an
-    index-valued array once per (shape, cfg, device) gives a gather map (the filters change every optimiser step)."""
+    index-valued array once per (shape, cfg, device) gives a gather map (the filters change every optimiser step).
+    native = (parameter, dgrad): w4 is the parameter itself (dgrad False) or its flipped, in/out-transposed view (dgrad True); the map is then
+    composed with that view, so ONE gather reads the parameter's own storage (no permute / flip copy first)."""
     lib = _lib.load()
     Cout, Cin = w4.shape[:2]
-    key = (Cin, Cout, cfg, str(w4.device))
+    mode = 0 if native is None else (2 if native[1] else 1)
+    key = (Cin, Cout, cfg, str(w4.device), mode)
     m = _PATCH_MAPS.get(key)
     if m is None:
         n = Cout * 9 * Cin
         idx = torch.arange(n, dtype=torch.float32)
         packed = torch.empty(int(lib.hmf_conv_patch_packed_floats(Cin, Cout, 3)), dtype=torch.float32)
         _lib.check(lib.hmf_conv_patch_pack_host(idx.data_ptr(), packed.data_ptr(), Cin, Cout, 3, cfg), 'hmf_conv_patch_pack_host')
-        m = _PATCH_MAPS[key] = packed.long().to(w4.device)
+        m = packed.long()                                              # position in (Cout, kh, kw, Cin) order
+        if mode:
+            src = torch.arange(n).reshape(native[0].shape)             # flat position in the parameter's (out, in, 3, 3) storage
+            if mode == 2:
+                src = src.flip(2, 3).transpose(0, 1)
+            m = src.permute(0, 2, 3, 1).reshape(-1)[m]
+        m = _PATCH_MAPS[key] = m.to(w4.device)
+    if mode:
+        return native[0].detach().reshape(-1)[m]
     return w4.permute(0, 2, 3, 1).reshape(-1)[m]                      # (Cout, kh, kw, Cin) order, gathered into MFMA lane order
 
 
-def _conv3x3_patch(x, w4, stride, residual=None):
+def _conv3x3_patch(x, w4, stride, residual=None, native=None):
     """Bias-free 3x3 convolution on the patch-resident kernel (2x the implicit-GEMM rate on these shapes): w4 (Cout, Cin, 3, 3), any memory format."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
     Cout = w4.shape[0]
     cfg = 8210 if (stride == 2 or Cin != 64) else 16410
-    packed = _patch_packed(w4, cfg)
+    packed = _patch_packed(w4, cfg, native)
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = _cl_empty(B, Cout, OH, OW, x.device)
     _lib.check(lib.hmf_conv_patch(x.data_ptr(), packed.data_ptr(), None, None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W,
@@ -73,24 +84,39 @@ def _conv3x3_patch(x, w4, stride, residual=None):
     return y
 
 
-def _conv_any(x, w4, stride, residual=None):
-    """Bias-free convolution, filter given in the parameter's (Cout, Cin, k, k) shape (any strides)."""
+def _conv_any(x, w4, stride, residual=None, native=None):
+    """Bias-free convolution, filter given in the parameter's (Cout, Cin, k, k) shape (any strides).  native: see _patch_packed."""
     if w4.shape[2] == 3 and x.shape[1] % 64 == 0 and w4.shape[0] % 64 == 0:
-        return _conv3x3_patch(x, w4, stride, residual)
+        return _conv3x3_patch(x, w4, stride, residual, native if (native is not None and native[0].is_contiguous()) else None)
     return _conv_raw(x, w4.contiguous(memory_format=CL), stride, residual)
+
+
+class _ZeroPool:
+    """fp64 accumulators of the BatchNorm reductions of one pass: one zero-filled buffer, handed out in (2, C) slices (one fill launch per pass
+    instead of one per BatchNorm)."""
+
+    def __init__(self, enc, device):
+        n = sum(2 * m.num_features for m in enc.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        self.buf, self.o = torch.zeros(n, dtype=torch.float64, device=device), 0
+
+    def take(self, C):
+        v = self.buf[self.o:self.o + 2 * C].view(2, C)
+        self.o += 2 * C
+        return v
 
 
 class _Saved:
     __slots__ = ('conv', 'bn', 'x', 'y', 'out', 'mean', 'rstd', 'relu', 'stride', 'stem')
 
 
-def _bn_forward(y, bn, residual, relu):
-    """Training-mode BatchNorm on the NHWC rows of y, running statistics updated in place.  Returns (out, mean, rstd)."""
+def _bn_forward(y, bn, residual, relu, pool=None, tracked=None):
+    """Training-mode BatchNorm on the NHWC rows of y, running statistics updated in place.  Returns (out, mean, rstd).
+    pool: _ZeroPool for the fp64 sums; tracked: list collecting num_batches_tracked tensors for ONE batched increment by the caller."""
     lib = _lib.load()
     B, C, H, W = y.shape
     M = B * H * W
     dev = y.device
-    acc = torch.zeros(2, C, dtype=torch.float64, device=dev)
+    acc = pool.take(C) if pool is not None else torch.zeros(2, C, dtype=torch.float64, device=dev)
     st = _lib.current_stream()
     _lib.check(lib.hmf_bn_stats(y.data_ptr(), M, C, acc.data_ptr(), st), 'hmf_bn_stats')
     mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
@@ -100,21 +126,24 @@ def _bn_forward(y, bn, residual, relu):
                                    bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                    mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st), 'hmf_bn_finalize')
     if track and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if tracked is not None:
+            tracked.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
     out = _cl_empty(B, C, H, W, dev)
     _lib.check(lib.hmf_bn_apply(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if residual is None else residual.data_ptr(), out.data_ptr(),
                                 M, C, int(relu), st), 'hmf_bn_apply')
     return out, mean, rstd
 
 
-def _bn_backward(g, s, want_gz):
+def _bn_backward(g, s, want_gz, pool=None):
     """g = dL/d out of unit s -> (gy = dL/d conv output, gz or None, d gamma, d beta)."""
     lib = _lib.load()
     B, C, H, W = s.y.shape
     M = B * H * W
     dev = g.device
     st = _lib.current_stream()
-    acc = torch.zeros(2, C, dtype=torch.float64, device=dev)
+    acc = pool.take(C) if pool is not None else torch.zeros(2, C, dtype=torch.float64, device=dev)
     out_ptr = s.out.data_ptr() if s.relu else None
     _lib.check(lib.hmf_bn_bwd_reduce(g.data_ptr(), out_ptr, s.y.data_ptr(), s.mean.data_ptr(), s.rstd.data_ptr(), M, C, int(s.relu), acc.data_ptr(), st),
                'hmf_bn_bwd_reduce')
@@ -149,8 +178,9 @@ def _dgrad(gy, s, residual=None):
     ks = w.shape[2]
     wt = w.flip(2, 3).transpose(0, 1) if ks > 1 else w.transpose(0, 1)          # (Cin, Cout, k, k) view: flipped, in/out swapped
     B, Cin, H, W = s.x.shape
+    nat = (s.conv.weight, True)
     if s.stride == 1:
-        return _conv_any(gy, wt, 1, residual)
+        return _conv_any(gy, wt, 1, residual, native=nat)
     if ks == 1:                                                       # strided 1x1 (downsample branch): only the sampled pixels receive gradient
         gx = torch.zeros((B, Cin, H, W), device=gy.device, dtype=torch.float32).contiguous(memory_format=CL) if residual is None else residual.clone()
         c = _conv_any(gy, wt, 1)
@@ -158,7 +188,7 @@ def _dgrad(gy, s, residual=None):
         return gx
     gd = torch.zeros((B, gy.shape[1], H, W), device=gy.device, dtype=torch.float32).contiguous(memory_format=CL)    # zero-inserted gradient map
     gd[:, :, ::s.stride, ::s.stride] = gy
-    return _conv_any(gd, wt, 1, residual)
+    return _conv_any(gd, wt, 1, residual, native=nat)
 
 
 class EncoderTrainFn(torch.autograd.Function):
@@ -167,6 +197,7 @@ class EncoderTrainFn(torch.autograd.Function):
         lib = _lib.load()
         dev = x.device
         saved = []
+        pool, tracked = _ZeroPool(enc, dev), []
 
         def unit(conv, bn, xin, relu, residual=None, stem=False):
             s = _Saved()
@@ -178,8 +209,8 @@ class EncoderTrainFn(torch.autograd.Function):
                 s.y = _cl_empty(B, 64, OH, OW, dev)
                 _lib.check(lib.hmf_stem_conv(xin.data_ptr(), packed.data_ptr(), None, s.y.data_ptr(), B, C, H, W, 0, _lib.current_stream()), 'hmf_stem_conv')
             else:
-                s.y = _conv_any(xin, conv.weight.detach(), s.stride)
-            s.out, s.mean, s.rstd = _bn_forward(s.y, bn, residual, relu)
+                s.y = _conv_any(xin, conv.weight.detach(), s.stride, native=(conv.weight, False))
+            s.out, s.mean, s.rstd = _bn_forward(s.y, bn, residual, relu, pool, tracked)
             saved.append(s)
             return s.out
 
@@ -205,6 +236,8 @@ class EncoderTrainFn(torch.autograd.Function):
                     cur = unit(conv, bn, h, True, residual=idt)
                     plan.append((first, len(saved), blk.downsample is not None))
             feats = cur.mean(dim=(2, 3))
+            if tracked:
+                torch._foreach_add_(tracked, 1)
         ctx.enc, ctx.saved, ctx.plan, ctx.a0, ctx.final_shape = enc, saved, plan, a0, tuple(cur.shape)
         ctx.param_ids = [id(p) for p in params]
         return feats
@@ -216,6 +249,7 @@ class EncoderTrainFn(torch.autograd.Function):
         grads = {}
         dev = g_feats.device
         with torch.cuda.device(dev), torch.no_grad():
+            pool = _ZeroPool(enc, dev)
             B, C, H, W = ctx.final_shape
             g = (g_feats.detach().float() / (H * W))[:, :, None, None].expand(B, C, H, W).contiguous(memory_format=CL)
             for first, last, has_ds in reversed(plan):
@@ -224,7 +258,7 @@ class EncoderTrainFn(torch.autograd.Function):
                 main = units[1:] if has_ds else units
                 # last unit of the block: out = relu(bn(conv(h)) + idt)
                 s = main[-1]
-                gy, gz, gg, gb = _bn_backward(g, s, want_gz=True)
+                gy, gz, gg, gb = _bn_backward(g, s, want_gz=True, pool=pool)
                 grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
                 grads[id(s.conv.weight)] = _wgrad(gy, s)
                 g_idt = gz                                            # gradient of the identity branch (masked by the block's ReLU)
@@ -232,12 +266,12 @@ class EncoderTrainFn(torch.autograd.Function):
                 g_h = _dgrad(gy, s, residual=g_idt if (only and ds is None) else None)
                 for k in range(len(main) - 2, -1, -1):
                     s = main[k]
-                    gy, _, gg, gb = _bn_backward(g_h, s, want_gz=False)
+                    gy, _, gg, gb = _bn_backward(g_h, s, want_gz=False, pool=pool)
                     grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
                     grads[id(s.conv.weight)] = _wgrad(gy, s)
                     g_h = _dgrad(gy, s, residual=g_idt if (k == 0 and ds is None) else None)     # block input: main path + identity in one launch
                 if ds is not None:
-                    gy, _, gg, gb = _bn_backward(g_idt, ds, want_gz=False)
+                    gy, _, gg, gb = _bn_backward(g_idt, ds, want_gz=False, pool=pool)
                     grads[id(ds.bn.weight)], grads[id(ds.bn.bias)] = gg, gb
                     grads[id(ds.conv.weight)] = _wgrad(gy, ds)
                     g_h = _dgrad(gy, ds, residual=g_h)
@@ -249,7 +283,7 @@ class EncoderTrainFn(torch.autograd.Function):
             _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(a0.data_ptr(), g.data_ptr(), g_a0.data_ptr(), B, H, W, C, _lib.current_stream()),
                        'hmf_maxpool3x3s2_nhwc_backward')
             s = saved[0]
-            gy, _, gg, gb = _bn_backward(g_a0, s, want_gz=False)
+            gy, _, gg, gb = _bn_backward(g_a0, s, want_gz=False, pool=pool)
             grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
             grads[id(s.conv.weight)] = _wgrad(gy, s)
         ctx.saved = None
