@@ -52,9 +52,14 @@ class HumaniflowLoss(nn.Module):
         pred_joints2D = pred_dict['joints2D']
         target_joints2D = target_dict['joints2D'][:, None, :, :].expand_as(pred_joints2D)
         vis = target_dict['joints2D_vis'][:, None, :].expand(-1, pred_joints2D.shape[1], -1)
-        pred_joints2D = pred_joints2D[vis, :]
-        target_joints2D = (2.0 * target_joints2D[vis, :]) / self.img_wh - 1.0
-        joints2D_loss = self.joints2D_loss(pred_joints2D, target_joints2D)
+        # the reference compacts the visible joints with a boolean index (a host synchronisation for the count) and applies nn.MSELoss;
+        # the same value as a masked reduction stays on the device (and inside a captured HIP graph)
+        d2 = (pred_joints2D - ((2.0 * target_joints2D) / self.img_wh - 1.0)) ** 2 * vis[..., None].to(pred_joints2D.dtype)
+        joints2D_loss = d2.sum()
+        if cfg.REDUCTION == 'mean':
+            joints2D_loss = joints2D_loss / (vis.sum() * d2.shape[-1]).clamp(min=1).to(pred_joints2D.dtype)
+        elif cfg.REDUCTION != 'sum':
+            raise NotImplementedError("humaniflow_amd: LOSS.REDUCTION '%s' for the 2D-joint term (mean / sum are built)" % cfg.REDUCTION)
         glob_rotmats_loss = self.glob_rotmats_loss(pred_dict['glob_rotmats'], target_dict['glob_rotmats'])     # :63
         total = pose_nll * cfg.WEIGHTS.POSE + shape_nll * cfg.WEIGHTS.SHAPE + joints2D_loss * cfg.WEIGHTS.JOINTS2D \
             + glob_rotmats_loss * cfg.WEIGHTS.GLOB_ROTMATS

@@ -191,12 +191,14 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     losses, skipped = [], torch.zeros((), device=dev)
     log('train flavour: B=%d, N=%d, ResNet-%d, %d parameters (%.1f MB of gradients per step), %d ranks'
         % (B, N, args.layers, sum(p.numel() for p in params), sum(p.numel() for p in params) * 4 / 2 ** 20, world))
+    def run_step(k):
+        return train_step(model, smpl, criterion, optimiser, reducer, *batches[k % NB], N)
     for k in range(args.warmup):
-        train_step(model, smpl, criterion, optimiser, reducer, *batches[k % NB], N)
+        run_step(k)
     dist_sync(dist, dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        loss, sk = train_step(model, smpl, criterion, optimiser, reducer, *batches[(args.warmup + k) % NB], N)
+        loss, sk = run_step(args.warmup + k)
         losses.append(loss)
         skipped = skipped + sk
     metric_vec = torch.stack([torch.stack(losses).double().mean(), skipped.double().reshape(())])
@@ -273,7 +275,7 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[4] train step: B=%d synthetic on-the-fly SMPL batch, N=%d reparameterised samples, ResNet-%d + flow + SMPL joints, '
                                    'HumaniflowLoss (pose NLL + shape NLL + 2D reprojection + global rotation), Adam' % (B, N, args.layers),
-                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world,
+                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'issue': 'eager, no host synchronisation inside a step',
                        'exchange': ('gradient all-reduce over RCCL, %d buckets of <= 25 MB, launched from gradient-ready hooks' % len(reducer.buckets))
                        if world > 1 else 'none'},
             'rccl_ranks_seen': int(gathered.shape[0]), 'mean_loss': float(gathered[:, 0].mean()), 'skipped_steps': int(gathered[:, 1].sum()),
