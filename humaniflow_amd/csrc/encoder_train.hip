@@ -654,7 +654,7 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
         int slices = std::max(1, std::min(w.nchunks, (256 * 3 + kblocks - 1) / kblocks));
         w.chunks_per_slice = (w.nchunks + slices - 1) / slices;
         slices = (w.nchunks + w.chunks_per_slice - 1) / w.chunks_per_slice;
-        HMF_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * w.K * sizeof(float), st));
+        if (int zr = zero_async(dw, (size_t)Cout * w.K * sizeof(float), st)) return zr;
         hipLaunchKernelGGL(k_stem_wgrad, dim3(kblocks, slices), dim3(256), 0, st, w);
         HMF_LAUNCH_CHECK();
         return HMF_OK;
@@ -673,7 +673,7 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
             int slices = std::max(1, std::min(w.nchunks, (256 * 3 + tiles - 1) / tiles));
             w.chunks_per_slice = (w.nchunks + slices - 1) / slices;
             slices = (w.nchunks + w.chunks_per_slice - 1) / w.chunks_per_slice;
-            HMF_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * 9 * Cin * sizeof(float), st));
+            if (int zr = zero_async(dw, (size_t)Cout * 9 * Cin * sizeof(float), st)) return zr;
             if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad3<1>, dim3(tiles, slices), dim3(256), 0, st, w);
             else hipLaunchKernelGGL(k_conv_wgrad3<2>, dim3(tiles, slices), dim3(256), 0, st, w);
             HMF_LAUNCH_CHECK();
@@ -687,7 +687,7 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
     int slices = std::max(1, std::min((int)((M + 255) / 256), (256 * 6 + tiles - 1) / tiles));
     a.rows_per_slice = (int)(((M + slices - 1) / slices + 31) / 32 * 32);
     slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
-    HMF_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * a.K * sizeof(float), st));
+    if (int zr = zero_async(dw, (size_t)Cout * a.K * sizeof(float), st)) return zr;
     if (stem_nchw) hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(tiles, slices), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(tiles, slices), dim3(256), 0, st, a);
     HMF_LAUNCH_CHECK();

@@ -41,6 +41,11 @@ struct ProfScope {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Zero `bytes` (a multiple of 4, pointer 4-byte aligned) on `st` with a KERNEL.  hipMemsetAsync is not used by this library: captured into a HIP
+// graph (torch.cuda.graph) its memset node was observed not to clear the buffer on later replays (ROCm 7.2) -- the pooled stem map and the
+// weight-gradient accumulators then carried the previous replay's values into their atomic updates.
+int zero_async(void* ptr, size_t bytes, hipStream_t st);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

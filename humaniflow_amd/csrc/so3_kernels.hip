@@ -1,6 +1,8 @@
 // Standalone element-wise SO(3) kernels (one rotation per lane) + error plumbing of the C ABI.
 // They back humaniflow_amd/rigid_transform_utils.py; the fused flow kernels inline the same
 // device functions from so3_math.h.
+#include <algorithm>
+#include <cstdint>
 #include "hmf_common.h"
 #include "so3_math.h"
 
@@ -17,6 +19,20 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(err_buf(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+__global__ __launch_bounds__(256) void k_zero(unsigned int* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
+int zero_async(void* ptr, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return HMF_OK;
+    if (!ptr || (bytes & 3) || ((uintptr_t)ptr & 3)) return fail(HMF_ERR_INVALID, "zero_async: %zu bytes at %p (4-byte granularity)", bytes, ptr);
+    const size_t n = bytes / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, st, (unsigned int*)ptr, n);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
 }
 
 // ---- per-launch event timing --------------------------------------------------------------------

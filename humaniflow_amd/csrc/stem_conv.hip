@@ -239,7 +239,7 @@ extern "C" int hmf_stem_conv_pool(const float* x, const float* w_packed, const f
     const long long blocks = (long long)B * th * tw;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_stem_conv_pool: too many tiles");
     hipStream_t st = (hipStream_t)stream;
-    HMF_HIP(hipMemsetAsync(y_pooled, 0, (size_t)B * PH * PW * kStemN * sizeof(float), st));       // the identity of the max over post-ReLU values
+    if (int zr = zero_async(y_pooled, (size_t)B * PH * PW * kStemN * sizeof(float), st)) return zr;       // the identity of the max over post-ReLU values
     ProfScope ps(9, B, st);
     hipLaunchKernelGGL(k_stem_conv<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y_pooled, B, H, W, OH, OW, tw, th * tw, 1);
     HMF_LAUNCH_CHECK();

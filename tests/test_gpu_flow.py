@@ -410,3 +410,42 @@ def test_in_place_weight_updates_repack_on_the_device():
     with torch.no_grad():
         again = m2(None, input_feats=feats.cuda(), num_samples=N, noise=noise)['pose_rotmats_samples']
     assert torch.equal(again, fresh)
+
+
+def test_hip_graph_replay_of_the_whole_step_equals_eager_issue():
+    """bench.py replays one captured HIP graph per batch: the replayed step (encoder -> heads -> flow -> fused SMPL launch, with the base
+    noise supplied so that both runs draw the same samples) returns bit-identical tensors to the eagerly issued step, replay after replay."""
+    import humaniflow_amd as H
+    from humaniflow_amd.synthetic import init_benchmark_weights, synthetic_proxy_input
+    cfg = H.get_humaniflow_cfg_defaults()
+    torch.manual_seed(0)
+    dev = torch.device('cuda')
+    model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).eval().to(dev)
+    B, N = 4, 6
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=B, create_transl=False).to(dev)
+    x = synthetic_proxy_input(B, 256, seed=3).to(dev)
+    g = torch.Generator().manual_seed(9)
+    noise = {'shape': torch.randn(N, B, 10, generator=g).to(dev), 'pose': torch.randn(23, B, N, 3, generator=g).to(dev)}
+
+    def step():
+        with torch.no_grad():
+            pred = model(x, num_samples=N, noise=noise)
+            pe, sa = smpl.forward_samples_and_point_est(pred)
+            return sa.vertices, sa.joints, pe.vertices, pred['pose_rotmats_samples'], pred['shape_samples']
+    ref = [t.clone() for t in step()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        outs = step()
+    for _ in range(3):
+        for t in outs:
+            t.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        diffs = [float((a - b).abs().max()) if torch.isfinite(b).all() else float('nan') for a, b in zip(ref, outs)]
+        assert all(torch.equal(a, b) for a, b in zip(ref, outs)), diffs
