@@ -182,7 +182,8 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
         p.requires_grad_(False)
     criterion = HumaniflowLoss(cfg.LOSS, cfg.DATA.PROXY_REP_SIZE)
     params = [p for p in model.parameters() if p.requires_grad]
-    optimiser = torch.optim.Adam(params, lr=cfg.TRAIN.LR, fused=True)          # one multi-tensor launch instead of ~10 tiny ones per parameter
+    use_graph = world == 1 and not args.no_graph                        # one captured HIP graph per distinct batch (single GPU; the RCCL hooks stay eager)
+    optimiser = torch.optim.Adam(params, lr=cfg.TRAIN.LR, fused=True, capturable=use_graph)   # one multi-tensor launch instead of ~10 tiny ones per parameter
     reducer = GradBucketReducer(params, dist if world > 1 else None)
     B, N = args.batch, args.samples
     NB = max(1, args.batches)
@@ -191,7 +192,37 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     losses, skipped = [], torch.zeros((), device=dev)
     log('train flavour: B=%d, N=%d, ResNet-%d, %d parameters (%.1f MB of gradients per step), %d ranks'
         % (B, N, args.layers, sum(p.numel() for p in params), sum(p.numel() for p in params) * 4 / 2 ** 20, world))
+    graphs = None
+    if use_graph:
+        # whole-step capture: forward + loss + backward + device-side finite check + fused Adam are ONE graph per batch (the step has no host
+        # synchronisation, so its ~1,000 launches can be replayed instead of issued)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for k in range(max(3, NB)):
+                train_step(model, smpl, criterion, optimiser, reducer, *batches[k % NB], N)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        try:
+            graphs = []
+            for i in range(NB):
+                g = torch.cuda.CUDAGraph()
+                optimiser.zero_grad(set_to_none=True)
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    out = train_step(model, smpl, criterion, optimiser, reducer, *batches[i], N)
+                graphs.append((g, out))
+            torch.cuda.synchronize()
+            log('captured %d training-step graphs' % NB)
+        except Exception as e:                                          # eager issue instead, and say so in the JSON line
+            log('training-step graph capture failed (%r): eager steps' % (e,))
+            graphs = None
+            torch.cuda.synchronize()
+
     def run_step(k):
+        if graphs is not None:
+            g, out = graphs[k % NB]
+            g.replay()
+            return out[0].clone(), out[1].clone()
         return train_step(model, smpl, criterion, optimiser, reducer, *batches[k % NB], N)
     for k in range(args.warmup):
         run_step(k)
@@ -275,7 +306,7 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[4] train step: B=%d synthetic on-the-fly SMPL batch, N=%d reparameterised samples, ResNet-%d + flow + SMPL joints, '
                                    'HumaniflowLoss (pose NLL + shape NLL + 2D reprojection + global rotation), Adam' % (B, N, args.layers),
-                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'issue': 'eager, no host synchronisation inside a step',
+                       'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'issue': 'HIP graph replay (one captured training-step graph per batch)' if graphs is not None else 'eager, no host synchronisation inside a step',
                        'exchange': ('gradient all-reduce over RCCL, %d buckets of <= 25 MB, launched from gradient-ready hooks' % len(reducer.buckets))
                        if world > 1 else 'none'},
             'rccl_ranks_seen': int(gathered.shape[0]), 'mean_loss': float(gathered[:, 0].mean()), 'skipped_steps': int(gathered[:, 1].sum()),
