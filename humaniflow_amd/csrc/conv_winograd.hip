@@ -241,6 +241,46 @@ extern "C" int hmf_conv_winograd_pack_host(const float* w /*[Cout][3][3][Cin]*/,
     return HMF_OK;
 }
 
+// The same packing on the device, from a parameter's NATIVE (out, in, 3, 3) storage (training: the filters change every optimiser step).
+// dgrad = 0: the convolution's own filter f[n][p][q][c] = w[n][c][p][q]  (Cout = out, Cin = in);
+// dgrad = 1: the input-gradient filter (flipped, in/out swapped) f[n][p][q][c] = w[c][n][2-p][2-q]  (Cout = in, Cin = out of the parameter).
+namespace hmf {
+__global__ __launch_bounds__(256) void k_wino_pack_device(const float* __restrict__ w, float* __restrict__ packed, int Cin, int Cout, int dgrad, long long total) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    // o = (((((t * 4 + xi) * nslab + s) * 8 + g) * 4 + nu) * 64 + l) * 4 + u
+    const int nslab = Cin / kWSC;
+    long long r = o;
+    const int u = (int)(r & 3); r >>= 2;
+    const int l = (int)(r & 63); r >>= 6;
+    const int nu = (int)(r & 3); r >>= 2;
+    const int g = (int)(r & 7); r >>= 3;
+    const int s = (int)(r % nslab); r /= nslab;
+    const int xi = (int)(r & 3);
+    const int t = (int)(r >> 2);
+    const int n = 32 * t + (l & 31), c = s * kWSC + 8 * g + 4 * (l >> 5) + u;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    float acc = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float wv = dgrad ? w[(((long long)c * Cout + n) * 3 + (2 - p)) * 3 + (2 - q)] : w[(((long long)n * Cin + c) * 3 + p) * 3 + q];
+            acc = fmaf(G[xi][p] * G[nu][q], wv, acc);
+        }
+    packed[o] = acc;
+}
+}  // namespace hmf
+
+extern "C" int hmf_conv_winograd_pack_device(const float* w_native, float* packed, int Cin, int Cout, int dgrad, void* stream) {
+    if (!w_native || !packed) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_pack_device: null pointer");
+    if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd_pack_device: Cin=%d %% 64 or Cout=%d %% 32", Cin, Cout);
+    const long long total = (long long)Cout * 16 * Cin;
+    hipLaunchKernelGGL(k_wino_pack_device, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_native, packed, Cin, Cout, dgrad, total);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
 extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }
 
 static int conv_winograd_impl(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,

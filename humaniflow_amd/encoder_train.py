@@ -4,14 +4,15 @@ What `ResNetEncoder.forward` runs in train() mode under autograd (train/train_hu
 models/resnet.py).  One `torch.autograd.Function` spans the whole encoder, so no per-layer autograd bookkeeping happens between launches:
 
   forward, per conv + BN (+ ReLU) (+ residual) unit
-      y    = conv(x, W)                    hmf_conv2d_nhwc (1x1 / 3x3, natural channels_last filters) | hmf_stem_conv (7x7/2, filters re-packed on the device)
+      y    = conv(x, W)                    hmf_conv_winograd (stride-1 3x3: G W G^T rebuilt on the device each step) | hmf_conv_patch (stride-2 3x3) |
+                                           hmf_conv2d_nhwc (1x1) | hmf_stem_conv (7x7/2, filters re-packed on the device)
       stats                                hmf_bn_stats + hmf_bn_finalize (mean, rstd, scale, shift; running statistics updated as nn.BatchNorm2d does)
       out  = relu?(scale y + shift (+ idt)) hmf_bn_apply
   backward, per unit (g = dL/d out)
       gz = g * (out > 0); sums            hmf_bn_bwd_reduce + hmf_bn_bwd_finalize (d gamma, d beta, coefficients)
       gy = a gz + b y + c                  hmf_bn_bwd_apply (also emits gz = the identity branch's gradient)
       dW                                   hmf_conv_wgrad (MFMA GEMM over the pixel axis; the stem reads the NCHW input directly)
-      dx                                   hmf_conv2d_nhwc with the flipped / transposed filter (stride-2 layers: zero-inserted gradient map);
+      dx                                   the forward kernels with the flipped / transposed filter (stride-2 layers: zero-inserted gradient map);
                                            the identity branch's gradient rides in that launch's residual epilogue
   max-pool: hmf_maxpool3x3s2_nhwc / hmf_maxpool3x3s2_nhwc_backward; global average pool: torch mean / broadcast (B x C values).
 Filter re-layouts (flip, transpose, channels_last) are small torch copies per step (the filters total 45-94 MB).
@@ -84,8 +85,28 @@ def _conv3x3_patch(x, w4, stride, residual=None, native=None):
     return y
 
 
+def _conv3x3_winograd(x, native, residual=None):
+    """Bias-free stride-1 3x3 convolution on the Winograd F(2x2,3x3) kernel (1.6-1.8x the patch kernel at B = 72): the transformed filters
+    G g G^T are rebuilt on the device from the parameter's own storage (hmf_conv_winograd_pack_device), for the layer itself or, with
+    native = (parameter, True), for its input-gradient convolution."""
+    lib = _lib.load()
+    param, dgrad = native
+    B, Cin, H, W = x.shape
+    Cout = param.shape[1] if dgrad else param.shape[0]
+    st = _lib.current_stream()
+    packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(Cin, Cout)), dtype=torch.float32, device=x.device)
+    _lib.check(lib.hmf_conv_winograd_pack_device(param.detach().data_ptr(), packed.data_ptr(), Cin, Cout, int(dgrad), st), 'hmf_conv_winograd_pack_device')
+    y = _cl_empty(B, Cout, H, W, x.device)
+    _lib.check(lib.hmf_conv_winograd(x.data_ptr(), packed.data_ptr(), None, None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W,
+                                     Cin, Cout, 0, st), 'hmf_conv_winograd')
+    return y
+
+
 def _conv_any(x, w4, stride, residual=None, native=None):
     """Bias-free convolution, filter given in the parameter's (Cout, Cin, k, k) shape (any strides).  native: see _patch_packed."""
+    if (w4.shape[2] == 3 and stride == 1 and native is not None and native[0].is_contiguous() and x.shape[1] % 64 == 0 and w4.shape[0] % 32 == 0
+            and (x.shape[3] >= 16 or x.shape[3] == 8)):
+        return _conv3x3_winograd(x, native, residual)
     if w4.shape[2] == 3 and x.shape[1] % 64 == 0 and w4.shape[0] % 64 == 0:
         return _conv3x3_patch(x, w4, stride, residual, native if (native is not None and native[0].is_contiguous()) else None)
     return _conv_raw(x, w4.contiguous(memory_format=CL), stride, residual)

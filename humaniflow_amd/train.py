@@ -286,7 +286,7 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
         t_w = float(ms[tag == 13].sum()) / P * 1e-3
         t_c = float(ms[(tag >= 8) & (tag <= 11)].sum()) / P * 1e-3
         fam = {'weight gradients (k_stem_wgrad, k_conv_wgrad3, k_conv_wgrad)': (f_all, t_w, int((tag == 13).sum()) // P),
-               'forward + input-gradient convolutions (k_stem_conv, k_conv_patch, k_conv_igemm)': (f_all + f_dgrad, t_c, int(((tag >= 8) & (tag <= 11)).sum()) // P)}
+               'forward + input-gradient convolutions (k_stem_conv, k_conv_winograd, k_conv_patch, k_conv_igemm)': (f_all + f_dgrad, t_c, int(((tag >= 8) & (tag <= 11)).sum()) // P)}
         name = max(fam, key=lambda k: fam[k][1])
         f, t, nl = fam[name]
         roof = {'kernel': name + ': the kernel family with the largest share of the training step (%d launches/step)' % nl, 'bound': 'mfma',
@@ -311,7 +311,7 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
                        if world > 1 else 'none'},
             'rccl_ranks_seen': int(gathered.shape[0]), 'mean_loss': float(gathered[:, 0].mean()), 'skipped_steps': int(gathered[:, 1].sum()),
             'train_images_per_s': round(world * B * args.steps / elapsed, 1), 'stages_ms': {k: round(v, 3) for k, v in stages.items()},
-            'hand_written': 'encoder training graph (conv kernels + hmf_bn_* + hmf_conv_wgrad + dgrad through hmf_conv2d_nhwc), flow forward/backward '
+            'hand_written': 'encoder training graph (conv kernels incl. Winograd with device-side filter transform + hmf_bn_* + hmf_conv_wgrad + dgrad through the forward kernels), flow forward/backward '
                             '(hmf_flow_forward, hmf_flow_log_prob_SO3[_backward], hmf_flow_sample_backward), SMPL forward + joints backward, proxy front end; '
                             'library GEMMs (torch) for the heads and the dense weight-gradient reductions of the flow',
             'roofline': roof, 'cpu_baseline': None}))

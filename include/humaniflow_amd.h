@@ -288,6 +288,11 @@ int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout
 int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                       int Cin, int Cout, int relu, void* stream);
 
+/* hmf_conv_winograd_pack_host on the device, from a parameter's native (out, in, 3, 3) storage (the training graph re-packs every step):
+ * dgrad = 0 packs the layer's own filter (Cout = out, Cin = in); dgrad = 1 packs the filter of the input-gradient convolution (flipped taps,
+ * in/out swapped: Cout = the parameter's in-channels, Cin = its out-channels).  packed: hmf_conv_winograd_packed_floats(Cin, Cout) floats. */
+int hmf_conv_winograd_pack_device(const float* w_native, float* packed, int Cin, int Cout, int dgrad, void* stream);
+
 
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
  * kernel that reads the NCHW proxy representation x (B,18,H,W) and writes the NHWC map y (B,OH,OW,64), OH = (H-1)/2+1.

@@ -161,3 +161,23 @@ def test_whole_encoder_training_graph_matches_module_autograd(layers, B, size):
         a = enc(x)
         b = enc.forward_module(x)
     assert _rel(a, b) < 1e-4
+
+
+def test_winograd_filter_pack_on_the_device_matches_the_host_packer():
+    """hmf_conv_winograd_pack_device (from the parameter's native storage, forward and input-gradient filter) vs hmf_conv_winograd_pack_host."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    for cout, cin in [(64, 64), (128, 64), (64, 256)]:
+        w = torch.randn(cout, cin, 3, 3, generator=g)
+        n = int(lib.hmf_conv_winograd_packed_floats(cin, cout))
+        for dgrad in (0, 1):
+            f = w.flip(2, 3).transpose(0, 1).contiguous() if dgrad else w               # filter of the convolution that is executed: (Cout_eff, Cin_eff, 3, 3)
+            co, ci = f.shape[:2]
+            host = torch.empty(n)
+            fh = f.permute(0, 2, 3, 1).contiguous()                                      # (Cout, kh, kw, Cin): what the host packer reads
+            _lib.check(lib.hmf_conv_winograd_pack_host(fh.data_ptr(), host.data_ptr(), ci, co), 'pack host')
+            devp = torch.full((n,), float('nan'), device='cuda')
+            wd = w.cuda()
+            _lib.check(lib.hmf_conv_winograd_pack_device(wd.data_ptr(), devp.data_ptr(), ci, co, dgrad, _lib.current_stream()), 'pack device')
+            torch.cuda.synchronize()
+            assert (devp.cpu() - host).abs().max().item() < 2e-6 * host.abs().max().item()
