@@ -292,7 +292,9 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
         roof = {'kernel': name + ': the kernel family with the largest share of the training step (%d launches/step)' % nl, 'bound': 'mfma',
                 'achieved': round(f / t / 1e12, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(f / t / 1e12 / 157.3, 4), 'traffic': None,
                 'ms_per_step': round(t * 1e3, 3), 'algorithmic_gflop_per_step': round(f / 1e9, 1),
-                'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (HIP event pair around every launch of %d extra steps)' % P,
+                'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (HIP event pair around every launch of %d extra steps); '
+                       'the stride-1 3x3 layers run as Winograd F(2x2,3x3) and are booked at direct-form FLOPs (the MFMA pipe executes 4/9 of them), '
+                       'the input gradients of stride-2 layers run on zero-inserted maps and are booked at the FLOPs of the layer' % P,
                 'families': {k: {'gflop_per_step': round(v[0] / 1e9, 1), 'ms_per_step': round(v[1] * 1e3, 3), 'tflops': round(v[0] / v[1] / 1e12, 2),
                                  'launches_per_step': v[2]} for k, v in fam.items()}}
     except Exception as e:                                              # the measurement pass must not cost the bench line
