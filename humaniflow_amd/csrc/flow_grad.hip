@@ -388,36 +388,46 @@ __global__ __launch_bounds__(256) void k_flow_logprob_bwd(FlowDev d, const float
     so3_log_f64(R, x);
     const double kTwoPi = 6.28318530717958647692;
     const double n = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    float cand[3][3], terms[3], ldexp[3];
-    bool ok[3];
+    // The three pre-images are walked by ROLLED loops (the body inlines the whole density + reverse sweep: unrolled three times it does not fit the
+    // unroller's budget, and a partly unrolled loop indexes its per-candidate arrays dynamically, which puts them in scratch memory).  Per-candidate
+    // values therefore live in named registers, selected by compare chains.
+    float c0[3] = {0.f, 0.f, 0.f}, c1[3] = {0.f, 0.f, 0.f}, c2[3] = {0.f, 0.f, 0.f};
+    float t0 = -INFINITY, t1 = -INFINITY, t2 = -INFINITY;
+    bool ok0 = true, ok1 = false, ok2 = false;
     float dummy = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         double cd[3] = {x[0], x[1], x[2]};
-        ok[c] = true;
+        bool okc = true;
         if (c > 0) {
             const double k = c == 1 ? -1.0 : 1.0;
             const double sc = (n + kTwoPi * k);
             cd[0] = x[0] / n * sc; cd[1] = x[1] / n * sc; cd[2] = x[2] / n * sc;
             const double cn = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
-            ok[c] = cn < (double)d.radius;
-            if (!ok[c]) { cd[0] = 0.0; cd[1] = 0.0; cd[2] = 0.0; }
+            okc = cn < (double)d.radius;
+            if (!okc) { cd[0] = 0.0; cd[1] = 0.0; cd[2] = 0.0; }
         }
-        ldexp[c] = -(float)so3_logdet_f64(cd);
-        cand[c][0] = (float)cd[0]; cand[c][1] = (float)cd[1]; cand[c][2] = (float)cd[2];
-        const float lp = ok[c] ? algebra_logprob(d, pt, lane, ctx_lane, cand[c], false, 0.f, dummy, G, p, 0) : 0.f;
-        terms[c] = ok[c] ? (ldexp[c] + lp) : -INFINITY;
+        const float ldc = -(float)so3_logdet_f64(cd);
+        const float cc[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
+        const float lp = okc ? algebra_logprob(d, pt, lane, ctx_lane, cc, false, 0.f, dummy, G, p, 0) : 0.f;
+        const float tc = okc ? (ldc + lp) : -INFINITY;
+        if (c == 0) { c0[0] = cc[0]; c0[1] = cc[1]; c0[2] = cc[2]; t0 = tc; ok0 = okc; }
+        else if (c == 1) { c1[0] = cc[0]; c1[1] = cc[1]; c1[2] = cc[2]; t1 = tc; ok1 = okc; }
+        else { c2[0] = cc[0]; c2[1] = cc[1]; c2[2] = cc[2]; t2 = tc; ok2 = okc; }
     }
-    const float m = fmaxf(terms[0], fmaxf(terms[1], terms[2]));
-    const float s = expf(terms[0] - m) + expf(terms[1] - m) + expf(terms[2] - m);
+    const float m = fmaxf(t0, fmaxf(t1, t2));
+    const float s = expf(t0 - m) + expf(t1 - m) + expf(t2 - m);
     const float gup = g_logp[gw];
     float g_acc = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         const int row = c * B + b;
-        if (ok[c]) {
-            const float wgt = expf(terms[c] - m) / s;                 // d logsumexp / d term_c
-            algebra_logprob(d, pt, lane, ctx_lane, cand[c], true, gup * wgt, g_acc, G, p, row);
+        const bool okc = c == 0 ? ok0 : (c == 1 ? ok1 : ok2);
+        const float tc = c == 0 ? t0 : (c == 1 ? t1 : t2);
+        const float cc[3] = {c == 0 ? c0[0] : (c == 1 ? c1[0] : c2[0]), c == 0 ? c0[1] : (c == 1 ? c1[1] : c2[1]), c == 0 ? c0[2] : (c == 1 ? c1[2] : c2[2])};
+        if (okc) {
+            const float wgt = expf(tc - m) / s;                       // d logsumexp / d term_c
+            algebra_logprob(d, pt, lane, ctx_lane, cc, true, gup * wgt, g_acc, G, p, row);
         } else {                                                      // masked pre-image: no contribution
             NetDelta Z = {0.f, 0.f, 0.f, 0.f};
             NetAct ZA = {0.f, 0.f, 0.f};
