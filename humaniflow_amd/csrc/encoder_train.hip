@@ -670,7 +670,8 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
             w.nchunks = B * w.chunks_per_img;
             w.ci_tiles = Cin / 32;
             const int tiles = (Cout / 64) * w.ci_tiles;
-            int slices = std::max(1, std::min(w.nchunks, (256 * 3 + tiles - 1) / tiles));
+            const int per_cu = stride == 1 ? 3 : 2;                     // work-groups that fit a CU (LDS 42 / 58 KB); measured best WG count = one full round
+            int slices = std::max(1, std::min(w.nchunks, (256 * per_cu + tiles - 1) / tiles));
             w.chunks_per_slice = (w.nchunks + slices - 1) / slices;
             slices = (w.nchunks + w.chunks_per_slice - 1) / w.chunks_per_slice;
             if (int zr = zero_async(dw, (size_t)Cout * 9 * Cin * sizeof(float), st)) return zr;
