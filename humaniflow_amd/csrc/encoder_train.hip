@@ -148,48 +148,75 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const f32x4* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------------
 // max-pool 3x3 / stride 2 / pad 1 backward (NHWC): the gradient goes to the FIRST maximum of each window in (kh, kw) scan order
-// (what torch's forward records with its strict `>` comparison).  Gather form: every input pixel checks the <= 4 windows covering it.
+// (what torch's forward records with its strict `>` comparison).  Gather form, one thread per 2 x 2 block of input pixels (x 4 channels): the four
+// windows (a, b), (a, b+1), (a+1, b), (a+1, b+1) that cover the block live in a 5 x 5 neighbourhood held in registers, so an input element costs
+// 6.25 loads instead of the 20 of a per-pixel gather (every pixel re-deriving the arg-max of each of its <= 4 windows); deterministic, no atomics.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_maxpool_bwd(const f32x4* __restrict__ x, const f32x4* __restrict__ gout, f32x4* __restrict__ gx, int B, int H,
                                                      int W, int C4, int OH, int OW) {
-    const long long n = (long long)B * H * W * C4;
+    const int HB = (H + 1) / 2, WB = (W + 1) / 2;
+    const long long n = (long long)B * HB * WB * C4;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
         const int c = (int)(e % C4);
         long long p = e / C4;
-        const int iw = (int)(p % W);
-        p /= W;
-        const int ih = (int)(p % H), b = (int)(p / H);
-        const f32x4 xv = x[e];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int oh = (ih - 1 + 1) / 2; oh <= (ih + 1) / 2; ++oh) {          // windows with |2 oh - ih| <= 1
-            if (oh < 0 || oh >= OH) continue;
-            for (int ow = (iw - 1 + 1) / 2; ow <= (iw + 1) / 2; ++ow) {
-                if (ow < 0 || ow >= OW) continue;
-                // first maximum of window (oh, ow) per channel
-                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                int bi[4] = {-1, -1, -1, -1};
-                for (int dh = -1; dh <= 1; ++dh) {
-                    const int jh = 2 * oh + dh;
-                    if ((unsigned)jh >= (unsigned)H) continue;
-                    for (int dw = -1; dw <= 1; ++dw) {
-                        const int jw = 2 * ow + dw;
-                        if ((unsigned)jw >= (unsigned)W) continue;
-                        const f32x4 v = x[(((long long)b * H + jh) * W + jw) * C4 + c];
-                        const int id = (dh + 1) * 3 + (dw + 1);
+        const int bb = (int)(p % WB);
+        p /= WB;
+        const int a = (int)(p % HB), b = (int)(p / HB);
+        // neighbourhood rows 2a-1 .. 2a+3, columns 2bb-1 .. 2bb+3
+        f32x4 v[5][5];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (v[k] > best[k]) { best[k] = v[k]; bi[k] = id; }
-                    }
-                }
-                const int me = (ih - 2 * oh + 1) * 3 + (iw - 2 * ow + 1);
-                const f32x4 gv = gout[(((long long)b * OH + oh) * OW + ow) * C4 + c];
+        for (int i = 0; i < 5; ++i) {
+            const int jh = 2 * a - 1 + i;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (bi[k] == me) acc[k] += gv[k];
+            for (int j = 0; j < 5; ++j) {
+                const int jw = 2 * bb - 1 + j;
+                const bool in = ((unsigned)jh < (unsigned)H) & ((unsigned)jw < (unsigned)W);
+                const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                v[i][j] = in ? x[(((long long)b * H + jh) * W + jw) * C4 + c] : ninf;
             }
         }
-        (void)xv;
-        gx[e] = acc;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int da = 0; da < 2; ++da)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int oh = a + da, ow = bb + db;
+                if (oh >= OH || ow >= OW) continue;
+                const f32x4 gv = gout[(((long long)b * OH + oh) * OW + ow) * C4 + c];
+                // first maximum of window (oh, ow): local rows 2 da .. 2 da + 2, columns 2 db .. 2 db + 2
+                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bi[4] = {-1, -1, -1, -1};
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const f32x4 u = v[2 * da + dh][2 * db + dw];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (u[k] > best[k]) { best[k] = u[k]; bi[k] = (2 * da + dh) * 5 + (2 * db + dw); }
+                    }
+                // the block's own pixels are local (1,1), (1,2), (2,1), (2,2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int me = (1 + i) * 5 + (1 + j);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (bi[k] == me) acc[i][j][k] += gv[k];
+                    }
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ih = 2 * a + i, iw = 2 * bb + j;
+                if (ih < H && iw < W) gx[(((long long)b * H + ih) * W + iw) * C4 + c] = acc[i][j];
+            }
     }
 }
 
@@ -624,7 +651,7 @@ int hmf_bn_bwd_apply(const float* g, const float* out, const float* y, const flo
 int hmf_maxpool3x3s2_nhwc_backward(const float* x, const float* g_out, float* g_x, int B, int H, int W, int C, void* stream) {
     if (!x || !g_out || !g_x || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return fail(HMF_ERR_INVALID, "hmf_maxpool3x3s2_nhwc_backward: bad args");
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-    const long long n = (long long)B * H * W * (C / 4);
+    const long long n = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
     long long blocks = std::min<long long>((n + 255) / 256, 256 * 64);
     hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, (const f32x4*)g_out, (f32x4*)g_x, B, H, W,
                        C / 4, OH, OW);

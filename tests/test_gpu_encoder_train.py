@@ -103,15 +103,16 @@ def test_stem_weight_gradient_and_maxpool_backward_match_torch():
         dw = et._wgrad(gy, s)
     assert dw.shape == (64, 18, 7, 7) and _rel(dw, cr.weight.grad) < 5e-5
     # max-pool backward incl. ties (post-ReLU zeros): the first maximum of a window receives the gradient, as in torch
-    a = F.relu(torch.randn(B, 64, 32, 32, device='cuda')).contiguous(memory_format=CL)
-    ar = a.double().requires_grad_(True)
-    pr = F.max_pool2d(ar, 3, 2, 1)
-    gp = torch.randn_like(pr).float().contiguous(memory_format=CL)
-    pr.backward(gp.double())
     lib = _lib.load()
-    ga = torch.empty_like(a)
-    _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(a.data_ptr(), gp.data_ptr(), ga.data_ptr(), B, 32, 32, 64, _lib.current_stream()), 'maxpool bwd')
-    assert _rel(ga, ar.grad) < 1e-6
+    for hh, ww in ((32, 32), (31, 29), (7, 10), (1, 5)):
+        a = F.relu(torch.randn(B, 64, hh, ww, device='cuda')).contiguous(memory_format=CL)
+        ar = a.double().requires_grad_(True)
+        pr = F.max_pool2d(ar, 3, 2, 1)
+        gp = torch.randn_like(pr).float().contiguous(memory_format=CL)
+        pr.backward(gp.double())
+        ga = torch.full_like(a, float('nan'))
+        _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(a.data_ptr(), gp.data_ptr(), ga.data_ptr(), B, hh, ww, 64, _lib.current_stream()), 'maxpool bwd')
+        assert _rel(ga, ar.grad) < 1e-6, (hh, ww)
 
 
 @pytest.mark.parametrize('layers,B,size', [(18, 4, 64), (50, 3, 64), (18, 6, 128)])
