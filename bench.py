@@ -61,16 +61,16 @@ def encoder_conv_flops(enc, B, size):
                     f += 2.0 * B * oh * oh * c.out_channels * blk.downsample[0].in_channels
                 flops.append(f)
                 kind.append('%dx%d' % (c.kernel_size[0], c.kernel_size[0]))
-                role.append((bi, 'first' if c is stages[0] else ('last' if c is stages[-1] else 'mid')))
+                role.append((bi, 'first' if c is stages[0] else ('last' if c is stages[-1] else 'mid'), B * oh * oh))
                 if not is_ds:
                     cur = oh
             hw = cur
             bi += 1
     plan = getattr(enc, '_plan', None)
-    pairs = set(plan['pair']) if plan and plan.get('pair') and B * (size // 4) ** 2 % 64 == 0 else set()
+    pairs = set(plan['pair']) if plan and plan.get('pair') else set()
     out_f, out_k = [], []
     for f, k, r in zip(flops, kind, role):
-        if r is not None and r[1] == 'first' and (r[0] - 1) in pairs:
+        if r is not None and r[1] == 'first' and (r[0] - 1) in pairs and r[2] % 64 == 0:      # the plan fuses a seam only on a multiple of 64 pixels
             li_ = max(i for i in range(len(out_f)) if out_k[i].startswith('1x1'))          # the seam launch = the previous block's last 1x1
             out_f[li_] += f
             out_k[li_] = '1x1+1x1 (seam)'

@@ -85,3 +85,23 @@ def test_oracle_forward_is_differentiable_in_float64():
             sm[key][idx] -= h
             fd = (loss_of(sp) - loss_of(sm)).item() / (2 * h)
         assert abs(fd - sd[key].grad[idx].item()) <= 1e-4 * max(1.0, abs(fd)), (key, fd, sd[key].grad[idx].item())
+
+
+def test_bench_conv_flop_accounting_is_invariant_under_seam_fusion():
+    """bench.py books algorithmic FLOPs per launch of the encoder's plan: fusing bottleneck seams into single launches changes the launch
+    list (6 launches fewer for ResNet-50 at 256 x 256), never the total (391.0 GFLOP at B = 32)."""
+    import importlib.util
+    import os
+    from helpers import ROOT
+    from humaniflow_amd.encoder import ResNetEncoder
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    enc = ResNetEncoder(50, 18)
+    f0, k0 = bench.encoder_conv_flops(enc, 32, 256)                      # no plan yet: one launch per convolution (downsample branches fused)
+    assert len(f0) == 49 and abs(sum(f0) / 1e9 - 391.0) < 0.1
+    enc._plan = {'pair': {0: None, 1: None, 2: None, 4: None, 5: None, 6: None}}     # the seams the device plan fuses (block indices)
+    f1, k1 = bench.encoder_conv_flops(enc, 32, 256)
+    assert len(f1) == 43 and abs(sum(f1) - sum(f0)) < 1.0 and sum(1 for k in k1 if 'seam' in k) == 6
+    f2, _ = bench.encoder_conv_flops(enc, 1, 224)                         # layer1 56 x 56 = 49 * 64 pixels: fused; layer2 28 x 28 = 784: not a multiple of 64
+    assert len(f2) == 46
