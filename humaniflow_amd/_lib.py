@@ -98,13 +98,10 @@ _SIGS = {
     'hmf_conv_winograd_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 2),
     'hmf_conv_winograd': (C.c_int, [_VP] * 5 + [C.c_int] * 6 + [_VP]),
     'hmf_conv_winograd_pack_device': (C.c_int, [_VP] * 2 + [C.c_int] * 3 + [_VP]),
-    'hmf_conv_winograd_variant': (C.c_int, [_VP] * 5 + [C.c_int] * 7 + [_VP]),      # tools/winograd_ablate.py
     'hmf_conv1x1_dual_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 10 + [_VP]),
     'hmf_conv2d_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
     'hmf_profile_enable': (C.c_int, [C.c_int]),
     'hmf_profile_collect': (C.c_int, [c_double_p, c_int_p, c_int_p, C.c_int]),
-    'hmf_debug_set_timeline': (C.c_int, [_VP]),
-    'hmf_debug_set_lbs_cycles': (C.c_int, [_VP]),
     'hmf_smpl_packed_blend_floats': (C.c_size_t, [C.c_int]),
     'hmf_smpl_pack_blend_host': (C.c_int, [C.POINTER(SmplHost), c_float_p]),
     'hmf_smpl_packed_blend_index': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -112,8 +109,28 @@ _SIGS = {
     'hmf_flow_pack_host': (C.c_int, [C.POINTER(FlowHost), c_float_p]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
+# include/humaniflow_amd_experiments.h: only in tools/libhumaniflow_amd_experiments.so (the same sources built with -DHMF_EXPERIMENTS)
+_EXPERIMENT_SIGS = {
+    'hmf_conv_winograd_variant': (C.c_int, [_VP] * 5 + [C.c_int] * 7 + [_VP]),      # tools/winograd_ablate.py
+    'hmf_debug_set_timeline': (C.c_int, [_VP]),                                     # tools/flow_timeline.py
+    'hmf_debug_set_lbs_cycles': (C.c_int, [_VP]),                                   # tools/lbs_tune.py
+}
 
 _lib = None
+
+
+def _bind(path, sigs, hint):
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise RuntimeError('humaniflow_amd: cannot load %s (%s). Build it with `%s`; there is no CPU fallback.' % (path, e, hint))
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hmf_abi_version() != 2:
+        raise RuntimeError('humaniflow_amd: ABI version mismatch')
+    return lib
 
 
 def load():
@@ -123,19 +140,20 @@ def load():
         return _lib
     from .build import build_library
     build_library()          # no-op unless the library is missing or older than its sources (content hash); serialised across ranks
-    try:
-        lib = C.CDLL(LIB_PATH)
-    except OSError as e:
-        raise RuntimeError('humaniflow_amd: cannot load %s (%s). Build it with `python -m humaniflow_amd.build`; '
-                           'there is no CPU fallback.' % (LIB_PATH, e))
-    for name, (res, args) in _SIGS.items():
-        fn = getattr(lib, name)
-        fn.restype = res
-        fn.argtypes = args
-    if lib.hmf_abi_version() != 2:
-        raise RuntimeError('humaniflow_amd: ABI version mismatch')
-    _lib = lib
-    return lib
+    _lib = _bind(LIB_PATH, _SIGS, 'python -m humaniflow_amd.build')
+    return _lib
+
+
+def use_experiments_library():
+    """tools/ only: make load() return tools/libhumaniflow_amd_experiments.so -- the same sources compiled with -DHMF_EXPERIMENTS, i.e. the product
+    entry points plus the timing variants of include/humaniflow_amd_experiments.h.  Call before anything else loads the library."""
+    global _lib
+    from .build import build_library
+    path = build_library(experiments=True)
+    sigs = dict(_SIGS)
+    sigs.update(_EXPERIMENT_SIGS)
+    _lib = _bind(path, sigs, 'python -m humaniflow_amd.build --experiments')
+    return _lib
 
 
 def check(rc, what=''):

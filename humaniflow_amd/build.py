@@ -1,8 +1,11 @@
 """Build libhumaniflow_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m humaniflow_amd.build [--force]
+    python -m humaniflow_amd.build [--force] [--experiments]
 
-The .so is git-ignored but travels with the repo snapshot to the GPU box.
+The .so is git-ignored but travels with the repo snapshot to the GPU box.  `--experiments` builds a SECOND library,
+tools/libhumaniflow_amd_experiments.so, from the same sources with -DHMF_EXPERIMENTS: the product entry points plus the timing / ablation
+variants declared in include/humaniflow_amd_experiments.h (most of which compute wrong results).  Only scripts under tools/ load it;
+libhumaniflow_amd.so never contains them.
 """
 import os
 import subprocess
@@ -24,54 +27,63 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', 
 
 STAMP = LIB + '.stamp'
 LOCK = os.path.join(HERE, '.build.lock')
+EXP_DIR = os.path.join(os.path.dirname(HERE), 'tools')
+EXP_LIB = os.path.join(EXP_DIR, 'libhumaniflow_amd_experiments.so')
 
 
-def source_hash():
+def source_hash(experiments=False):
     """Content hash of everything the library is built from (sources, headers, flags, this file): staleness is decided by content, not
     by mtimes -- the snapshot that carries the tree to the GPU box does not preserve them."""
     import hashlib
-    h = hashlib.sha256(' '.join(FLAGS).encode())
+    h = hashlib.sha256(' '.join(FLAGS + (['-DHMF_EXPERIMENTS'] if experiments else [])).encode())
     for d in sorted(SOURCES) + sorted(HEADERS):
         with open(os.path.join(CSRC, d), 'rb') as f:
             h.update(d.encode() + b'\0' + f.read())
     return h.hexdigest()
 
 
-def _stale():
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+def _stale(experiments=False):
+    lib = EXP_LIB if experiments else LIB
+    if not os.path.exists(lib) or not os.path.exists(lib + '.stamp'):
         return True
     try:
-        with open(STAMP) as f:
-            return f.read().strip() != source_hash()
+        with open(lib + '.stamp') as f:
+            return f.read().strip() != source_hash(experiments)
     except OSError:
         return True
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, experiments=False):
     """Compile every HIP source into one shared library; returns its path.  Cheap when nothing changed.  Safe under N ranks starting
     together: one process builds under an exclusive file lock, the others wait and find a fresh library; the link goes to a temporary
     file that is renamed into place, so a concurrent CDLL never sees a half-written .so."""
-    if not force and not _stale():
-        return LIB
+    lib = EXP_LIB if experiments else LIB
+    if not force and not _stale(experiments):
+        return lib
     import fcntl
     with open(LOCK, 'w') as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not _stale():             # another rank built it while we waited
-                return LIB
-            return _build_locked(verbose)
+            if not force and not _stale(experiments):             # another rank built it while we waited
+                return lib
+            return _build_locked(verbose, experiments)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
-    want = source_hash()
+def _build_locked(verbose, experiments=False):
+    want = source_hash(experiments)
+    LIB = EXP_LIB if experiments else globals()['LIB']
+    STAMP = LIB + '.stamp'
+    flags = FLAGS + (['-DHMF_EXPERIMENTS'] if experiments else [])
+    objdir = os.path.join(EXP_DIR, '.obj') if experiments else CSRC
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace('.hip', '.o'))
+        o = os.path.join(objdir, s.replace('.hip', '.o'))
         objs.append(o)
-        cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [HIPCC] + flags + ['-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -94,4 +106,4 @@ def _build_locked(verbose):
 
 
 if __name__ == '__main__':
-    print(build_library(force='--force' in sys.argv, verbose=True))
+    print(build_library(force='--force' in sys.argv, verbose=True, experiments='--experiments' in sys.argv))

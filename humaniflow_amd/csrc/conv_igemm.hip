@@ -247,12 +247,14 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
+#ifdef HMF_EXPERIMENTS        // tools/ only (humaniflow_amd.build --experiments): never part of libhumaniflow_amd.so
 template <int ABL>
 static int launch_conv_abl(const ConvArgs& a, hipStream_t st) {
     const int T = ((a.M + 63) / 64) * (a.Cout / 64);
     hipLaunchKernelGGL((k_conv_igemm<64, 64, 1, false, ABL>), dim3(T), dim3(256), 0, st, a);
     return 0;
 }
+#endif
 
 }  // namespace hmf
 
@@ -288,13 +290,15 @@ extern "C" int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias
     switch (tile) {
         case 64128: if (Cout % 128) return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: tile 64x128 needs Cout %% 128 == 0"); CONV_CASE(64, 128)
         case 64064: CONV_CASE(64, 64)
+#ifdef HMF_EXPERIMENTS
         case 1064064: launch_conv_abl<1>(a, st); break;
         case 2064064: launch_conv_abl<2>(a, st); break;
         case 3064064: launch_conv_abl<3>(a, st); break;
         case 4064064: launch_conv_abl<4>(a, st); break;
         case 7064064: launch_conv_abl<7>(a, st); break;
         case 8064064: launch_conv_abl<8>(a, st); break;
-        default: return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: unknown tile %d", tile);
+#endif
+        default: return fail(HMF_ERR_INVALID, "hmf_conv2d_nhwc: unknown tile %d (0 = auto, 64064, 64128)", tile);
     }
 #undef CONV_CASE
     HMF_LAUNCH_CHECK();

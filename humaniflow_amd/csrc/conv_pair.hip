@@ -252,7 +252,9 @@ extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_p
         else if (Kt == 128 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<128, 128, 2>), dim3(grid), dim3(256), 0, st, a);
         else if (Kt == 64 && N2 == 256) hipLaunchKernelGGL((k_conv_pair<64, 256, 2>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_conv_pair<128, 256, 2>), dim3(grid), dim3(256), 0, st, a);
-    } else if (Kt == 64 && N2 == 64) {           // timing experiments on the layer1 shape (tools/pair_probe.py)
+    }
+#ifdef HMF_EXPERIMENTS
+    else if (Kt == 64 && N2 == 64) {           // timing experiments on the layer1 shape (tools/pair_probe.py)
         switch (variant) {
             case 1: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 1>), dim3(grid), dim3(256), 0, st, a); break;
             case 2: hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 2>), dim3(grid), dim3(256), 0, st, a); break;
@@ -266,8 +268,10 @@ extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_p
             case 27: hipLaunchKernelGGL((k_conv_pair<64, 64, 2, 7>), dim3(grid), dim3(256), 0, st, a); break;
             default: return fail(HMF_ERR_INVALID, "hmf_conv_pair: unknown variant %d", variant);
         }
-    } else {
-        return fail(HMF_ERR_INVALID, "hmf_conv_pair: variants are built for K = 64, N2 = 64 only");
+    }
+#endif
+    else {
+        return fail(HMF_ERR_INVALID, "hmf_conv_pair: variant must be 0 (timing variants live in the tools/ experiments build)");
     }
     HMF_LAUNCH_CHECK();
     return HMF_OK;

@@ -310,6 +310,7 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
     } while (0)
     switch (variant) {
         case 0: HMF_WINO_LAUNCH(0, 0, 2); break;
+#ifdef HMF_EXPERIMENTS
         case 1: HMF_WINO_LAUNCH(1, 0, 2); break;       // 1..3, 10.., 20..: tools/winograd_ablate.py only
         case 2: HMF_WINO_LAUNCH(2, 0, 2); break;
         case 3: HMF_WINO_LAUNCH(3, 0, 2); break;
@@ -319,6 +320,7 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
         case 4: HMF_WINO_LAUNCH(4, 0, 2); break;
         case 8: HMF_WINO_LAUNCH(8, 0, 2); break;
         case 11: HMF_WINO_LAUNCH(11, 0, 2); break;
+#endif
         default: return fail(HMF_ERR_INVALID, "hmf_conv_winograd_variant: unknown variant %d", variant);
     }
 #undef HMF_WINO_LAUNCH
@@ -331,8 +333,10 @@ extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const fl
     return conv_winograd_impl(x, w_packed, bias, residual, y, B, H, W, Cin, Cout, relu, 0, stream);
 }
 
+#ifdef HMF_EXPERIMENTS
 // timing experiments (tools/winograd_ablate.py); a variant other than 0 / 10 / 20 computes wrong results
 extern "C" int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                                          int Cin, int Cout, int relu, int variant, void* stream) {
     return conv_winograd_impl(x, w_packed, bias, residual, y, B, H, W, Cin, Cout, relu, variant, stream);
 }
+#endif

@@ -628,8 +628,10 @@ static long long* g_timeline = nullptr;
 
 extern "C" {
 
+#ifdef HMF_EXPERIMENTS
 /* diagnostic (tools/flow_timeline.py): device buffer of 23 x 8 int64 shader-clock stamps written by tile 0, or NULL */
 int hmf_debug_set_timeline(void* dev_ptr) { g_timeline = (long long*)dev_ptr; return HMF_OK; }
+#endif
 
 static int n_tiles(int B, int N, int flags) { return ((B * N + ((flags & HMF_FLOW_POINT_EST) ? B : 0)) + 31) / 32; }
 

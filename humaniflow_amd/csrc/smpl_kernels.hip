@@ -835,8 +835,10 @@ static long long* g_lbs_cycles = nullptr;
 
 extern "C" {
 
+#ifdef HMF_EXPERIMENTS
 /* diagnostic (tools/lbs_tune.py): device buffer of >= 256 int64; every k_lbs_mfma block stores its shader-clock span */
 int hmf_debug_set_lbs_cycles(void* dev_ptr) { g_lbs_cycles = (long long*)dev_ptr; return HMF_OK; }
+#endif
 
 size_t hmf_smpl_packed_blend_floats(int) { return (size_t)kVT * kKG * 3 * 64 * 4; }
 size_t hmf_smpl_packed_blend_index(int k, int v, int c) { return blend_index(k, v, c); }
@@ -1016,6 +1018,9 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: M=%d Mb=%d Mg=%d (Mb, Mg must be 1 or M)", M, Mb, Mg);
     if (!workspace || workspace_bytes < hmf_smpl_lbs_workspace_bytes(M))
         return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
+#ifndef HMF_EXPERIMENTS
+    if (impl < 0 || impl > 2) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: impl=%d (0 = fp32 MFMA, 1 = scalar cross-check, 2 = bf16 operands)", impl);
+#endif
     hipStream_t st = (hipStream_t)stream;
     float* atr = (float*)workspace;
     float* panel = (float*)((char*)workspace + ws_atr_bytes(M));
@@ -1050,12 +1055,16 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         const dim3 grid(8 * wpx), block(512);
 #define HMF_LBS(S, ABL) hipLaunchKernelGGL((k_lbs_mfma<S, ABL>), grid, block, 0, st, h->d, M, nrg, wpx, panel, atr, verts, g_lbs_cycles)
         if (h->d.skin_slots == 4) {
+#ifdef HMF_EXPERIMENTS
             switch (impl >> 4) {          // impl = 16 * ABL: ablation variants for tools/lbs_tune.py; 0 = product kernel
                 case 1: HMF_LBS(4, 1); break;        // no skinning epilogue
                 case 3: HMF_LBS(4, 3); break;        // ... and no B-operand stream
                 case 7: HMF_LBS(4, 7); break;        // ... and no A-operand LDS reads: bare MFMA loop
                 default: HMF_LBS(4, 0); break;
             }
+#else
+            HMF_LBS(4, 0);
+#endif
         } else if (h->d.skin_slots == 8) {
             HMF_LBS(8, 0);
         } else {

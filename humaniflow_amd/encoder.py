@@ -18,8 +18,6 @@ BatchNorm, for which the folded plan does not apply: that mode runs encoder_trai
 hmf_bn_apply around the same convolution kernels and a hand-written backward (hmf_bn_bwd_*, hmf_conv_wgrad, dgrad
 through hmf_conv2d_nhwc with transformed filters, hmf_maxpool3x3s2_nhwc_backward).
 """
-import warnings
-
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -335,8 +333,6 @@ class ResNetEncoder(nn.Module):
                     x = self._conv_hip(h, w, b, s[0], idt, True)
             return x.mean(dim=(2, 3))
 
-    _warned_autograd = False
-
     def _stem_packed_from_device(self, w):
         """The stem kernel's packed filter operand from the live (64, 18, 7, 7) parameter without leaving the device: the host packer is a
         pure permutation + zero padding, so packing an index-valued array ONCE yields a gather map (training re-packs every step)."""
@@ -363,12 +359,12 @@ class ResNetEncoder(nn.Module):
             from .encoder_train import EncoderTrainFn
             return EncoderTrainFn.apply(self, x, *list(self.parameters()))
         # remaining combinations (train() without gradients, eval() with gradients = frozen statistics under autograd, gradients w.r.t. the
-        # input): the plain module graph on ATen, announced once
-        if not ResNetEncoder._warned_autograd:
-            ResNetEncoder._warned_autograd = True
-            warnings.warn('humaniflow_amd: this encoder mode (train() without gradients, eval() with gradients, or gradients w.r.t. the input) runs '
-                          'the plain module graph on ATen; the hand-written paths are inference (eval, no grad) and the training step (train, grad)')
-        return self.forward_module(x)
+        # input) have no hand-written path and there is no vendor-library path in the product: fail loudly.  (`forward_module` is the plain
+        # nn.Module graph; tests call it explicitly as the float64 reference.)
+        raise NotImplementedError(
+            'humaniflow_amd: ResNetEncoder.forward is built for inference (eval() under torch.no_grad()) and for the training step (train() with '
+            'gradients w.r.t. the parameters, 18-channel input that does not require grad); got training=%s, grad=%s, input.requires_grad=%s, '
+            'in_channels=%d' % (self.training, wants_grad, x.requires_grad, self.conv1.in_channels))
 
 
 def resnet18(in_channels, pretrained=False):

@@ -360,12 +360,6 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
  * 7 = k_isgc, 8 = k_conv_igemm, 9 = k_stem_conv, 10 = k_conv_patch, 11 = k_conv_winograd (rows = output pixels B*OH*OW; stem: B).  Returns the number of launches copied (<= max), or a negative error.                */
 int hmf_profile_enable(int enable);
 int hmf_profile_collect(double* ms_host, int32_t* tag_host, int32_t* rows_host, int max);
-/* Diagnostic: device buffer of 23 x 8 int64 that k_flow_chain's tile 0 fills with shader-clock stamps per part phase
- * (tools/flow_timeline.py); NULL (default) disables it.                                            */
-int hmf_debug_set_timeline(void* dev_ptr);
-/* Diagnostic: device buffer of >= 256 int64; every k_lbs_mfma block stores its shader-clock span (effective clock =
- * span / event time, tools/lbs_tune.py); NULL disables it.                                          */
-int hmf_debug_set_lbs_cycles(void* dev_ptr);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host-side packing probes (no GPU needed; used by the CPU test-suite to check operand layouts) */

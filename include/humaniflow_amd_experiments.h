@@ -1,5 +1,7 @@
-/* Timing-experiment entry points of libhumaniflow_amd.so (tools/ only; NOT part of the drop-in boundary of humaniflow_amd.h).
- * They launch ablated builds of product kernels to attribute a launch's time to its phases; most variants compute wrong results. */
+/* Timing-experiment entry points.  They are NOT in libhumaniflow_amd.so: `python -m humaniflow_amd.build --experiments` compiles the same
+ * sources with -DHMF_EXPERIMENTS into tools/libhumaniflow_amd_experiments.so, which only the scripts under tools/ load.  They launch ablated
+ * builds of product kernels to attribute a launch's time to its phases; most variants compute WRONG results.  In that build
+ * hmf_conv2d_nhwc additionally accepts tile = {1,2,3,4,7,8}064064, hmf_conv_pair variant != 0 and hmf_smpl_lbs impl = 16 * ABL. */
 #ifndef HUMANIFLOW_AMD_EXPERIMENTS_H
 #define HUMANIFLOW_AMD_EXPERIMENTS_H
 
@@ -12,6 +14,13 @@ extern "C" {
  * WRONG results.  Not used by the product path. */
 int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                               int Cin, int Cout, int relu, int variant, void* stream);
+
+/* Diagnostic: device buffer of 23 x 8 int64 that k_flow_chain's tile 0 fills with shader-clock stamps per part phase
+ * (tools/flow_timeline.py); NULL (default) disables it. */
+int hmf_debug_set_timeline(void* dev_ptr);
+/* Diagnostic: device buffer of >= 256 int64; every k_lbs_mfma block stores its shader-clock span (effective clock =
+ * span / event time, tools/lbs_tune.py); NULL disables it. */
+int hmf_debug_set_lbs_cycles(void* dev_ptr);
 
 #ifdef __cplusplus
 }

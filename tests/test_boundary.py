@@ -16,15 +16,38 @@ from helpers import ROOT, init_model_for_tests, oracle_cfg_from
 import mfma_emulator as E
 
 
+def _declared(header):
+    return sorted(set(re.findall(r'\b(hmf_[a-zA-Z0-9_]+)\s*\(', open(os.path.join(ROOT, 'include', header)).read())))
+
+
 def test_library_exports_every_declared_symbol(lib):
-    inc = os.path.join(ROOT, 'include')
-    hdr = ''.join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith('.h'))       # the boundary + the tools' experiment entries
-    declared = sorted(set(re.findall(r'\b(hmf_[a-zA-Z0-9_]+)\s*\(', hdr)))
+    declared = _declared('humaniflow_amd.h')                                     # the drop-in boundary
     assert len(declared) >= 25
     for name in declared:
-        assert hasattr(lib, name), 'symbol %s declared in include/*.h is not exported' % name
+        assert hasattr(lib, name), 'symbol %s declared in include/humaniflow_amd.h is not exported' % name
     assert sorted(declared) == sorted(_lib.EXPORTED_SYMBOLS)
     assert lib.hmf_abi_version() == 2
+
+
+def test_product_library_has_no_timing_variants(lib):
+    """The ablation / timing builds of the kernels (they compute wrong results) live in tools/libhumaniflow_amd_experiments.so
+    (-DHMF_EXPERIMENTS); the product library neither exports their entry points nor accepts their selector values."""
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r' T (hmf_[a-zA-Z0-9_]+)', out))
+    assert exported == set(_lib.EXPORTED_SYMBOLS), exported ^ set(_lib.EXPORTED_SYMBOLS)
+    experiments = _declared('humaniflow_amd_experiments.h')
+    assert experiments and sorted(experiments) == sorted(_lib._EXPERIMENT_SIGS)
+    assert not exported & set(experiments)
+    assert not any(s in n for n in exported for s in ('variant', 'debug', 'ablat'))
+    buf = (C.c_float * 64)()                                                      # argument validation runs before any launch: no GPU needed
+    p = C.cast(buf, C.c_void_p)
+    p = C.c_void_p((p.value + 15) & ~15)
+    for tile in (1064064, 2064064, 3064064, 4064064, 7064064, 8064064, 128064):
+        assert lib.hmf_conv2d_nhwc(p, p, None, None, p, 1, 8, 8, 32, 64, 1, 1, 1, tile, None) == -1 and b'unknown tile' in lib.hmf_last_error()
+    assert lib.hmf_conv_pair(p, None, p, p, None, p, p, p, p, 1, 8, 8, 64, 0, 0, 0, 1, 256, 64, 7, None) == -1 and b'variant' in lib.hmf_last_error()
+    src = open(os.path.join(ROOT, 'humaniflow_amd', 'encoder.py')).read()
+    fwd = src[src.rindex('    def forward(self, x):'):]
+    assert 'forward_module(' not in fwd.split('\ndef ')[0].replace('`forward_module`', '')       # no ATen / vendor-library path inside forward
 
 
 def test_error_reporting_without_device(lib):

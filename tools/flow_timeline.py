@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import humaniflow_amd as H
 from humaniflow_amd import _lib
 from humaniflow_amd.synthetic import init_benchmark_weights
-lib = _lib.load()
+lib = _lib.use_experiments_library()      # tools/libhumaniflow_amd_experiments.so: product entry points + timing variants
 dev = torch.device('cuda:0')
 model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), H.get_benchmark_cfg().MODEL, H.SMPL_PARENTS)).eval().to(dev)
 feats = torch.randn(32, 2048, device=dev) * 0.3

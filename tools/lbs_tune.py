@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import humaniflow_amd as H
 from humaniflow_amd import _lib
-lib = _lib.load()
+lib = _lib.use_experiments_library()      # tools/libhumaniflow_amd_experiments.so: product entry points + timing variants
 dev = torch.device('cuda:0')
 smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to(dev)
 M = int(os.environ.get('M', 3200))

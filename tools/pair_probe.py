@@ -5,7 +5,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from humaniflow_amd import _lib
-lib = _lib.load()
+lib = _lib.use_experiments_library()      # tools/libhumaniflow_amd_experiments.so: product entry points + timing variants
 dev = 'cuda:0'
 CL = torch.channels_last
 
