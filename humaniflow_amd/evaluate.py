@@ -183,24 +183,49 @@ class EvalMetricsTracker:
             self._add('joints2Dsamples-L2E', e, frame)
 
     def reduce(self, dist=None):
-        """The ONE exchange step: all-reduce(SUM) of the packed sums; all-gather of per-frame arrays (padded to equal length)."""
+        """The ONE exchange step of the path, as exactly two collectives whatever the number of metrics:
+          1. all_reduce(SUM) of one float64 vector = the packed metric sums | one frame-count slot per rank (only the own slot is non-zero),
+             so every rank learns every rank's frame count in the same message that sums the metrics;
+          2. all_gather of ONE (n_metrics, nmax) float32 tensor holding every per-frame array, padded to the largest rank's count.
+        Messages are bytes to KB: latency-bound, so the count of collectives is what matters on the xGMI ring."""
         sums = self.sums.clone()
         frames = {m: (torch.cat(v) if v else torch.zeros(0, device=self.sums.device)) for m, v in self.per_frame.items()}
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-            W = dist.get_world_size()
-            n_local = torch.tensor([max(len(v) for v in frames.values())], device=sums.device)
-            counts = [torch.zeros_like(n_local) for _ in range(W)]
-            dist.all_gather(counts, n_local)
-            nmax = int(max(c.item() for c in counts))
-            for m in list(frames):
-                if len(frames[m]) == 0:
-                    continue
-                pad = torch.zeros(nmax, dtype=frames[m].dtype, device=sums.device)
-                pad[:len(frames[m])] = frames[m]
-                got = [torch.zeros_like(pad) for _ in range(W)]
-                dist.all_gather(got, pad)
-                frames[m] = torch.cat([g[:int(c.item())] for g, c in zip(got, counts)])
+            W, rank, dev = dist.get_world_size(), dist.get_rank(), sums.device
+            names = [m for m in frames]                                       # same order on every rank (dict order of the constructor)
+            n_local = max(len(v) for v in frames.values())
+            present = torch.tensor([float(len(frames[m]) > 0) for m in names], dtype=sums.dtype, device=dev)
+            for m in names:
+                assert len(frames[m]) in (0, n_local), 'per-frame arrays of one rank must have one length (%s: %d vs %d)' % (m, len(frames[m]), n_local)
+            packed = torch.zeros(sums.numel() + len(names) + W + 2, dtype=sums.dtype, device=dev)
+            packed[:sums.numel()] = sums
+            packed[sums.numel():sums.numel() + len(names)] = present           # a metric present on ANY rank is gathered (a rank may own zero frames)
+            packed[sums.numel() + len(names) + rank] = n_local
+            if n_local > 0:                                                     # mesh size / sample count of the ranks that saw data (a rank that owns
+                packed[-2] = getattr(self, 'num_verts', 0)                      # no item learns them here: the final ratios divide by them)
+                packed[-1] = getattr(self, 'num_samples', 0)
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)                       # collective 1
+            sums = packed[:sums.numel()].clone()
+            host = packed[sums.numel():].tolist()                               # one D2H of n_metrics + W + 2 numbers
+            have, counts = [h > 0 for h in host[:len(names)]], [int(c) for c in host[len(names):-2]]
+            nmax = max(counts)
+            with_data = sum(c > 0 for c in counts)
+            if with_data:
+                nv, ns = int(round(host[-2] / with_data)), int(round(host[-1] / with_data))
+                if nv > 0:
+                    self.num_verts = nv
+                if ns > 0:
+                    self.num_samples = ns
+            sel = [m for m, h in zip(names, have) if h]
+            if sel and nmax > 0:
+                mine = torch.zeros((len(sel), nmax), dtype=torch.float32, device=dev)
+                for i, m in enumerate(sel):
+                    if len(frames[m]):
+                        mine[i, :n_local] = frames[m].float()
+                got = torch.empty((W, len(sel), nmax), dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(got.view(-1), mine.view(-1))       # collective 2
+                for i, m in enumerate(sel):
+                    frames[m] = torch.cat([got[r, i, :counts[r]] for r in range(W)])
         return sums, frames
 
     def compute_final_metrics(self, dist=None, num_verts=None, num_joints=14, num_samples=None):

@@ -105,18 +105,41 @@ def _run_eval(rank, world, n, dist_mod):
                                   dist=dist_mod, rank=rank, world_size=world, tracker=CpuShimTracker(torch.device('cpu')))
 
 
+class _CountingDist:
+    """torch.distributed with every collective call counted (the evaluation's exchange step must be exactly two)."""
+    COLLECTIVES = ('all_reduce', 'all_gather', 'all_gather_into_tensor', 'all_gather_object', 'broadcast', 'reduce', 'gather', 'scatter',
+                   'all_to_all', 'reduce_scatter', 'barrier')
+
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, name):
+        fn = getattr(dist, name)
+        if name in self.COLLECTIVES:
+            def counted(*a, **k):
+                self.calls.append(name)
+                return fn(*a, **k)
+            return counted
+        return fn
+
+
 def _worker(rank, world, port, n, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    metrics, frames = _run_eval(rank, world, n, dist)
+    cd = _CountingDist()
+    metrics, frames = _run_eval(rank, world, n, cd)
+    assert cd.calls == ['all_reduce', 'all_gather_into_tensor'], cd.calls       # ~20 metrics, two collectives
     q.put((rank, metrics, {k: v.numpy() for k, v in frames.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_eval_equals_single_process():
-    n = 11                                             # ragged: 6 + 5 items, last batches of different sizes
+import pytest
+
+
+@pytest.mark.parametrize('n', [11, 1])                 # 11: ragged, 6 + 5 items, last batches of different sizes; 1: rank 1 owns no item at all
+def test_two_rank_gloo_eval_equals_single_process(n):
     single, frames1 = _run_eval(0, 1, n, None)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
