@@ -7,6 +7,12 @@ the outputs the reference's functions produce are stored):
                           tensors, with stub per-part distributions returning fixed log-probabilities; values and input gradients.
 * linear_plu_golden.npz -- models/norm_flows/transforms/linearPLU_transform.py ConditionedLinearPLUTransform (_call, _inverse,
                           log_abs_det_jacobian) with given permutation / LU matrices (pure torch once the pyro base classes are stubbed).
+* encoder_train_golden.npz -- models/resnet.py resnet18(in_channels=18) in TRAIN mode (batch-statistics BatchNorm, the encoder of the
+                          training step, train/train_humaniflow.py:248-352) at B=4, 64x64: features, every BatchNorm's running-statistics
+                          update and the gradient of every parameter (small tensors in full, large ones as a fixed strided sample + their L2
+                          norm) for the loss sum(feats * w).  Weights = helpers.deterministic_state_dict(seed=11), input / w from numpy's
+                          RandomState (stable by contract): nothing but outputs is stored.  The reference ran in float64 (ground truth) and
+                          in float32 (its own rounding distance from float64 = the slack of the GPU test).
 """
 import importlib.util
 import os
@@ -111,7 +117,59 @@ def linear_plu_golden():
     np.savez_compressed(os.path.join(OUT, 'linear_plu_golden.npz'), **out)
 
 
+def encoder_train_inputs(B=4, size=64, out_dim=512):
+    """Input batch and loss weights of the encoder-training golden: numpy's legacy RandomState stream is stable across versions."""
+    rs = np.random.RandomState(20240611)
+    x = rs.standard_normal((B, 18, size, size)).astype(np.float32)
+    w = rs.standard_normal((B, out_dim)).astype(np.float32)
+    return torch.from_numpy(x), torch.from_numpy(w)
+
+
+def grad_sample(t, full_below=8192, samples=4096):
+    """Small tensors in full; large ones as every stride-th entry of the flattened tensor (stride fixed by the element count)."""
+    f = t.reshape(-1)
+    if f.numel() <= full_below:
+        return f
+    return f[::f.numel() // samples]
+
+
+def encoder_train_golden():
+    sys.path.insert(0, os.path.join(OUT, '..'))
+    from helpers import deterministic_state_dict
+    sys.path.insert(0, REF)
+    import models.resnet as resnet
+    x, w = encoder_train_inputs()
+    runs = {}
+    for dt in (torch.float64, torch.float32):
+        net = resnet.resnet18(in_channels=18)
+        sd = deterministic_state_dict({k: tuple(t.shape) for k, t in net.state_dict().items()}, seed=11)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dt).train()
+        feats = net(x.to(dt))
+        (feats * w.to(dt)).sum().backward()
+        runs[dt] = (net, feats.detach())
+    n64, f64 = runs[torch.float64]
+    n32, f32 = runs[torch.float32]
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-300)).item()
+    out = {'feats': f64.numpy(), 'feats_f32_dist': np.array(l2(f32, f64))}
+    names, dists = [], []
+    for (name, p), (_, q) in zip(n64.named_parameters(), n32.named_parameters()):
+        names.append(name)
+        dists.append(l2(q.grad, p.grad))
+        out['g_' + name] = grad_sample(p.grad).float().numpy()
+        out['n_' + name] = np.array(p.grad.norm().item())
+    out['param_names'] = np.array(names)
+    out['grad_f32_dist'] = np.array(dists)
+    for name, b in n64.named_buffers():
+        if not name.endswith('num_batches_tracked'):
+            out['b_' + name] = b.float().numpy()
+        else:
+            assert int(b) == 1
+    np.savez_compressed(os.path.join(OUT, 'encoder_train_golden.npz'), **out)
+
+
 if __name__ == '__main__':
     loss_golden()
     linear_plu_golden()
-    print('written loss_golden.npz, linear_plu_golden.npz to', OUT)
+    encoder_train_golden()
+    print('written loss_golden.npz, linear_plu_golden.npz, encoder_train_golden.npz to', OUT)

@@ -122,3 +122,45 @@ def _cpu_shim_tracker():
 
 
 CpuShimTracker = _cpu_shim_tracker()
+
+
+# ---- encoder-training golden (tests/golden/make_golden_train.py::encoder_train_golden, generated from the reference's models/resnet.py) ----
+def encoder_train_golden_inputs(B=4, size=64, out_dim=512):
+    """The golden's input batch and loss weights (numpy legacy RandomState: stable across versions; same code as the generator)."""
+    rs = np.random.RandomState(20240611)
+    x = rs.standard_normal((B, 18, size, size)).astype(np.float32)
+    w = rs.standard_normal((B, out_dim)).astype(np.float32)
+    return torch.from_numpy(x), torch.from_numpy(w)
+
+
+def golden_grad_sample(t, full_below=8192, samples=4096):
+    f = t.reshape(-1)
+    return f if f.numel() <= full_below else f[::f.numel() // samples]
+
+
+def check_encoder_against_train_golden(enc, feats, z, grad_bar=2e-3, feat_bar=1e-4, stat_bar=5e-4):
+    """`enc` (ResNetEncoder(18, 18) loaded with deterministic_state_dict(seed=11), train mode) after forward on the golden input and
+    backward of sum(feats * w): features, every parameter gradient (sampled as the golden samples it) and every running statistic vs the
+    REFERENCE's resnet18 in float64.  Bars: relative L2; the reference's own float32 run sits feats_f32_dist / grad_f32_dist from float64
+    (3e-6 / <= 7e-6 at this size), deep-ReLU gradients move by ~1e-3 where one pre-activation flips sign, hence grad_bar."""
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-300)).item()
+    df = l2(feats.detach().cpu(), torch.from_numpy(z['feats']))
+    assert df < max(feat_bar, 4 * float(z['feats_f32_dist'])), df
+    names = [str(n) for n in z['param_names']]
+    params = dict(enc.named_parameters())
+    assert sorted(names) == sorted(params)
+    worst = (0.0, '')
+    for n, d32 in zip(names, z['grad_f32_dist']):
+        g = params[n].grad
+        assert g is not None and torch.isfinite(g).all(), n
+        ref = torch.from_numpy(z['g_' + n])
+        r = l2(golden_grad_sample(g.detach().cpu()), ref)
+        rn = abs(g.detach().double().norm().item() - float(z['n_' + n])) / max(float(z['n_' + n]), 1e-300)
+        worst = max(worst, (r, n))
+        assert r < max(grad_bar, 4 * float(d32)) and rn < max(grad_bar, 4 * float(d32)), (n, r, rn, float(d32))
+    for n, b in enc.named_buffers():
+        if n.endswith('num_batches_tracked'):
+            assert int(b) == 1, n
+        else:
+            assert l2(b.detach().cpu(), torch.from_numpy(z['b_' + n])) < stat_bar, n
+    return df, worst

@@ -164,6 +164,26 @@ def test_whole_encoder_training_graph_matches_module_autograd(layers, B, size):
     assert _rel(a, b) < 1e-4
 
 
+def test_hip_training_graph_matches_reference_resnet18_train_mode_golden():
+    """EncoderTrainFn (hand-written forward with batch-statistics BatchNorm + hand-written backward) vs the REFERENCE's
+    models/resnet.py:202-217 resnet18(in_channels=18) in train mode, float64 (tests/golden/encoder_train_golden.npz, generated by
+    tests/golden/make_golden_train.py from the imported reference): features, all 62 parameter gradients, all running statistics."""
+    import os
+    import numpy as np
+    from helpers import GOLDEN, deterministic_state_dict, check_encoder_against_train_golden, encoder_train_golden_inputs
+    z = np.load(os.path.join(GOLDEN, 'encoder_train_golden.npz'), allow_pickle=False)
+    x, w = encoder_train_golden_inputs()
+    enc = ResNetEncoder(18, 18)
+    enc.load_state_dict(deterministic_state_dict({k: tuple(t.shape) for k, t in enc.state_dict().items()}, seed=11), strict=True)
+    enc = enc.cuda().train()
+    feats = enc(x.cuda())
+    assert 'EncoderTrainFn' in type(feats.grad_fn).__name__
+    (feats * w.cuda()).sum().backward()
+    df, worst = check_encoder_against_train_golden(enc, feats, z)
+    print('features rel L2 %.2e; worst parameter gradient %s rel L2 %.2e (reference float32 vs float64: %.2e / %.2e)'
+          % (df, worst[1], worst[0], float(z['feats_f32_dist']), float(z['grad_f32_dist'].max())))
+
+
 def test_winograd_filter_pack_on_the_device_matches_the_host_packer():
     """hmf_conv_winograd_pack_device (from the parameter's native storage, forward and input-gradient filter) vs hmf_conv_winograd_pack_host."""
     lib = _lib.load()

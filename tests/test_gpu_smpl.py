@@ -111,6 +111,44 @@ def test_vertex_variance(smpl):
     assert (a.cpu() - ra).abs().max() < 1e-5 and (s.cpu() - rs).abs().max() < 1e-5
 
 
+def test_joints2D_error_sorted_verts_sampling_on_device(smpl):
+    """utils/sampling_utils.py:36-74 on device tensors as predict/predict_humaniflow.py uses it: N posed SMPL meshes + their 90 joints from the
+    fused SMPL launch, heat-maps with invisible joints, weak-perspective camera -> the meshes sorted by their worst visible-joint reprojection
+    error.  Checked against a float64 host restatement of the reference's lines (flip about x = (x,-y,-z), orthographic projection,
+    pixel un-normalisation, arg-max of the heat-maps, max over visible joints, ascending sort)."""
+    from humaniflow_amd import sampling_utils as su
+    from humaniflow_amd.evaluate import ALL_JOINTS_TO_COCO_MAP
+    g = torch.Generator().manual_seed(11)
+    N, S = 25, 256
+    betas = (torch.randn(1, 10, generator=g) * 0.5).expand(N, 10).contiguous().cuda()
+    R = random_rotmats(N * 24, 0.25, seed=12).view(N, 24, 3, 3).cuda()
+    out = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+    cam = torch.tensor([[0.85, 0.03, -0.05]], device='cuda')
+    # target 2D joints = projection of sample 7 + noise, so the errors are distinct and a few pixels large; joints 3 and 12 invisible
+    jc7 = out.joints[7, ALL_JOINTS_TO_COCO_MAP].double().cpu() * torch.tensor([1.0, -1.0, -1.0], dtype=torch.float64)
+    c = cam[0].double().cpu()
+    tgt = ((c[0] * (jc7[:, :2] + c[1:]) + 1.0) * (S / 2.0) + torch.randn(17, 2, generator=g, dtype=torch.float64) * 3.0).round().clamp(2, S - 3).long()
+    hm = torch.zeros(1, 17, S, S)
+    for k in range(17):
+        if k not in (3, 12):
+            hm[0, k, tgt[k, 1], tgt[k, 0]] = 1.0
+    got = su.joints2D_error_sorted_verts_sampling(out.vertices, out.joints, hm.cuda(), cam)
+    assert got.is_cuda and tuple(got.shape) == (N, 6890, 3)
+    jc = out.joints[:, ALL_JOINTS_TO_COCO_MAP].double().cpu() * torch.tensor([1.0, -1.0, -1.0], dtype=torch.float64)
+    p2 = (c[0] * (jc[..., :2] + c[1:]) + 1.0) * (S / 2.0)
+    keep = [k for k in range(17) if k not in (3, 12)]
+    worst = (p2[:, keep] - tgt[keep].double()).norm(dim=-1).max(dim=-1).values
+    gaps = worst.sort().values.diff()
+    assert gaps.min() > 1e-3                                                        # no near-tie that float32 could reorder
+    order = torch.argsort(worst)
+    assert torch.equal(got.cpu(), out.vertices.cpu()[order])
+    # vertex-variance helper re-exported under the reference's module name runs on the same samples
+    from oracle.smpl import vertex_variance
+    avg, std = su.compute_vertex_variance_from_samples(out.vertices)
+    ra, rs = vertex_variance(out.vertices.cpu())
+    assert (avg.cpu() - ra).abs().max() < 1e-5 and (std.cpu() - rs).abs().max() < 1e-5
+
+
 def test_empty_and_bad_shapes(smpl):
     with pytest.raises(ValueError):
         smpl(body_pose=torch.zeros(3, 69).cuda(), global_orient=torch.zeros(2, 3).cuda(), betas=torch.zeros(3, 10).cuda())

@@ -230,6 +230,81 @@ def test_full_train_step_loss_and_gradients_at_batch_72():
     assert n == 424                                                              # every non-encoder parameter of the checkpoint layout
 
 
+def test_train_step_from_the_proxy_input_at_configs4_size():
+    """BASELINE configs[4] in one piece at its size: TRAIN.BATCH_SIZE = 72 proxy inputs of 256x256, ResNet-18, LOSS.NUM_J2D_SAMPLES = 8
+    (configs/humaniflow_config.py:40,99; the step is train/train_humaniflow.py:248-352).  Product: HIP training graph of the encoder
+    (batch-statistics BatchNorm) -> heads -> teacher-forced log-density + reparameterised samples -> SMPL joints -> HumaniflowLoss ->
+    backward through all of it.  Oracle: the plain module encoder in float64 on the CPU (pinned to the reference's resnet18 in train mode by
+    tests/golden/encoder_train_golden.npz) feeding oracle/train.py in float64, torch autograd.  Loss within 2e-4; every parameter gets a
+    finite gradient; head / flow gradients at the bar of the feature-entry test; encoder gradients in relative L2 (deep-ReLU mask flips)."""
+    import copy
+    from humaniflow_amd import train as T
+    from humaniflow_amd.encoder import ResNetEncoder
+    model, sd, cfg = _model(seed=9)
+    model.train()
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    dev = torch.device('cuda:0')
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to(dev)
+    for p in smpl.parameters():
+        p.requires_grad_(False)
+    om = {k: (v.double() if v.is_floating_point() else v) for k, v in smpl_oracle_model(smpl.model_dict()).items()}
+    B, N, S = 72, 8, cfg.DATA.PROXY_REP_SIZE
+    assert S == 256 and cfg.TRAIN.BATCH_SIZE == 72 and cfg.LOSS.NUM_J2D_SAMPLES == 8
+    x, targets = T.synthetic_train_batch(smpl, B, S, dev, seed=31, data_cfg=cfg.DATA)
+    assert tuple(x.shape) == (B, 18, S, S)
+    g = torch.Generator().manual_seed(32)
+    noise = {'shape': torch.randn(N, B, 10, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+    enc_sd = {k[len('image_encoder.'):]: v for k, v in sd.items() if k.startswith('image_encoder.')}
+
+    def oracle(dt):
+        enc = ResNetEncoder(18, 18)
+        enc.load_state_dict(enc_sd, strict=True)
+        enc = enc.to(dt).train()
+        sdd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items() if not k.startswith('image_encoder')}
+        t = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in targets.items()}
+        omd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in om.items()}
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dt)
+        try:
+            feats = enc.forward_module(x.cpu().to(dt))
+            loss_o, _ = ot.train_step_loss(sdd, ocfg, omd, cfg.LOSS, S, feats, t, {k: v.to(dt) for k, v in noise.items()}, N)
+        finally:
+            torch.set_default_dtype(old)
+        loss_o.backward()
+        grads = {k: v.grad.double() for k, v in sdd.items() if v.is_floating_point()}
+        grads.update({'image_encoder.' + k: p.grad.double() for k, p in enc.named_parameters()})
+        stats = {'image_encoder.' + k: b.detach().double() for k, b in enc.named_buffers() if not k.endswith('num_batches_tracked')}
+        return loss_o.item(), feats.detach().double(), grads, stats
+    loss_ref, f64, g64, st64 = oracle(torch.float64)
+    _, f32, g32, _ = oracle(torch.float32)
+    model.zero_grad()
+    loss, pred = T.train_forward_loss(model, smpl, H.HumaniflowLoss(cfg.LOSS, S), x, targets, N, noise={k: v.to(dev) for k, v in noise.items()})
+    assert abs(loss.item() - loss_ref) <= 2e-4 * abs(loss_ref), (loss.item(), loss_ref)
+    loss.backward()
+    l2 = lambda a, b: ((a.double().cpu() - b).norm() / b.norm().clamp(min=1e-300)).item()
+    n_enc = n_rest = 0
+    worst_enc = (0.0, '')
+    for name, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name             # every parameter of the checkpoint layout is reached
+        ref, ref32 = g64[name], g32[name]
+        if name.startswith('image_encoder'):
+            r, r32 = l2(p.grad, ref), ((ref32 - ref).norm() / ref.norm().clamp(min=1e-300)).item()
+            worst_enc = max(worst_enc, (r, name))
+            assert r < max(5e-3, 2 * r32), (name, r, r32)
+            n_enc += 1
+        else:
+            got = p.grad.detach().double().cpu()
+            scale = max(ref.abs().max().item(), 1e-12)
+            err, slack = (got - ref).abs().max().item(), (ref32 - ref).abs().max().item()
+            assert err <= 5e-4 * scale + 2.0 * slack, '%s: |hip - f64| %.3e, |f32 oracle - f64| %.3e, scale %.3e' % (name, err, slack, scale)
+            n_rest += 1
+    assert n_enc == 62 and n_rest == 424
+    for name, b in model.named_buffers():                                                  # running statistics of the one forward
+        if name in st64:
+            assert l2(b, st64[name]) < 5e-4, name
+    print('loss %.6f vs %.6f; worst encoder gradient %s rel L2 %.2e' % (loss.item(), loss_ref, worst_enc[1], worst_enc[0]))
+
+
 def test_train_step_skips_non_finite_updates_on_the_device():
     """train/train_humaniflow.py:264-278 (NaN roll-back): with the fused Adam the skip is decided on the device -- parameters, moments and step
     counts stay untouched when a gradient is non-finite, and a clean step afterwards updates as usual."""

@@ -92,6 +92,26 @@ def test_resnet_matches_reference_and_key_names():
             enc(x)                                                       # the product forward has no host path
 
 
+def test_training_mode_encoder_module_matches_reference_resnet_golden():
+    """The module graph the training step differentiates (`ResNetEncoder.forward_module`, train mode: batch-statistics BatchNorm, running
+    statistics update) vs the reference's models/resnet.py:202-217 resnet18(in_channels=18).train() run in float64 by
+    tests/golden/make_golden_train.py: features, all 62 parameter gradients, all 40 running statistics.  This module in float64 is the
+    encoder half of the oracle of the full-size train-step test (tests/test_gpu_train.py); the HIP training graph is held to the same
+    golden in tests/test_gpu_encoder_train.py."""
+    from helpers import check_encoder_against_train_golden, encoder_train_golden_inputs
+    from humaniflow_amd.encoder import ResNetEncoder
+    z = _g('encoder_train_golden.npz')
+    x, w = encoder_train_golden_inputs()
+    for dt, bar in ((torch.float64, 1e-9), (torch.float32, 2e-3)):
+        enc = ResNetEncoder(18, 18)
+        enc.load_state_dict(deterministic_state_dict({k: tuple(t.shape) for k, t in enc.state_dict().items()}, seed=11), strict=True)
+        enc = enc.to(dt).train()
+        feats = enc.forward_module(x.to(dt))
+        (feats * w.to(dt)).sum().backward()
+        # stored in float32: 6e-8 relative; float64 module == float64 reference up to that
+        df, worst = check_encoder_against_train_golden(enc, feats, z, grad_bar=max(bar, 2e-7), feat_bar=max(bar, 2e-7), stat_bar=max(bar, 2e-7))
+
+
 def test_linear_plu_oracle_matches_reference_transform():
     """oracle.flow.plu_forward / plu_inverse / conditional diagonal constraint vs the reference's ConditionedLinearPLUTransform
     (models/norm_flows/transforms/linearPLU_transform.py:12-82, generated by tests/golden/make_golden_train.py)."""
