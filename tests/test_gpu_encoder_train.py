@@ -167,7 +167,7 @@ def test_whole_encoder_training_graph_matches_module_autograd(layers, B, size):
 def test_hip_training_graph_matches_reference_resnet18_train_mode_golden():
     """EncoderTrainFn (hand-written forward with batch-statistics BatchNorm + hand-written backward) vs the REFERENCE's
     models/resnet.py:202-217 resnet18(in_channels=18) in train mode, float64 (tests/golden/encoder_train_golden.npz, generated by
-    tests/golden/make_golden_train.py from the imported reference): features, all 62 parameter gradients, all running statistics."""
+    tests/golden/make_golden_train.py from the imported reference): features, all 60 parameter gradients, all running statistics."""
     import os
     import numpy as np
     from helpers import GOLDEN, deterministic_state_dict, check_encoder_against_train_golden, encoder_train_golden_inputs

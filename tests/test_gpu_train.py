@@ -298,7 +298,7 @@ def test_train_step_from_the_proxy_input_at_configs4_size():
             err, slack = (got - ref).abs().max().item(), (ref32 - ref).abs().max().item()
             assert err <= 5e-4 * scale + 2.0 * slack, '%s: |hip - f64| %.3e, |f32 oracle - f64| %.3e, scale %.3e' % (name, err, slack, scale)
             n_rest += 1
-    assert n_enc == 62 and n_rest == 424
+    assert n_enc == 60 and n_rest == 424
     for name, b in model.named_buffers():                                                  # running statistics of the one forward
         if name in st64:
             assert l2(b, st64[name]) < 5e-4, name

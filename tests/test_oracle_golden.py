@@ -95,7 +95,7 @@ def test_resnet_matches_reference_and_key_names():
 def test_training_mode_encoder_module_matches_reference_resnet_golden():
     """The module graph the training step differentiates (`ResNetEncoder.forward_module`, train mode: batch-statistics BatchNorm, running
     statistics update) vs the reference's models/resnet.py:202-217 resnet18(in_channels=18).train() run in float64 by
-    tests/golden/make_golden_train.py: features, all 62 parameter gradients, all 40 running statistics.  This module in float64 is the
+    tests/golden/make_golden_train.py: features, all 60 parameter gradients, all 40 running statistics.  This module in float64 is the
     encoder half of the oracle of the full-size train-step test (tests/test_gpu_train.py); the HIP training graph is held to the same
     golden in tests/test_gpu_encoder_train.py."""
     from helpers import check_encoder_against_train_golden, encoder_train_golden_inputs
