@@ -230,7 +230,7 @@ def dry_run_cpu(args):
 
 
 KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
-CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_igemm + k_conv_pair (1x1)', 11: 'k_conv_winograd (3x3)'}
+CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_gemm + k_conv_pair (1x1)', 11: 'k_conv_winograd (3x3)'}
 
 
 def collect_profile(lib, _lib, cap=65536):
@@ -457,7 +457,7 @@ def main():
             dom_name = max(conv, key=lambda k: conv[k]['us_per_step'])
             dom = conv[dom_name]
             per_launch_flop = dom['gflop_per_step'] * 1e9 / dom['launches_per_step']
-            key = {'k_conv_igemm + k_conv_pair (1x1)': ('k_conv_igemm', 'k_conv_pair'), 'k_conv_patch (3x3)': 'k_conv_patch', 'k_conv_winograd (3x3)': 'k_conv_winograd',
+            key = {'k_conv_gemm + k_conv_pair (1x1)': ('k_conv_gemm', 'k_conv_igemm', 'k_conv_pair'), 'k_conv_patch (3x3)': 'k_conv_patch', 'k_conv_winograd (3x3)': 'k_conv_winograd',
                    'k_stem_conv (7x7/2)': 'k_stem_conv'}[dom_name]
             res['roofline'] = {
                 'kernel': '%s convolutions of the encoder: %d launches/step, the kernel family with the largest share of the step' % (dom_name, dom['launches_per_step']),

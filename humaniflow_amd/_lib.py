@@ -100,6 +100,7 @@ _SIGS = {
     'hmf_conv_winograd_pack_device': (C.c_int, [_VP] * 2 + [C.c_int] * 3 + [_VP]),
     'hmf_conv1x1_dual_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 10 + [_VP]),
     'hmf_conv2d_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
+    'hmf_conv1x1_gemm': (C.c_int, [_VP] * 6 + [C.c_int] * 11 + [_VP]),
     'hmf_profile_enable': (C.c_int, [C.c_int]),
     'hmf_profile_collect': (C.c_int, [c_double_p, c_int_p, c_int_p, C.c_int]),
     'hmf_smpl_packed_blend_floats': (C.c_size_t, [C.c_int]),
@@ -114,6 +115,7 @@ _EXPERIMENT_SIGS = {
     'hmf_conv_winograd_variant': (C.c_int, [_VP] * 5 + [C.c_int] * 7 + [_VP]),      # tools/winograd_ablate.py
     'hmf_debug_set_timeline': (C.c_int, [_VP]),                                     # tools/flow_timeline.py
     'hmf_debug_set_lbs_cycles': (C.c_int, [_VP]),                                   # tools/lbs_tune.py
+    'hmf_debug_gemm_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/gemm1x1_probe.py
 }
 
 _lib = None

@@ -96,7 +96,8 @@ class ResNetEncoder(nn.Module):
     # downsample branch's bias is added to the block's last bias so that branch needs no pass of its own.
     fuse_stem_pool = True    # stem convolution + max-pool as one launch (hmf_stem_conv_pool)
     fuse_pairs = True        # a bottleneck's last 1x1 + the next bottleneck's first 1x1 as one launch where built (hmf_conv_pair: layer1 / layer2)
-    fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_dual_nhwc)
+    fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_gemm with a second K range)
+    gemm_1x1 = True          # stride-1 1x1 layers on the LDS-DMA pipelined GEMM (hmf_conv1x1_gemm); False: the implicit-GEMM kernel (hmf_conv2d_nhwc)
 
     def _fold(self, conv, bn):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
@@ -181,6 +182,12 @@ class ResNetEncoder(nn.Module):
                 C, Kt, N2 = wk.shape[0], wk.shape[1], w1.shape[0]
                 if Kt not in (64, 128) or C % 64 or N2 not in (64, 128, 256) or C > 512 or (dual is not None and dual[2] != 1):
                     continue
+                if self.gemm_1x1 and Kt != 64:
+                    # measured at B = 32 against two launches of hmf_conv1x1_gemm (tools/gemm1x1_probe.py, tools/encoder_layers.py): the seam
+                    # launch wins only where the wide tensor between the two layers bounds them through HBM (layer1: conv3 64 -> 256 + identity
+                    # at 64x64, 73.8 + 39.3 us as two launches vs 103 us fused); with a 128-channel input (layer1.0's K-concatenated downsample
+                    # branch, all of layer2) two launches are 5 - 12 us faster than the seam kernel (82 vs 87 us, 113 vs 125 us, 122 vs 134 us)
+                    continue
                 plan['pair'][i] = self._pack_pair(wk, w1.reshape(N2, C)) + (N2,)
         if self.conv1.weight.is_cuda:
             for stages, ds, dual in plan['blocks']:
@@ -246,6 +253,10 @@ class ResNetEncoder(nn.Module):
         _, Cin2, H2, W2 = x.shape
         Cout = wcat.shape[0]
         y = torch.empty((B, Cout, OH, OW), device=h.device, dtype=torch.float32, memory_format=torch.channels_last)
+        if self.gemm_1x1:
+            _lib.check(lib.hmf_conv1x1_gemm(h.data_ptr(), x.data_ptr(), wcat.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, OH, OW, Cin,
+                                            H2, W2, Cin2, stride, Cout, 1, 0, _lib.current_stream()), 'hmf_conv1x1_gemm')
+            return y
         _lib.check(lib.hmf_conv1x1_dual_nhwc(h.data_ptr(), x.data_ptr(), wcat.data_ptr(), bias.data_ptr(), y.data_ptr(), B, OH, OW, Cin,
                                              H2, W2, Cin2, stride, Cout, 1, _lib.current_stream()), 'hmf_conv1x1_dual_nhwc')
         return y
@@ -280,6 +291,11 @@ class ResNetEncoder(nn.Module):
             _lib.check(lib.hmf_conv_patch(x.data_ptr(), pk[1].data_ptr(), None if bias is None else bias.data_ptr(),
                                           None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
                                           int(relu), cfg, _lib.current_stream()), 'hmf_conv_patch')
+            return y
+        if ks == 1 and stride == 1 and self.gemm_1x1 and Cin % 32 == 0 and Cout % 64 == 0:
+            _lib.check(lib.hmf_conv1x1_gemm(x.data_ptr(), None, w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                            None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, 0, 0, 0, 1, Cout,
+                                            int(relu), 0, _lib.current_stream()), 'hmf_conv1x1_gemm')
             return y
         _lib.check(lib.hmf_conv2d_nhwc(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                                        None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,

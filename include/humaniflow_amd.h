@@ -257,6 +257,15 @@ int hmf_conv2d_nhwc(const float* x, const float* w, const float* bias, const flo
 int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const float* bias, float* y, int B, int OH, int OW, int Cin,
                           int H2, int W2, int Cin2, int stride2, int Cout, int relu, void* stream);
 
+/* 1x1 convolution (models/resnet.py:102-122 conv1 / conv3 of a Bottleneck with the eval-mode BatchNorm folded in, optionally + the block's
+ * downsample branch :111-127 as a second K range, + identity, + ReLU) as an LDS-DMA pipelined fp32-MFMA GEMM (csrc/conv_gemm.hip):
+ * y = relu?(x . W[:, :K1]^T (+ x2[:, ::stride2, ::stride2, :] . W[:, K1:]^T) + bias (+ residual)).  x (B,OH,OW,K1) NHWC, x2 (B,H2,W2,K2) or
+ * NULL, w (N, K1+K2) row-major, y / residual (B,OH,OW,N); K1, K2 % 32 == 0, N % 64 == 0, every pointer 16-byte aligned.
+ * tile: 0 = from the shape, else [ring stages * 1000000 +] BM*1000+BN in {64064, 3064064, 3064128}.  Same results as hmf_conv2d_nhwc(ks=1) /
+ * hmf_conv1x1_dual_nhwc up to the fp32 accumulation order.  Profiler tag 8. */
+int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, int B, int OH, int OW,
+                     int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream);
+
 /* The seam between two bottlenecks (models/resnet.py:102-127: block i's conv3 + bn3 (+ downsample branch) + identity + ReLU, then block
  * i+1's conv1 + bn1 + ReLU) as ONE launch: y = relu([x1 | x2(strided)] . W3^T + bias3 (+ residual)) is written (the next identity branch) and
  * its 64-channel chunks feed z = relu(y . W1^T + bias1) through LDS, so the C-channel tensor y is not read back from HBM.

@@ -22,6 +22,10 @@ int hmf_debug_set_timeline(void* dev_ptr);
  * span / event time, tools/lbs_tune.py); NULL disables it. */
 int hmf_debug_set_lbs_cycles(void* dev_ptr);
 
+/* Diagnostic (tools/gemm1x1_probe.py --timeline): shader-clock stamps of the last k_conv_gemm launch, 4 per work-group (start, first chunk
+ * visible, main loop done, stores retired), for work-groups 0 .. blocks-1 (<= 4096). */
+int hmf_debug_gemm_stamps(long long* out_host, int blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,77 @@ def test_conv_ragged_rows_and_flags():
     _case(2, 8, 8, 2048, 512, 1, 1, res=False, relu=True, tile=0, seed=5)           # deepest K of the 1x1 layers
 
 
+def _gemm_case(B, OH, OW, k1, n, tile, k2=0, stride2=1, res=False, relu=True, bias=True, seed=0):
+    """hmf_conv1x1_gemm (LDS-DMA pipelined GEMM, csrc/conv_gemm.hip) vs float64 torch: y = relu?(conv1x1(x) (+ conv1x1(x2, stride2)) + bias (+ res))."""
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, k1, OH, OW, generator=g)
+    w = torch.randn(n, k1 + k2, generator=g) / (k1 + k2) ** 0.5
+    bv = torch.randn(n, generator=g) if bias else None
+    ref = F.conv2d(x.double(), w[:, :k1].double()[:, :, None, None], None if bv is None else bv.double())
+    x2 = None
+    H2 = W2 = 0
+    if k2:
+        H2, W2 = (OH - 1) * stride2 + 1 + (stride2 - 1) * (seed % 2), (OW - 1) * stride2 + 1           # odd and even source sizes
+        x2 = torch.randn(B, k2, H2, W2, generator=g)
+        ref = ref + F.conv2d(x2.double(), w[:, k1:].double()[:, :, None, None], None, stride2)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    CL = torch.channels_last
+    xd, wd = x.cuda().contiguous(memory_format=CL), w.cuda().contiguous()
+    x2d = x2.cuda().contiguous(memory_format=CL) if k2 else None
+    bd = bv.cuda() if bias else None
+    rd = r.cuda().contiguous(memory_format=CL) if res else None
+    y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=CL)
+    guard = torch.full((4096,), 7.0, device='cuda')                      # allocated right after y: a store beyond M would likely land here
+    _lib.check(lib.hmf_conv1x1_gemm(xd.data_ptr(), None if x2d is None else x2d.data_ptr(), wd.data_ptr(), None if bd is None else bd.data_ptr(),
+                                    None if rd is None else rd.data_ptr(), y.data_ptr(), B, OH, OW, k1, H2, W2, k2, stride2, n, int(relu), tile,
+                                    _lib.current_stream()), 'hmf_conv1x1_gemm')
+    torch.cuda.synchronize()
+    assert bool((guard == 7.0).all())
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), (B, OH, OW, k1, k2, n, tile, res, relu, err)
+    return y
+
+
+@pytest.mark.parametrize('tile', [0, 64064, 3064064, 3064128])
+def test_conv1x1_gemm_matches_float64_reference(tile):
+    _gemm_case(2, 16, 16, 256, 128, tile, res=True, relu=True)                                   # M = 512: whole tiles
+    _gemm_case(3, 7, 7, 96, 256, tile, res=True, relu=False, seed=1)                             # M = 147: ragged last tile, 3 k-chunks (< pipeline depth)
+    _gemm_case(1, 5, 9, 32, 128, tile, res=False, relu=True, bias=False, seed=2)                 # ONE k-chunk, M = 45 < every tile height
+    _gemm_case(2, 8, 8, 2048, 512, tile, res=False, relu=True, seed=3)                           # deepest K of the 1x1 layers (64 chunks)
+    _gemm_case(2, 6, 6, 128, 256, tile, k2=64, stride2=2, relu=True, seed=4)                     # downsample branch as a second K range, stride 2
+    _gemm_case(2, 6, 6, 64, 128, tile, k2=160, stride2=2, res=True, relu=True, seed=5)           # ... odd source size, 2 + 5 chunks
+    _gemm_case(1, 12, 12, 64, 256, tile, k2=64, stride2=1, relu=False, seed=6)                   # layer1.0: stride-1 branch
+
+
+def test_conv1x1_gemm_agrees_with_igemm_and_rejects_bad_shapes():
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    B, H, W, cin, cout = 4, 16, 16, 1024, 256                              # layer3 conv1 shape at a small batch
+    x = torch.randn(B, cin, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    ya = torch.empty(B, cout, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    yb = torch.empty_like(ya)
+    _lib.check(lib.hmf_conv2d_nhwc(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, ya.data_ptr(), B, H, W, cin, cout, 1, 1, 1, 0, _lib.current_stream()), 'igemm')
+    _lib.check(lib.hmf_conv1x1_gemm(x.data_ptr(), None, w.data_ptr(), b.data_ptr(), None, yb.data_ptr(), B, H, W, cin, 0, 0, 0, 1, cout, 1, 0,
+                                    _lib.current_stream()), 'gemm')
+    assert (ya - yb).abs().max().item() < 1e-5 * max(1.0, ya.abs().max().item())
+    p = x.data_ptr()
+    assert lib.hmf_conv1x1_gemm(p, None, p, None, None, p, 1, 4, 4, 48, 0, 0, 0, 1, 64, 1, 0, None) == -2          # K % 32
+    assert lib.hmf_conv1x1_gemm(p, None, p, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 96, 1, 0, None) == -2          # N % 64
+    assert lib.hmf_conv1x1_gemm(p, None, p, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 64, 1, 3064128, None) == -1    # tile needs N % 128
+    assert lib.hmf_conv1x1_gemm(p, None, p, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 128, 1, 128128, None) == -1    # not a product tile
+    assert lib.hmf_conv1x1_gemm(p, p, p, None, None, p, 1, 4, 4, 64, 9, 9, 64, 2, 64, 1, 0, None) == -1            # x2 size / stride mismatch
+    assert lib.hmf_conv1x1_gemm(p + 4, None, p, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 64, 1, 0, None) == -1      # misaligned
+
+
 def _patch_case(B, H, W, cin, cout, ks, stride, res, relu, cfg, seed=0):
     from humaniflow_amd import _lib
     lib = _lib.load()
