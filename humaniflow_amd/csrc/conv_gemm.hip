@@ -40,10 +40,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define HMF_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 #ifdef HMF_EXPERIMENTS           // tools/gemm1x1_probe.py --timeline: shader-clock stamps of every work-group (start, first chunk visible, main loop done, end)
-__device__ long long g_gemm_stamps[4 * 4096];
+__device__ long long g_gemm_stamps[6 * 4096];          // per work-group: 4 shader-clock stamps + the constant 100 MHz counter at start and end
 #define HMF_STAMP(k)                                                                                                   \
     do {                                                                                                               \
-        if (tid == 0 && blockIdx.x < 4096) g_gemm_stamps[blockIdx.x * 4 + (k)] = (long long)__builtin_readcyclecounter(); \
+        if (tid == 0 && blockIdx.x < 4096) {                                                                           \
+            g_gemm_stamps[blockIdx.x * 6 + (k)] = (long long)__builtin_readcyclecounter();                             \
+            if ((k) == 0) g_gemm_stamps[blockIdx.x * 6 + 4] = (long long)wall_clock64();                               \
+            if ((k) == 3) g_gemm_stamps[blockIdx.x * 6 + 5] = (long long)wall_clock64();                               \
+        }                                                                                                              \
     } while (0)
 #else
 #define HMF_STAMP(k) \
@@ -279,7 +283,7 @@ using namespace hmf;
 #ifdef HMF_EXPERIMENTS
 extern "C" int hmf_debug_gemm_stamps(long long* out_host, int blocks) {
     if (!out_host || blocks < 1 || blocks > 4096) return fail(HMF_ERR_INVALID, "hmf_debug_gemm_stamps: bad args");
-    HMF_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gemm_stamps), (size_t)blocks * 4 * sizeof(long long)));
+    HMF_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gemm_stamps), (size_t)blocks * 6 * sizeof(long long)));
     return HMF_OK;
 }
 #endif

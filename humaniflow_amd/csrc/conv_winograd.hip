@@ -25,6 +25,21 @@ struct WinoArgs {
     int B, H, W, Cin, Cout, relu, tiles_w, tiles_hw, n_tiles;
 };
 
+#ifdef HMF_EXPERIMENTS           // tools/wino_probe.py: per work-group stamps (shader clock: start, first patch in LDS, main loop done, end; the cycles
+// spent between a slab's top and its second barrier summed over slabs; the 100 MHz counter at start and end)
+__device__ long long g_wino_stamps[8 * 4096];
+#define HMF_WSTAMP(k, v)                                                              \
+    do {                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_wino_stamps[blockIdx.x * 8 + (k)] = (long long)(v); \
+    } while (0)
+#define HMF_WCLK() ((long long)__builtin_readcyclecounter())
+#else
+#define HMF_WSTAMP(k, v) \
+    do {                 \
+    } while (0)
+#define HMF_WCLK() 0LL
+#endif
+
 constexpr int kWTH = 8, kWTW = 16, kWSC = 64;
 constexpr int kWPH = kWTH + 2;
 constexpr int kWCS = kWSC + 4;                       // LDS pixel stride (floats)
@@ -40,12 +55,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     // LDS image of the patch.  NIMG = 1: columns de-interleaved by parity (pixel (r, c) at slot (c & 1) * 9 + (c >> 1) of row r): the four patch
     // columns 2 tj + {0,1,2,3} of tile tj are then slots {tj, 9 + tj, tj + 1, 9 + tj + 1}, i.e. consecutive lanes read consecutive pixels (17 x 16 B
     // apart), and with a row pitch of 4 (mod 8) slots the four 16-lane groups of ds_read_b128 each cover 16 distinct bank slots: conflict-free.
-    constexpr int kWPW = NIMG == 1 ? kWTW + 2 : 20, kWRP = NIMG == 1 ? (kWPW * kWCS + 8) : kWPW * kWCS;
+    // NIMG = 2: the same de-interleave inside each image's 10 columns (slot img * 10 + (c & 1) * 5 + (c >> 1)), and MFMA row i of the wave is tile
+    // (ti = i >> 3, tj = 4 h + (i & 3)) with h = bit 2 of i flipped for i in 8..23: the 16 lanes that ds_read_b128 serves together are then the 4 x 4
+    // tiles of ONE image, and with a row pitch of 10 (mod 16) slots their 16 reads hit 16 distinct bank slots (round 2 measured 40.8 % of the LDS
+    // cycles of this variant as bank conflicts).
+    constexpr int kWPW = NIMG == 1 ? kWTW + 2 : 20, kWRP = NIMG == 1 ? (kWPW * kWCS + 8) : (kWPW * kWCS + 24);
     static_assert(NIMG != 1 || (kWRP / 4) % 8 == 4, "row pitch must be 4 (mod 8) 16-byte slots");
+    static_assert(NIMG != 2 || (kWRP / 4) % 16 == 10, "row pitch must be 10 (mod 16) 16-byte slots");
     constexpr int NV = kWPH * kWPW * (kWSC / 4), NIT = (NV + 255) / 256;
     __shared__ float lds[kWPH * kWRP];               // patch (49 / 54 KB); reused for the accumulator exchange (2 x 32 KB halves)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
+    HMF_WSTAMP(0, HMF_WCLK());
+#ifdef HMF_EXPERIMENTS
+    HMF_WSTAMP(5, wall_clock64());
+    long long fetch_cyc = 0;
+#endif
 
     const int T = gridDim.x;
     int L = blockIdx.x;
@@ -66,7 +91,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         const int ih = oh0 + r - 1, iw = NIMG == 1 ? ow0 + col - 1 : col - img * 10 - 1;
         const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (b + img < a.B);
         goff[k] = ok ? ((((b + img) * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
-        loff[k] = r * kWRP + (NIMG == 1 ? (col & 1) * 9 + (col >> 1) : col) * kWCS + 4 * c4;
+        const int cl = col - img * 10;
+        loff[k] = r * kWRP + (NIMG == 1 ? (col & 1) * 9 + (col >> 1) : img * 10 + (cl & 1) * 5 + (cl >> 1)) * kWCS + 4 * c4;
     }
     const int nslab = a.Cin / kWSC;
     // weight stream of this wave: [n-tile][wave xi][slab][g][nu][lane][4]
@@ -74,11 +100,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #pragma unroll
     for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((MODE & 8) ? 0LL : (long long)((nt * TN + t) * 4 + wave) * nslab * kWNG * 4) * 64 + lane;   // MODE & 8: every wave streams the SAME weights (L1 hits)
 
-    // row transform of this wave: t[b] = s1 * d[a1][b] + s2 * d[a2][b]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
-    const int a1 = wave == 0 ? 0 : 1, a2 = wave == 3 ? 3 : 2;
-    const float s1 = wave == 2 ? -1.f : 1.f, s2 = (wave == 0 || wave == 3) ? -1.f : 1.f;
-    const int ti = li >> 3, tj = li & 7;
-    const float* pbase = lds + (2 * ti) * kWRP + (NIMG == 1 ? tj : (tj >> 2) * 10 + 2 * (tj & 3)) * kWCS + 4 * lq;
+    // row transform of this wave: t[b] = d[a1][b] + sg * d[a2][b]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3): one fma per element, the sign is wave-uniform
+    const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1), a2 = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float sg = wave == 1 ? 1.f : -1.f;
+    // MFMA row i of this wave <-> tile (ti, tj) of the 4 x 8 tiles of the work-group
+    auto row_tile = [](int i) {
+        return NIMG == 1 ? i : (i & ~4) | ((((i >> 2) ^ (((i >> 3) + 1) >> 1)) & 1) << 2);
+    };
+    const int tl = row_tile(li);
+    const int ti = tl >> 3, tj = tl & 7;
+    const float* pbase = lds + (2 * ti) * kWRP + (NIMG == 1 ? tj : (tj >> 2) * 10 + (tj & 3)) * kWCS + 4 * lq;
     const float* p1 = pbase + a1 * kWRP;
     const float* p2 = pbase + a2 * kWRP;
 
@@ -97,6 +128,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         for (int n = 0; n < 4; ++n) bw[0][t][n] = pw[t][n * 64];
 
     for (int s = 0; s < nslab; ++s) {
+#ifdef HMF_EXPERIMENTS
+        const long long tA = HMF_WCLK();
+#endif
         f32x4 pv[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -110,17 +144,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         for (int k = 0; k < NIT; ++k)
             if (NV % 256 == 0 || k < NIT - 1 || tid + 256 * k < NV) *(f32x4*)&lds[loff[k]] = pv[k];
         __syncthreads();
+#ifdef HMF_EXPERIMENTS
+        fetch_cyc += HMF_WCLK() - tA;
+        if (s == 0) HMF_WSTAMP(1, HMF_WCLK());
+#endif
 
         const bool last = (s + 1 == nslab);
         auto xform = [&](int g, f32x4 (&v)[4]) {
             f32x4 t[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                constexpr int cs = NIMG == 1 ? 1 : 0;          // column c of the tile: slot offset (c & 1) * 9 + (c >> 1) in the de-interleaved image
-                const int co = (cs ? (c & 1) * 9 + (c >> 1) : c) * kWCS;
+                // column c of the tile: slot offset (c & 1) * (9 | 5) + (c >> 1) in the de-interleaved image
+                const int co = ((c & 1) * (NIMG == 1 ? 9 : 5) + (c >> 1)) * kWCS;
                 const f32x4 d1 = *(const f32x4*)(p1 + co + 8 * g);
                 const f32x4 d2 = *(const f32x4*)(p2 + co + 8 * g);
-                t[c] = s1 * d1 + s2 * d2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sg, d2[e], d1[e]);
             }
             v[0] = t[0] - t[2];
             v[1] = t[1] + t[2];
@@ -168,15 +207,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     // thread finishes (tile, channel) pairs along xi.  (Round 1 exchanged all 16 positions in two half passes: twice the LDS traffic and barriers;
     // the output transform was 5-20 us of a 50-65 us launch, tools/winograd_ablate.py.)
     // accumulator register r of lane (j = li, q) holds tile (r & 3) + 8 (r >> 2) + 4 q, channel j
-    const int ch = tid & 31;
+#ifdef HMF_EXPERIMENTS
+    HMF_WSTAMP(2, HMF_WCLK());
+    HMF_WSTAMP(4, fetch_cyc);
+#endif
     if (MODE & 2) {
         if (acc[0][0][0] + acc[0][1][1] + acc[0][2][2] + acc[0][3][3] == 12345.678f) a.y[tid] = 1.f;      // keep the accumulators alive
         return;
     }
+    // Second half of the exchange: thread = (tile, 4 consecutive channels): eight 16-byte LDS reads, the xi direction of the transform on float4s, and
+    // one 16-byte store per output pixel (8 lanes = the 128 contiguous bytes of a pixel's 32 channels).  Round 2 finished (tile, channel) pairs with
+    // 32 scalar LDS reads and 16 scalar stores per thread: the output phase was 10-13k cycles of a 40-100k cycle work-group (tools/wino_probe.py).
+    const int otile = tid >> 3, oq = tid & 7;
+    const int otl = row_tile(otile);
+    const int oh = oh0 + 2 * (otl >> 3), ow = NIMG == 1 ? ow0 + 2 * (otl & 7) : 2 * (otl & 3);
+    const int bi = b + (NIMG == 1 ? 0 : (otl >> 2) & 1);
+    constexpr int kOOBo = (int)0x80000000;
+    const int ybytes = a.B * a.H * a.W * a.Cout * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.y), 0, ybytes, 0x00020000);
+    const float lo = a.relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-        const int n_out = (nt * TN + t) * 32 + ch;
-        const float bv = a.bias ? a.bias[n_out] : 0.f;
+        const int n_out = (nt * TN + t) * 32 + 4 * oq;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bv = *(const f32x4*)(a.bias + n_out);
+        int off[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                off[dy][dx] = (oh + dy < a.H && ow + dx < a.W && bi < a.B) ? ((((bi * a.H + oh + dy) * a.W + ow + dx) * a.Cout) + n_out) * 4 : kOOBo;
+        f32x4 rv[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                rv[dy][dx] = a.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[dy][dx], 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -186,32 +253,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             lds[((wave * 2 + 1) * 32 + tile) * 32 + li] = m1 - m2 - m3;
         }
         __syncthreads();
+        f32x4 pm[4][2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int tile = (tid >> 5) + 8 * k;
-            float pm[4][2];
+        for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-            for (int xi = 0; xi < 4; ++xi)
+            for (int dx = 0; dx < 2; ++dx) pm[xi][dx] = *(const f32x4*)&lds[((xi * 2 + dx) * 32 + otile) * 32 + 4 * oq];
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) pm[xi][dx] = lds[((xi * 2 + dx) * 32 + tile) * 32 + ch];
-            const float yv[2][2] = {{pm[0][0] + pm[1][0] + pm[2][0], pm[0][1] + pm[1][1] + pm[2][1]},
-                                    {pm[1][0] - pm[2][0] - pm[3][0], pm[1][1] - pm[2][1] - pm[3][1]}};
-            const int oh = oh0 + 2 * (tile >> 3), ow = NIMG == 1 ? ow0 + 2 * (tile & 7) : 2 * (tile & 3);
-            const int bi = b + (NIMG == 1 ? 0 : (tile >> 2) & 1);
+        for (int dx = 0; dx < 2; ++dx) {
+            f32x4 y0 = pm[0][dx] + pm[1][dx] + pm[2][dx] + bv + rv[0][dx];
+            f32x4 y1 = pm[1][dx] - pm[2][dx] - pm[3][dx] + bv + rv[1][dx];
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    if (oh + dy < a.H && ow + dx < a.W && bi < a.B) {
-                        const long long o = (((long long)bi * a.H + oh + dy) * a.W + ow + dx) * a.Cout + n_out;
-                        float v = yv[dy][dx] + bv;
-                        if (a.res) v += a.res[o];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (!(MODE & 4) || v == 12345.678f) a.y[o] = v;
-                    }
-                }
+            for (int e = 0; e < 4; ++e) {
+                y0[e] = fmaxf(y0[e], lo);
+                y1[e] = fmaxf(y1[e], lo);
+            }
+            typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
+            if (!(MODE & 4) || y0[0] == 12345.678f) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y0), ry, off[0][dx], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y1), ry, off[1][dx], 0, 0);
+            }
         }
     }
+#ifdef HMF_EXPERIMENTS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HMF_WSTAMP(3, HMF_WCLK());
+    HMF_WSTAMP(6, wall_clock64());
+#endif
 }
 
 }  // namespace hmf
@@ -309,14 +376,24 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
         else hipLaunchKernelGGL((k_conv_winograd<1, 1, MODE, PIPE, OCC>), dim3((unsigned)blocks), dim3(256), 0, st, a);    \
     } while (0)
     switch (variant) {
-        case 0: HMF_WINO_LAUNCH(0, 0, 2); break;
+        case 0:
+            // Measured round-robin, median of 7 (tools/winograd_ablate.py, B = 32): with one or two 64-channel slabs (layer1 / layer2) a work-group is
+            // mostly its first patch fetch and its output phase, so a third work-group per CU and the transform of group g + 1 issued under the MFMAs of
+            // group g pay (52.4 -> 47.7 us, 51.3 -> 44.6 us); with 4+ slabs they do not (layer3 43.2 vs 44.3 us) and on 8-pixel maps (one wave per
+            // SIMD) the pipelined transform loses outright (49.3 vs 62.7 us).
+            if (!pair && Cin <= 128) hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 1, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else HMF_WINO_LAUNCH(0, 0, 2);
+            break;
 #ifdef HMF_EXPERIMENTS
+        case 100: HMF_WINO_LAUNCH(0, 0, 2); break;          // tools: the round-2 configuration on every shape
         case 1: HMF_WINO_LAUNCH(1, 0, 2); break;       // 1..3, 10.., 20..: tools/winograd_ablate.py only
         case 2: HMF_WINO_LAUNCH(2, 0, 2); break;
         case 3: HMF_WINO_LAUNCH(3, 0, 2); break;
         case 10: HMF_WINO_LAUNCH(0, 0, 3); break;
         case 13: HMF_WINO_LAUNCH(3, 0, 3); break;
         case 20: HMF_WINO_LAUNCH(0, 1, 2); break;
+        case 30: HMF_WINO_LAUNCH(0, 1, 3); break;
+        case 22: HMF_WINO_LAUNCH(0, 2, 2); break;
         case 4: HMF_WINO_LAUNCH(4, 0, 2); break;
         case 8: HMF_WINO_LAUNCH(8, 0, 2); break;
         case 11: HMF_WINO_LAUNCH(11, 0, 2); break;
@@ -334,6 +411,12 @@ extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const fl
 }
 
 #ifdef HMF_EXPERIMENTS
+extern "C" int hmf_debug_wino_stamps(long long* out_host, int blocks) {
+    if (!out_host || blocks < 1 || blocks > 4096) return fail(HMF_ERR_INVALID, "hmf_debug_wino_stamps: bad args");
+    HMF_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wino_stamps), (size_t)blocks * 8 * sizeof(long long)));
+    return HMF_OK;
+}
+
 // timing experiments (tools/winograd_ablate.py); a variant other than 0 / 10 / 20 computes wrong results
 extern "C" int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                                          int Cin, int Cout, int relu, int variant, void* stream) {

@@ -51,7 +51,7 @@ def timeit(fn, reps=20, rounds=5):
 
 TIMELINE = '--timeline' in sys.argv
 if TIMELINE:
-    TILES = [64064, 3064064, 3064128, 3128064, 3128128]
+    TILES = [64064, 3064064, 3064128]
 
 
 def timeline(fn, blocks):
@@ -66,22 +66,17 @@ def timeline(fn, blocks):
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3
     n = min(blocks, 4096)
-    buf = np.zeros((n, 4), np.int64)
+    buf = np.zeros((n, 6), np.int64)
     _lib.check(lib.hmf_debug_gemm_stamps(buf.ctypes.data_as(ctypes.c_void_p), n), 'stamps')
-    # the shader-clock counters of the 8 XCDs are not synchronised: spans and skews are taken per XCD (block b runs on XCD b % 8)
-    spans, sk0, sk3 = [], [], []
-    for x in range(8):
-        s = buf[x::8]
-        if len(s) == 0:
-            continue
-        t0 = s[:, 0].min()
-        spans.append(s[:, 3].max() - t0)
-        sk0.append((s[:, 0] - t0).max())
-        sk3.append((s[:, 3].max() - s[:, 3]).mean())
-    span = float(np.mean(spans))
-    return ('span/XCD %6d cyc, %5.1f us by one event pair -> >= %.0f MHz | last start +%5d | prologue %5d | main %6d | epilogue %5d | mean idle at end %5d'
-            % (span, us, span / us, np.mean(sk0), (buf[:, 1] - buf[:, 0]).mean(), (buf[:, 2] - buf[:, 1]).mean(),
-               (buf[:, 3] - buf[:, 2]).mean(), np.mean(sk3)))
+    # shader-clock counters are per CU group and not synchronised: only per-work-group differences mean something.  The 100 MHz counter IS global.
+    cyc = (buf[:, 3] - buf[:, 0]).astype(np.float64)
+    wall = (buf[:, 5] - buf[:, 4]).astype(np.float64) / 100.0                     # us
+    ok = wall > 1.0
+    mhz = float(np.median(cyc[ok] / wall[ok])) if ok.any() else float('nan')
+    first, last_start, last_end = buf[:, 4].min(), buf[:, 4].max(), buf[:, 5].max()
+    return ('%5.1f us by one event pair | first start -> last end %5.1f us, last start +%4.1f us | per work-group: prologue %5d  main %6d  epilogue %5d cyc = %5.1f us at %4.0f MHz'
+            % (us, (last_end - first) / 100.0, (last_start - first) / 100.0, (buf[:, 1] - buf[:, 0]).mean(), (buf[:, 2] - buf[:, 1]).mean(),
+               (buf[:, 3] - buf[:, 2]).mean(), float(np.median(wall)), mhz))
 
 
 print('B = %d; us per launch (back-to-back launches on one stream, so ~1.5 us of launch boundary included)' % B)

@@ -24,7 +24,10 @@ def timeit(fn, iters=100):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-VARIANTS = ((0, 'product'), (10, '3 waves/SIMD'), (20, 'pipelined transform'), (1, 'no-fetch'), (4, 'no-stores'), (8, 'one weight stream for all waves'), (11, 'bare + one weight stream'), (2, 'no-epilogue'), (3, 'bare loop'), (13, 'bare 3 waves/SIMD'))
+VARIANTS = ((100, 'fenced transform, 2 waves/SIMD'), (10, '3 waves/SIMD'), (20, 'pipelined transform'), (30, 'pipelined + 3 waves/SIMD'), (1, 'no-fetch'), (2, 'no-epilogue'), (3, 'bare loop'))
+if '--full' not in sys.argv:
+    VARIANTS = VARIANTS[:4]
+ROUNDS = 7           # variants are timed round-robin and the median over rounds is reported: a single pass is dominated by clock ramp / order effects (+-15 %)
 for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256), ('layer4', 8, 512)):
     x = torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(c, 3, 3, c) / (3 * c ** 0.5)).contiguous()
@@ -36,8 +39,12 @@ for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256)
     st = _lib.current_stream()
     fl = 2.0 * B * hw * hw * c * c * 9
     line = '%-6s %5.2f GF direct (%.2f executed)' % (name, fl / 1e9, fl / 1e9 * 4 / 9)
+    import statistics
+    ts = {var: [] for var, _ in VARIANTS}
+    for _ in range(ROUNDS):
+        for var, lab in VARIANTS:
+            fn = lambda: _lib.check(lib.hmf_conv_winograd_variant(x.data_ptr(), wk.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, hw, hw, c, c, 1, var, st), 'wino')
+            ts[var].append(timeit(fn, iters=30))
     for var, lab in VARIANTS:
-        fn = lambda: _lib.check(lib.hmf_conv_winograd_variant(x.data_ptr(), wk.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, hw, hw, c, c, 1, var, st), 'wino')
-        t = timeit(fn)
-        line += ' | %s %5.1f us' % (lab, t)
+        line += ' | %s %5.1f us (%.1f-%.1f)' % (lab, statistics.median(ts[var]), min(ts[var]), max(ts[var]))
     print(line, flush=True)
