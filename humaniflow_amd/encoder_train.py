@@ -36,6 +36,11 @@ def _conv_raw(x, w_cl, stride, residual=None):
     pad = ks // 2
     OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
     y = _cl_empty(B, Cout, OH, OW, x.device)
+    if ks == 1 and stride == 1 and Cin % 32 == 0 and Cout % 64 == 0:
+        # 1x1 layers and their input-gradient convolutions (the transposed filter): the LDS-DMA pipelined GEMM (csrc/conv_gemm.hip)
+        _lib.check(lib.hmf_conv1x1_gemm(x.data_ptr(), None, w_cl.data_ptr(), None, None if residual is None else residual.data_ptr(), y.data_ptr(),
+                                        B, H, W, Cin, 0, 0, 0, 1, Cout, 0, 0, _lib.current_stream()), 'hmf_conv1x1_gemm')
+        return y
     _lib.check(lib.hmf_conv2d_nhwc(x.data_ptr(), w_cl.data_ptr(), None, None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W,
                                    Cin, Cout, ks, stride, 0, 0, _lib.current_stream()), 'hmf_conv2d_nhwc')
     return y
