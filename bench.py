@@ -40,10 +40,15 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_
 WINOGRAD_MFMA_FRACTION = 4.0 / 9.0     # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed MFMA FLOPs = 4/9 of direct
 
 
-def encoder_conv_flops(enc, B, size):
+def encoder_conv_flops(enc, B, size, with_bytes=False):
     """Algorithmic FLOPs (2*M*N*K, no padding taps removed) of every convolution launch of the encoder's inference plan, in launch order.
-    A fused seam (hmf_conv_pair: block i's last 1x1 + block i+1's first 1x1, `enc._plan['pair']`) is one launch carrying both layers' FLOPs."""
+    A fused seam (hmf_conv_pair: block i's last 1x1 + block i+1's first 1x1, `enc._plan['pair']`) is one launch carrying both layers' FLOPs.
+    with_bytes: also the ALGORITHMIC HBM bytes of every launch -- each tensor the launch must read (input, filter, identity branch, strided
+    source of a fused downsample branch) or write (output; the stem writes only the pooled map) counted once, fp32; a seam does not re-read its
+    intermediate tensor.  `roofline.traffic` (PMC) divided by this is the re-read factor."""
     flops, kind, role = [2.0 * B * (size // 2) ** 2 * 64 * enc.conv1.in_channels * 49], ['7x7/2'], [None]
+    pooled = (size // 4) ** 2 if getattr(enc, 'fuse_stem_pool', False) else (size // 2) ** 2
+    nbytes = [4.0 * (B * size * size * enc.conv1.in_channels + 64 * enc.conv1.in_channels * 49 + B * pooled * 64)]
     hw = size // 4
     bi = 0
     for li in range(1, 5):
@@ -57,9 +62,14 @@ def encoder_conv_flops(enc, B, size):
                 inhw = hw if is_ds else cur
                 oh = inhw // c.stride[0]
                 f = 2.0 * B * oh * oh * c.out_channels * c.in_channels * c.kernel_size[0] ** 2
+                nb = B * inhw * inhw * c.in_channels + c.out_channels * c.in_channels * c.kernel_size[0] ** 2 + B * oh * oh * c.out_channels
+                if c is stages[-1] and not is_ds and (blk.downsample is None or not fused):
+                    nb += B * oh * oh * c.out_channels                        # + the identity branch (block input, or the downsample launch's output)
                 if fused and c is stages[-1]:
                     f += 2.0 * B * oh * oh * c.out_channels * blk.downsample[0].in_channels
+                    nb += B * oh * oh * blk.downsample[0].in_channels + c.out_channels * blk.downsample[0].in_channels   # the pixels the strided branch reads
                 flops.append(f)
+                nbytes.append(4.0 * nb)
                 kind.append('%dx%d' % (c.kernel_size[0], c.kernel_size[0]))
                 role.append((bi, 'first' if c is stages[0] else ('last' if c is stages[-1] else 'mid'), B * oh * oh))
                 if not is_ds:
@@ -68,16 +78,20 @@ def encoder_conv_flops(enc, B, size):
             bi += 1
     plan = getattr(enc, '_plan', None)
     pairs = set(plan['pair']) if plan and plan.get('pair') else set()
-    out_f, out_k = [], []
-    for f, k, r in zip(flops, kind, role):
+    out_f, out_k, out_b = [], [], []
+    for f, k, r, nb in zip(flops, kind, role, nbytes):
         if r is not None and r[1] == 'first' and (r[0] - 1) in pairs and r[2] % 64 == 0:      # the plan fuses a seam only on a multiple of 64 pixels
             li_ = max(i for i in range(len(out_f)) if out_k[i].startswith('1x1'))          # the seam launch = the previous block's last 1x1
             out_f[li_] += f
             out_k[li_] = '1x1+1x1 (seam)'
+            blk = [b_ for l_ in range(1, 5) for b_ in getattr(enc, 'layer%d' % l_)][r[0]]
+            c1 = blk.stages()[0][0]
+            out_b[li_] += nb - 4.0 * r[2] * c1.in_channels                                # the seam's second GEMM reads its input from LDS, not HBM
             continue
         out_f.append(f)
         out_k.append(k)
-    return out_f, out_k
+        out_b.append(nb)
+    return (out_f, out_k, out_b) if with_bytes else (out_f, out_k)
 
 
 def parse():
@@ -241,7 +255,7 @@ def collect_profile(lib, _lib, cap=65536):
     return ms[:n], tag[:n], rows[:n]
 
 
-def conv_families(ms_, tag_, reps, conv_flops):
+def conv_families(ms_, tag_, reps, conv_flops, conv_bytes=None):
     """Per-family table of the encoder convolutions from `reps` recorded encoder passes (one record per launch, plan order)."""
     csel = (tag_ >= 8) & (tag_ <= 11)
     if csel.sum() != reps * len(conv_flops) or reps == 0:
@@ -249,11 +263,12 @@ def conv_families(ms_, tag_, reps, conv_flops):
     cms = ms_[csel].reshape(reps, len(conv_flops)).mean(0)                      # ms per launch, per layer
     ctag = tag_[csel].reshape(reps, len(conv_flops))[0]
     fam = {}
-    for f, t, tg in zip(conv_flops, cms, ctag):
-        d = fam.setdefault(CONV_TAGS[int(tg)], {'launches_per_step': 0, 'us_per_step': 0.0, 'flop': 0.0})
+    for i, (f, t, tg) in enumerate(zip(conv_flops, cms, ctag)):
+        d = fam.setdefault(CONV_TAGS[int(tg)], {'launches_per_step': 0, 'us_per_step': 0.0, 'flop': 0.0, 'algorithmic_bytes_per_step': 0.0})
         d['launches_per_step'] += 1
         d['us_per_step'] += t * 1e3
         d['flop'] += f
+        d['algorithmic_bytes_per_step'] += conv_bytes[i] if conv_bytes else 0.0
     for name, d in fam.items():
         d['tflops'] = round(d['flop'] / (d['us_per_step'] * 1e-6) / 1e12, 2)
         if 'winograd' in name:               # what the MFMA pipe executes: 4/9 of the direct-form multiplies
@@ -379,8 +394,27 @@ def main():
     elapsed = dist_elapsed(t0, dist, dev)
     log('timed region done: %.3f ms/step' % (elapsed / args.steps * 1e3))
 
+    # ---- shader clock under this load (separate pass after the timed region): the same round-robin replay of the step graphs with a one-wave probe
+    # kernel on a side stream that reads the shader-clock counter against the constant 100 MHz counter (hmf_profile_clock_probe).  The fp32 MFMA
+    # peak of 157.3 TFLOP/s that `roofline.frac` is quoted against assumes 2400 MHz; what the DVFS governor grants under MFMA load is recorded here.
+    clock = None
+    if args.profile_steps > 0 and not args.dry_run_cpu:
+        cbuf = torch.zeros(2, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        nrep = max(12, args.steps)
+        issue(0, 3)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            _lib.check(lib.hmf_profile_clock_probe(int(max(2000, 0.8 * nrep * elapsed / args.steps * 1e6)), cbuf.data_ptr(), _lib.current_stream()), 'clock probe')
+        issue(0, nrep)
+        torch.cuda.synchronize()
+        c_ = cbuf.tolist()
+        clock = {'shader_mhz_during_step_replay': round(c_[0] / max(c_[1], 1) * 100.0, 1), 'peak_assumes_mhz': 2400,
+                 'how': 'one-wave probe kernel on a side stream for ~80 %% of %d replayed steps: shader-clock counter (s_memtime) delta / 100 MHz counter '
+                        '(s_memrealtime) delta on the CU it ran on' % nrep}
+
     # ---- per-kernel measurement pass: eager, ONE stream, HIP events around every launch (execution time, nothing else running) ----
-    conv_flops, conv_kind = encoder_conv_flops(model.image_encoder, B, 256)
+    conv_flops, conv_kind, conv_bytes = encoder_conv_flops(model.image_encoder, B, 256, with_bytes=True)
     P = args.profile_steps
     kern, conv, stages = {}, None, {}
     lbs_rows = B * N + B
@@ -395,7 +429,7 @@ def main():
             for r in sorted(set(rows[tag == tg].tolist())):
                 sel = (tag == tg) & (rows == r)
                 kern['%s[M=%d]' % (nm, r)] = {'us': round(float(ms[sel].mean()) * 1e3, 2), 'launches_per_step': int(sel.sum()) // P}
-        conv = conv_families(ms, tag, P, conv_flops)
+        conv = conv_families(ms, tag, P, conv_flops, conv_bytes)
         ltag = 12 if args.blend_dtype == 'bf16' else 1
         lsel = (tag == ltag) & (rows == lbs_rows)
         lbs_ms = float(ms[lsel].mean()) if lsel.any() else float('nan')
@@ -436,6 +470,7 @@ def main():
                        'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},
             'rccl_ranks_seen': int(gathered.shape[0]),
             'roofline': None,
+            'shader_clock': clock,
             'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 3),
             'conv_kernels': conv, 'stages_ms': stages, 'kernels_us': kern,
             'measurement_pass': '%d eager steps on one stream after the timed region, HIP event pair around every launch (kernel execution time with nothing '
@@ -468,9 +503,13 @@ def main():
                                 else 'null: no profiles/*_pmc.json was collected at this library source hash on this workload',
                 'avg_launch_us': round(dom['us_per_step'] / dom['launches_per_step'], 2), 'launches_measured': dom['launches_per_step'] * P,
                 'algorithmic_flop_per_launch': per_launch_flop,
+                'algorithmic_bytes_per_launch': round(dom['algorithmic_bytes_per_step'] / dom['launches_per_step']),
+                'traffic_over_algorithmic_bytes': None,
                 'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (measurement pass: HIP events on the launch stream, one stream)',
                 'step_aggregate': {'what': 'algorithmic FLOPs of every convolution (Winograd layers at direct-form FLOPs) + SMPL blend GEMMs of a step / step time of the timed region',
                                    'achieved': round(agg, 2), 'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4)}}
+            if res['roofline']['traffic']:
+                res['roofline']['traffic_over_algorithmic_bytes'] = round(res['roofline']['traffic'] / res['roofline']['algorithmic_bytes_per_launch'], 3)
         lbs_bytes = lbs_rows * (82680 + 1080 + 868) + 19.3e6          # vertices + joints written, rotations + betas read, constants once
         if args.blend_dtype == 'fp32':
             ach = LBS_FLOP_PER_UNIT * lbs_rows / (lbs_ms * 1e-3) / 1e12 if lbs_ms == lbs_ms else None

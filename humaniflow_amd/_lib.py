@@ -103,6 +103,7 @@ _SIGS = {
     'hmf_conv1x1_gemm': (C.c_int, [_VP] * 6 + [C.c_int] * 11 + [_VP]),
     'hmf_profile_enable': (C.c_int, [C.c_int]),
     'hmf_profile_collect': (C.c_int, [c_double_p, c_int_p, c_int_p, C.c_int]),
+    'hmf_profile_clock_probe': (C.c_int, [C.c_int, _VP, _VP]),
     'hmf_smpl_packed_blend_floats': (C.c_size_t, [C.c_int]),
     'hmf_smpl_pack_blend_host': (C.c_int, [C.POINTER(SmplHost), c_float_p]),
     'hmf_smpl_packed_blend_index': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -121,6 +121,22 @@ __global__ void k_rodrigues(const float* __restrict__ v, int n, float* __restric
 
 }  // namespace hmf
 
+namespace hmf {
+__global__ void k_clock_probe(long long ticks, long long* out) {
+    const long long w0 = (long long)wall_clock64(), c0 = (long long)__builtin_readcyclecounter();
+    long long w1 = w0;
+    while (w1 - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w1 = (long long)wall_clock64();
+    }
+    const long long c1 = (long long)__builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w1 - w0;
+    }
+}
+}  // namespace hmf
+
 using namespace hmf;
 
 extern "C" {
@@ -153,6 +169,17 @@ int hmf_profile_collect(double* ms, int32_t* tag, int32_t* rows, int max) {
         ms[i] = t; tag[i] = g_prof[i].tag; rows[i] = g_prof[i].rows;
     }
     return n;
+}
+
+/* One wave spins for ~spin_us of wall time and reports how far the shader-clock counter (s_memtime) and the constant 100 MHz counter
+ * (s_memrealtime) advanced: out_dev[0] / out_dev[1] * 100 = the shader clock in MHz that the CU it ran on sustained meanwhile.  Launched on a
+ * side stream beside the measured work, it occupies one wave slot of one CU: the clock the DVFS governor grants under THAT load (the
+ * 157.3 TFLOP/s fp32 MFMA peak assumes 2400 MHz). */
+int hmf_profile_clock_probe(int spin_us, long long* out_dev, void* stream) {
+    if (!out_dev || spin_us < 1 || spin_us > 2000000) return fail(HMF_ERR_INVALID, "hmf_profile_clock_probe: bad args");
+    hipLaunchKernelGGL(hmf::k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)spin_us * 100, out_dev);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
 }
 
 #define HMF_ELEMENTWISE(name, kern, TIN, TOUT)                                                  \

@@ -369,6 +369,10 @@ int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int
  * 7 = k_isgc, 8 = k_conv_igemm, 9 = k_stem_conv, 10 = k_conv_patch, 11 = k_conv_winograd (rows = output pixels B*OH*OW; stem: B).  Returns the number of launches copied (<= max), or a negative error.                */
 int hmf_profile_enable(int enable);
 int hmf_profile_collect(double* ms_host, int32_t* tag_host, int32_t* rows_host, int max);
+/* One wave spins for ~spin_us (<= 2 s) on `stream` and writes {shader-clock cycles, 100 MHz ticks} elapsed to out_dev[0..1] (device memory):
+ * cycles / ticks * 100 = the shader clock in MHz a CU sustained while whatever else was running on the device ran (bench.py records it
+ * beside `roofline`: the 157.3 TFLOP/s fp32 MFMA peak assumes 2400 MHz). */
+int hmf_profile_clock_probe(int spin_us, long long* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host-side packing probes (no GPU needed; used by the CPU test-suite to check operand layouts) */
