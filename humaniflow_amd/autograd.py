@@ -104,7 +104,11 @@ class FlowParamAnchor(torch.autograd.Function):
     gradients and autograd would add them tensor by tensor (~830 tiny launches per step).  Instead the parameters enter the graph ONCE, here;
     the node's output is a scalar token the consumers take as an input.  In backward a consumer leaves its STACKED gradients (all parts in
     one tensor) in `stash` and returns a zero for the token; this node runs after all of them (autograd's dependency order), sums the stacked
-    tensors (a dozen launches) and returns per-parameter views."""
+    tensors (a dozen launches) and returns per-parameter views.
+
+    `stash` is a dict keyed by (consumer node, kind): a consumer that runs again before this node has run (torch.autograd.grad restricted to
+    inputs that do not reach the parameters, then a second backward over the retained graph) REPLACES its entry instead of adding a stale one.
+    A consumer whose token input needs no gradient (flow parameters frozen) leaves nothing here and skips its weight-gradient products."""
 
     @staticmethod
     def forward(ctx, model, stash, *params):
@@ -113,7 +117,7 @@ class FlowParamAnchor(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        model, entries = ctx.model, list(ctx.stash)
+        model, entries = ctx.model, list(ctx.stash.values())
         ctx.stash.clear()
         P = model.num_bodyparts
         needs = ctx.needs_input_grad[2:]
@@ -151,7 +155,7 @@ class FlowParamAnchor(torch.autograd.Function):
 
 def new_flow_anchor(model):
     """(token, stash) for one forward pass: pass both to every consumer of that pass."""
-    stash = []
+    stash = {}
     token = FlowParamAnchor.apply(model, stash, *(_ctx_params(model) + _hypernet_params(model, 0, model.num_bodyparts)))
     return token, stash
 
@@ -174,7 +178,8 @@ class FlowContext(torch.autograd.Function):
         isgc, rot, out = ctx.saved_tensors
         delta = (g * torch.where(out > 0, torch.ones_like(out), out + 1.0)).transpose(0, 1).contiguous()   # ELU', (P, B, 64)
         g_full, db, g_isgc = _context_pullback(ctx.model, delta, isgc, rot)
-        ctx.stash.append(('ctx', g_full, db))
+        if ctx.needs_input_grad[3]:                                   # the token: some flow parameter wants its gradient
+            ctx.stash[(id(ctx), 'ctx')] = ('ctx', g_full, db)
         return None, g_isgc, None, g.new_zeros(()), None
 
 
@@ -203,7 +208,8 @@ class FlowLogProbSO3(torch.autograd.Function):
             _lib.check(lib.hmf_flow_log_prob_SO3_backward(model._flow_handle(cvec.device), _lib.dptr(cvec), ids, P, _lib.dptr(R64), B,
                                                           _lib.dptr(gc), _lib.dptr(g_ctx), C.byref(st), _lib.current_stream()),
                        'hmf_flow_log_prob_SO3_backward')
-        ctx.stash.append(('hyper', part0, P, rec.hypernet_grads()))
+        if ctx.needs_input_grad[5]:                                   # the token
+            ctx.stash[(id(ctx), 'hyper')] = ('hyper', part0, P, rec.hypernet_grads())
         return None, None, None, g_ctx if ctx.needs_input_grad[3] else None, None, g.new_zeros(()), None
 
 
@@ -232,13 +238,17 @@ class FlowSampleChain(torch.autograd.Function):
             _lib.check(lib.hmf_flow_sample_backward(model._flow_handle(H.device), _lib.dptr(H), _lib.dptr(rot), _lib.dptr(eps), B, N,
                                                     _lib.dptr(g_rot), C.byref(st), _lib.current_stream()), 'hmf_flow_sample_backward')
         g_full, db, g_H = _context_pullback(model, rec.DCTX, H, rot.reshape(B * N, P, 9))
-        ctx.stash.append(('ctx', g_full, db))
-        ctx.stash.append(('hyper', 0, P, rec.hypernet_grads()))
+        if ctx.needs_input_grad[4]:                                   # the token
+            ctx.stash[(id(ctx), 'ctx')] = ('ctx', g_full, db)
+            ctx.stash[(id(ctx), 'hyper')] = ('hyper', 0, P, rec.hypernet_grads())
         return None, g_H, None, None, g_rot.new_zeros(()), None
 
 
 class SmplJoints(torch.autograd.Function):
-    """hmf_smpl_lbs with a backward for the JOINTS output (vertex gradients are not built)."""
+    """hmf_smpl_lbs with a backward for the JOINTS output (vertex gradients are not built).  The backward (hmf_smpl_joints_backward) re-derives
+    the joints from the fp32 blend operand whatever `impl` the forward ran with: with impl = 2 (bf16 blend-shape operands, BASELINE configs[2])
+    the gradient is that of the fp32 function at the same inputs -- the two forwards differ by <= 1.5e-3 m, the Jacobians to the same relative
+    order; training (configs[4]) runs impl = 0."""
 
     @staticmethod
     def forward(ctx, smpl, glob9, body207, betas, impl):

@@ -146,7 +146,12 @@ def _bn_forward(y, bn, residual, relu, pool=None, tracked=None):
     st = _lib.current_stream()
     _lib.check(lib.hmf_bn_stats(y.data_ptr(), M, C, acc.data_ptr(), st), 'hmf_bn_stats')
     mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    if bn.momentum is None:
+        raise NotImplementedError('humaniflow_amd: BatchNorm2d(momentum=None) (cumulative moving average) is not built for the training graph; the '
+                                  'reference uses the default momentum 0.1 (models/resnet.py)')
+    if not bn.training:
+        raise NotImplementedError('humaniflow_amd: a BatchNorm2d in eval() mode inside a train() encoder (frozen statistics) is not built for the training graph')
+    mom = bn.momentum
     track = bn.track_running_stats and bn.running_mean is not None
     _lib.check(lib.hmf_bn_finalize(acc.data_ptr(), M, C, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(mom),
                                    bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
@@ -266,11 +271,23 @@ class EncoderTrainFn(torch.autograd.Function):
                 torch._foreach_add_(tracked, 1)
         ctx.enc, ctx.saved, ctx.plan, ctx.a0, ctx.final_shape = enc, saved, plan, a0, tuple(cur.shape)
         ctx.param_ids = [id(p) for p in params]
+        # backward reads the LIVE conv / BatchNorm weights (input-gradient filters, BN coefficients): remember their versions so that an in-place
+        # update between forward and backward (two forwards then one step, an EMA swap) raises as torch autograd would, instead of silently
+        # differentiating a different function
+        ctx.param_versions = [p._version for p in params]
+        ctx.params_ref = params
         return feats
 
     @staticmethod
     def backward(ctx, g_feats):
         lib = _lib.load()
+        if ctx.saved is None:
+            raise RuntimeError('humaniflow_amd: the encoder training graph was already back-propagated; its saved activations are freed after the '
+                               'first backward (retain_graph is not supported for EncoderTrainFn)')
+        for p, v in zip(ctx.params_ref, ctx.param_versions):
+            if p._version != v:
+                raise RuntimeError('humaniflow_amd: an encoder parameter was modified in place between the forward and the backward of the training '
+                                   'graph (version %d -> %d); the backward reads the live weights' % (v, p._version))
         enc, saved, plan = ctx.enc, ctx.saved, ctx.plan
         grads = {}
         dev = g_feats.device
@@ -313,4 +330,5 @@ class EncoderTrainFn(torch.autograd.Function):
             grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
             grads[id(s.conv.weight)] = _wgrad(gy, s)
         ctx.saved = None
+        ctx.params_ref = None
         return (None, None) + tuple(grads.get(i) for i in ctx.param_ids)

@@ -230,12 +230,25 @@ class HumaniflowModel(nn.Module):
     # Dropped by train()/eval(), .to() and load_state_dict; re-validated on every use against the parameters' version counters, so
     # in-place updates (optimizer.step(), p.data.copy_(), load_state_dict on a sub-module, in-place EMA swaps) re-pack.  Re-binding
     # `p.data = other` does not bump a version counter: call invalidate_flow_weights() after that.
-    def invalidate_flow_weights(self):
-        if self.__dict__.get('_handles'):
+    # A captured HIP graph of a step (bench.py --train, torch.cuda.graph around forward/backward) bakes in the device pointers of the handle's
+    # packed-weight arena: the handle is therefore KEPT across train()/eval()/load_state_dict and re-packed IN PLACE on its next use
+    # (hmf_flow_update_from_device keeps every pointer); only a device / dtype move (_apply) or destruction frees it.  Graph replays update the
+    # parameters without bumping their version counters: call mark_params_changed() after replaying a captured training step and before an
+    # eager forward, or the eager forward runs on the weights packed before the replays.
+    def mark_params_changed(self):
+        """The parameters changed behind autograd's back (HIP-graph replay of an optimiser step, `p.data = ...`): re-pack on the next use."""
+        self.__dict__['_flow_key'] = None
+        self.__dict__['_flow_tensors'] = None
+        enc = getattr(self, 'image_encoder', None)
+        if enc is not None and hasattr(enc, 'invalidate_plan'):
+            enc.invalidate_plan()
+
+    def invalidate_flow_weights(self, destroy=True):
+        if destroy and self.__dict__.get('_handles'):
             lib = _lib.load()
             for h in self._handles.values():
                 lib.hmf_flow_destroy(h)
-        self.__dict__['_handles'] = {}
+            self.__dict__['_handles'] = {}
         self.__dict__['_flow_tensors'] = None
         self.__dict__['_flow_key'] = None
 
@@ -252,7 +265,7 @@ class HumaniflowModel(nn.Module):
         return st
 
     def train(self, mode=True):
-        self.invalidate_flow_weights()
+        self.invalidate_flow_weights(destroy=False)
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
@@ -260,7 +273,7 @@ class HumaniflowModel(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self.invalidate_flow_weights()
+        self.invalidate_flow_weights(destroy=False)
         return super()._load_from_state_dict(*a, **k)
 
     def __del__(self):

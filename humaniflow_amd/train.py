@@ -72,7 +72,13 @@ class GradBucketReducer:
     """Data-parallel gradient exchange: parameters are grouped (in reverse registration order, i.e. roughly the order their gradients
     become ready) into flat buckets of <= bucket_mb; a post-accumulate hook counts a bucket's parameters in, and the moment the last one
     arrives the bucket is flattened and all-reduced asynchronously (RCCL's own stream) while autograd keeps producing the earlier
-    layers' gradients.  finish() waits, averages and scatters the results back into .grad."""
+    layers' gradients.  finish() waits, averages and scatters the results back into .grad.
+
+    Life cycle of one step: begin() (counters reset, nothing may be in flight) -> backward (hooks) -> finish().  Every rank must issue the same
+    collectives in the same order: a bucket is launched either by the hook of its last parameter or -- for buckets holding a parameter that
+    received no gradient -- by finish(), which launches the stragglers in ascending bucket index; the all_reduce of the shared skip flag
+    (all_finite) comes last.  Backward passes that are not a training step (measurement passes, gradient checks) run under `with
+    reducer.disabled():` -- an armed hook would launch collectives nobody waits for."""
 
     def __init__(self, params, dist, bucket_mb=25.0):
         self.dist = dist
@@ -89,19 +95,47 @@ class GradBucketReducer:
             self.buckets.append(cur)
         self.where = {id(p): bi for bi, b in enumerate(self.buckets) for p in b}
         self.pending = [len(b) for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
         self.inflight = []
         self.hooks = []
+        self.enabled = True
+        self.consecutive_skips = None          # device counter of update steps skipped in a row (train_step), see check_progress()
         if self.world > 1:
             for p in self.params:
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._ready))
 
+    def begin(self):
+        """Start of a step: nothing of the previous step may still be in flight (finish() was not called, or a stray backward ran armed)."""
+        if self.inflight or any(self.launched):
+            raise RuntimeError('GradBucketReducer.begin(): %d bucket(s) of a previous backward were never finished -- call finish() after every '
+                               'backward of a step and wrap other backward passes in `with reducer.disabled():`' % (len(self.inflight) or sum(self.launched)))
+        self.pending = [len(b) for b in self.buckets]
+
+    def disabled(self):
+        """Context manager: backward passes inside do not exchange gradients (measurement passes, gradient checks)."""
+        red = self
+
+        class _Off:
+            def __enter__(self_):
+                self_.prev, red.enabled = red.enabled, False
+
+            def __exit__(self_, *exc):
+                red.enabled = self_.prev
+                return False
+        return _Off()
+
     def _ready(self, p):
+        if not self.enabled:
+            return
         bi = self.where[id(p)]
         self.pending[bi] -= 1
+        assert self.pending[bi] >= 0, 'GradBucketReducer: a parameter produced two gradients in one step (begin() not called?)'
         if self.pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi):
+        assert not self.launched[bi], 'GradBucketReducer: bucket %d launched twice in one step' % bi
+        self.launched[bi] = True
         ps = self.buckets[bi]
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
         work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True)
@@ -111,8 +145,8 @@ class GradBucketReducer:
         """Call after backward(): launches buckets whose parameters never produced a gradient hook, waits, writes the averages back."""
         if self.world == 1:
             return
-        for bi, n in enumerate(self.pending):
-            if n > 0:                                    # parameters unused by this step's graph: still exchange (zeros) so ranks agree
+        for bi in range(len(self.buckets)):              # stragglers in ascending bucket index: the same order on every rank
+            if not self.launched[bi]:                    # a parameter unused by this step's graph: still exchange (zeros) so ranks agree
                 self.pending[bi] = 0
                 self._launch(bi)
         for bi, flat, work in self.inflight:
@@ -128,6 +162,22 @@ class GradBucketReducer:
                 o += n
         self.inflight = []
         self.pending = [len(b) for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
+
+    def all_finite(self, flag):
+        """AND of a 0-dim boolean tensor over the ranks (one 4-byte all_reduce, after the gradient buckets): the skip decision of a step must be
+        the same everywhere, or one rank skips an update the others apply and the replicas drift apart for good."""
+        if self.world == 1:
+            return flag
+        bad = (~flag).to(torch.float32).reshape(1)
+        self.dist.all_reduce(bad, op=self.dist.ReduceOp.MAX)
+        return bad.reshape(()) == 0
+
+    def check_progress(self, limit=20):
+        """Host-side guard for the training loop (one device read; call it every few hundred steps): raises when the last `limit` or more
+        updates in a row were skipped as non-finite -- a weight state that always yields NaN would otherwise stall training silently."""
+        if self.consecutive_skips is not None and float(self.consecutive_skips) >= limit:
+            raise RuntimeError('humaniflow_amd.train: the last %d optimiser updates were all skipped (non-finite loss or gradients)' % int(self.consecutive_skips))
 
 
 def grads_finite(params):
@@ -140,22 +190,31 @@ def train_step(model, smpl, criterion, optimiser, reducer, proxy_input, targets,
     """One optimisation step.  Returns (loss tensor, skipped): a non-finite loss or gradient skips the update (the reference reloads the previous
     state dicts, train/train_humaniflow.py:264-278).  With a fused Adam on the device the decision never leaves the device: the finite flag is
     handed to the optimiser as `found_inf` (the fused kernel then leaves parameters, moments and step counts untouched), `skipped` is a 0-dim
-    tensor and the host never waits for the step -- consecutive steps overlap launch with execution.  Other optimisers: one host read."""
+    tensor and the host never waits for the step -- consecutive steps overlap launch with execution.  Other optimisers: one host read.
+    The flag is AND-reduced over the ranks (reducer.all_finite): the local loss differs per rank, the decision must not.
+    Difference from the reference's roll-back: the BatchNorm running statistics (and num_batches_tracked) of a skipped step's forward stay
+    updated -- the reference restores the whole state dict including buffers; the trained parameters, Adam moments and step counts are
+    untouched in both.  Skips in a row are counted on the device (reducer.consecutive_skips); reducer.check_progress() raises on a stall."""
     optimiser.zero_grad(set_to_none=True)
+    reducer.begin()
     loss, _ = train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=noise)
     loss.backward()
     reducer.finish()
     params = [p for g in optimiser.param_groups for p in g['params']]
     on_device = isinstance(optimiser, torch.optim.Adam) and loss.is_cuda and all(g.get('fused') for g in optimiser.param_groups)
+    norms = torch._foreach_norm([p.grad for p in params if p.grad is not None])
+    ok = reducer.all_finite(torch.isfinite(loss.detach()) & torch.isfinite(torch.stack(norms)).all())
+    bad = (~ok).to(torch.float32)
+    if reducer.consecutive_skips is None:                               # created by the first (eager, warm-up) step; updated in place afterwards so a
+        reducer.consecutive_skips = torch.zeros((), device=loss.device)  # captured step keeps counting into the same tensor
+    reducer.consecutive_skips.copy_((reducer.consecutive_skips + 1.0) * bad)
     if on_device:
-        norms = torch._foreach_norm([p.grad for p in params if p.grad is not None])
-        bad = (~(torch.isfinite(loss.detach()) & torch.isfinite(torch.stack(norms)).all())).to(torch.float32)
         optimiser.grad_scale, optimiser.found_inf = None, bad
         optimiser.step()
         optimiser.found_inf = None
         skipped = bad
     else:
-        if not (bool(torch.isfinite(loss)) and grads_finite(params)):
+        if not bool(ok):
             optimiser.zero_grad(set_to_none=True)
             return loss.detach(), True
         optimiser.step()
@@ -244,14 +303,18 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
         r = fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t) * 1e3, r
+    if graphs is not None:
+        model.mark_params_changed()          # the replays stepped the parameters without bumping their version counters: re-pack before eager passes
     optimiser.zero_grad(set_to_none=True)
+    reducer.begin()
     stages['forward+loss_ms'], (loss, _) = tm(lambda: train_forward_loss(model, smpl, criterion, *batches[0], N))
     stages['backward_ms'], _ = tm(lambda: loss.backward())
     stages['exchange+update_ms'], _ = tm(lambda: (reducer.finish(), optimiser.step()))
-    enc_ms, feats = tm(lambda: model.image_encoder(batches[0][0]))
-    stages['of_forward: encoder training graph (batch-statistics BN)_ms'] = enc_ms
-    w_ = torch.randn_like(feats)
-    stages['of_backward: encoder_ms'], _ = tm(lambda: (feats * w_).sum().backward())
+    with reducer.disabled():                 # measurement passes: no collectives
+        enc_ms, feats = tm(lambda: model.image_encoder(batches[0][0]))
+        stages['of_forward: encoder training graph (batch-statistics BN)_ms'] = enc_ms
+        w_ = torch.randn_like(feats)
+        stages['of_backward: encoder_ms'], _ = tm(lambda: (feats * w_).sum().backward())
     optimiser.zero_grad(set_to_none=True)
     # ---- per-kernel-family measurement pass: HIP event pair around every convolution / weight-gradient launch of 2 more steps ----
     roof = None
@@ -273,10 +336,11 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
         f_dgrad = f_all - B * per_img[menc.conv1]                      # the proxy input needs no gradient
         P = 2
         lib.hmf_profile_enable(1)
-        for k in range(P):
-            optimiser.zero_grad(set_to_none=True)
-            loss, _ = train_forward_loss(model, smpl, criterion, *batches[k % len(batches)], N)
-            loss.backward()
+        with reducer.disabled():
+            for k in range(P):
+                optimiser.zero_grad(set_to_none=True)
+                loss, _ = train_forward_loss(model, smpl, criterion, *batches[k % len(batches)], N)
+                loss.backward()
         torch.cuda.synchronize()
         cap = 65536
         ms, tag, rows = np.zeros(cap), np.zeros(cap, np.int32), np.zeros(cap, np.int32)

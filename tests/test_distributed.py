@@ -229,8 +229,28 @@ def _reducer_worker(rank, world, port, q):
     for step in range(2):                                    # twice: the bookkeeping must reset
         for p in params:
             p.grad = None
+        red.begin()
         net[:5](x).square().sum().backward()
         red.finish()
+        with red.disabled():                                 # a backward that is not a step (measurement pass): no collective, no bookkeeping
+            net[:3](x).square().sum().backward()
+        assert not red.inflight and not any(red.launched)
+    # the skip decision is shared: rank 1's non-finite flag makes BOTH ranks skip (one 4-byte all_reduce, same order on every rank)
+    ok = red.all_finite(torch.tensor(rank == 0))
+    assert bool(ok) is False
+    assert bool(red.all_finite(torch.tensor(True))) is True
+    # an armed backward that nobody finishes is caught at the next begin()
+    for p in params:
+        p.grad = None
+    red.begin()
+    net[:5](x).square().sum().backward()
+    try:
+        red.begin()
+        caught = False
+    except RuntimeError:
+        caught = True
+    assert caught
+    red.finish()
     q.put((rank, len(red.buckets), [None if p.grad is None else p.grad.numpy().copy() for p in params]))
     dist.barrier()
     dist.destroy_process_group()

@@ -305,6 +305,55 @@ def test_train_step_from_the_proxy_input_at_configs4_size():
     print('loss %.6f vs %.6f; worst encoder gradient %s rel L2 %.2e' % (loss.item(), loss_ref, worst_enc[1], worst_enc[0]))
 
 
+def test_training_graph_guards_and_packed_weight_handle_persistence():
+    """Guards of the hand-written training graph (it reads the LIVE weights in backward, frees its activations after one backward) and the
+    packed flow-weight handle's life cycle (kept across train()/eval()/load_state_dict and re-packed in place: a captured HIP graph of a step
+    holds its device pointers; mark_params_changed() after replays)."""
+    model, sd, cfg = _model(seed=5)
+    enc = model.image_encoder.train()
+    x = torch.randn(2, 18, 64, 64, device='cuda')
+    f = enc(x)
+    with torch.no_grad():
+        enc.layer1[0].conv1.weight.mul_(1.0)                              # in-place update between forward and backward
+    with pytest.raises(RuntimeError, match='modified in place'):
+        f.sum().backward()
+    f = enc(x)
+    f.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='already back-propagated'):
+        f.sum().backward()
+    enc.layer2[0].bn1.momentum = None
+    with pytest.raises(NotImplementedError, match='momentum'):
+        enc(x)
+    enc.layer2[0].bn1.momentum = 0.1
+    enc.layer3[0].bn2.eval()
+    with pytest.raises(NotImplementedError, match='eval'):
+        enc(x)
+    model.eval()
+    with torch.no_grad():
+        a = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
+    h0 = model._handles[('cuda', 0)].value
+    model.train()
+    model.eval()
+    model.load_state_dict({k: v.cuda() for k, v in sd.items()}, strict=True)
+    with torch.no_grad():
+        b = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
+    assert model._handles[('cuda', 0)].value == h0                        # same arena: re-packed in place
+    # (BatchNorm statistics moved in the train-mode forwards above and load_state_dict restored them: the two eval outputs agree)
+    assert torch.allclose(a['pose_rotmats_samples'], b['pose_rotmats_samples'], atol=1e-6)
+    # a parameter changed behind the version counters (what a graph replay of an optimiser step does): stale until mark_params_changed()
+    p = model.pose_so3flow_transform_modules[3].nn.layers[0].weight if hasattr(model.pose_so3flow_transform_modules[3], 'nn') else None
+    w = next(model.fc_flow_context[0].parameters())
+    w.data = w.data * 1.5                                                 # re-binding .data does not bump the version counter
+    with torch.no_grad():
+        c = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
+    assert torch.equal(c['pose_rotmats_samples'], b['pose_rotmats_samples'])      # stale pack (documented)
+    model.mark_params_changed()
+    with torch.no_grad():
+        d = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
+    assert not torch.equal(d['pose_rotmats_samples'], b['pose_rotmats_samples'])
+    assert model._handles[('cuda', 0)].value == h0
+
+
 def test_train_step_skips_non_finite_updates_on_the_device():
     """train/train_humaniflow.py:264-278 (NaN roll-back): with the fused Adam the skip is decided on the device -- parameters, moments and step
     counts stay untouched when a gradient is non-finite, and a clean step afterwards updates as usual."""
