@@ -307,19 +307,27 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
         // Work items of this wave inside the segment: full rounds of 8 vertex tiles (64 rows x 32 vertices per wave), then the partial round.
         // A partial round of <= 4 tiles is split by rows: two waves share a vertex tile, 32 rows each, so the 27 tiles of a range cost
         // 3.5 rounds instead of 4 (the B operand of those tiles is fetched by both waves).
+        // Round 3: the half tiles are also what de-phases the two waves of a SIMD.  Waves w and w + 4 share a SIMD (a work-group's waves are
+        // placed on SIMDs 0,2,1,3,0,2,1,3); run in lock step they reach their skinning epilogues -- ~40 % of a tile's time, no MFMA -- together
+        // and the matrix pipe idles (MfmaUtil 61 % in round 2).  So the <= 4 split tiles of a segment come FIRST for waves 4-7 (up to four
+        // half tiles) and LAST for waves 0-3: from then on a SIMD's two waves are half a tile apart, one in its MFMA loop while the other skins.
         const int cnt = seg_end - t, rf = cnt >> 3, rem = cnt & 7;
         const bool split = rem > 0 && rem <= 4;
+        const int nB = split ? min(2 * rem, 4) : 0, nA = split ? 2 * rem - nB : 0;
+        const bool lead = wave >= 4 && (wave - 4) < nB;          // this wave starts with a half tile
         auto item = [&](int k, int& rh) -> int {
             rh = -1;
-            if (k < rf) return t + k * 8 + wave;
-            if (k == rf && rem > 0) {
-                if (split) {
-                    if (wave >= 2 * rem) return -1;
-                    rh = wave & 1;
-                    return t + rf * 8 + (wave >> 1);
+            if (split) {
+                if (lead) {
+                    if (k == 0) { rh = (wave - 4) & 1; return t + ((wave - 4) >> 1); }
+                    --k;
                 }
-                return wave < rem ? t + rf * 8 + wave : -1;
+                if (k < rf) return t + rem + k * 8 + wave;
+                if (k == rf && wave < 4 && wave < nA) { rh = (nB + wave) & 1; return t + ((nB + wave) >> 1); }
+                return -1;
             }
+            if (k < rf) return t + k * 8 + wave;
+            if (k == rf && rem > 0) return wave < rem ? t + rf * 8 + wave : -1;
             return -1;
         };
         int kitem = 0, rh;
