@@ -10,7 +10,9 @@ What the reference differentiates in train/train_humaniflow.py:248-330 and where
   6D -> R of the global rotation                                                              Rot6dToRotmat
 
 The HIP kernels do the structured part (spline / hyper-network / kinematic-chain / skinning reverse sweeps) and emit per-row deltas
-and activations; the weight gradients are dense reductions over the row axis, done with library GEMMs (torch.matmul) below.
+and activations; the weight gradients are dense reductions over the row axis (dW = delta^T . a, db = column sums of delta): the library's
+batched A^T B kernel (hmf_rows_atb_batched, csrc/flow_grad.hip); the one dense pull-back to the shared input features (delta . W over all
+23 context layers) runs on the 1x1-convolution GEMM (hmf_conv1x1_gemm).  No vendor GEMM is called from the flow's backward.
 Forward values always come from the same inference kernels as under no_grad.
 """
 import ctypes as C
@@ -19,6 +21,17 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+
+
+def _atb(A, B, batch, rows, m, n, lda, ldb, sA, sB, want_sum):
+    """C (batch, m, n) = A^T B over `rows` (+ column sums of A (batch, m)); A / B are fp32 device tensors addressed by pitch and batch stride."""
+    lib = _lib.load()
+    Cm = torch.empty(batch, m, n, dtype=torch.float32, device=A.device)
+    sm = torch.empty(batch, m, dtype=torch.float32, device=A.device) if want_sum else None
+    with torch.cuda.device(A.device):
+        _lib.check(lib.hmf_rows_atb_batched(A.data_ptr(), B.data_ptr(), Cm.data_ptr(), None if sm is None else sm.data_ptr(), batch, rows, m, n, lda, ldb,
+                                            sA, sB, _lib.current_stream()), 'hmf_rows_atb_batched')
+    return Cm, sm
 
 
 # ---- records of the flow backward kernels ---------------------------------------------------------------------------------
@@ -44,11 +57,14 @@ class _Records:
 
     def hypernet_grads(self):
         """[(dW, db) for layer 1..4], each (P, 2, out, in) / (P, 2, out): dW_l = D_l^T . A_{l-1} over the row axis."""
-        a0 = torch.cat([self.ACTX[:, None].expand(-1, 2, -1, -1), self.XIN[..., None]], dim=-1)           # (P,2,rows,65) = [context | x1]
-        tm = lambda d, a: torch.matmul(d.transpose(-1, -2), a)
-        d4 = self.D4[..., :62]
-        return [(tm(self.D1, a0), self.D1.sum(2)), (tm(self.D2, self.A1), self.D2.sum(2)),
-                (tm(self.D3, self.A2), self.D3.sum(2)), (tm(d4, self.A3), d4.sum(2))]
+        P, R = self.P, self.rows
+        a0 = torch.cat([self.ACTX[:, None].expand(-1, 2, -1, -1), self.XIN[..., None]], dim=-1).contiguous()   # (P,2,rows,65) = [context | x1]
+
+        def tm(d, m, a, n):                                       # (P,2,rows,wd)^T . (P,2,rows,wa) -> (P,2,m,n), (P,2,m)
+            wd, wa = d.shape[-1], a.shape[-1]
+            Cm, sm = _atb(d, a, 2 * P, R, m, n, wd, wa, R * wd, R * wa, True)
+            return Cm.view(P, 2, m, n), sm.view(P, 2, m)
+        return [tm(self.D1, 64, a0, 65), tm(self.D2, 32, self.A1, 64), tm(self.D3, 32, self.A2, 32), tm(self.D4, 62, self.A3, 32)]
 
 
 def _hypernet_params(model, part0, P):
@@ -77,12 +93,20 @@ def _context_pullback(model, delta, isgc_rows, rot_rows):
     """delta (P, rows, 64) = d L / d (pre-activation of fc_flow_context[j]); isgc_rows (rows, 256); rot_rows (rows, 23, 9).
     Returns (g_full (P, 64, 256 + 207) = delta^T . [isgc | all rotations], db (P, 64), g_isgc (rows, 256)); the per-part weight gradient is a
     column selection of g_full (`_context_weight_grads`), done once per backward pass in FlowParamAnchor."""
-    x_full = torch.cat([isgc_rows, rot_rows.reshape(rot_rows.shape[0], -1)], dim=1)                       # (rows, 256 + 207)
-    g_full = torch.matmul(delta.transpose(1, 2), x_full)                                                   # (P, 64, 463)
+    lib = _lib.load()
+    P, R = delta.shape[0], delta.shape[1]
+    x_full = torch.cat([isgc_rows, rot_rows.reshape(rot_rows.shape[0], -1)], dim=1).float().contiguous()   # (rows, 256 + 207)
+    delta = delta.float().contiguous()
+    g_full, db = _atb(delta, x_full, P, R, 64, x_full.shape[1], 64, x_full.shape[1], R * 64, 0, True)      # (P, 64, 463): one shared B operand
     nin = isgc_rows.shape[1]
-    w0 = torch.stack([m.weight.detach()[:, :nin] for m in model.fc_flow_context])                           # (P, 64, 256)
-    g_isgc = torch.einsum('pro,pok->rk', delta, w0)
-    return g_full, delta.sum(1), g_isgc
+    # g_isgc[r] = sum_p delta[p, r] . W_p[:, :nin]: ONE GEMM (rows, P * 64) x (P * 64, nin) on the 1x1-convolution kernel (K = 1472, N = 256)
+    d_rows = delta.permute(1, 0, 2).reshape(R, P * 64).contiguous()
+    w0t = torch.cat([m.weight.detach()[:, :nin].float() for m in model.fc_flow_context], dim=0).t().contiguous()   # (nin, P * 64) = [N][K]
+    g_isgc = torch.empty(R, nin, dtype=torch.float32, device=delta.device)
+    with torch.cuda.device(delta.device):
+        _lib.check(lib.hmf_conv1x1_gemm(d_rows.data_ptr(), None, w0t.data_ptr(), None, None, g_isgc.data_ptr(), 1, R, 1, P * 64, 0, 0, 0, 1, nin, 0, 0,
+                                        _lib.current_stream()), 'hmf_conv1x1_gemm')
+    return g_full, db, g_isgc
 
 
 def _context_weight_grads(model, g_full, nin=256):

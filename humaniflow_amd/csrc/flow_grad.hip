@@ -579,6 +579,57 @@ __global__ __launch_bounds__(256) void k_flow_chain_bwd(FlowDev d, int lev, cons
     G.DCTX[((size_t)j * G.R + row) * 64 + lane] = dctx;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight-gradient reductions of the flow: C[b] = A[b]^T . B[b] over the row axis (dW_l = delta_l^T . a_{l-1}; train/train_humaniflow.py:351
+// reaches them through loss.backward()), plus the column sums of A (the bias gradients).  A[b] is (rows, m) with row pitch lda, B[b] (rows, n)
+// with pitch ldb, both fp32; a batch stride of 0 shares one operand across the batch (the context layers all multiply the same input rows).
+// One wave per 32 x 32 tile of C: MFMA row i / column j of lane (i, q) are operand COLUMNS, so a k-step reads one row pair of A and of B with
+// lane = column -- 128-byte coalesced loads, no transpose, no LDS.  rows <= a few hundred: a launch is latency-sized (tens of us), it replaces
+// the library GEMMs (torch.matmul / einsum) the round-2 backward called here.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_atb_batched(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm, float* __restrict__ asum,
+                                                    int rows, int m, int n, int lda, int ldb, long long sA, long long sB, int mt, int nt) {
+    const int lane = threadIdx.x, li = lane & 31, lq = lane >> 5;
+    int t = blockIdx.x;
+    const int jn = t % nt; t /= nt;
+    const int im = t % mt;
+    const int b = t / mt;
+    const float* a = A + (long long)b * sA;
+    const float* bb = Bm + (long long)b * sB;
+    const int ca = im * 32 + li, cb = jn * 32 + li;
+    const bool va = ca < m, vb = cb < n;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float s = 0.f;
+    constexpr int U = 8;                                         // k-steps (row pairs) in flight
+    for (int r0 = 0; r0 < rows; r0 += 2 * U) {
+        float fa[U], fb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 2 * u + lq;
+            fa[u] = (va && r < rows) ? a[(long long)r * lda + ca] : 0.f;
+            fb[u] = (vb && r < rows) ? bb[(long long)r * ldb + cb] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], acc, 0, 0, 0);
+            s += fa[u];
+        }
+    }
+    // accumulator register r of lane (j = li, q): C row (r & 3) + 8 (r >> 2) + 4 q of the tile, column j
+    float* c = Cm + (long long)b * m * n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+        if (row < m && vb) c[(long long)row * n + cb] = acc[r];
+    }
+    if (asum && jn == 0) {                                       // column sums of A: the two row parities of a column sit in lanes li and li + 32
+        s += __shfl_xor(s, 32);
+        if (lq == 0 && va) asum[(long long)b * m + ca] = s;
+    }
+}
+
 }  // namespace hmf
 
 using namespace hmf;
@@ -630,6 +681,18 @@ int hmf_flow_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const 
                            g_rotmats, G);
         HMF_LAUNCH_CHECK();
     }
+    return HMF_OK;
+}
+
+int hmf_rows_atb_batched(const float* A, const float* B, float* C, float* a_colsum, int batch, int rows, int m, int n, int lda, int ldb,
+                         long long batch_stride_a, long long batch_stride_b, void* stream) {
+    if (!A || !B || !C || batch <= 0 || rows <= 0 || m <= 0 || n <= 0 || lda < m || ldb < n) return fail(HMF_ERR_INVALID, "hmf_rows_atb_batched: bad args");
+    const int mt = (m + 31) / 32, nt = (n + 31) / 32;
+    const long long blocks = (long long)batch * mt * nt;
+    if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_rows_atb_batched: too many tiles");
+    hipLaunchKernelGGL(k_atb_batched, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, A, B, C, a_colsum, rows, m, n, lda, ldb, batch_stride_a,
+                       batch_stride_b, mt, nt);
+    HMF_LAUNCH_CHECK();
     return HMF_OK;
 }
 

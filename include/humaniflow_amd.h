@@ -223,6 +223,13 @@ int hmf_flow_log_prob_SO3_backward(const hmf_flow_t* h, const float* ctx, const 
  * rotmats_samples (B N) x 23 x 9 the forward result, eps_pose as in the forward; g_rotmats (B N) x 23 x 9 holds d L / d samples on entry
  * and additionally every descendant's contribution on exit (in/out).  Records: rows = B N, P = 23, DCTX filled.
  * Point-estimate rows carry no gradient in the reference (torch.set_grad_enabled(grad_for_pose_point_est), :294).          */
+/* Dense weight-gradient reductions of the training step (what loss.backward() does for every Linear of the flow, train/train_humaniflow.py:351):
+ * C[b] = A[b]^T . B[b] over the row axis, b = 0..batch-1.  A[b] (rows, m) fp32 with row pitch lda at A + b * batch_stride_a, B[b] (rows, n) with
+ * pitch ldb at B + b * batch_stride_b (a stride of 0 shares the operand), C (batch, m, n) contiguous; a_colsum (batch, m) or NULL receives the
+ * column sums of A (bias gradients).  Device pointers. */
+int hmf_rows_atb_batched(const float* A, const float* B, float* C, float* a_colsum, int batch, int rows, int m, int n, int lda, int ldb,
+                         long long batch_stride_a, long long batch_stride_b, void* stream);
+
 int hmf_flow_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const float* rotmats_samples, const float* eps_pose, int B, int N,
                              float* g_rotmats, const hmf_flow_grad_records_t* rec, void* stream);
 

@@ -305,6 +305,29 @@ def test_train_step_from_the_proxy_input_at_configs4_size():
     print('loss %.6f vs %.6f; worst encoder gradient %s rel L2 %.2e' % (loss.item(), loss_ref, worst_enc[1], worst_enc[0]))
 
 
+def test_rows_atb_batched_matches_float64():
+    """hmf_rows_atb_batched (the flow's weight-gradient reductions dW = delta^T . a, db = column sums) vs float64 matmul: pitched operands with unused
+    columns, ragged 32-tiles (m = 62, n = 65), odd row counts, an operand shared across the batch (batch stride 0)."""
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    for batch, rows, m, n, lda, ldb, shared in [(46, 576, 64, 65, 64, 65, False), (46, 216, 62, 32, 64, 32, False), (23, 577, 64, 463, 64, 463, True),
+                                                (3, 1, 5, 7, 8, 7, False), (2, 31, 33, 31, 40, 31, True)]:
+        A = torch.randn(batch, rows, lda, generator=g)
+        Bm = torch.randn(1 if shared else batch, rows, ldb, generator=g)
+        ref = torch.matmul(A[..., :m].double().transpose(1, 2), Bm[..., :n].double().expand(batch, -1, -1))
+        rs = A[..., :m].double().sum(1)
+        Ad, Bd = A.cuda(), Bm.cuda()
+        Cd = torch.full((batch, m, n), float('nan'), device='cuda')
+        sd = torch.full((batch, m), float('nan'), device='cuda')
+        _lib.check(lib.hmf_rows_atb_batched(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), sd.data_ptr(), batch, rows, m, n, lda, ldb, rows * lda,
+                                            0 if shared else rows * ldb, _lib.current_stream()), 'atb')
+        torch.cuda.synchronize()
+        assert (Cd.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (batch, rows, m, n)
+        assert (sd.cpu().double() - rs).abs().max().item() < 2e-5 * max(1.0, rs.abs().max().item())
+    assert lib.hmf_rows_atb_batched(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), None, 1, 4, 8, 8, 4, 8, 0, 0, None) == -1      # pitch < columns
+
+
 def test_training_graph_guards_and_packed_weight_handle_persistence():
     """Guards of the hand-written training graph (it reads the LIVE weights in backward, frees its activations after one backward) and the
     packed flow-weight handle's life cycle (kept across train()/eval()/load_state_dict and re-packed in place: a captured HIP graph of a step
