@@ -14,6 +14,18 @@
 
 namespace hmf {
 
+#ifdef HMF_EXPERIMENTS           // tools/stem_probe.py: per work-group stamps (shader clock: start, patch in LDS, main loop done, end; 100 MHz counter at start / end)
+__device__ long long g_stem_stamps[6 * 4096];
+#define HMF_SSTAMP(k, v)                                                              \
+    do {                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stem_stamps[blockIdx.x * 6 + (k)] = (long long)(v); \
+    } while (0)
+#else
+#define HMF_SSTAMP(k, v) \
+    do {                 \
+    } while (0)
+#endif
+
 constexpr int kStemC = 18, kStemK = 7, kStemN = 64;
 constexpr int kStemTH = 8, kStemTW = 16;                                  // output tile
 constexpr int kStemPH = 2 * kStemTH + 5, kStemPW = 2 * kStemTW + 5;       // 21 x 37 input patch
@@ -41,6 +53,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int b = blockIdx.x / tiles_hw, trem = blockIdx.x - b * tiles_hw;
     const int oh0 = (trem / tiles_w) * kStemTH, ow0 = (trem % tiles_w) * kStemTW;
     const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+    HMF_SSTAMP(0, __builtin_readcyclecounter());
+    HMF_SSTAMP(4, wall_clock64());
+    // Two work-groups share a CU: while one runs its MFMA loop the other fetches its patch or pools its tile.  Measured per work-group
+    // (tools/stem_probe.py, B = 32): patch fetch 42k cycles, main loop 64k, pooling epilogue 37k -- the two VALU-dense phases (index arithmetic
+    // of 55 + 55 patch elements, ~12 pooled windows per thread) crawl at ~28 cycles per instruction because they lose issue arbitration to the
+    // partner's older MFMA waves, although an MFMA wave needs the issue port once per 64 cycles.  So those phases run at raised priority.
+    __builtin_amdgcn_s_setprio(3);
 
     // ---- input patch -> LDS (NCHW source: 37-float runs per (channel, row)).  Raw buffer loads: an element outside the image gets an
     // out-of-range offset and comes back as zero, so all 55 loads of a thread are in flight together (no branch, no select). ----
@@ -64,6 +83,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         patch[e < kPatch ? c * kStemPlane + r * kStemPitch + stem_slot(col) : kStemC * kStemPlane] = pv[k];      // beyond the patch: the pad word
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    HMF_SSTAMP(1, __builtin_readcyclecounter());
 
     // ---- 441 k-steps ----
     const int py = 2 * wave + (li >> 4), px = li & 15;
@@ -109,6 +130,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    HMF_SSTAMP(2, __builtin_readcyclecounter());
+    __builtin_amdgcn_s_setprio(3);
     if (POOL) {
         // ---- epilogue with the max-pool: tile [8][16][64] -> LDS (the patch is dead), pooled windows from LDS ----
         __syncthreads();
@@ -148,6 +171,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             if (whole) *dst = m;
             else atomicMax((unsigned int*)dst, __float_as_uint(m));
         }
+#ifdef HMF_EXPERIMENTS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HMF_SSTAMP(3, __builtin_readcyclecounter());
+        HMF_SSTAMP(5, wall_clock64());
+#endif
         return;
     }
     // ---- epilogue: + bias, ReLU, NHWC stores (lane = channel, 128-byte runs) ----
@@ -194,6 +222,14 @@ __global__ __launch_bounds__(256) void k_maxpool_nhwc(const f32x4* __restrict__ 
 }  // namespace hmf
 
 using namespace hmf;
+
+#ifdef HMF_EXPERIMENTS
+extern "C" int hmf_debug_stem_stamps(long long* out_host, int blocks) {
+    if (!out_host || blocks < 1 || blocks > 4096) return fail(HMF_ERR_INVALID, "hmf_debug_stem_stamps: bad args");
+    HMF_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stem_stamps), (size_t)blocks * 6 * sizeof(long long)));
+    return HMF_OK;
+}
+#endif
 
 extern "C" long long hmf_stem_packed_floats(void) { return (long long)kStemGroups * 2 * 64 * 4; }
 

@@ -26,6 +26,10 @@ int hmf_debug_set_lbs_cycles(void* dev_ptr);
  * main loop done, end; cycles between a slab's top and its second barrier summed over the slabs; the 100 MHz counter at start and end; unused. */
 int hmf_debug_wino_stamps(long long* out_host, int blocks);
 
+/* Diagnostic (tools/stem_probe.py): stamps of the last k_stem_conv<POOL> launch, 6 int64 per work-group (shader clock at start, patch in LDS, main
+ * loop done, end; the 100 MHz counter at start and end). */
+int hmf_debug_stem_stamps(long long* out_host, int blocks);
+
 /* Diagnostic (tools/gemm1x1_probe.py --timeline): stamps of the last k_conv_gemm launch, 6 int64 per work-group: shader clock at start, first
  * chunk visible, main loop done, stores retired; the constant 100 MHz counter at start and end.  Work-groups 0 .. blocks-1 (<= 4096). */
 int hmf_debug_gemm_stamps(long long* out_host, int blocks);
