@@ -33,8 +33,14 @@ constexpr int kStemPH = 2 * kStemTH + 5, kStemPW = 2 * kStemTW + 5;       // 21 
 // A k-step reads column 2 px + kw for the 16 px of a row: one parity, consecutive slots -> consecutive banks; the lanes' second pixel row
 // is two patch rows = 80 floats further = the other 16 banks.  (Round 1 stored rows linearly with pitch 37: stride-2 columns put the 32
 // lanes of a half-wave on 16 banks, 47 % of the LDS cycles were bank conflicts.)
+// Round 3: a channel plane is padded from 21 to 24 rows (960 floats), so that the patch is 54 blocks of 8 rows x 40 slots = 320 floats = five
+// 64-lane LDS-DMA requests each, none of which straddles a channel: the patch is fetched by `buffer_load_dword ... lds` (no staging registers,
+// no ds_write, ~5 VALU per 64 elements instead of ~40 per element).  On gfx950 the fp32 MFMAs of one wave and the VALU work of the other wave of
+// a SIMD do not overlap (tools/micro/mfma_valu_overlap.hip: times ADD), so every VALU instruction of the fetch and of the epilogue is paid in
+// full beside the partner work-group's MFMA loop: round 2's fetch + pooling ran 42k + 37k cycles per work-group beside a 64k-cycle main loop.
 constexpr int kStemPitch = 40, kStemOdd = 20;
-constexpr int kStemPlane = kStemPH * kStemPitch;                          // 840 floats per channel
+constexpr int kStemPR = 24;                                               // rows per channel plane in LDS (21 used)
+constexpr int kStemPlane = kStemPR * kStemPitch;                          // 960 floats per channel
 __device__ __forceinline__ constexpr int stem_slot(int col) { return (col & 1) * kStemOdd + (col >> 1); }
 constexpr int kStemSteps = (kStemC / 2) * kStemK * kStemK;                // 441 k-steps
 constexpr int kStemGroups = (kStemSteps + 3) / 4;                         // 111 groups of 4
@@ -43,11 +49,17 @@ constexpr int kStemGroups = (kStemSteps + 3) / 4;                         // 111
 // the CU: y is then the POOLED map (B, PH, PW, 64), zeroed by the caller.  Pool windows that lie inside the tile (3 x 7 of the 5 x 9 the tile
 // touches) are stored; windows shared with a neighbouring tile are combined with an integer atomic max (post-ReLU values are >= +0, so the
 // float order is the unsigned order).  The 134 MB conv map (B = 32) is never written or re-read and the pool launch disappears.
+typedef __attribute__((address_space(3))) void* lds_dma_ptr_t;
+// one LDS-DMA request of 64 lanes x 4 bytes (non-template helper: see conv_gemm.hip dma16)
+static __device__ __forceinline__ void stem_dma4(__amdgpu_buffer_rsrc_t rsrc, lds_dma_ptr_t dst, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 4, voff, 0, 0, 0);
+}
+
 template <bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_conv(
     const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
     int OH, int OW, int tiles_w, int tiles_hw, int relu) {
-    __shared__ float patch[kStemC * kStemPlane + 8];            // 60.5 KB: two work-groups per CU
+    __shared__ __attribute__((aligned(16))) float patch[kStemC * kStemPlane];     // 67.5 KB: two work-groups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
     const int b = blockIdx.x / tiles_hw, trem = blockIdx.x - b * tiles_hw;
@@ -58,32 +70,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // Two work-groups share a CU: while one runs its MFMA loop the other fetches its patch or pools its tile.  Measured per work-group
     // (tools/stem_probe.py, B = 32): patch fetch 42k cycles, main loop 64k, pooling epilogue 37k -- the two VALU-dense phases (index arithmetic
     // of 55 + 55 patch elements, ~12 pooled windows per thread) crawl at ~28 cycles per instruction because they lose issue arbitration to the
-    // partner's older MFMA waves, although an MFMA wave needs the issue port once per 64 cycles.  So those phases run at raised priority.
-    __builtin_amdgcn_s_setprio(3);
+    // partner's older MFMA waves, although an MFMA wave needs the issue port once per 64 cycles.  (Raising the wave priority of those phases
+    // changed nothing: the two kinds of work share the vector datapath.)  Hence the DMA fetch and the float4 pooling below.
 
-    // ---- input patch -> LDS (NCHW source: 37-float runs per (channel, row)).  Raw buffer loads: an element outside the image gets an
-    // out-of-range offset and comes back as zero, so all 55 loads of a thread are in flight together (no branch, no select). ----
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * kStemC * H * W), 0, kStemC * H * W * 4, 0x00020000);
-    constexpr int kPatch = kStemC * kStemPH * kStemPW, kIter = (kPatch + 255) / 256;          // patch elements in (channel, row, column) order
-    float pv[kIter];
+    // ---- input patch -> LDS by LDS-DMA.  Request idx (0..269) fills LDS floats [64 idx, 64 idx + 64): block k = idx / 5 (channel k / 3, rows
+    // 8 (k % 3) ..+7), fifth j = idx % 5.  Lane l of fifth j is LDS float 64 j + l of the block: row rb = (64 j + l) / 40, slot (64 j + l) % 40,
+    // i.e. patch column 2 slot (slots 0..18) or 2 (slot - 20) + 1 (slots 20..37); slots 19, 38, 39, rows >= 21 and pixels outside the image get
+    // an out-of-range offset: the buffer load returns 0 for them and the DMA writes that 0 (the zero padding of the convolution). ----
+    // The requests carry NO per-request VALU work: while the partner work-group streams MFMAs this wave gets a VALU issue slot only now and then
+    // (round 3 measured 37k cycles for a fetch with 5 VALU instructions per request).  The 15 lane offsets (3 row blocks x 5 fifths, tile-relative)
+    // are computed once; a request is then one SALU-built descriptor per channel plane (base = the plane, range = H * W floats, so rows above or
+    // below the image fall out of range by themselves: a negative row offset wraps to a huge unsigned one) plus the precomputed VGPR.
+    constexpr int kOOBs = 0x40000000;
+    int vo[3][5];
 #pragma unroll
-    for (int k = 0; k < kIter; ++k) {
-        const int e = tid + 256 * k;
-        const int cr = e / kStemPW, col = e - cr * kStemPW;
-        const int c = cr / kStemPH, r = cr - c * kStemPH;
-        const int ih = ih0 + r, iw = iw0 + col;
-        const bool ok = (e < kPatch) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
-        pv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? ((c * H + ih) * W + iw) * 4 : (int)0x80000000, 0, 0));
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < 5; ++j) {
+        const int f = 64 * j + lane, rb = f / kStemPitch, slot = f - rb * kStemPitch;
+        const int col = slot < 19 ? 2 * slot : ((slot >= kStemOdd && slot < kStemOdd + 18) ? 2 * (slot - kStemOdd) + 1 : -1000);
+        const bool cok = (col >= 0) & ((unsigned)(iw0 + col) < (unsigned)W);
 #pragma unroll
-    for (int k = 0; k < kIter; ++k) {
-        const int e = tid + 256 * k;
-        const int c = e / (kStemPH * kStemPW), rem = e - c * (kStemPH * kStemPW), r = rem / kStemPW, col = rem - r * kStemPW;
-        patch[e < kPatch ? c * kStemPlane + r * kStemPitch + stem_slot(col) : kStemC * kStemPlane] = pv[k];      // beyond the patch: the pad word
+        for (int b3 = 0; b3 < 3; ++b3) {
+            const int r = 8 * b3 + rb;                            // patch row; rows >= 21 are LDS padding that no k-step reads: masked for determinism
+            vo[b3][j] = (cok && r < kStemPH && (unsigned)(ih0 + r) < (unsigned)H) ? ((ih0 + r) * W + iw0 + col) * 4 : kOOBs;
+        }
     }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const float* ximg = x + (long long)b * kStemC * H * W;
+    for (int ch = 0; ch < kStemC; ++ch) {
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(ximg + (long long)ch * H * W), 0, H * W * 4, 0x00020000);
+#pragma unroll
+        for (int b3 = 0; b3 < 3; ++b3) {
+            const int k = ch * 3 + b3;
+            if ((k & 3) != wv) continue;                          // wave-uniform: wave w fetches blocks w, w + 4, ...
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                stem_dma4(rc, (lds_dma_ptr_t)((__attribute__((address_space(3))) float*)patch + k * 320 + 64 * j), vo[b3][j]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
     HMF_SSTAMP(1, __builtin_readcyclecounter());
 
     // ---- 441 k-steps ----
@@ -131,7 +156,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 
     HMF_SSTAMP(2, __builtin_readcyclecounter());
-    __builtin_amdgcn_s_setprio(3);
     if (POOL) {
         // ---- epilogue with the max-pool: tile [8][16][64] -> LDS (the patch is dead), pooled windows from LDS ----
         __syncthreads();
@@ -149,13 +173,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
         }
         __syncthreads();
+        // thread = (pooled position, 4 channels): nine 16-byte LDS reads per window, one 16-byte store (windows inside the tile) or four integer
+        // atomic maxima (windows shared with a neighbour tile); 45 positions x 16 channel quads = 720 items over 256 threads
         const int PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;
-        const int ch = tid & 63, q = tid >> 6;
         const int pr0 = oh0 >> 1, pc0 = ow0 >> 1;
-        for (int p = q; p < 45; p += 4) {
+        for (int it = tid; it < 45 * 16; it += 256) {
+            const int p = it >> 4, cq = (it & 15) * 4;
             const int a = p / 9, c = p - a * 9;                   // pooled position (pr0 + a, pc0 + c): conv rows 2a-1 .. 2a+1 of the tile
             if (pr0 + a >= PH || pc0 + c >= PW) continue;
-            float m = 0.f;
+            f32x4 m = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int dr = -1; dr <= 1; ++dr) {
                 const int rr = 2 * a + dr;
@@ -163,13 +189,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int dc = -1; dc <= 1; ++dc) {
                     const int cc = 2 * c + dc;
-                    if ((unsigned)cc < 16u) m = fmaxf(m, tl[(rr * 16 + cc) * 64 + ch]);
+                    if ((unsigned)cc < 16u) {
+                        const f32x4 v = *(const f32x4*)&tl[(rr * 16 + cc) * 64 + cq];
+                        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+                    }
                 }
             }
-            float* dst = y + (((long long)b * PH + pr0 + a) * PW + pc0 + c) * kStemN + ch;
+            float* dst = y + (((long long)b * PH + pr0 + a) * PW + pc0 + c) * kStemN + cq;
             const bool whole = (a >= 1) & (a <= 3) & (c >= 1) & (c <= 7);
-            if (whole) *dst = m;
-            else atomicMax((unsigned int*)dst, __float_as_uint(m));
+            if (whole) {
+                *(f32x4*)dst = m;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicMax((unsigned int*)dst + e, __float_as_uint(m[e]));
+            }
         }
 #ifdef HMF_EXPERIMENTS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
