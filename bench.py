@@ -478,7 +478,7 @@ def main():
         }
         step_flops = sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)
         agg = step_flops / (elapsed / args.steps) / 1e12
-        pmc = load_pmc_traffic(source_hash(), 'B=%d,N=%d,%s' % (args.batch, args.samples, args.blend_dtype))
+        pmc = load_pmc_traffic(source_hash(), 'B=%d,N=%d,%s%s' % (args.batch, args.samples, args.blend_dtype, ',eval' if args.eval else ''))
 
         def traffic_of(key):
             if pmc is None:

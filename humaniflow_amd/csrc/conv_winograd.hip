@@ -393,6 +393,13 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
         case 13: HMF_WINO_LAUNCH(3, 0, 3); break;
         case 20: HMF_WINO_LAUNCH(0, 1, 2); break;
         case 30: HMF_WINO_LAUNCH(0, 1, 3); break;
+        case 40:            // two n-tiles per wave (64 output channels per work-group): half the patch fetches and input transforms per MFMA
+        case 41:
+            if (pair || Cout % 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_variant: variant 40/41 needs Cout %% 64 == 0 and maps wider than 8");
+            a.n_tiles = Cout / 64;
+            if (variant == 40) hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 0, 2>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 1, 2>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
+            break;
         case 22: HMF_WINO_LAUNCH(0, 2, 2); break;
         case 4: HMF_WINO_LAUNCH(4, 0, 2); break;
         case 8: HMF_WINO_LAUNCH(8, 0, 2); break;

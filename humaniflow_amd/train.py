@@ -353,8 +353,27 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
                'forward + input-gradient convolutions (k_stem_conv, k_conv_winograd, k_conv_patch, k_conv_igemm)': (f_all + f_dgrad, t_c, int(((tag >= 8) & (tag <= 11)).sum()) // P)}
         name = max(fam, key=lambda k: fam[k][1])
         f, t, nl = fam[name]
+        # HBM bytes per launch of that family from the separate rocprofv3 --pmc passes (tools/profile_round.sh), quoted only when the summary was
+        # collected at this library source hash on this workload
+        traffic, traffic_note = None, 'null: no profiles/*_pmc.json at this library source hash for the train workload'
+        try:
+            import json as _json
+            import os as _os
+            from .build import source_hash
+            pdir = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'profiles')
+            keys = ('k_stem_wgrad', 'k_conv_wgrad') if name.startswith('weight') else ('k_stem_conv', 'k_conv_winograd', 'k_conv_patch', 'k_conv_igemm', 'k_conv_gemm')
+            for fn in sorted(_os.listdir(pdir)):
+                if fn.endswith('_pmc.json'):
+                    d = _json.load(open(_os.path.join(pdir, fn)))
+                    if d.get('lib_source_hash') == source_hash() and d.get('workload') == 'train,B=%d,N=%d' % (B, N):
+                        cand = [v for k, v in d['kernels'].items() if any(kk in k for kk in keys)]
+                        if cand:
+                            traffic = int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
+                            traffic_note = 'mean HBM bytes/launch over this family (profiles/%s)' % fn
+        except Exception:
+            pass
         roof = {'kernel': name + ': the kernel family with the largest share of the training step (%d launches/step)' % nl, 'bound': 'mfma',
-                'achieved': round(f / t / 1e12, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(f / t / 1e12 / 157.3, 4), 'traffic': None,
+                'achieved': round(f / t / 1e12, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(f / t / 1e12 / 157.3, 4), 'traffic': traffic, 'traffic_note': traffic_note,
                 'ms_per_step': round(t * 1e3, 3), 'algorithmic_gflop_per_step': round(f / 1e9, 1),
                 'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (HIP event pair around every launch of %d extra steps); '
                        'the stride-1 3x3 layers run as Winograd F(2x2,3x3) and are booked at direct-form FLOPs (the MFMA pipe executes 4/9 of them), '

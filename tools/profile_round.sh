@@ -22,6 +22,26 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_B
 python tools/pmc_mfma.py "$(find /tmp/prof_m -name '*.db' | head -1)" > "$OUT/${R}_mfma_busy.txt"
 python tools/pmc_summary.py "$(find /tmp/prof_f -name '*.db' | head -1)" "$(find /tmp/prof_w -name '*.db' | head -1)" > "$OUT/${R}_pmc.json"
 cp "$OUT"/${R}_* profiles/
+# ---- the other BASELINE configurations: eval step (configs[3] per GPU), bf16 blend operands at B = 64 (configs[2]), training step (configs[4]):
+# two PMC passes each (FETCH_SIZE, WRITE_SIZE), then the bench line that quotes them
+pmc_pair() {   # $1 = tag, $2 = workload label, rest = bench flags
+    tag=$1; wl=$2; shift 2
+    rm -rf /tmp/pf_$tag /tmp/pw_$tag
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf_$tag -o f -- python bench.py --no-cpu-baseline --profile-steps 0 --steps 12 --warmup 4 "$@" >/dev/null 2>/tmp/pf_$tag.log
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw_$tag -o w -- python bench.py --no-cpu-baseline --profile-steps 0 --steps 12 --warmup 4 "$@" >/dev/null 2>/tmp/pw_$tag.log
+    HMF_PMC_WORKLOAD="$wl" python tools/pmc_summary.py "$(find /tmp/pf_$tag -name '*.db' | head -1)" "$(find /tmp/pw_$tag -name '*.db' | head -1)" > "$OUT/${R}_${tag}_pmc.json"
+    cp "$OUT/${R}_${tag}_pmc.json" profiles/
+}
+if [ "${HMF_PROFILE_FLAVOURS:-1}" = "1" ]; then
+    pmc_pair eval "B=32,N=100,fp32,eval" --eval
+    python bench.py --eval --no-cpu-baseline > "$OUT/${R}_bench_eval_configs3.json" 2> "$OUT/${R}_bench_eval.log"
+    pmc_pair bf16 "B=64,N=100,bf16" --batch 64 --blend-dtype bf16
+    python bench.py --batch 64 --blend-dtype bf16 --no-cpu-baseline > "$OUT/${R}_bench_configs2_bf16_B64.json" 2> "$OUT/${R}_bench_bf16.log"
+    pmc_pair train "train,B=72,N=8" --train
+    python bench.py --train --no-cpu-baseline > "$OUT/${R}_bench_train_configs4.json" 2> "$OUT/${R}_bench_train.log"
+    rocprofv3 --kernel-trace --stats -d /tmp/prof_tr -o tr -- python bench.py --train --no-cpu-baseline --steps 12 --warmup 4 --profile-steps 0 > /dev/null 2>/tmp/tr.log
+    python tools/rocpd_stats.py "$(find /tmp/prof_tr -name '*.db' | head -1)" 60 > "$OUT/${R}_train_kernel_stats.md"
+fi
 # the headline line LAST: it quotes `traffic` from the PMC summary just written (same library source hash)
 python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.log"
 cp "$OUT"/${R}_* profiles/ && python tools/roofline_table.py $R > "$OUT/${R}_roofline.md"
