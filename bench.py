@@ -460,7 +460,7 @@ def main():
             'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': round(value, 1), 'unit': 'images*samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.blend_dtype == 'fp32' else 'bf16 blend-shape GEMM operands (f32 accumulate), f32 elsewhere', 'data': 'synthetic',
+            'dtype': 'f32' if args.blend_dtype == 'fp32' else 'bf16 blend-shape GEMM operands as hi+lo pairs, 3 bf16 MFMAs per product (f32 accumulate), f32 elsewhere', 'data': 'synthetic',
             'config': {'workload': flavour + ': B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL %s, random-init weights, '
                                    'synthetic SMPL-shaped body model%s'
                                    % (B, N, args.layers, 'fp32' if args.blend_dtype == 'fp32' else 'fp32 with bf16 blend-shape GEMM operands',

@@ -42,6 +42,7 @@ struct SmplDev {
     float* tp_dirs;                  // [nb][3V]
     float* tp_tmpl;                  // [3V]
     unsigned short* blend16;         // bf16 operand of the configs[2] variant: [kVT][kKG16][3][64 lanes][8]
+    unsigned short* blend16_lo;      // bf16(x - bf16(x)) of the same operand (impl = 3: hi + lo split, three MFMAs per product)
     // vertex-major transpose of the gathered-joint CSR (backward of joints 24..89): unique vertices and, per vertex, (output joint, weight)
     int n_ju;
     int* ju_vid;                     // [n_ju]
@@ -80,6 +81,12 @@ __host__ __device__ inline unsigned short f32_to_bf16(float x) {
     u += 0x7FFFu + ((u >> 16) & 1u);              // round to nearest even
     return (unsigned short)(u >> 16);
 }
+__host__ __device__ inline float bf16_to_f32(unsigned short h) {
+    const unsigned int u = (unsigned int)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
 __host__ __device__ inline size_t blend16_index(int k, int v, int c) {
     return ((((size_t)(v >> 5) * kKG16 + (k >> 4)) * 3 + c) * 64 + (((k >> 3) & 1) * 32 + (v & 31))) * 8 + (k & 7);
 }
@@ -102,7 +109,8 @@ __device__ __forceinline__ float pose_feature(int k, int nb, const float* __rest
 __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __restrict__ glob, int Mg,
                                                      const float* __restrict__ body, const float* __restrict__ betas,
                                                      int Mb, int M, float* __restrict__ atr, float* __restrict__ joints,
-                                                     float* __restrict__ panel, unsigned short* __restrict__ panel16) {
+                                                     float* __restrict__ panel, unsigned short* __restrict__ panel16,
+                                                     unsigned short* __restrict__ panel16_lo) {
     __shared__ float sJ[8][kJ][3];
     __shared__ float sG[8][kJ][12];
     const int j = threadIdx.x % kJ, r = threadIdx.x / kJ;
@@ -145,14 +153,20 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
                 pr[k * 64] = !live ? 0.0f : (k < kPoseFeat + nb ? b[k - kPoseFeat] : (k == kPoseFeat + nb ? 1.0f : 0.0f));
         }
     }
-    if (panel16) {                                  // row-major bf16 copy of the same features (no constant-1 column)
+    if (panel16) {                                  // row-major bf16 copy of the same features (no constant-1 column); impl = 3: + the bf16 remainders
         unsigned short* pr = panel16 + (size_t)row * kP16Stride;
+        unsigned short* pl = panel16_lo ? panel16_lo + (size_t)row * kP16Stride : nullptr;
+        auto put = [&](int k, float x) {
+            const unsigned short h = f32_to_bf16(x);
+            pr[k] = h;
+            if (pl) pl[k] = f32_to_bf16(x - bf16_to_f32(h));
+        };
         if (j > 0) {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) pr[(j - 1) * 9 + e] = live ? f32_to_bf16(R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f)) : 0;
+            for (int e = 0; e < 9; ++e) put((j - 1) * 9 + e, live ? R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f) : 0.f);
         } else {
             const float* b = betas + (size_t)((Mb == 1 || !live) ? 0 : row) * nb;
-            for (int k = kPoseFeat; k < kP16Stride; ++k) pr[k] = (live && k < kPoseFeat + nb) ? f32_to_bf16(b[k - kPoseFeat]) : 0;
+            for (int k = kPoseFeat; k < kP16Stride; ++k) put(k, (live && k < kPoseFeat + nb) ? b[k - kPoseFeat] : 0.f);
         }
     }
     sJ[r][j][0] = Jc[0]; sJ[r][j][1] = Jc[1]; sJ[r][j][2] = Jc[2];
@@ -561,12 +575,16 @@ __global__ void k_vertex_variance(const float* __restrict__ verts, int N, int V,
 // ---------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int SLOTS>
+// SPLIT (impl = 3): both operands as bf16 hi + bf16 lo (x = hi + lo to 2^-17 relative); every product is three bf16 MFMAs
+// (hi.hi + hi.lo + lo.hi, fp32 accumulate; lo.lo ~ 2^-18 dropped), which brings the vertices from 1.5e-3 m (plain bf16 operands) to within
+// 1e-4 m of the fp32 oracle -- the north-star tolerance -- at 3/16 of the fp32 MFMA time: still bound by the vertex write.
+template <int SLOTS, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
-                                                     const float* __restrict__ atr, float* __restrict__ verts) {
-    __shared__ __attribute__((aligned(16))) float smem[kRowsPerWG * kP16Stride / 2 + kRowsPerWG * kAtr];   // 29 + 72 KB
+                                                     const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts) {
+    constexpr int kPanelF = kRowsPerWG * kP16Stride / 2;                     // floats of one bf16 panel
+    __shared__ __attribute__((aligned(16))) float smem[(SPLIT ? 2 : 1) * kPanelF + kRowsPerWG * kAtr];   // 29 (+ 29) + 72 KB
     const unsigned short* sP = (const unsigned short*)smem;
-    float* sA = smem + kRowsPerWG * kP16Stride / 2;
+    float* sA = smem + (SPLIT ? 2 : 1) * kPanelF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int xr = blockIdx.x & 7;
@@ -584,6 +602,10 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
             f32x4* dst = (f32x4*)smem;
             constexpr int n16 = kRowsPerWG * kP16Stride * 2 / 16;
             for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+            if (SPLIT) {
+                const f32x4* srcl = (const f32x4*)(panel16_lo + (size_t)row0 * kP16Stride);
+                for (int i = tid; i < n16; i += 512) dst[n16 + i] = srcl[i];
+            }
             const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
             f32x4* dst2 = (f32x4*)sA;
             const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
@@ -617,16 +639,29 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
             const f32x4* bp = (const f32x4*)(d.blend16 + (size_t)vt * kKG16 * 3 * 64 * 8) + lane;
+            const f32x4* bpl = (const f32x4*)(d.blend16_lo + (size_t)vt * kKG16 * 3 * 64 * 8) + lane;
             const unsigned short* ap = sP + l31 * kP16Stride + half * 8;
+            const unsigned short* apl = ap + kRowsPerWG * kP16Stride;                  // the lo panel follows the hi panel in LDS
             f32x4 b0 = bp[0], b1 = bp[64], b2 = bp[128];
             f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 32 * kP16Stride);
+            f32x4 bl0 = b0, bl1 = b1, bl2 = b2, al0 = a0, al1 = a1;
+            if (SPLIT) {
+                bl0 = bpl[0]; bl1 = bpl[64]; bl2 = bpl[128];
+                al0 = *(const f32x4*)apl; al1 = *(const f32x4*)(apl + 32 * kP16Stride);
+            }
 #pragma unroll
             for (int kg = 0; kg < kKG16; ++kg) {
                 f32x4 n0 = b0, n1 = b1, n2 = b2, m0 = a0, m1 = a1;
+                f32x4 nl0 = bl0, nl1 = bl1, nl2 = bl2, ml0 = al0, ml1 = al1;
                 if (kg + 1 < kKG16) {
                     n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128];
                     m0 = *(const f32x4*)(ap + (kg + 1) * 16);
                     m1 = *(const f32x4*)(ap + 32 * kP16Stride + (kg + 1) * 16);
+                    if (SPLIT) {
+                        nl0 = bpl[(kg + 1) * 192]; nl1 = bpl[(kg + 1) * 192 + 64]; nl2 = bpl[(kg + 1) * 192 + 128];
+                        ml0 = *(const f32x4*)(apl + (kg + 1) * 16);
+                        ml1 = *(const f32x4*)(apl + 32 * kP16Stride + (kg + 1) * 16);
+                    }
                 }
                 const bf16x8 A0 = __builtin_bit_cast(bf16x8, a0), A1 = __builtin_bit_cast(bf16x8, a1);
                 const bf16x8 B[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
@@ -635,7 +670,19 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
                     acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[c], acc[0][c], 0, 0, 0);
                     acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[c], acc[1][c], 0, 0, 0);
                 }
+                if (SPLIT) {
+                    const bf16x8 L0 = __builtin_bit_cast(bf16x8, al0), L1 = __builtin_bit_cast(bf16x8, al1);
+                    const bf16x8 BL[3] = {__builtin_bit_cast(bf16x8, bl0), __builtin_bit_cast(bf16x8, bl1), __builtin_bit_cast(bf16x8, bl2)};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, BL[c], acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BL[c], acc[1][c], 0, 0, 0);
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(L0, B[c], acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(L1, B[c], acc[1][c], 0, 0, 0);
+                    }
+                }
                 b0 = n0; b1 = n1; b2 = n2; a0 = m0; a1 = m1;
+                bl0 = nl0; bl1 = nl1; bl2 = nl2; al0 = ml0; al1 = ml1;
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -825,13 +872,14 @@ static void pack_blend(const hmf_smpl_host_t* m, float* out) {
         }
 }
 
-static void pack_blend16(const hmf_smpl_host_t* m, unsigned short* out) {
+static void pack_blend16(const hmf_smpl_host_t* m, unsigned short* out, bool lo = false) {
     const int nb = m->num_betas;
     memset(out, 0, sizeof(unsigned short) * (size_t)kVT * kKG16 * 3 * 64 * 8);
     for (int v = 0; v < kV; ++v)
         for (int c = 0; c < 3; ++c) {
-            for (int k = 0; k < kPoseFeat; ++k) out[blend16_index(k, v, c)] = f32_to_bf16(m->posedirs_host[(size_t)k * kV * 3 + v * 3 + c]);
-            for (int k = 0; k < nb; ++k) out[blend16_index(kPoseFeat + k, v, c)] = f32_to_bf16(m->shapedirs_host[((size_t)v * 3 + c) * nb + k]);
+            auto enc = [&](float x) { const unsigned short h = f32_to_bf16(x); return lo ? f32_to_bf16(x - bf16_to_f32(h)) : h; };
+            for (int k = 0; k < kPoseFeat; ++k) out[blend16_index(k, v, c)] = enc(m->posedirs_host[(size_t)k * kV * 3 + v * 3 + c]);
+            for (int k = 0; k < nb; ++k) out[blend16_index(kPoseFeat + k, v, c)] = enc(m->shapedirs_host[((size_t)v * 3 + c) * nb + k]);
         }
 }
 
@@ -941,8 +989,9 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
             for (int k = 0; k < nb; ++k) tpd[(size_t)k * kV * 3 + v * 3 + c] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
     std::vector<float> blend((size_t)kVT * kKG * 3 * 64 * 4);
     pack_blend(m, blend.data());
-    std::vector<unsigned short> blend16((size_t)kVT * kKG16 * 3 * 64 * 8);
+    std::vector<unsigned short> blend16((size_t)kVT * kKG16 * 3 * 64 * 8), blend16l(blend16.size());
     pack_blend16(m, blend16.data());
+    pack_blend16(m, blend16l.data(), true);
 
     // --- one device arena -----------------------------------------------------------------------------
     size_t off = 0;
@@ -950,7 +999,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     const size_t o_blend = place(blend.size() * 4), o_soff = place(soff.size() * 4), o_sw = place(sw.size() * 4);
     const size_t o_jt = place(jt.size() * 4), o_jd = place(jd.size() * 4), o_ptr = place(ptr.size() * 4);
     const size_t o_idx = place(idx.size() * 4), o_w = place(wts.size() * 4), o_tpd = place(tpd.size() * 4);
-    const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2);
+    const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2), o_b16l = place(blend16l.size() * 2);
     const size_t o_jv = place(ju_vid.size() * 4 + 4), o_jp = place(ju_ptr.size() * 4), o_jo = place(ju_out.size() * 4 + 4), o_jw = place(ju_w.size() * 4 + 4);
     void* arena = nullptr;
     HMF_HIP(hipMalloc(&arena, off));
@@ -967,6 +1016,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     if (e == hipSuccess) e = up(o_tpd, tpd.data(), tpd.size() * 4);
     if (e == hipSuccess) e = up(o_tpt, m->v_template_host, (size_t)kV * 3 * 4);
     if (e == hipSuccess) e = up(o_b16, blend16.data(), blend16.size() * 2);
+    if (e == hipSuccess) e = up(o_b16l, blend16l.data(), blend16l.size() * 2);
     if (e == hipSuccess && !ju_vid.empty()) e = up(o_jv, ju_vid.data(), ju_vid.size() * 4);
     if (e == hipSuccess) e = up(o_jp, ju_ptr.data(), ju_ptr.size() * 4);
     if (e == hipSuccess && !ju_out.empty()) e = up(o_jo, ju_out.data(), ju_out.size() * 4);
@@ -997,6 +1047,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     d.tp_dirs = (float*)(base + o_tpd);
     d.tp_tmpl = (float*)(base + o_tpt);
     d.blend16 = (unsigned short*)(base + o_b16);
+    d.blend16_lo = (unsigned short*)(base + o_b16l);
     d.n_ju = (int)ju_vid.size();
     d.ju_vid = (int*)(base + o_jv);
     d.ju_ptr = (int*)(base + o_jp);
@@ -1015,7 +1066,7 @@ void hmf_smpl_destroy(hmf_smpl_t* h) {
 static size_t ws_atr_bytes(int M) { return align_up((size_t)std::max(M, 1) * kAtr * sizeof(float), 256); }
 static size_t ws_panel_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kKpad * 64 * sizeof(float); }
 static size_t ws_panel16_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kRowsPerWG * kP16Stride * 2; }
-size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + ws_panel16_bytes(M); }
+size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + 2 * ws_panel16_bytes(M); }
 
 int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose, const float* betas,
                  int Mb, int M, float* verts, float* joints, void* workspace, size_t workspace_bytes, int impl,
@@ -1027,18 +1078,21 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
     if (!workspace || workspace_bytes < hmf_smpl_lbs_workspace_bytes(M))
         return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
 #ifndef HMF_EXPERIMENTS
-    if (impl < 0 || impl > 2) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: impl=%d (0 = fp32 MFMA, 1 = scalar cross-check, 2 = bf16 operands)", impl);
+    if (impl < 0 || impl > 3) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: impl=%d (0 = fp32 MFMA, 1 = scalar cross-check, 2 = bf16 operands, 3 = bf16 hi+lo split operands)", impl);
 #endif
     hipStream_t st = (hipStream_t)stream;
     float* atr = (float*)workspace;
     float* panel = (float*)((char*)workspace + ws_atr_bytes(M));
     unsigned short* panel16 = (unsigned short*)((char*)workspace + ws_atr_bytes(M) + ws_panel_bytes(M));
-    const bool bf16 = (impl & 15) == 2;
+    unsigned short* panel16_lo = (unsigned short*)((char*)panel16 + ws_panel16_bytes(M));
+    const bool split = (impl & 15) == 3;
+    const bool bf16 = (impl & 15) == 2 || split;
     const int nrg_all = (M + kRowsPerWG - 1) / kRowsPerWG;
     {
         ProfScope ps(2, M, st);      // grid padded to whole row groups: dead rows zero their slice of the panel
         hipLaunchKernelGGL(k_rigid_chain, dim3(nrg_all * (kRowsPerWG / 8)), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas,
-                           Mb, M, atr, joints, bf16 ? (float*)nullptr : panel, bf16 ? panel16 : (unsigned short*)nullptr);
+                           Mb, M, atr, joints, bf16 ? (float*)nullptr : panel, bf16 ? panel16 : (unsigned short*)nullptr,
+                           split ? panel16_lo : (unsigned short*)nullptr);
     }
     HMF_LAUNCH_CHECK();
     if ((impl & 15) == 1) {
@@ -1051,9 +1105,15 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         const int T = nrg * kVTperX;
         const int wpx = std::max(1, std::min(32, (T + 7) / 8));
         const dim3 grid(8 * wpx), block(512);
-        if (h->d.skin_slots == 4) hipLaunchKernelGGL((k_lbs_mfma16<4>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, atr, verts);
-        else if (h->d.skin_slots == 8) hipLaunchKernelGGL((k_lbs_mfma16<8>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, atr, verts);
-        else hipLaunchKernelGGL((k_lbs_mfma16<0>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, atr, verts);
+#define HMF_LBS16(S)                                                                                                                       \
+    do {                                                                                                                                   \
+        if (split) hipLaunchKernelGGL((k_lbs_mfma16<S, true>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts);     \
+        else hipLaunchKernelGGL((k_lbs_mfma16<S, false>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts);          \
+    } while (0)
+        if (h->d.skin_slots == 4) HMF_LBS16(4);
+        else if (h->d.skin_slots == 8) HMF_LBS16(8);
+        else HMF_LBS16(0);
+#undef HMF_LBS16
     } else {
         ProfScope ps(1, M, st);
         const int nrg = (M + kRowsPerWG - 1) / kRowsPerWG;

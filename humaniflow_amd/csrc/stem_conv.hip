@@ -28,7 +28,7 @@ __device__ long long g_stem_stamps[6 * 4096];
 
 constexpr int kStemC = 18, kStemK = 7, kStemN = 64;
 constexpr int kStemTH = 8, kStemTW = 16;                                  // output tile
-constexpr int kStemPH = 2 * kStemTH + 5, kStemPW = 2 * kStemTW + 5;       // 21 x 37 input patch
+constexpr int kStemPH = 2 * kStemTH + 5;                                  // 21 x 37 input patch (37 = 2 * kStemTW + 5 columns: 19 even + 18 odd slots)
 // LDS image of the patch: columns de-interleaved by parity (even columns in slots 0..18, odd ones in 20..37) with a row pitch of 40 floats.
 // A k-step reads column 2 px + kw for the 16 px of a row: one parity, consecutive slots -> consecutive banks; the lanes' second pixel row
 // is two patch rows = 80 floats further = the other 16 banks.  (Round 1 stored rows linearly with pitch 37: stride-2 columns put the 32

@@ -96,8 +96,9 @@ class SMPL(nn.Module):
     def __init__(self, model_path=None, batch_size=1, gender='neutral', num_betas=10, create_transl=True,
                  model_data=None, blend_dtype='fp32', **kwargs):
         super().__init__()
-        if blend_dtype not in ('fp32', 'bf16'):
-            raise ValueError("blend_dtype must be 'fp32' or 'bf16' (BASELINE configs[2]: bf16 MFMA blend-shape GEMMs, fp32 accumulate)")
+        if blend_dtype not in ('fp32', 'bf16', 'bf16_plain'):
+            raise ValueError("blend_dtype must be 'fp32', 'bf16' (BASELINE configs[2]: bf16 MFMA blend-shape GEMMs, fp32 accumulate; operands as bf16 hi + lo "
+                             "pairs, three MFMAs per product: vertices within 1e-4 m of fp32) or 'bf16_plain' (single bf16 operands: 1.5e-3 m)")
         self.blend_dtype = blend_dtype
         if model_data is None:
             model_data = load_smpl_pkl(model_path, gender, num_betas)
@@ -214,7 +215,7 @@ class SMPL(nn.Module):
             ws = self._workspace(dev, M)
             _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
                                         _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(),
-                                        int((2 if self.blend_dtype == 'bf16' else 0) if impl is None else impl),
+                                        int({'fp32': 0, 'bf16': 3, 'bf16_plain': 2}[self.blend_dtype] if impl is None else impl),
                                         _lib.current_stream()), 'hmf_smpl_lbs')
         return verts, joints
 

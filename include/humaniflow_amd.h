@@ -86,9 +86,10 @@ size_t hmf_smpl_lbs_workspace_bytes(int M);
 /* Posed bodies.  global_orient: Mg x 9, body_pose: M x 23 x 9 (rotation matrices, pose2rot=False
  * layout; use hmf_batch_rodrigues first for axis-angle input); betas: Mb x num_betas with Mb in
  * {1, M} (smplx broadcast rule); Mg in {1, M}.  verts: M x 6890 x 3; joints: M x 90 x 3 (nullable).
- * impl: 0 = fp32 MFMA kernel (product path), 1 = scalar cross-check kernel (tests only), 2 = BASELINE configs[2] variant:
- * blend-shape GEMM operands in bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fp32 template add and fp32 skinning
- * (vertices within ~1e-3 m of the fp32 path for SMPL-sized bases; profiler tag 12).                */
+ * impl: 0 = fp32 MFMA kernel (product path), 1 = scalar cross-check kernel (tests only), 2 / 3 = BASELINE configs[2] variants:
+ * blend-shape GEMM operands in bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fp32 template add and fp32 skinning (profiler
+ * tag 12).  2: single bf16 operands (vertices within ~1.5e-3 m of the fp32 path for SMPL-sized bases).  3: both operands as bf16 hi + lo
+ * pairs, hi.hi + hi.lo + lo.hi per product (vertices within 1e-4 m: the mode SMPL(blend_dtype='bf16') uses).                        */
 int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose,
                  const float* betas, int Mb, int M, float* verts, float* joints, void* workspace,
                  size_t workspace_bytes, int impl, void* stream);
