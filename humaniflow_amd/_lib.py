@@ -81,6 +81,9 @@ _SIGS = {
     'hmf_bn_bwd_apply': (C.c_int, [_VP] * 8 + [C.c_int] * 3 + [_VP]),
     'hmf_maxpool3x3s2_nhwc_backward': (C.c_int, [_VP] * 3 + [C.c_int] * 4 + [_VP]),
     'hmf_conv_wgrad': (C.c_int, [_VP] * 3 + [C.c_int] * 8 + [_VP]),
+    'hmf_conv_wgrad_winograd_workspace_floats': (C.c_size_t, [C.c_int, C.c_int]),
+    'hmf_conv_wgrad_winograd_supported': (C.c_int, [C.c_int] * 4),
+    'hmf_conv_wgrad_winograd': (C.c_int, [_VP] * 4 + [C.c_int] * 5 + [_VP]),
     'hmf_proxy_rep': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                 _VP, _VP, _VP, _VP, _VP]),
     'hmf_stem_packed_floats': (C.c_longlong, []),

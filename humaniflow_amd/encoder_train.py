@@ -22,6 +22,7 @@ import torch
 from . import _lib
 
 CL = torch.channels_last
+WINOGRAD_WGRAD = True          # stride-1 3x3 weight gradients on hmf_conv_wgrad_winograd where the shape is built (False: hmf_conv_wgrad everywhere)
 
 
 def _cl_empty(B, C, H, W, device):
@@ -198,6 +199,13 @@ def _wgrad(gy, s):
         _lib.check(lib.hmf_conv_wgrad(gy.data_ptr(), s.x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, ks, s.stride, 1, _lib.current_stream()), 'hmf_conv_wgrad')
         return dw
     B, _, H, W = s.x.shape
+    if ks == 3 and s.stride == 1 and WINOGRAD_WGRAD and lib.hmf_conv_wgrad_winograd_supported(H, W, Cin, Cout):
+        # stride-1 3x3 layers: Winograd F(3x3, 2x2) weight gradient, written in the parameter's (Cout, Cin, 3, 3) layout (no permute pass)
+        dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=gy.device)
+        ws = torch.empty(int(lib.hmf_conv_wgrad_winograd_workspace_floats(Cin, Cout)), dtype=torch.float32, device=gy.device)
+        _lib.check(lib.hmf_conv_wgrad_winograd(gy.data_ptr(), s.x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, Cin, Cout, _lib.current_stream()),
+                   'hmf_conv_wgrad_winograd')
+        return dw
     dw = torch.empty(Cout, ks, ks, Cin, dtype=torch.float32, device=gy.device)
     _lib.check(lib.hmf_conv_wgrad(gy.data_ptr(), s.x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, ks, s.stride, 0, _lib.current_stream()), 'hmf_conv_wgrad')
     return dw.permute(0, 3, 1, 2).contiguous()

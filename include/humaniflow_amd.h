@@ -366,6 +366,14 @@ int hmf_maxpool3x3s2_nhwc_backward(const float* x, const float* g_out, float* g_
  * stem_nchw = 1: x is the NCHW proxy input (B,Cin,H,W) and dw comes out as [Cout][Cin][ks][ks] (torch's native layout).
  * dw is zeroed, then accumulated with float atomics over slices of the pixel axis (run-to-run differences at rounding level).            */
 int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int ks, int stride, int stem_nchw, void* stream);
+/* The same gradient for stride-1 3x3 layers as Winograd F(3x3, 2x2) (csrc/conv_wgrad_wino.hip: 16 instead of 36 multiplies per 2x2 tile of gy,
+ * the sum over tiles as 16 MFMA GEMMs, one inverse transform at the end): gy (B,H,W,Cout), x (B,H,W,Cin) NHWC -> dw_native (Cout,Cin,3,3), the
+ * parameter's own layout.  workspace: hmf_conv_wgrad_winograd_workspace_floats(Cin, Cout) floats of device memory (zeroed by the call).
+ * Built for the shapes hmf_conv_wgrad_winograd_supported() accepts (H even; W a multiple of 32, or 16 with H % 4 == 0, or 8 with H % 8 == 0;
+ * Cin % 64 == 0, Cout % 32 == 0); float atomics over slices of the tiles (run-to-run differences at rounding level).                       */
+size_t hmf_conv_wgrad_winograd_workspace_floats(int Cin, int Cout);
+int hmf_conv_wgrad_winograd_supported(int H, int W, int Cin, int Cout);
+int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* dw_native, float* workspace, int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */

@@ -71,6 +71,36 @@ def test_conv_weight_and_input_gradients_match_torch(cin, cout, ks, stride, hw):
     assert _rel(dx_res - res, xr.grad) < 5e-5
 
 
+@pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 3, 64, 64), (64, 64, 2, 10, 32), (128, 128, 5, 32, 32), (256, 256, 3, 16, 16), (512, 512, 4, 8, 8),
+                                            (64, 96, 2, 4, 16), (128, 64, 1, 2, 96), (64, 32, 7, 8, 8)])
+def test_winograd_weight_gradient_matches_float64(cin, cout, B, H, W):
+    """hmf_conv_wgrad_winograd (F(3x3, 2x2): Winograd-domain GEMMs + one inverse transform) vs torch autograd in float64, and vs the direct
+    weight-gradient kernel: every chunk geometry (1 x 16, 2 x 8, 4 x 4 tiles), image borders, two chunks per row (W = 64, 96), ragged slices."""
+    lib = _lib.load()
+    assert lib.hmf_conv_wgrad_winograd_supported(H, W, cin, cout)
+    torch.manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, device='cuda').contiguous(memory_format=CL)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).cuda()
+    cr = copy.deepcopy(conv).double()
+    yr = cr(x.double())
+    gy = torch.randn_like(yr).float().contiguous(memory_format=CL)
+    yr.backward(gy.double())
+    s = et._Saved()
+    s.conv, s.x, s.stride, s.stem = conv, x, 1, False
+    with torch.no_grad():
+        dw = et._wgrad(gy, s)
+        et.WINOGRAD_WGRAD = False
+        try:
+            dw_direct = et._wgrad(gy, s)
+        finally:
+            et.WINOGRAD_WGRAD = True
+    assert dw.shape == conv.weight.shape and dw.is_contiguous()
+    assert _rel(dw, cr.weight.grad) < 5e-5, _rel(dw, cr.weight.grad)
+    assert _rel(dw_direct, cr.weight.grad) < 5e-5
+    assert not lib.hmf_conv_wgrad_winograd_supported(7, 16, 64, 64) and not lib.hmf_conv_wgrad_winograd_supported(16, 24, 64, 64)
+    assert not lib.hmf_conv_wgrad_winograd_supported(16, 16, 32, 64)
+
+
 @pytest.mark.parametrize('B,H,W', [(2, 256, 256), (2, 160, 200), (1, 32, 36)])
 def test_stem_weight_gradient_row_segments(B, H, W):
     """Stem weight gradient on maps wider than one 64-pixel chunk (two full segments per row; a full + a partial one; a single short one)."""
