@@ -15,10 +15,12 @@
 // the tile: lanes 0-31 take tile 2s, lanes 32-63 tile 2s + 1), so both operands are read from LDS as conflict-free ds_read_b32 with
 // compile-time offsets and transformed in registers: per k-step 6 VALU (g) + 16 VALU (d, two halves) + 20 LDS reads for 8 MFMAs.  On gfx950 that
 // VALU work adds to the MFMA time, so the expected MFMA utilisation is ~0.75 -- of 4/9 of the direct work.
-// Tiles are staged 16 at a time (TR x TC tile rows x columns): the gy patch (2 TR x 2 TC pixels x 32 channels) and the input patch
+// Tiles are staged 16 or 32 at a time (TR x TC tile rows x columns): the gy patch (2 TR x 2 TC pixels x 32 channels) and the input patch
 // ((2 TR + 2) x (2 TC + 2) pixels x 64 channels, zero outside the image) arrive by LDS-DMA with lane offsets computed once per work-group
 // (an out-of-range offset makes the DMA write 0: the convolution's zero padding); pixel-major LDS rows are what lane = channel reads want, so no
-// swizzle is needed.  Split over the tiles: every work-group adds its 8 x 16 accumulator registers to M with float atomics (M zeroed first).
+// swizzle is needed.  Lanes 0-31 / 32-63 walk two disjoint runs of ADJACENT tiles, so two of the four row-transformed input columns of a k-step are
+// the previous k-step's (kept in registers): per k-step 6 + 2 x 6 VALU and 4 + 2 x 4 LDS reads for 8 MFMAs.  Measured at B = 72 (ResNet-18
+// layers, rocprof): 141-154 us per layer with 16-tile chunks and no reuse vs 246-252 us for the direct kernel.  Split over the tiles: every work-group adds its 8 x 16 accumulator registers to M with float atomics (M zeroed first).
 #include "hmf_common.h"
 
 namespace hmf {
@@ -35,7 +37,7 @@ static __device__ __forceinline__ void wgw_dma16(__amdgpu_buffer_rsrc_t rsrc, ld
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, 0, 0, 0);
 }
 
-// TR x TC = 16 tiles per chunk (TC = tiles per chunk row)
+// TR x TC = 16 or 32 tiles per chunk (TC = tiles per chunk row); k-step s: lanes 0-31 take tile s, lanes 32-63 tile KS + s of the chunk
 template <int TR, int TC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_wgw(const WgwArgs a) {
     constexpr int GH = 2 * TR, GW = 2 * TC;                 // gy patch (pixels)
@@ -81,9 +83,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const float c1 = wave == 3 ? 0.f : 1.f, c2 = wave == 0 ? 0.f : (wave == 2 ? -1.f : 1.f);
     const int a1 = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 2 : 3)), a2 = wave == 0 ? 2 : (wave == 1 ? 2 : 1);
     const float sd = wave == 1 ? 1.f : -1.f;
-    const float* pg = sG + lq * 2 * 32 + li;                                   // tile 2 s + q: gy pixel column 2 (tile column) -> + 2 pixels per q
-    const float* px1 = sX + (a1 * XW) * 64 + lq * 2 * 64 + li;
-    const float* px2 = sX + (a2 * XW) * 64 + lq * 2 * 64 + li;
+    constexpr int KS = TR * TC / 2;                                            // k-steps per chunk
+    // the second lane half starts KS tiles further: KS / TC tile rows (KS >= TC) or KS tile columns (KS < TC) into the patch
+    constexpr int QG = KS >= TC ? (2 * (KS / TC)) * GW : 2 * KS, QX = KS >= TC ? (2 * (KS / TC)) * XW : 2 * KS;     // pixels
+    const float* pg = sG + lq * QG * 32 + li;
+    const float* px1 = sX + (a1 * XW) * 64 + lq * QX * 64 + li;
+    const float* px2 = sX + (a2 * XW) * 64 + lq * QX * 64 + li;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -117,9 +122,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
+        float tk[2][2];                                            // row-transformed columns 2, 3 of the previous tile = columns 0, 1 of this one
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {                              // k-step: tiles 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63) of the chunk
-            const int tr = (2 * s) / TC, tc = (2 * s) % TC;       // compile time after unrolling
+        for (int s = 0; s < KS; ++s) {                             // tile s of this lane half: (tr, tc) = (s / TC, s % TC) relative to the half's first tile
+            const int tr = s / TC, tc = s % TC;                    // compile time after unrolling (KS < TC: one row, tr = 0)
             // ---- V = G g G^T, row xi ----
             const float* g0 = pg + ((2 * tr) * GW + 2 * tc) * 32;
             const float g00 = g0[0], g01 = g0[32], g10 = g0[GW * 32], g11 = g0[GW * 32 + 32];
@@ -132,8 +138,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const float* d1 = px1 + ((2 * tr) * XW + 2 * tc) * 64 + 32 * h;
                 const float* d2 = px2 + ((2 * tr) * XW + 2 * tc) * 64 + 32 * h;
                 float t[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) t[c] = __builtin_fmaf(sd, d2[c * 64], d1[c * 64]);
+                if (tc == 0) {
+                    t[0] = __builtin_fmaf(sd, d2[0], d1[0]);
+                    t[1] = __builtin_fmaf(sd, d2[64], d1[64]);
+                } else {
+                    t[0] = tk[h][0];
+                    t[1] = tk[h][1];
+                }
+                t[2] = __builtin_fmaf(sd, d2[2 * 64], d1[2 * 64]);
+                t[3] = __builtin_fmaf(sd, d2[3 * 64], d1[3 * 64]);
+                tk[h][0] = t[2];
+                tk[h][1] = t[3];
                 u[h][0] = t[0] - t[2];
                 u[h][1] = t[1] + t[2];
                 u[h][2] = t[2] - t[1];
@@ -190,33 +205,43 @@ __global__ __launch_bounds__(256) void k_wgw_finish(const float* __restrict__ m,
 
 using namespace hmf;
 
+static int g_wgw_target_wgs = 512;
+#ifdef HMF_EXPERIMENTS
+extern "C" int hmf_debug_set_wgw_target_wgs(int n) { g_wgw_target_wgs = n > 0 ? n : 512; return HMF_OK; }      // tools/wgw_probe.py
+#endif
+
 // workspace = 16 * Cout * Cin floats (the Winograd-domain accumulator); dw_native = (Cout, Cin, 3, 3) row-major, the parameter's own layout
 extern "C" size_t hmf_conv_wgrad_winograd_workspace_floats(int Cin, int Cout) { return (size_t)16 * Cin * Cout; }
 
-extern "C" int hmf_conv_wgrad_winograd_supported(int H, int W, int Cin, int Cout) {
-    if (H < 2 || W < 8 || (H & 1) || Cin % 64 || Cout % 32) return 0;
-    if (W % 32 == 0) return 1;                                     // 1 x 16 tiles per chunk
-    if (W == 16) return H % 4 == 0;                                // 2 x 8
-    if (W == 8) return H % 8 == 0;                                 // 4 x 4
+// chunk geometry TR * 100 + TC for a map, or 0: the largest chunk (32 tiles: fewer barriers and first-fetch waits per MFMA) whose rows tile the map
+static int wgw_geometry(int H, int W) {
+    if (H < 2 || W < 8 || (H & 1)) return 0;
+    if (W % 32 == 0) return H % 4 == 0 ? 216 : 116;
+    if (W == 16) return H % 8 == 0 ? 408 : (H % 4 == 0 ? 208 : 0);
+    if (W == 8) return H % 8 == 0 ? 404 : 0;
     return 0;
+}
+
+extern "C" int hmf_conv_wgrad_winograd_supported(int H, int W, int Cin, int Cout) {
+    return (Cin % 64 == 0 && Cout % 32 == 0 && wgw_geometry(H, W) != 0) ? 1 : 0;
 }
 
 extern "C" int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* dw_native, float* workspace, int B, int H, int W, int Cin, int Cout,
                                        void* stream) {
     if (!gy || !x || !dw_native || !workspace || B <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_wgrad_winograd: bad args");
     if (!hmf_conv_wgrad_winograd_supported(H, W, Cin, Cout))
-        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad_winograd: H=%d W=%d Cin=%d Cout=%d (W a multiple of 32, or 16 / 8 with H %% 4 / 8 == 0; Cin %% 64, Cout %% 32)", H, W, Cin, Cout);
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad_winograd: H=%d W=%d Cin=%d Cout=%d (H even and W a multiple of 32, or W = 16 with H %% 4 == 0, or W = 8 with H %% 8 == 0; Cin %% 64, Cout %% 32)", H, W, Cin, Cout);
     if (((uintptr_t)gy & 15) || ((uintptr_t)x & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_wgrad_winograd: gy and x must be 16-byte aligned");
     if ((long long)H * W * std::max(Cin, Cout) * 4 >= (1LL << 30)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad_winograd: image exceeds the 32-bit offset range");
     WgwArgs a;
     a.gy = gy; a.x = x; a.m = workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    const int TC = W % 32 == 0 ? 16 : (W == 16 ? 8 : 4), TR = 16 / TC;
+    const int geo = wgw_geometry(H, W), TR = geo / 100, TC = geo % 100;
     a.chunks_per_row = (W / 2) / TC;
     a.chunks_per_img = ((H / 2) / TR) * a.chunks_per_row;
     a.nchunks = B * a.chunks_per_img;
     a.ci_blocks = Cin / 64;
     const int tiles = (Cout / 32) * a.ci_blocks;
-    int slices = std::max(1, std::min(a.nchunks, (256 * 2 + tiles - 1) / tiles));            // ~2 work-groups per CU in one round
+    int slices = std::max(1, std::min(a.nchunks, (g_wgw_target_wgs + tiles - 1) / tiles));   // ~2 work-groups per CU in one round
     a.chunks_per_slice = (a.nchunks + slices - 1) / slices;
     slices = (a.nchunks + a.chunks_per_slice - 1) / a.chunks_per_slice;
     hipStream_t st = (hipStream_t)stream;
@@ -224,9 +249,13 @@ extern "C" int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* d
     if (int zr = zero_async(workspace, mfloats * sizeof(float), st)) return zr;
     {
         ProfScope ps(13, B * H * W, st);                             // weight-gradient family (bench.py --train)
-        if (TC == 16) hipLaunchKernelGGL((k_wgw<1, 16>), dim3(tiles, slices), dim3(256), 0, st, a);
-        else if (TC == 8) hipLaunchKernelGGL((k_wgw<2, 8>), dim3(tiles, slices), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_wgw<4, 4>), dim3(tiles, slices), dim3(256), 0, st, a);
+        switch (geo) {
+            case 216: hipLaunchKernelGGL((k_wgw<2, 16>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+            case 116: hipLaunchKernelGGL((k_wgw<1, 16>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+            case 408: hipLaunchKernelGGL((k_wgw<4, 8>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+            case 208: hipLaunchKernelGGL((k_wgw<2, 8>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((k_wgw<4, 4>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+        }
         HMF_LAUNCH_CHECK();
         const int n = Cin * Cout;
         hipLaunchKernelGGL(k_wgw_finish, dim3((n + 255) / 256), dim3(256), 0, st, workspace, dw_native, n);

@@ -26,6 +26,9 @@ int hmf_debug_set_lbs_cycles(void* dev_ptr);
  * main loop done, end; cycles between a slab's top and its second barrier summed over the slabs; the 100 MHz counter at start and end; unused. */
 int hmf_debug_wino_stamps(long long* out_host, int blocks);
 
+/* tools/wgw_probe.py: number of work-groups hmf_conv_wgrad_winograd aims for when it splits the tiles into slices (default 512). */
+int hmf_debug_set_wgw_target_wgs(int n);
+
 /* Diagnostic (tools/stem_probe.py): stamps of the last k_stem_conv<POOL> launch, 6 int64 per work-group (shader clock at start, patch in LDS, main
  * loop done, end; the 100 MHz counter at start and end). */
 int hmf_debug_stem_stamps(long long* out_host, int blocks);
