@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 LBS_FLOP_PER_UNIT = 9.775e6
 HBM_PEAK_GBS = 8000.0                  # guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2516.6         # v_mfma_f32_32x32x16_bf16: 16x the k per instruction at half the issue time (the guide's ~2.5 PFLOP/s dense)
 WINOGRAD_MFMA_FRACTION = 4.0 / 9.0     # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed MFMA FLOPs = 4/9 of direct
 
 
@@ -109,6 +110,10 @@ def parse():
     ap.add_argument('--blend-dtype', choices=['fp32', 'bf16'], default='fp32',
                     help="'bf16': BASELINE configs[2] (use with --batch 64): SMPL blend-shape GEMM operands in bf16, fp32 accumulate -- a parity-test "
                          'configuration, not the headline line')
+    ap.add_argument('--gemm-terms', type=int, choices=[0, 3, 6], default=0,
+                    help='OPT-IN flavour, never the headline line: the encoder 1x1 GEMMs on the bf16 matrix pipe with split fp32 operands '
+                         '(hmf_conv1x1_gemm_split): 3 = hi/lo pieces, 3 bf16 MFMAs per product (~2^-16 relative per product); 6 = three pieces, 6 MFMAs '
+                         '(fp32-level products).  0 (default) = fp32 MFMA everywhere')
     ap.add_argument('--dry-run-cpu', action='store_true', help='exercise only the rank plumbing (gloo, CPU, stand-in step): used by the CPU tests')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the steps are round-robined over (batches are independent: the '
                     'low-occupancy flow kernels of step i overlap the encoder convolutions of step i+1)')
@@ -321,6 +326,7 @@ def main():
     model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).eval()
     model_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
+    model.image_encoder.gemm_terms = args.gemm_terms
     smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=args.batch, create_transl=False, blend_dtype=args.blend_dtype).to(dev)
     B, N = args.batch, args.samples
     NB = max(1, args.batches)
@@ -456,11 +462,16 @@ def main():
     if rank == 0:
         value = world * B * N * args.steps / elapsed
         flavour = 'configs[3] eval step' if args.eval else ('configs[1]' if args.blend_dtype == 'fp32' else 'configs[2]')
+        if args.gemm_terms:
+            flavour += ' with the opt-in split-operand 1x1 GEMMs (gemm_terms=%d)' % args.gemm_terms
+        dtype = 'f32' if args.blend_dtype == 'fp32' else 'bf16 blend-shape GEMM operands as hi+lo pairs, 3 bf16 MFMAs per product (f32 accumulate), f32 elsewhere'
+        if args.gemm_terms:
+            dtype += '; encoder 1x1 GEMM operands as %d bf16 pieces each, %d bf16 MFMAs per product, f32 accumulate' % (2 if args.gemm_terms == 3 else 3, args.gemm_terms)
         res = {
             'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': round(value, 1), 'unit': 'images*samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.blend_dtype == 'fp32' else 'bf16 blend-shape GEMM operands as hi+lo pairs, 3 bf16 MFMAs per product (f32 accumulate), f32 elsewhere', 'data': 'synthetic',
+            'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': flavour + ': B=%d synthetic 256x256 18-ch proxy inputs, N=%d samples, ResNet-%d + flow + SMPL %s, random-init weights, '
                                    'synthetic SMPL-shaped body model%s'
                                    % (B, N, args.layers, 'fp32' if args.blend_dtype == 'fp32' else 'fp32 with bf16 blend-shape GEMM operands',
@@ -478,7 +489,8 @@ def main():
         }
         step_flops = sum(conv_flops) + LBS_FLOP_PER_UNIT * B * (N + 1)
         agg = step_flops / (elapsed / args.steps) / 1e12
-        pmc = load_pmc_traffic(source_hash(), 'B=%d,N=%d,%s%s' % (args.batch, args.samples, args.blend_dtype, ',eval' if args.eval else ''))
+        pmc = load_pmc_traffic(source_hash(), 'B=%d,N=%d,%s%s%s' % (args.batch, args.samples, args.blend_dtype, ',eval' if args.eval else '',
+                                                                     ',x%d' % args.gemm_terms if args.gemm_terms else ''))
 
         def traffic_of(key):
             if pmc is None:
@@ -508,6 +520,11 @@ def main():
                 'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (measurement pass: HIP events on the launch stream, one stream)',
                 'step_aggregate': {'what': 'algorithmic FLOPs of every convolution (Winograd layers at direct-form FLOPs) + SMPL blend GEMMs of a step / step time of the timed region',
                                    'achieved': round(agg, 2), 'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4)}}
+            if args.gemm_terms and dom_name.startswith('k_conv_gemm'):
+                # the family runs on the bf16 pipe: its ceiling is the dense bf16 peak over the MFMAs spent per product
+                pk = BF16_MFMA_PEAK_TFLOPS / args.gemm_terms
+                res['roofline'].update({'peak': round(pk, 1), 'frac': round(dom['tflops'] / pk, 4),
+                                        'how': res['roofline']['how'] + '; peak = dense bf16 MFMA peak %.0f / %d MFMAs per product' % (BF16_MFMA_PEAK_TFLOPS, args.gemm_terms)})
             if res['roofline']['traffic']:
                 res['roofline']['traffic_over_algorithmic_bytes'] = round(res['roofline']['traffic'] / res['roofline']['algorithmic_bytes_per_launch'], 3)
         lbs_bytes = lbs_rows * (82680 + 1080 + 868) + 19.3e6          # vertices + joints written, rotations + betas read, constants once

@@ -98,6 +98,8 @@ class ResNetEncoder(nn.Module):
     fuse_pairs = True        # a bottleneck's last 1x1 + the next bottleneck's first 1x1 as one launch where built (hmf_conv_pair: layer1 / layer2)
     fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_gemm with a second K range)
     gemm_1x1 = True          # stride-1 1x1 layers on the LDS-DMA pipelined GEMM (hmf_conv1x1_gemm); False: the implicit-GEMM kernel (hmf_conv2d_nhwc)
+    gemm_terms = 0           # OPT-IN: 3 / 6 = the 1x1 GEMMs on the bf16 matrix pipe with split fp32 operands (hmf_conv1x1_gemm_split: 3 = hi/lo
+                             # products, ~2^-16 relative per product; 6 = three-piece products, fp32-level); 0 = fp32 MFMA (the default everywhere)
 
     def _fold(self, conv, bn):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
@@ -167,8 +169,17 @@ class ResNetEncoder(nn.Module):
                     wcat = torch.cat([w3.reshape(w3.shape[0], -1), wd.reshape(wd.shape[0], -1)], dim=1).contiguous()
                     dual = (wcat, stages[-1][1], ds[2][0])
                 plan['blocks'].append((stages, ds, dual))
-        plan['packed'], plan['wino'], plan['pair'] = {}, {}, {}
-        if self.conv1.weight.is_cuda and self.fuse_pairs:
+        plan['packed'], plan['wino'], plan['pair'], plan['split'] = {}, {}, {}, {}
+        if self.gemm_terms not in (0, 3, 6):
+            raise ValueError('humaniflow_amd: gemm_terms = %r (0 = fp32 MFMA, 3 or 6 = split bf16 operands)' % (self.gemm_terms,))
+        if self.conv1.weight.is_cuda and self.gemm_terms and self.gemm_1x1:
+            # split every GEMM-shaped 1x1 filter once (the seam kernel is fp32 only: no seams in this mode)
+            for stages, ds, dual in plan['blocks']:
+                for w in [st[0] for st in (stages[:-1] if dual is not None else stages)] + ([dual[0]] if dual is not None else []):
+                    w2 = w.reshape(w.shape[0], -1) if (w.dim() == 2 or w.shape[2] == 1) else None
+                    if w2 is not None and w2.shape[0] % 64 == 0 and w2.shape[1] % 32 == 0:
+                        plan['split'][id(w)] = self._pack_split(w2)
+        if self.conv1.weight.is_cuda and self.fuse_pairs and not plan['split']:
             # block i's last 1x1 (+ downsample branch) and block i+1's first 1x1 as one launch where the kernel is built for the shapes
             # (layer1 and layer2 of ResNet-50: the 256 / 512-channel tensor between them is what bounds both layers)
             blocks = plan['blocks']
@@ -220,6 +231,16 @@ class ResNetEncoder(nn.Module):
         _lib.check(lib.hmf_conv_patch_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout, ks, cfg), 'hmf_conv_patch_pack_host')
         return packed.to(w.device)
 
+    def _pack_split(self, w2):
+        from . import _lib
+        lib = _lib.load()
+        N, K = w2.shape
+        w2 = w2.detach().float().contiguous()
+        packed = torch.empty(int(lib.hmf_conv1x1_split_packed_bytes(N, K, self.gemm_terms)), dtype=torch.uint8, device=w2.device)
+        with torch.cuda.device(w2.device):
+            _lib.check(lib.hmf_conv1x1_split_pack(w2.data_ptr(), packed.data_ptr(), N, K, self.gemm_terms, _lib.current_stream()), 'hmf_conv1x1_split_pack')
+        return packed
+
     def _pack_pair(self, w3, w1):
         from . import _lib
         lib = _lib.load()
@@ -253,6 +274,11 @@ class ResNetEncoder(nn.Module):
         _, Cin2, H2, W2 = x.shape
         Cout = wcat.shape[0]
         y = torch.empty((B, Cout, OH, OW), device=h.device, dtype=torch.float32, memory_format=torch.channels_last)
+        sp = self._plan['split'].get(id(wcat)) if self._plan is not None else None
+        if sp is not None:
+            _lib.check(lib.hmf_conv1x1_gemm_split(h.data_ptr(), x.data_ptr(), sp.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, OH, OW, Cin,
+                                                  H2, W2, Cin2, stride, Cout, 1, self.gemm_terms, 0, _lib.current_stream()), 'hmf_conv1x1_gemm_split')
+            return y
         if self.gemm_1x1:
             _lib.check(lib.hmf_conv1x1_gemm(h.data_ptr(), x.data_ptr(), wcat.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, OH, OW, Cin,
                                             H2, W2, Cin2, stride, Cout, 1, 0, _lib.current_stream()), 'hmf_conv1x1_gemm')
@@ -292,6 +318,12 @@ class ResNetEncoder(nn.Module):
                                           None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
                                           int(relu), cfg, _lib.current_stream()), 'hmf_conv_patch')
             return y
+        sp = self._plan['split'].get(id(w)) if (self._plan is not None and ks == 1 and stride == 1) else None
+        if sp is not None:
+            _lib.check(lib.hmf_conv1x1_gemm_split(x.data_ptr(), None, sp.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                  None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, 0, 0, 0, 1, Cout,
+                                                  int(relu), self.gemm_terms, 0, _lib.current_stream()), 'hmf_conv1x1_gemm_split')
+            return y
         if ks == 1 and stride == 1 and self.gemm_1x1 and Cin % 32 == 0 and Cout % 64 == 0:
             _lib.check(lib.hmf_conv1x1_gemm(x.data_ptr(), None, w.data_ptr(), None if bias is None else bias.data_ptr(),
                                             None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, 0, 0, 0, 1, Cout,
@@ -325,7 +357,7 @@ class ResNetEncoder(nn.Module):
         """Inference plan on the HIP kernels: (B, 18, H, W) NCHW proxy input on a HIP device -> (B, out_dim)."""
         from . import _lib
         _lib.require_cuda(x, 'input')
-        key = self._params_key()
+        key = self._params_key() + (self.gemm_terms,)
         if self._plan is None or self._plan_key != key:
             self._plan, self._plan_key = self._build_plan(), key
         p = self._plan

@@ -274,6 +274,17 @@ int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const
 int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, int B, int OH, int OW,
                      int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream);
 
+/* OPT-IN: the same GEMM on the bf16 matrix pipe with split fp32 operands (csrc/conv_gemm_split.hip; not the default of any plan).  Every fp32
+ * value x = p0 + p1 (+ p2) in bf16 pieces (round-to-nearest remainders); terms = 3: x*w ~ p0 q0 + p0 q1 + p1 q0 (product error ~2^-16 relative),
+ * terms = 6: + p0 q2 + p2 q0 + p1 q1 (dropped products <= 2^-24: fp32-level).  fp32 accumulation, bias, residual and ReLU.  The filter is split
+ * once: hmf_conv1x1_split_pack(w_dev (N, K1+K2) row-major fp32 ON THE DEVICE, packed_dev of hmf_conv1x1_split_packed_bytes(N, K, terms) bytes);
+ * activations are split in registers by the kernel (no second copy of a tensor).  Other arguments and constraints as hmf_conv1x1_gemm;
+ * tile: 0 = from the shape, else ring stages * 1000 + BN in {3128, 4064}.  Profiler tag 8. */
+long long hmf_conv1x1_split_packed_bytes(int N, int K, int terms);
+int hmf_conv1x1_split_pack(const float* w_dev, void* packed_dev, int N, int K, int terms, void* stream);
+int hmf_conv1x1_gemm_split(const float* x, const float* x2, const void* w_packed, const float* bias, const float* residual, float* y, int B, int OH,
+                           int OW, int K1, int H2, int W2, int K2, int stride2, int N, int relu, int terms, int tile, void* stream);
+
 /* The seam between two bottlenecks (models/resnet.py:102-127: block i's conv3 + bn3 (+ downsample branch) + identity + ReLU, then block
  * i+1's conv1 + bn1 + ReLU) as ONE launch: y = relu([x1 | x2(strided)] . W3^T + bias3 (+ residual)) is written (the next identity branch) and
  * its 64-channel chunks feed z = relu(y . W1^T + bias1) through LDS, so the C-channel tensor y is not read back from HBM.

@@ -49,7 +49,7 @@ def test_conv_ragged_rows_and_flags():
     _case(2, 8, 8, 2048, 512, 1, 1, res=False, relu=True, tile=0, seed=5)           # deepest K of the 1x1 layers
 
 
-def _gemm_case(B, OH, OW, k1, n, tile, k2=0, stride2=1, res=False, relu=True, bias=True, seed=0):
+def _gemm_case(B, OH, OW, k1, n, tile, k2=0, stride2=1, res=False, relu=True, bias=True, seed=0, terms=0):
     """hmf_conv1x1_gemm (LDS-DMA pipelined GEMM, csrc/conv_gemm.hip) vs float64 torch: y = relu?(conv1x1(x) (+ conv1x1(x2, stride2)) + bias (+ res))."""
     from humaniflow_amd import _lib
     lib = _lib.load()
@@ -76,13 +76,22 @@ def _gemm_case(B, OH, OW, k1, n, tile, k2=0, stride2=1, res=False, relu=True, bi
     rd = r.cuda().contiguous(memory_format=CL) if res else None
     y = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=CL)
     guard = torch.full((4096,), 7.0, device='cuda')                      # allocated right after y: a store beyond M would likely land here
-    _lib.check(lib.hmf_conv1x1_gemm(xd.data_ptr(), None if x2d is None else x2d.data_ptr(), wd.data_ptr(), None if bd is None else bd.data_ptr(),
-                                    None if rd is None else rd.data_ptr(), y.data_ptr(), B, OH, OW, k1, H2, W2, k2, stride2, n, int(relu), tile,
-                                    _lib.current_stream()), 'hmf_conv1x1_gemm')
+    if terms:
+        wp = torch.empty(int(lib.hmf_conv1x1_split_packed_bytes(n, k1 + k2, terms)), dtype=torch.uint8, device='cuda')
+        _lib.check(lib.hmf_conv1x1_split_pack(wd.data_ptr(), wp.data_ptr(), n, k1 + k2, terms, _lib.current_stream()), 'hmf_conv1x1_split_pack')
+        _lib.check(lib.hmf_conv1x1_gemm_split(xd.data_ptr(), None if x2d is None else x2d.data_ptr(), wp.data_ptr(), None if bd is None else bd.data_ptr(),
+                                              None if rd is None else rd.data_ptr(), y.data_ptr(), B, OH, OW, k1, H2, W2, k2, stride2, n, int(relu), terms,
+                                              tile, _lib.current_stream()), 'hmf_conv1x1_gemm_split')
+    else:
+        _lib.check(lib.hmf_conv1x1_gemm(xd.data_ptr(), None if x2d is None else x2d.data_ptr(), wd.data_ptr(), None if bd is None else bd.data_ptr(),
+                                        None if rd is None else rd.data_ptr(), y.data_ptr(), B, OH, OW, k1, H2, W2, k2, stride2, n, int(relu), tile,
+                                        _lib.current_stream()), 'hmf_conv1x1_gemm')
     torch.cuda.synchronize()
     assert bool((guard == 7.0).all())
     err = (y.cpu().double() - ref).abs().max().item()
-    assert err < 2e-5 * max(1.0, ref.abs().max().item()), (B, OH, OW, k1, k2, n, tile, res, relu, err)
+    # fp32 MFMA and the 6-term split (fp32-level products) share one bound; the 3-term split keeps ~16 mantissa bits per product
+    tol = 2e-4 if terms == 3 else 2e-5
+    assert err < tol * max(1.0, ref.abs().max().item()), (B, OH, OW, k1, k2, n, tile, terms, res, relu, err)
     return y
 
 
@@ -95,6 +104,34 @@ def test_conv1x1_gemm_matches_float64_reference(tile):
     _gemm_case(2, 6, 6, 128, 256, tile, k2=64, stride2=2, relu=True, seed=4)                     # downsample branch as a second K range, stride 2
     _gemm_case(2, 6, 6, 64, 128, tile, k2=160, stride2=2, res=True, relu=True, seed=5)           # ... odd source size, 2 + 5 chunks
     _gemm_case(1, 12, 12, 64, 256, tile, k2=64, stride2=1, relu=False, seed=6)                   # layer1.0: stride-1 branch
+
+
+@pytest.mark.parametrize('terms', [3, 6])
+@pytest.mark.parametrize('tile', [0, 2128128, 2064128, 3064064, 4064064])
+def test_conv1x1_gemm_split_matches_float64_reference(tile, terms):
+    """The opt-in split-operand GEMM (bf16 pieces of fp32 operands on the bf16 matrix pipe) on the cases of the fp32 GEMM: the 6-term form meets
+    the fp32 kernel's bound, the 3-term form 10x of it."""
+    _gemm_case(2, 16, 16, 256, 128, tile, res=True, relu=True, terms=terms)
+    _gemm_case(3, 7, 7, 96, 256, tile, res=True, relu=False, seed=1, terms=terms)                # ragged last tile (M = 147 < 2 x 128)
+    _gemm_case(1, 5, 9, 32, 128, tile, res=False, relu=True, bias=False, seed=2, terms=terms)    # ONE k-chunk, M = 45
+    _gemm_case(2, 8, 8, 2048, 512, tile, res=False, relu=True, seed=3, terms=terms)              # 64 chunks
+    _gemm_case(2, 6, 6, 128, 256, tile, k2=64, stride2=2, relu=True, seed=4, terms=terms)        # downsample branch as a second K range
+    _gemm_case(2, 6, 6, 64, 128, tile, k2=160, stride2=2, res=True, relu=True, seed=5, terms=terms)
+    _gemm_case(1, 12, 12, 64, 256, tile, k2=64, stride2=1, relu=False, seed=6, terms=terms)
+
+
+def test_conv1x1_gemm_split_rejects_bad_arguments():
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    p = torch.zeros(1 << 16, device='cuda').data_ptr()
+    assert lib.hmf_conv1x1_split_packed_bytes(128, 64, 3) == 128 * 64 * 4 and lib.hmf_conv1x1_split_packed_bytes(128, 64, 6) == 128 * 64 * 6
+    assert lib.hmf_conv1x1_split_packed_bytes(128, 48, 3) == -1 and lib.hmf_conv1x1_split_packed_bytes(128, 64, 4) == -1
+    assert lib.hmf_conv1x1_split_pack(p, p, 128, 64, 5, None) == -1
+    assert lib.hmf_conv1x1_gemm_split(p, None, p, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 64, 1, 4, 0, None) == -1          # terms
+    assert lib.hmf_conv1x1_gemm_split(p, None, p, None, None, p, 1, 4, 4, 48, 0, 0, 0, 1, 64, 1, 3, 0, None) == -2          # K % 32
+    assert lib.hmf_conv1x1_gemm_split(p, None, p, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 64, 1, 3, 2064128, None) == -1    # tile needs N % 128
+    assert lib.hmf_conv1x1_gemm_split(p, None, p, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 128, 1, 3, 3064128, None) == -1   # not a product tile
+    assert lib.hmf_conv1x1_gemm_split(p, None, p + 4, None, None, p, 1, 4, 4, 64, 0, 0, 0, 1, 64, 1, 3, 0, None) == -1      # misaligned
 
 
 def test_conv1x1_gemm_agrees_with_igemm_and_rejects_bad_shapes():
@@ -368,6 +405,40 @@ def test_folded_encoder_matches_module_path():
             ref = enc.forward_module(x.double()) if False else enc.double().forward_module(x.double())
         assert got.shape == (2, enc.out_dim)
         assert (got.double() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('terms,tol', [(6, 5e-5), (3, 1e-3)])
+def test_encoder_with_split_operand_gemms(terms, tol):
+    """gemm_terms (opt-in): ResNet-50 with every 1x1 GEMM on the split-operand kernel against the float64 module path; the plan follows the flag."""
+    from humaniflow_amd.encoder import ResNetEncoder
+    from humaniflow_amd.synthetic import synthetic_proxy_input
+    torch.manual_seed(50)
+    enc = ResNetEncoder(50, 18)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    enc = enc.eval().cuda()
+    x = synthetic_proxy_input(2, 128, seed=50).cuda()
+    with torch.no_grad():
+        base = enc(x)
+        assert not enc._plan['split'] and enc._plan['pair']
+        enc.gemm_terms = terms
+        got = enc(x)
+        assert len(enc._plan['split']) == 16 + 16 + 4 - 4 and not enc._plan['pair']      # conv1 + conv3 of 16 blocks; 4 of the conv3 carry the downsample branch
+        enc.gemm_terms = 0
+        again = enc(x)
+        assert torch.equal(again, base)
+        ref = enc.double().forward_module(x.double())
+    scale = max(1.0, ref.abs().max().item())
+    assert (got.double() - ref).abs().max().item() < tol * scale
+    assert not torch.equal(got, base)
+    enc.float()
+    enc.gemm_terms = 5
+    with pytest.raises(ValueError), torch.no_grad():
+        enc(x)
 
 
 def test_encoder_full_size_properties():

@@ -309,6 +309,36 @@ def test_end_to_end_from_gpu_encoder_features_within_north_star_tolerances():
     assert (lp - lp_ref).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize('terms,feat_bar,vert_bar', [(6, 2e-5, 1e-4), (3, 5e-4, 1e-3)])
+def test_end_to_end_with_split_operand_gemms(terms, feat_bar, vert_bar):
+    """The opt-in encoder flavour (image_encoder.gemm_terms: 1x1 GEMMs on the bf16 pipe with split fp32 operands) through the whole path against
+    the oracle: the 6-term form meets the north-star bars of the fp32 path (features 2e-5, vertices / joints 1e-4 m); the 3-term form is the
+    documented approximation (bars 25x / 10x looser)."""
+    model, sd, cfg = _model(50, seed=5)
+    model.image_encoder.gemm_terms = terms
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B, N = 2, 6
+    x = synthetic_proxy_input(B, 256, seed=0)
+    noise = _noise(B, N, seed=2)
+    ref = omodel.forward(sd, ocfg, input=x, num_samples=N, noise=noise)
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    with torch.no_grad():
+        out = model(x.cuda(), num_samples=N, noise=_cuda(noise), return_input_feats=True)
+        pe, sa = smpl.forward_samples_and_point_est(out)
+    assert model.image_encoder._plan['split']
+    scale = ref['input_feats'].abs().max().item()
+    fe = (out['input_feats'].cpu() - ref['input_feats']).abs().max().item() / max(1.0, scale)
+    om = smpl_oracle_model(smpl.model_dict())
+    g = ref['glob_rotmat']
+    v_ref, j_ref = osmpl.smpl_forward(om, ref['shape_samples'].reshape(-1, 10), ref['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
+                                      g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3), pose2rot=False)
+    vp_ref, jp_ref = osmpl.smpl_forward(om, ref['shape_mode'], ref['pose_rotmats_point_est'], g[:, None], pose2rot=False)
+    ve = max((sa.vertices.cpu() - v_ref).abs().max().item(), (sa.joints.cpu() - j_ref).abs().max().item(),
+             (pe.vertices.cpu() - vp_ref).abs().max().item(), (pe.joints.cpu() - jp_ref).abs().max().item())
+    print('gemm_terms=%d: features %.2e (relative to the largest feature), vertices / joints %.2e m' % (terms, fe, ve))
+    assert fe < feat_bar and ve < vert_bar, (terms, fe, ve)
+
+
 def test_fused_smpl_launch_equals_the_two_reference_calls():
     model, sd, cfg = _model(18, seed=11)
     smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
