@@ -23,6 +23,7 @@ from . import _lib
 
 CL = torch.channels_last
 WINOGRAD_WGRAD = True          # stride-1 3x3 weight gradients on hmf_conv_wgrad_winograd where the shape is built (False: hmf_conv_wgrad everywhere)
+STRIDED_DGRAD = True           # stride-2 3x3 input gradients as parity-class GEMMs (hmf_conv_dgrad_s2); False: zero-inserted map + stride-1 convolution
 
 
 def _cl_empty(B, C, H, W, device):
@@ -211,12 +212,30 @@ def _wgrad(gy, s):
     return dw.permute(0, 3, 1, 2).contiguous()
 
 
-def _dgrad(gy, s, residual=None):
-    """dL/dx of unit s (+ residual): a convolution of gy with the flipped, in/out-transposed filter."""
+def _dgrad(gy, s, residual=None, extra=None):
+    """dL/dx of unit s (+ residual): a convolution of gy with the flipped, in/out-transposed filter.  extra = (gy2, unit2): + dL/dx of the block's
+    stride-2 1x1 downsample unit in the same launch (stride-2 3x3 units only)."""
     w = s.conv.weight.detach()
     ks = w.shape[2]
-    wt = w.flip(2, 3).transpose(0, 1) if ks > 1 else w.transpose(0, 1)          # (Cin, Cout, k, k) view: flipped, in/out swapped
     B, Cin, H, W = s.x.shape
+    Cout = w.shape[0]
+    if s.stride == 2 and ks == 3 and STRIDED_DGRAD and Cout % 32 == 0 and Cin % 64 == 0:
+        # four parity-class GEMMs in one launch (csrc/conv_dgrad_s2.hip): no zero-inserted map, a quarter of its MFMA work
+        lib = _lib.load()
+        wt = w.permute(1, 2, 3, 0).contiguous()                      # (Cin, 3, 3, Cout)
+        gy2 = wt2 = None
+        Co2 = 0
+        if extra is not None:
+            gy2, s2 = extra
+            Co2 = s2.conv.weight.shape[0]
+            wt2 = s2.conv.weight.detach().reshape(Co2, Cin).t().contiguous()
+        gx = _cl_empty(B, Cin, H, W, gy.device)
+        _lib.check(lib.hmf_conv_dgrad_s2(gy.data_ptr(), wt.data_ptr(), None if gy2 is None else gy2.data_ptr(), None if wt2 is None else wt2.data_ptr(),
+                                         None if residual is None else residual.data_ptr(), gx.data_ptr(), B, H, W, Cout, Co2, Cin, _lib.current_stream()),
+                   'hmf_conv_dgrad_s2')
+        return gx
+    assert extra is None
+    wt = w.flip(2, 3).transpose(0, 1) if ks > 1 else w.transpose(0, 1)          # (Cin, Cout, k, k) view: flipped, in/out swapped
     nat = (s.conv.weight, True)
     if s.stride == 1:
         return _conv_any(gy, wt, 1, residual, native=nat)
@@ -228,6 +247,14 @@ def _dgrad(gy, s, residual=None):
     gd = torch.zeros((B, gy.shape[1], H, W), device=gy.device, dtype=torch.float32).contiguous(memory_format=CL)    # zero-inserted gradient map
     gd[:, :, ::s.stride, ::s.stride] = gy
     return _conv_any(gd, wt, 1, residual, native=nat)
+
+
+def _folds_downsample(main0, ds):
+    """The block's first unit is a stride-2 3x3 convolution of the block input and its downsample branch a stride-2 1x1 of the same input
+    (BasicBlock of layer2-4.0): both input gradients come out of one hmf_conv_dgrad_s2 launch."""
+    w, w2 = main0.conv.weight, ds.conv.weight
+    return (STRIDED_DGRAD and main0.stride == 2 and ds.stride == 2 and w.shape[2] == 3 and w2.shape[2] == 1 and main0.x is ds.x
+            and w.shape[0] % 32 == 0 and w2.shape[0] % 32 == 0 and w.shape[1] % 64 == 0)
 
 
 class EncoderTrainFn(torch.autograd.Function):
@@ -315,13 +342,22 @@ class EncoderTrainFn(torch.autograd.Function):
                 g_idt = gz                                            # gradient of the identity branch (masked by the block's ReLU)
                 only = len(main) == 1
                 g_h = _dgrad(gy, s, residual=g_idt if (only and ds is None) else None)
+                fold = ds is not None and len(main) >= 2 and _folds_downsample(main[0], ds)
+                gy_ds = None
+                if fold:                                              # downsample branch first: its input gradient rides in the main path's launch
+                    gy_ds, _, gg, gb = _bn_backward(g_idt, ds, want_gz=False, pool=pool)
+                    grads[id(ds.bn.weight)], grads[id(ds.bn.bias)] = gg, gb
+                    grads[id(ds.conv.weight)] = _wgrad(gy_ds, ds)
                 for k in range(len(main) - 2, -1, -1):
                     s = main[k]
                     gy, _, gg, gb = _bn_backward(g_h, s, want_gz=False, pool=pool)
                     grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
                     grads[id(s.conv.weight)] = _wgrad(gy, s)
-                    g_h = _dgrad(gy, s, residual=g_idt if (k == 0 and ds is None) else None)     # block input: main path + identity in one launch
-                if ds is not None:
+                    if k == 0 and fold:
+                        g_h = _dgrad(gy, s, extra=(gy_ds, ds))
+                    else:
+                        g_h = _dgrad(gy, s, residual=g_idt if (k == 0 and ds is None) else None)     # block input: main path + identity in one launch
+                if ds is not None and not fold:
                     gy, _, gg, gb = _bn_backward(g_idt, ds, want_gz=False, pool=pool)
                     grads[id(ds.bn.weight)], grads[id(ds.bn.bias)] = gg, gb
                     grads[id(ds.conv.weight)] = _wgrad(gy, ds)

@@ -386,6 +386,14 @@ size_t hmf_conv_wgrad_winograd_workspace_floats(int Cin, int Cout);
 int hmf_conv_wgrad_winograd_supported(int H, int W, int Cin, int Cout);
 int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* dw_native, float* workspace, int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* Input gradient of a 3x3 / stride 2 / pad 1 convolution (models/resnet.py:53-67, :95-100 in the backward of train/train_humaniflow.py:287-290) as
+ * four parity-class GEMMs in one launch (csrc/conv_dgrad_s2.hip): gx (B,H,W,Ci) = dgrad(gy (B,OH,OW,Co), w) [+ dgrad of the block's 1x1 / stride 2
+ * downsample convolution of gy2 (B,OH,OW,Co2)] [+ residual (B,H,W,Ci)], OH = (H-1)/2+1.  wt (Ci,3,3,Co) = the (Co,Ci,3,3) parameter permuted (1,2,3,0);
+ * wt2 (Ci,Co2) = the (Co2,Ci) parameter transposed; gy2 and wt2 both given or both NULL.  Co, Co2 % 32 == 0, Ci % 64 == 0, pointers 16-byte aligned.
+ * Every element of gx is written (no zero fill).  Profiler tag 10. */
+int hmf_conv_dgrad_s2(const float* gy, const float* wt, const float* gy2, const float* wt2, const float* residual, float* gx, int B, int H, int W,
+                      int Co, int Co2, int Ci, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline figures)           */
 /* ------------------------------------------------------------------------------------------ */

@@ -71,6 +71,43 @@ def test_conv_weight_and_input_gradients_match_torch(cin, cout, ks, stride, hw):
     assert _rel(dx_res - res, xr.grad) < 5e-5
 
 
+@pytest.mark.parametrize('cin,cout,B,H,W', [(64, 128, 3, 16, 16), (128, 256, 2, 13, 10), (256, 512, 5, 8, 8), (64, 96, 1, 2, 2), (64, 128, 72, 64, 64)])
+def test_strided_dgrad_with_downsample_branch(cin, cout, B, H, W):
+    """hmf_conv_dgrad_s2: input gradient of a BasicBlock's stride-2 3x3 conv1 + its stride-2 1x1 downsample branch (+ residual) in one launch,
+    against float64 autograd; odd map sizes, a single 2 x 2 map, the layer2.0 shape at the training batch."""
+    torch.manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, device='cuda').contiguous(memory_format=CL)
+    c1 = torch.nn.Conv2d(cin, cout, 3, 2, 1, bias=False).cuda()
+    c2 = torch.nn.Conv2d(cin, cout, 1, 2, 0, bias=False).cuda()
+    big = B * H * W * cin > (1 << 24)
+    dt = torch.float32 if big else torch.float64                     # the B = 72 case: fp32 reference, looser bar
+    xr = x.to(dt).requires_grad_(True)
+    y1, y2 = copy.deepcopy(c1).to(dt)(xr), copy.deepcopy(c2).to(dt)(xr)
+    g1 = torch.randn_like(y1).float().contiguous(memory_format=CL)
+    g2 = torch.randn_like(y2).float().contiguous(memory_format=CL)
+    (y1 * g1.to(dt)).sum().backward(retain_graph=True)
+    gx1 = xr.grad.clone()
+    (y2 * g2.to(dt)).sum().backward()
+    gx12 = xr.grad.clone()
+    res = torch.randn(B, cin, H, W, device='cuda').contiguous(memory_format=CL)
+    s1, s2 = et._Saved(), et._Saved()
+    s1.conv, s1.x, s1.stride, s1.stem = c1, x, 2, False
+    s2.conv, s2.x, s2.stride, s2.stem = c2, x, 2, False
+    with torch.no_grad():
+        a = et._dgrad(g1, s1)
+        b = et._dgrad(g1, s1, extra=(g2, s2))
+        c = et._dgrad(g1, s1, residual=res, extra=(g2, s2))
+        assert et._folds_downsample(s1, s2)
+        saved, et.STRIDED_DGRAD = et.STRIDED_DGRAD, False
+        try:
+            old = et._dgrad(g1, s1)                                   # the zero-inserted form
+        finally:
+            et.STRIDED_DGRAD = saved
+    bar = 2e-4 if big else 5e-5
+    assert _rel(a, gx1) < bar and _rel(b, gx12) < bar and _rel(c - res, gx12) < bar
+    assert _rel(old, gx1) < bar
+
+
 @pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 3, 64, 64), (64, 64, 2, 10, 32), (128, 128, 5, 32, 32), (256, 256, 3, 16, 16), (512, 512, 4, 8, 8),
                                             (64, 96, 2, 4, 16), (128, 64, 1, 2, 96), (64, 32, 7, 8, 8)])
 def test_winograd_weight_gradient_matches_float64(cin, cout, B, H, W):
