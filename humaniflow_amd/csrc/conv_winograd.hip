@@ -312,40 +312,86 @@ extern "C" int hmf_conv_winograd_pack_host(const float* w /*[Cout][3][3][Cin]*/,
 // dgrad = 0: the convolution's own filter f[n][p][q][c] = w[n][c][p][q]  (Cout = out, Cin = in);
 // dgrad = 1: the input-gradient filter (flipped, in/out swapped) f[n][p][q][c] = w[c][n][2-p][2-q]  (Cout = in, Cin = out of the parameter).
 namespace hmf {
-__global__ __launch_bounds__(256) void k_wino_pack_device(const float* __restrict__ w, float* __restrict__ packed, int Cin, int Cout, int dgrad, long long total) {
-    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (o >= total) return;
-    // o = (((((t * 4 + xi) * nslab + s) * 8 + g) * 4 + nu) * 64 + l) * 4 + u
+constexpr int kWPackJobs = 48;
+struct WinoPackJobs {
+    const float* w[kWPackJobs];
+    float* packed[kWPackJobs];
+    int cin[kWPackJobs], cout[kWPackJobs], dgrad[kWPackJobs];
+    int first[kWPackJobs + 1];                  // first wave of job j; first[n] = total waves
+    int n;
+};
+
+// One wave per (job, n-tile t, slab s, k-group g): lane l = q * 32 + j transforms the four channels c0 .. c0 + 3 = slab * 64 + 8 g + 4 q + u of filter
+// n = 32 t + j -- 36 floats read once (contiguous in the parameter for dgrad = 0), U = G g G^T in registers, sixteen 16-byte stores, each a 1 KiB run
+// per wave.  (Round 2 used one thread per packed float: nine scattered reads each, 16x the read traffic; 46-72 us per layer4 filter.)
+__global__ __launch_bounds__(256) void k_wino_pack_device(const WinoPackJobs jobs) {
+    const int wv = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (wv >= jobs.first[jobs.n]) return;
+    int j = 0;
+    while (wv >= jobs.first[j + 1]) ++j;
+    const int Cin = jobs.cin[j], Cout = jobs.cout[j], dgrad = jobs.dgrad[j];
+    const float* __restrict__ w = jobs.w[j];
     const int nslab = Cin / kWSC;
-    long long r = o;
-    const int u = (int)(r & 3); r >>= 2;
-    const int l = (int)(r & 63); r >>= 6;
-    const int nu = (int)(r & 3); r >>= 2;
-    const int g = (int)(r & 7); r >>= 3;
-    const int s = (int)(r % nslab); r /= nslab;
-    const int xi = (int)(r & 3);
-    const int t = (int)(r >> 2);
-    const int n = 32 * t + (l & 31), c = s * kWSC + 8 * g + 4 * (l >> 5) + u;
+    int r = wv - jobs.first[j];
+    const int g = r & 7; r >>= 3;
+    const int s = r % nslab, t = r / nslab;
+    const int n = 32 * t + (l & 31), c0 = s * kWSC + 8 * g + 4 * (l >> 5);
+    float f[4][3][3];                           // [u][p][q]
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                f[u][p][q] = dgrad ? w[(((long long)(c0 + u) * Cout + n) * 3 + (2 - p)) * 3 + (2 - q)] : w[(((long long)n * Cin + c0 + u) * 3 + p) * 3 + q];
+    f32x4* out = (f32x4*)jobs.packed[j] + ((((long long)(t * 4) * nslab + s) * 8 + g) * 4) * 64 + l;      // + ((xi * nslab * 8) * 4 + nu) * 64
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-    float acc = 0.f;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const float wv = dgrad ? w[(((long long)c * Cout + n) * 3 + (2 - p)) * 3 + (2 - q)] : w[(((long long)n * Cin + c) * 3 + p) * 3 + q];
-            acc = fmaf(G[xi][p] * G[nu][q], wv, acc);
+        for (int nu = 0; nu < 4; ++nu) {
+            f32x4 v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float acc = 0.f;                // the same product order as the round-2 packer (and the host packer up to fp64 -> fp32)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) acc = fmaf(G[xi][p] * G[nu][q], f[u][p][q], acc);
+                v[u] = acc;
+            }
+            out[((long long)xi * nslab * 8 * 4 + nu) * 64] = v;
         }
-    packed[o] = acc;
 }
 }  // namespace hmf
 
+// n filters in ONE launch (the training graph packs every Winograd layer's forward and input-gradient filter at the top of the step).
+extern "C" int hmf_conv_winograd_pack_device_batch(const float* const* w_native, float* const* packed, const int* cin, const int* cout, const int* dgrad, int n,
+                                                   void* stream) {
+    if (!w_native || !packed || !cin || !cout || !dgrad || n < 1) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_pack_device_batch: bad args");
+    for (int base = 0; base < n; base += kWPackJobs) {
+        WinoPackJobs jobs;
+        jobs.n = (n - base) < kWPackJobs ? (n - base) : kWPackJobs;
+        int waves = 0;
+        for (int j = 0; j < jobs.n; ++j) {
+            const int k = base + j;
+            if (!w_native[k] || !packed[k]) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_pack_device_batch: null pointer in job %d", k);
+            if (cin[k] % kWSC || cout[k] % 32 || cin[k] <= 0 || cout[k] <= 0)
+                return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd_pack_device_batch: job %d: Cin=%d %% 64 or Cout=%d %% 32", k, cin[k], cout[k]);
+            jobs.w[j] = w_native[k]; jobs.packed[j] = packed[k]; jobs.cin[j] = cin[k]; jobs.cout[j] = cout[k]; jobs.dgrad[j] = dgrad[k] ? 1 : 0;
+            jobs.first[j] = waves;
+            waves += (cout[k] / 32) * (cin[k] / kWSC) * 8;
+        }
+        jobs.first[jobs.n] = waves;
+        hipLaunchKernelGGL(k_wino_pack_device, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, jobs);
+        HMF_LAUNCH_CHECK();
+    }
+    return HMF_OK;
+}
+
 extern "C" int hmf_conv_winograd_pack_device(const float* w_native, float* packed, int Cin, int Cout, int dgrad, void* stream) {
     if (!w_native || !packed) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_pack_device: null pointer");
-    if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd_pack_device: Cin=%d %% 64 or Cout=%d %% 32", Cin, Cout);
-    const long long total = (long long)Cout * 16 * Cin;
-    hipLaunchKernelGGL(k_wino_pack_device, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_native, packed, Cin, Cout, dgrad, total);
-    HMF_LAUNCH_CHECK();
-    return HMF_OK;
+    return hmf_conv_winograd_pack_device_batch(&w_native, &packed, &Cin, &Cout, &dgrad, 1, stream);
 }
 
 extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }

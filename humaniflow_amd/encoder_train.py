@@ -92,17 +92,66 @@ def _conv3x3_patch(x, w4, stride, residual=None, native=None):
     return y
 
 
+_WINO_PACKS = {}               # (id(parameter), dgrad) -> (parameter version, data_ptr, packed filter): filled by _pack_all_winograd at the top of a step
+
+
+def _pack_all_winograd(enc, device):
+    """Transformed filters G g G^T of every stride-1 3x3 convolution of `enc`, for the layer itself and for its input-gradient convolution, in ONE
+    launch (hmf_conv_winograd_pack_device_batch) into one buffer that lives with the module.  Entries carry the parameter's version and address:
+    a filter that changed since (optimiser step, re-bound .data) is re-packed by its consumer."""
+    lib = _lib.load()
+    convs = enc.__dict__.get('_wino_convs')
+    if convs is None:
+        convs = enc.__dict__['_wino_convs'] = [m for m in enc.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)]
+    jobs = []                                                        # (parameter, dgrad, Cin, Cout) in the kernel's sense
+    for m in convs:
+        w = m.weight
+        if not (w.is_contiguous() and w.dtype == torch.float32):
+            continue
+        co, ci = w.shape[:2]
+        if ci % 64 == 0 and co % 32 == 0:
+            jobs.append((w, 0, ci, co))
+        if co % 64 == 0 and ci % 32 == 0:
+            jobs.append((w, 1, co, ci))
+    if not jobs:
+        return
+    sizes = [int(lib.hmf_conv_winograd_packed_floats(ci, co)) for _, _, ci, co in jobs]
+    key = ('_wino_buf', str(device))
+    buf = enc.__dict__.get(key)
+    if buf is None or buf.numel() != sum(sizes):
+        buf = enc.__dict__[key] = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    import ctypes as C
+    n = len(jobs)
+    views, o = [], 0
+    for sz in sizes:
+        views.append(buf[o:o + sz])
+        o += sz
+    wp = (C.c_void_p * n)(*[j[0].detach().data_ptr() for j in jobs])
+    pp = (C.c_void_p * n)(*[v.data_ptr() for v in views])
+    ci = (C.c_int * n)(*[j[2] for j in jobs])
+    co = (C.c_int * n)(*[j[3] for j in jobs])
+    dg = (C.c_int * n)(*[j[1] for j in jobs])
+    _lib.check(lib.hmf_conv_winograd_pack_device_batch(wp, pp, ci, co, dg, n, _lib.current_stream()), 'hmf_conv_winograd_pack_device_batch')
+    for (w, d, _, _), v in zip(jobs, views):
+        _WINO_PACKS[(id(w), bool(d))] = (w._version, w.data_ptr(), v)
+
+
 def _conv3x3_winograd(x, native, residual=None):
     """Bias-free stride-1 3x3 convolution on the Winograd F(2x2,3x3) kernel (1.6-1.8x the patch kernel at B = 72): the transformed filters
-    G g G^T are rebuilt on the device from the parameter's own storage (hmf_conv_winograd_pack_device), for the layer itself or, with
-    native = (parameter, True), for its input-gradient convolution."""
+    G g G^T are rebuilt on the device from the parameter's own storage (one launch for the whole encoder at the top of the step,
+    _pack_all_winograd; here only if that copy is missing or stale), for the layer itself or, with native = (parameter, True), for its
+    input-gradient convolution."""
     lib = _lib.load()
     param, dgrad = native
     B, Cin, H, W = x.shape
     Cout = param.shape[1] if dgrad else param.shape[0]
     st = _lib.current_stream()
-    packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(Cin, Cout)), dtype=torch.float32, device=x.device)
-    _lib.check(lib.hmf_conv_winograd_pack_device(param.detach().data_ptr(), packed.data_ptr(), Cin, Cout, int(dgrad), st), 'hmf_conv_winograd_pack_device')
+    hit = _WINO_PACKS.get((id(param), bool(dgrad)))
+    if hit is not None and hit[0] == param._version and hit[1] == param.data_ptr() and hit[2].device == x.device:
+        packed = hit[2]
+    else:
+        packed = torch.empty(int(lib.hmf_conv_winograd_packed_floats(Cin, Cout)), dtype=torch.float32, device=x.device)
+        _lib.check(lib.hmf_conv_winograd_pack_device(param.detach().data_ptr(), packed.data_ptr(), Cin, Cout, int(dgrad), st), 'hmf_conv_winograd_pack_device')
     y = _cl_empty(B, Cout, H, W, x.device)
     _lib.check(lib.hmf_conv_winograd(x.data_ptr(), packed.data_ptr(), None, None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W,
                                      Cin, Cout, 0, st), 'hmf_conv_winograd')
@@ -281,6 +330,7 @@ class EncoderTrainFn(torch.autograd.Function):
             return s.out
 
         with torch.cuda.device(dev), torch.no_grad():
+            _pack_all_winograd(enc, dev)
             xin = x.detach().float().contiguous()
             a0 = unit(enc.conv1, enc.bn1, xin, True, stem=True)
             B, C, H, W = a0.shape

@@ -320,6 +320,10 @@ int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, 
  * dgrad = 0 packs the layer's own filter (Cout = out, Cin = in); dgrad = 1 packs the filter of the input-gradient convolution (flipped taps,
  * in/out swapped: Cout = the parameter's in-channels, Cin = its out-channels).  packed: hmf_conv_winograd_packed_floats(Cin, Cout) floats. */
 int hmf_conv_winograd_pack_device(const float* w_native, float* packed, int Cin, int Cout, int dgrad, void* stream);
+/* The same for n filters in one launch (host arrays of n pointers / sizes / flags; the training graph packs every layer's forward and
+ * input-gradient filter at the top of a step). */
+int hmf_conv_winograd_pack_device_batch(const float* const* w_native, float* const* packed, const int* cin, const int* cout, const int* dgrad, int n,
+                                        void* stream);
 
 
 /* Encoder stem (models/resnet.py:141-144,203-206): conv 7x7 / stride 2 / pad 3 (18 -> 64 channels) + folded BatchNorm + ReLU in one
