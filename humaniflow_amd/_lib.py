@@ -106,6 +106,7 @@ _SIGS = {
     'hmf_conv1x1_dual_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 10 + [_VP]),
     'hmf_conv2d_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
     'hmf_conv1x1_gemm': (C.c_int, [_VP] * 6 + [C.c_int] * 11 + [_VP]),
+    'hmf_i64_increment_batch': (C.c_int, [_VP, C.c_int, _VP]),
     'hmf_conv_dgrad_s2': (C.c_int, [_VP] * 6 + [C.c_int] * 6 + [_VP]),
     'hmf_conv1x1_split_packed_bytes': (C.c_longlong, [C.c_int] * 3),
     'hmf_conv1x1_split_pack': (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),

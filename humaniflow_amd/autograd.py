@@ -110,9 +110,27 @@ def _context_pullback(model, delta, isgc_rows, rot_rows):
 
 
 def _context_weight_grads(model, g_full, nin=256):
-    """[dW_j (64, nin + 9 a_j)] from g_full (P, 64, nin + 207): the columns of part j's ancestors."""
-    idx = _anc_index(model, g_full.device)
-    return [torch.cat([g_full[j, :, :nin], g_full[j].index_select(1, idx[j] + nin)], dim=1) for j in range(g_full.shape[0])]
+    """[dW_j (64, nin + 9 a_j)] from g_full (P, 64, nin + 207): the columns of part j's ancestors.  ONE gather for all parts through a cached flat
+    index (round 2: index arithmetic + index_select + cat per part = 69 launches per backward pass); the results are views of its output."""
+    P, rows, width = g_full.shape
+    key = ('ctx_gather', str(g_full.device), nin, rows, width)
+    cache = model.__dict__.setdefault('_grad_cache', {})
+    if key not in cache:
+        idx = _anc_index(model, g_full.device)
+        flat, widths = [], []
+        for j in range(P):
+            cols = torch.cat([torch.arange(nin, device=g_full.device), idx[j] + nin])
+            r = torch.arange(rows, device=g_full.device)
+            flat.append(((j * rows + r)[:, None] * width + cols[None, :]).reshape(-1))
+            widths.append(int(cols.numel()))
+        cache[key] = (torch.cat(flat), widths)
+    flat_idx, widths = cache[key]
+    out = g_full.reshape(-1).index_select(0, flat_idx)
+    res, o = [], 0
+    for w in widths:
+        res.append(out[o:o + rows * w].view(rows, w))
+        o += rows * w
+    return res
 
 
 def _ctx_params(model):

@@ -353,7 +353,9 @@ class EncoderTrainFn(torch.autograd.Function):
                     plan.append((first, len(saved), blk.downsample is not None))
             feats = cur.mean(dim=(2, 3))
             if tracked:
-                torch._foreach_add_(tracked, 1)
+                import ctypes as C
+                _lib.check(lib.hmf_i64_increment_batch((C.c_void_p * len(tracked))(*[t.data_ptr() for t in tracked]), len(tracked), _lib.current_stream()),
+                           'hmf_i64_increment_batch')
         ctx.enc, ctx.saved, ctx.plan, ctx.a0, ctx.final_shape = enc, saved, plan, a0, tuple(cur.shape)
         ctx.param_ids = [id(p) for p in params]
         # backward reads the LIVE conv / BatchNorm weights (input-gradient filters, BN coefficients): remember their versions so that an in-place

@@ -356,6 +356,10 @@ int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial,
 /* ------------------------------------------------------------------------------------------ */
 /* Encoder, training mode (models/resnet.py under train(): nn.BatchNorm2d batch statistics) and its backward                 */
 /* ------------------------------------------------------------------------------------------ */
+/* *counters[i] += 1 for n device int64 scalars in one launch per 64: the num_batches_tracked buffers of the BatchNorm layers of one training pass
+ * (torch.nn.BatchNorm2d semantics, models/resnet.py bn*). */
+int hmf_i64_increment_batch(long long* const* counters, int n, void* stream);
+
 /* All tensors NHWC rows [M][C], M = B*H*W, C % 64 == 0.  Forward of one conv+BN(+ReLU)(+residual) unit:
  *   y = hmf_conv2d_nhwc(x, w, bias = NULL, relu = 0)   (or hmf_stem_conv with relu = 0)
  *   hmf_bn_stats(y) -> acc[2][C] (double, zeroed by the caller); hmf_bn_finalize -> mean, rstd, scale = gamma rstd, shift = beta - mean scale,
