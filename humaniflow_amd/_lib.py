@@ -127,7 +127,8 @@ _EXPERIMENT_SIGS = {
     'hmf_debug_set_timeline': (C.c_int, [_VP]),                                     # tools/flow_timeline.py
     'hmf_debug_set_lbs_cycles': (C.c_int, [_VP]),                                   # tools/lbs_tune.py
     'hmf_debug_gemm_stamps': (C.c_int, [_VP, C.c_int]),
-    'hmf_debug_set_wgw_target_wgs': (C.c_int, [C.c_int]),                            # tools/wgw_probe.py
+    'hmf_debug_set_wgw_target_wgs': (C.c_int, [C.c_int]),
+    'hmf_debug_set_wgw_single_stage': (C.c_int, [C.c_int]),                            # tools/wgw_probe.py
     'hmf_debug_stem_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/stem_probe.py
     'hmf_debug_wino_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/wino_probe.py                             # tools/gemm1x1_probe.py
 }

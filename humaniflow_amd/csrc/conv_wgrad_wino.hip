@@ -22,14 +22,16 @@
 // the previous k-step's (kept in registers): per k-step 6 + 2 x 6 VALU and 4 + 2 x 4 LDS reads for 8 MFMAs.  Measured at B = 72 (ResNet-18
 // layers, rocprof): 141-154 us per layer with 16-tile chunks and no reuse vs 246-252 us for the direct kernel.  Split over the tiles: every work-group adds its 8 x 16 accumulator registers to M with float atomics (M zeroed first).
 #include "hmf_common.h"
+#include <type_traits>
 
 namespace hmf {
 
 struct WgwArgs {
     const float* gy;     // [B][H][W][Cout]
     const float* x;      // [B][H][W][Cin]
-    float* m;            // [16][Cout][Cin], zeroed
+    float* m;            // partial sums [slices][tiles][32768] (k_wgw) / [16][Cout][Cin] behind them (k_wgw_reduce)
     int B, H, W, Cin, Cout, chunks_per_img, chunks_per_row, nchunks, chunks_per_slice, ci_blocks;
+    int ablate;          // experiments only (tools/wgw_probe.py): 1 = no atomic pass (wrong result)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w;
@@ -37,15 +39,18 @@ static __device__ __forceinline__ void wgw_dma16(__amdgpu_buffer_rsrc_t rsrc, ld
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, 0, 0, 0);
 }
 
-// TR x TC = 16 or 32 tiles per chunk (TC = tiles per chunk row); k-step s: lanes 0-31 take tile s, lanes 32-63 tile KS + s of the chunk
-template <int TR, int TC>
+// TR x TC = 16 or 32 tiles per chunk (TC = tiles per chunk row); k-step s: lanes 0-31 take tile s, lanes 32-63 tile KS + s of the chunk.
+// DB: two LDS stages -- the DMA requests of chunk c + 1 are issued right after the barrier that opens chunk c and land under its MFMAs (one barrier
+// per chunk).  Single-staged (round 3 first version) every chunk began with its own fetch, exposed: 1-2 us of every ~4.5 us.
+template <int TR, int TC, bool DB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_wgw(const WgwArgs a) {
     constexpr int GH = 2 * TR, GW = 2 * TC;                 // gy patch (pixels)
     constexpr int XH = GH + 2, XW = GW + 2;                 // input patch
     constexpr int NGI = GH * GW / 8;                        // DMA requests for the gy patch: 8 pixels x 128 B each
     constexpr int NXI = (XH * XW + 3) / 4;                  // ... for the input patch: 4 pixels x 256 B each
     constexpr int XPIX = NXI * 4;
-    __shared__ __attribute__((aligned(16))) float lds[GH * GW * 32 + XPIX * 64];
+    constexpr int STAGE = GH * GW * 32 + XPIX * 64;
+    __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * STAGE];
     float* sG = lds;
     float* sX = lds + GH * GW * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,9 +91,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr int KS = TR * TC / 2;                                            // k-steps per chunk
     // the second lane half starts KS tiles further: KS / TC tile rows (KS >= TC) or KS tile columns (KS < TC) into the patch
     constexpr int QG = KS >= TC ? (2 * (KS / TC)) * GW : 2 * KS, QX = KS >= TC ? (2 * (KS / TC)) * XW : 2 * KS;     // pixels
-    const float* pg = sG + lq * QG * 32 + li;
-    const float* px1 = sX + (a1 * XW) * 64 + lq * QX * 64 + li;
-    const float* px2 = sX + (a2 * XW) * 64 + lq * QX * 64 + li;
+    const float* pg0 = sG + lq * QG * 32 + li;
+    const float* px10 = sX + (a1 * XW) * 64 + lq * QX * 64 + li;
+    const float* px20 = sX + (a2 * XW) * 64 + lq * QX * 64 + li;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][h][r] = 0.f;
 
-    for (int ch = c_begin; ch < c_end; ++ch) {
+    // DMA requests of chunk ch into stage `buf`
+    auto issue = [&](int ch, int buf) {
         const int b = ch / a.chunks_per_img, rem = ch - b * a.chunks_per_img;
         const int crow = rem / a.chunks_per_row, ccol = rem - crow * a.chunks_per_row;
         const int oh0 = crow * GH, ow0 = ccol * GW;
@@ -108,45 +114,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gy + (long long)b * a.H * a.W * a.Cout), 0, a.H * a.W * a.Cout * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.H * a.W * a.Cin), 0, a.H * a.W * a.Cin * 4, 0x00020000);
         const int gbase = (oh0 * a.W + ow0) * a.Cout * 4, xbase = (oh0 * a.W + ow0) * a.Cin * 4;
-        if (ch != c_begin) __builtin_amdgcn_s_barrier();          // every wave is done reading the previous chunk
+        float* dG = sG + buf * STAGE;
+        float* dX = sX + buf * STAGE;
 #pragma unroll
         for (int k = 0; k < NGW; ++k) {
             const int i = wave + 4 * k;
-            if (i < NGI) wgw_dma16(rg, (lds_ptr_w)(sG + i * 256), gofs[k] + gbase);
+            if (i < NGI) wgw_dma16(rg, (lds_ptr_w)(dG + i * 256), gofs[k] + gbase);
         }
 #pragma unroll
         for (int k = 0; k < NXW; ++k) {
             const int i = wave + 4 * k;
-            if (i < NXI) wgw_dma16(rx, (lds_ptr_w)(sX + i * 256), (xedge[k] & emask) ? kOOBw : xofs[k] + xbase);
+            if (i < NXI) wgw_dma16(rx, (lds_ptr_w)(dX + i * 256), (xedge[k] & emask) ? kOOBw : xofs[k] + xbase);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    };
+    if (DB && c_begin < c_end) issue(c_begin, 0);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int buf = DB ? ((ch - c_begin) & 1) : 0;
+        if (DB) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's requests of chunk ch have landed
+            __builtin_amdgcn_s_barrier();                             // ... everybody's; and every wave is done reading the other stage
+            if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+        } else {
+            if (ch != c_begin) __builtin_amdgcn_s_barrier();          // every wave is done reading the previous chunk
+            issue(ch, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const float* pg = pg0 + buf * STAGE;
+        const float* px1 = px10 + buf * STAGE;
+        const float* px2 = px20 + buf * STAGE;
 
         float tk[2][2];                                            // row-transformed columns 2, 3 of the previous tile = columns 0, 1 of this one
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {                             // tile s of this lane half: (tr, tc) = (s / TC, s % TC) relative to the half's first tile
-            const int tr = s / TC, tc = s % TC;                    // compile time after unrolling (KS < TC: one row, tr = 0)
-            // ---- V = G g G^T, row xi ----
+        // Raw operands of k-step s (tile s of this lane half: (tr, tc) = (s / TC, s % TC) relative to the half's first tile; compile time after
+        // unrolling): 4 gy values, and per channel half the two rows x (4 or, behind a left neighbour, 2) columns of the input tile.  They are read
+        // ONE STEP AHEAD of their use: the LDS round trip runs under the previous step's MFMAs instead of in front of its own (round 3 first version:
+        // reads, wait, transform, MFMAs in turn -- 52 % MFMA utilisation with two waves per SIMD).
+        struct Raw {
+            float g[4];
+            float d1[2][4], d2[2][4];
+        };
+        auto load = [&](Raw& R, auto S) {
+            constexpr int s_ = decltype(S)::value, tr = s_ / TC, tc = s_ % TC;
             const float* g0 = pg + ((2 * tr) * GW + 2 * tc) * 32;
-            const float g00 = g0[0], g01 = g0[32], g10 = g0[GW * 32], g11 = g0[GW * 32 + 32];
-            const float r0 = c1 * g00 + c2 * g10, r1 = c1 * g01 + c2 * g11;
+            R.g[0] = g0[0]; R.g[1] = g0[32]; R.g[2] = g0[GW * 32]; R.g[3] = g0[GW * 32 + 32];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* d1 = px1 + ((2 * tr) * XW + 2 * tc) * 64 + 32 * h;
+                const float* d2 = px2 + ((2 * tr) * XW + 2 * tc) * 64 + 32 * h;
+#pragma unroll
+                for (int c = (tc == 0 ? 0 : 2); c < 4; ++c) { R.d1[h][c] = d1[c * 64]; R.d2[h][c] = d2[c * 64]; }
+            }
+        };
+        auto step = [&](const Raw& R, auto S) {
+            constexpr int s_ = decltype(S)::value, tc = s_ % TC;
+            // ---- V = G g G^T, row xi ----
+            const float r0 = c1 * R.g[0] + c2 * R.g[2], r1 = c1 * R.g[1] + c2 * R.g[3];
             const float v[4] = {r0, r0 + r1, r0 - r1, r1};
             // ---- U = B^T d B, row xi, both 32-channel halves ----
             float u[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float* d1 = px1 + ((2 * tr) * XW + 2 * tc) * 64 + 32 * h;
-                const float* d2 = px2 + ((2 * tr) * XW + 2 * tc) * 64 + 32 * h;
                 float t[4];
                 if (tc == 0) {
-                    t[0] = __builtin_fmaf(sd, d2[0], d1[0]);
-                    t[1] = __builtin_fmaf(sd, d2[64], d1[64]);
+                    t[0] = __builtin_fmaf(sd, R.d2[h][0], R.d1[h][0]);
+                    t[1] = __builtin_fmaf(sd, R.d2[h][1], R.d1[h][1]);
                 } else {
                     t[0] = tk[h][0];
                     t[1] = tk[h][1];
                 }
-                t[2] = __builtin_fmaf(sd, d2[2 * 64], d1[2 * 64]);
-                t[3] = __builtin_fmaf(sd, d2[3 * 64], d1[3 * 64]);
+                t[2] = __builtin_fmaf(sd, R.d2[h][2], R.d1[h][2]);
+                t[3] = __builtin_fmaf(sd, R.d2[h][3], R.d1[h][3]);
                 tk[h][0] = t[2];
                 tk[h][1] = t[3];
                 u[h][0] = t[0] - t[2];
@@ -158,19 +195,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) acc[n][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[n], u[h][n], acc[n][h], 0, 0, 0);
+        };
+        Raw R0, R1;
+        load(R0, std::integral_constant<int, 0>{});
+        auto pair = [&](auto S) {                                   // k-steps S and S + 1
+            constexpr int s_ = decltype(S)::value;
+            if (s_ + 1 < KS) load(R1, std::integral_constant<int, (s_ + 1 < KS ? s_ + 1 : 0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+            step(R0, S);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s_ + 1 < KS) {
+                if (s_ + 2 < KS) load(R0, std::integral_constant<int, (s_ + 2 < KS ? s_ + 2 : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+                step(R1, std::integral_constant<int, (s_ + 1 < KS ? s_ + 1 : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        static_assert(KS == 8 || KS == 16, "k-steps per chunk");
+        pair(std::integral_constant<int, 0>{});
+        pair(std::integral_constant<int, 2>{});
+        pair(std::integral_constant<int, 4>{});
+        pair(std::integral_constant<int, 6>{});
+        if constexpr (KS == 16) {
+            pair(std::integral_constant<int, 8>{});
+            pair(std::integral_constant<int, 10>{});
+            pair(std::integral_constant<int, 12>{});
+            pair(std::integral_constant<int, 14>{});
         }
     }
 
-    // ---- one atomic pass: M[xi][nu][co0 + row][ci0 + 32 h + li] (128-byte runs; register r of lane (li, q) is row (r & 3) + 8 (r >> 2) + 4 q) ----
+    // ---- partial sums of this work-group, plain 256-byte stores in register order: P[slice][tile][xi = wave][nu][half][r][lane] (k_wgw_reduce adds the
+    // slices).  Round 3's first version added them to M with float atomics: 67 MB of atomic traffic per layer at the ~1.5 TB/s the L2 atomic units
+    // sustain = 40-47 us of a 134-143 us launch (tools/wgw_probe.py, atomic pass ablated: 94-100 us). ----
     if (c_begin >= c_end) return;
+#ifdef HMF_EXPERIMENTS
+    if (a.ablate == 1 && acc[0][0][0] != 12345.678f) return;
+#endif
+    float* pp = a.m + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * (4 * 2 * 16 * 64) + lane;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float* mp = a.m + ((size_t)(wave * 4 + n) * a.Cout + co0) * a.Cin + ci0 + 32 * h + li;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(mp + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lq) * a.Cin, acc[n][h][r]);
-        }
+            for (int r = 0; r < 16; ++r) pp[((n * 2 + h) * 16 + r) * 64] = acc[n][h][r];
+}
+
+// M[xi][nu][co][ci] = sum over slices of P[slice][tile][xi][nu][half][r][lane]; register r of lane (li, q) is row co0 + (r & 3) + 8 (r >> 2) + 4 q,
+// column ci0 + 32 half + li of the tile's 32 x 64 block
+__global__ __launch_bounds__(256) void k_wgw_reduce(const float* __restrict__ P, float* __restrict__ M, int tiles, int slices, int Cout, int Cin, int ci_blocks) {
+    const int gidx = blockIdx.x * 256 + threadIdx.x;             // tile * 32768 + idx
+    if (gidx >= tiles * 32768) return;
+    const int t = gidx >> 15, idx = gidx & 32767;
+    const size_t stride = (size_t)tiles * 32768;
+    const float* p = P + (size_t)t * 32768 + idx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 8 <= slices; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+        s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
+    }
+    for (; k < slices; ++k) s0 += p[(size_t)k * stride];
+    const int lane = idx & 63, r = (idx >> 6) & 15, h = (idx >> 10) & 1, nu = (idx >> 11) & 3, xi = idx >> 13;
+    const int co = (t / ci_blocks) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = (t % ci_blocks) * 64 + 32 * h + (lane & 31);
+    M[((size_t)(xi * 4 + nu) * Cout + co) * Cin + ci] = (s0 + s1) + (s2 + s3);
 }
 
 // dW[co][ci][kh][kw] = sum_{xi, nu} A^T[kh][xi] s[xi] A^T[kw][nu] s[nu] M[xi][nu][co][ci],  s = (1, 1/2, 1/2, 1): the 1/2 of G's middle rows
@@ -206,18 +295,35 @@ __global__ __launch_bounds__(256) void k_wgw_finish(const float* __restrict__ m,
 using namespace hmf;
 
 static int g_wgw_target_wgs = 512;
+static int g_wgw_ablate = 0;
+static int g_wgw_single_stage = 0;       // 1: the single-staged 32-tile-chunk form (round 3 first version), for tools/wgw_probe.py
 #ifdef HMF_EXPERIMENTS
 extern "C" int hmf_debug_set_wgw_target_wgs(int n) { g_wgw_target_wgs = n > 0 ? n : 512; return HMF_OK; }      // tools/wgw_probe.py
+extern "C" int hmf_debug_set_wgw_single_stage(int on) { g_wgw_single_stage = on & 1; g_wgw_ablate = on >> 1; return HMF_OK; }      // bit 1: no atomic pass
 #endif
 
-// workspace = 16 * Cout * Cin floats (the Winograd-domain accumulator); dw_native = (Cout, Cin, 3, 3) row-major, the parameter's own layout
-extern "C" size_t hmf_conv_wgrad_winograd_workspace_floats(int Cin, int Cout) { return (size_t)16 * Cin * Cout; }
+// workspace: the work-groups' partial sums ((target work-groups + tiles) x 32 x 64 x 16 floats at most) + the 16 * Cout * Cin Winograd-domain
+// accumulator behind them; dw_native = (Cout, Cin, 3, 3) row-major, the parameter's own layout
+#ifdef HMF_EXPERIMENTS
+constexpr int kWgwMaxWgs = 1024;            // tools/wgw_probe.py sweeps the work-group target
+#else
+constexpr int kWgwMaxWgs = 512;
+#endif
+static size_t wgw_partial_floats(int Cin, int Cout) { return (size_t)(kWgwMaxWgs + (Cout / 32) * (Cin / 64)) * 32768; }
+extern "C" size_t hmf_conv_wgrad_winograd_workspace_floats(int Cin, int Cout) { return wgw_partial_floats(Cin, Cout) + (size_t)16 * Cin * Cout; }
 
-// chunk geometry TR * 100 + TC for a map, or 0: the largest chunk (32 tiles: fewer barriers and first-fetch waits per MFMA) whose rows tile the map
-static int wgw_geometry(int H, int W) {
+// chunk geometry TR * 100 + TC for a map, or 0.  Double-staged (the product path): 16-tile chunks, two stages of ~36 KB = two work-groups per CU;
+// single-staged: the largest chunk (32 tiles) whose rows tile the map.
+static int wgw_geometry(int H, int W, int single = 0) {
     if (H < 2 || W < 8 || (H & 1)) return 0;
-    if (W % 32 == 0) return H % 4 == 0 ? 216 : 116;
-    if (W == 16) return H % 8 == 0 ? 408 : (H % 4 == 0 ? 208 : 0);
+    if (single) {
+        if (W % 32 == 0) return H % 4 == 0 ? 216 : 116;
+        if (W == 16) return H % 8 == 0 ? 408 : (H % 4 == 0 ? 208 : 0);
+        if (W == 8) return H % 8 == 0 ? 404 : 0;
+        return 0;
+    }
+    if (W % 16 == 0 && H % 4 == 0) return 208;
+    if (W % 32 == 0) return 116;
     if (W == 8) return H % 8 == 0 ? 404 : 0;
     return 0;
 }
@@ -234,8 +340,9 @@ extern "C" int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* d
     if (((uintptr_t)gy & 15) || ((uintptr_t)x & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_wgrad_winograd: gy and x must be 16-byte aligned");
     if ((long long)H * W * std::max(Cin, Cout) * 4 >= (1LL << 30)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad_winograd: image exceeds the 32-bit offset range");
     WgwArgs a;
-    a.gy = gy; a.x = x; a.m = workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    const int geo = wgw_geometry(H, W), TR = geo / 100, TC = geo % 100;
+    a.gy = gy; a.x = x; a.m = workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ablate = g_wgw_ablate;
+    const int single = (g_wgw_single_stage && wgw_geometry(H, W, 1)) ? 1 : 0;
+    const int geo = wgw_geometry(H, W, single), TR = geo / 100, TC = geo % 100;
     a.chunks_per_row = (W / 2) / TC;
     a.chunks_per_img = ((H / 2) / TR) * a.chunks_per_row;
     a.nchunks = B * a.chunks_per_img;
@@ -245,20 +352,33 @@ extern "C" int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* d
     a.chunks_per_slice = (a.nchunks + slices - 1) / slices;
     slices = (a.nchunks + a.chunks_per_slice - 1) / a.chunks_per_slice;
     hipStream_t st = (hipStream_t)stream;
-    const size_t mfloats = (size_t)16 * Cin * Cout;
-    if (int zr = zero_async(workspace, mfloats * sizeof(float), st)) return zr;
+    if ((size_t)tiles * slices * 32768 > wgw_partial_floats(Cin, Cout)) return fail(HMF_ERR_WORKSPACE, "hmf_conv_wgrad_winograd: %d x %d work-groups exceed the workspace", tiles, slices);
+    float* mred = workspace + wgw_partial_floats(Cin, Cout);
     {
         ProfScope ps(13, B * H * W, st);                             // weight-gradient family (bench.py --train)
-        switch (geo) {
-            case 216: hipLaunchKernelGGL((k_wgw<2, 16>), dim3(tiles, slices), dim3(256), 0, st, a); break;
-            case 116: hipLaunchKernelGGL((k_wgw<1, 16>), dim3(tiles, slices), dim3(256), 0, st, a); break;
-            case 408: hipLaunchKernelGGL((k_wgw<4, 8>), dim3(tiles, slices), dim3(256), 0, st, a); break;
-            case 208: hipLaunchKernelGGL((k_wgw<2, 8>), dim3(tiles, slices), dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((k_wgw<4, 4>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+#ifdef HMF_EXPERIMENTS
+        if (single) {
+            switch (geo) {
+                case 216: hipLaunchKernelGGL((k_wgw<2, 16, false>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+                case 116: hipLaunchKernelGGL((k_wgw<1, 16, false>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+                case 408: hipLaunchKernelGGL((k_wgw<4, 8, false>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+                case 208: hipLaunchKernelGGL((k_wgw<2, 8, false>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_wgw<4, 4, false>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+            }
+        } else
+#endif
+        {
+            switch (geo) {
+                case 208: hipLaunchKernelGGL((k_wgw<2, 8, true>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+                case 116: hipLaunchKernelGGL((k_wgw<1, 16, true>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_wgw<4, 4, true>), dim3(tiles, slices), dim3(256), 0, st, a); break;
+            }
         }
         HMF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_wgw_reduce, dim3((tiles * 32768 + 255) / 256), dim3(256), 0, st, workspace, mred, tiles, slices, Cout, Cin, a.ci_blocks);
+        HMF_LAUNCH_CHECK();
         const int n = Cin * Cout;
-        hipLaunchKernelGGL(k_wgw_finish, dim3((n + 255) / 256), dim3(256), 0, st, workspace, dw_native, n);
+        hipLaunchKernelGGL(k_wgw_finish, dim3((n + 255) / 256), dim3(256), 0, st, mred, dw_native, n);
         HMF_LAUNCH_CHECK();
     }
     return HMF_OK;

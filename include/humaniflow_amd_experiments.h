@@ -28,6 +28,7 @@ int hmf_debug_wino_stamps(long long* out_host, int blocks);
 
 /* tools/wgw_probe.py: number of work-groups hmf_conv_wgrad_winograd aims for when it splits the tiles into slices (default 512). */
 int hmf_debug_set_wgw_target_wgs(int n);
+int hmf_debug_set_wgw_single_stage(int on);     /* 1: the single-staged 32-tile-chunk form of k_wgw (csrc/conv_wgrad_wino.hip) */
 
 /* Diagnostic (tools/stem_probe.py): stamps of the last k_stem_conv<POOL> launch, 6 int64 per work-group (shader clock at start, patch in LDS, main
  * loop done, end; the 100 MHz counter at start and end). */
