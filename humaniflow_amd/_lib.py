@@ -48,6 +48,7 @@ _SIGS = {
     'hmf_last_error': (C.c_char_p, []),
     'hmf_device_count': (C.c_int, []),
     'hmf_rot6d_to_rotmat': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'hmf_rot6d_to_rotmat_backward': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     'hmf_so3_exp': (C.c_int, [_VP, C.c_int, _VP, _VP]),
     'hmf_so3_log': (C.c_int, [_VP, C.c_int, _VP, _VP]),
     'hmf_so3_log_abs_det_jacobian': (C.c_int, [_VP, C.c_int, _VP, _VP]),

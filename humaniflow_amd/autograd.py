@@ -330,7 +330,8 @@ def _rot6d_torch(x):
 
 
 class Rot6dToRotmat(torch.autograd.Function):
-    """hmf_rot6d_to_rotmat forward; the pull-back of the 6 -> 9 Gram-Schmidt map by re-tracing it in torch ops (B x 6 values)."""
+    """hmf_rot6d_to_rotmat forward; hmf_rot6d_to_rotmat_backward = the pull-back of the 6 -> 9 Gram-Schmidt map in one launch
+    (`_rot6d_torch` above restates the map in torch ops: the tests differentiate it as the reference)."""
 
     @staticmethod
     def forward(ctx, x):
@@ -341,8 +342,11 @@ class Rot6dToRotmat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        with torch.enable_grad():
-            xi = x.clone().requires_grad_(True)
-            y = _rot6d_torch(xi)
-            (gx,) = torch.autograd.grad(y, xi, g.reshape(y.shape))
-        return gx.reshape(x.shape)
+        lib = _lib.load()
+        x6 = x.reshape(-1, 6).float().contiguous()
+        gR = g.reshape(-1, 9).float().contiguous()
+        gx = torch.empty_like(x6)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.hmf_rot6d_to_rotmat_backward(x6.data_ptr(), gR.data_ptr(), x6.shape[0], gx.data_ptr(), _lib.current_stream()),
+                       'hmf_rot6d_to_rotmat_backward')
+        return gx.reshape(x.shape).to(x.dtype)

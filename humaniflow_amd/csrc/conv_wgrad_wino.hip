@@ -15,12 +15,14 @@
 // the tile: lanes 0-31 take tile 2s, lanes 32-63 tile 2s + 1), so both operands are read from LDS as conflict-free ds_read_b32 with
 // compile-time offsets and transformed in registers: per k-step 6 VALU (g) + 16 VALU (d, two halves) + 20 LDS reads for 8 MFMAs.  On gfx950 that
 // VALU work adds to the MFMA time, so the expected MFMA utilisation is ~0.75 -- of 4/9 of the direct work.
-// Tiles are staged 16 or 32 at a time (TR x TC tile rows x columns): the gy patch (2 TR x 2 TC pixels x 32 channels) and the input patch
+// Tiles are staged 16 at a time (TR x TC tile rows x columns; two LDS stages): the gy patch (2 TR x 2 TC pixels x 32 channels) and the input patch
 // ((2 TR + 2) x (2 TC + 2) pixels x 64 channels, zero outside the image) arrive by LDS-DMA with lane offsets computed once per work-group
 // (an out-of-range offset makes the DMA write 0: the convolution's zero padding); pixel-major LDS rows are what lane = channel reads want, so no
 // swizzle is needed.  Lanes 0-31 / 32-63 walk two disjoint runs of ADJACENT tiles, so two of the four row-transformed input columns of a k-step are
-// the previous k-step's (kept in registers): per k-step 6 + 2 x 6 VALU and 4 + 2 x 4 LDS reads for 8 MFMAs.  Measured at B = 72 (ResNet-18
-// layers, rocprof): 141-154 us per layer with 16-tile chunks and no reuse vs 246-252 us for the direct kernel.  Split over the tiles: every work-group adds its 8 x 16 accumulator registers to M with float atomics (M zeroed first).
+// the previous k-step's (kept in registers): per k-step 6 + 2 x 6 VALU and 4 + 2 x 4 LDS reads for 8 MFMAs.
+// Split over the tiles: every work-group writes its 8 x 16 accumulator registers as a partial sum (plain 256-byte stores); k_wgw_reduce adds
+// the slices into M and k_wgw_finish applies the inverse transform.  No atomics: the result is reproducible run to run.  Measured at B = 72
+// (ResNet-18 layers, tools/wgw_probe.py): 109-118 us per layer vs 240-250 us for the direct kernel (134-144 us with an atomic accumulation pass).
 #include "hmf_common.h"
 #include <type_traits>
 
@@ -336,7 +338,7 @@ extern "C" int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* d
                                        void* stream) {
     if (!gy || !x || !dw_native || !workspace || B <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_wgrad_winograd: bad args");
     if (!hmf_conv_wgrad_winograd_supported(H, W, Cin, Cout))
-        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad_winograd: H=%d W=%d Cin=%d Cout=%d (H even and W a multiple of 32, or W = 16 with H %% 4 == 0, or W = 8 with H %% 8 == 0; Cin %% 64, Cout %% 32)", H, W, Cin, Cout);
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad_winograd: H=%d W=%d Cin=%d Cout=%d (W a multiple of 16 with H %% 4 == 0, or W a multiple of 32 with H even, or W = 8 with H %% 8 == 0; Cin %% 64, Cout %% 32)", H, W, Cin, Cout);
     if (((uintptr_t)gy & 15) || ((uintptr_t)x & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_wgrad_winograd: gy and x must be 16-byte aligned");
     if ((long long)H * W * std::max(Cin, Cout) * 4 >= (1LL << 30)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_wgrad_winograd: image exceeds the 32-bit offset range");
     WgwArgs a;

@@ -82,6 +82,19 @@ __global__ void k_rot6d(const float* __restrict__ x, int n, float* __restrict__ 
     for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = out[k];
 }
 
+__global__ void k_rot6d_bwd(const float* __restrict__ x, const float* __restrict__ g, int n, float* __restrict__ gx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float in[6], gr[9], out[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in[k] = x[(size_t)i * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gr[k] = g[(size_t)i * 9 + k];
+    rot6d_to_rotmat_bwd_f32(in, gr, out);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gx[(size_t)i * 6 + k] = out[k];
+}
+
 __global__ void k_so3_exp(const double* __restrict__ v, int n, double* __restrict__ R) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -192,6 +205,14 @@ int hmf_profile_clock_probe(int spin_us, long long* out_dev, void* stream) {
     }
 
 HMF_ELEMENTWISE(hmf_rot6d_to_rotmat, k_rot6d, float, float)
+// dL/dx6 (n, 6) from dL/dR (n, 3, 3): the pull-back of hmf_rot6d_to_rotmat (one launch; round 2 re-traced the Gram-Schmidt map in ~45 torch launches)
+int hmf_rot6d_to_rotmat_backward(const float* x6, const float* gR, int n, float* gx6, void* stream) {
+    if (n < 0 || (n > 0 && (!x6 || !gR || !gx6))) return fail(HMF_ERR_INVALID, "hmf_rot6d_to_rotmat_backward: bad args");
+    if (n == 0) return HMF_OK;
+    hipLaunchKernelGGL(k_rot6d_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x6, gR, n, gx6);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
 HMF_ELEMENTWISE(hmf_so3_exp, k_so3_exp, double, double)
 HMF_ELEMENTWISE(hmf_so3_log, k_so3_log, double, double)
 HMF_ELEMENTWISE(hmf_so3_log_abs_det_jacobian, k_so3_logdet, double, double)

@@ -22,6 +22,47 @@ __device__ __forceinline__ void rot6d_to_rotmat_f32(const float* __restrict__ x,
     R[6] = b1[2]; R[7] = b2[2]; R[8] = b3[2];
 }
 
+// Pull-back of rot6d_to_rotmat_f32: G = dL/dR (row-major 3x3) -> gx = dL/dx (6), through the two F.normalize calls (gradient of a / max(|a|, eps))
+// and the cross product: dL/db1 = G1 + b2 x G3, dL/db2 = G2 + G3 x b1.
+__device__ __forceinline__ void rot6d_to_rotmat_bwd_f32(const float* __restrict__ x, const float* __restrict__ G, float* __restrict__ gx) {
+    const float eps = 1e-12f;
+    const float a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+    const float n1r = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), n1 = fmaxf(n1r, eps);
+    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    const float n2r = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), n2 = fmaxf(n2r, eps);
+    const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    const float G1[3] = {G[0], G[3], G[6]}, G2[3] = {G[1], G[4], G[7]}, G3[3] = {G[2], G[5], G[8]};
+    float gb1[3] = {G1[0] + (b2[1] * G3[2] - b2[2] * G3[1]), G1[1] + (b2[2] * G3[0] - b2[0] * G3[2]), G1[2] + (b2[0] * G3[1] - b2[1] * G3[0])};
+    const float gb2[3] = {G2[0] + (G3[1] * b1[2] - G3[2] * b1[1]), G2[1] + (G3[2] * b1[0] - G3[0] * b1[2]), G2[2] + (G3[0] * b1[1] - G3[1] * b1[0])};
+    float gu[3];
+    if (n2r > eps) {
+        const float p = gb2[0] * b2[0] + gb2[1] * b2[1] + gb2[2] * b2[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gu[k] = (gb2[k] - p * b2[k]) / n2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gu[k] = gb2[k] / eps;
+    }
+    const float gd = -(gu[0] * b1[0] + gu[1] * b1[1] + gu[2] * b1[2]);
+    float ga2[3], ga1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gb1[k] += -d * gu[k] + gd * a2[k];
+        ga2[k] = gu[k] + gd * b1[k];
+    }
+    if (n1r > eps) {
+        const float p = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ga1[k] = (gb1[k] - p * b1[k]) / n1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ga1[k] = gb1[k] / eps;
+    }
+    gx[0] = ga1[0]; gx[1] = ga2[0]; gx[2] = ga1[1]; gx[3] = ga2[1]; gx[4] = ga1[2]; gx[5] = ga2[2];
+}
+
 // so3_exp, :182-201.  R = I + alpha*X + (beta*X)@X with X = hat(v) (:142-165); the small-angle
 // branch is evaluated on theta AFTER it was replaced by 1 -- harmless since X=0.
 __device__ __forceinline__ void so3_exp_f64(const double v[3], double R[9]) {

@@ -139,6 +139,8 @@ class ResNetEncoder(nn.Module):
         st['_plan_key'] = None
         st['_plan_tensors'] = None
         st.pop('_stem_map', None)
+        for k in [k for k in st if (k if isinstance(k, str) else k[0]).startswith('_wino')]:     # training-graph filter packs (encoder_train.py)
+            st.pop(k)
         return st
 
     @torch.no_grad()

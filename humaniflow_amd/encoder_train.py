@@ -4,15 +4,18 @@ What `ResNetEncoder.forward` runs in train() mode under autograd (train/train_hu
 models/resnet.py).  One `torch.autograd.Function` spans the whole encoder, so no per-layer autograd bookkeeping happens between launches:
 
   forward, per conv + BN (+ ReLU) (+ residual) unit
-      y    = conv(x, W)                    hmf_conv_winograd (stride-1 3x3: G W G^T rebuilt on the device each step) | hmf_conv_patch (stride-2 3x3) |
+      y    = conv(x, W)                    hmf_conv_winograd (stride-1 3x3: G W G^T of every layer rebuilt on the device by ONE launch at the top of the
+                                           step, hmf_conv_winograd_pack_device_batch) | hmf_conv_patch (stride-2 3x3) | hmf_conv1x1_gemm /
                                            hmf_conv2d_nhwc (1x1) | hmf_stem_conv (7x7/2, filters re-packed on the device)
       stats                                hmf_bn_stats + hmf_bn_finalize (mean, rstd, scale, shift; running statistics updated as nn.BatchNorm2d does)
       out  = relu?(scale y + shift (+ idt)) hmf_bn_apply
   backward, per unit (g = dL/d out)
       gz = g * (out > 0); sums            hmf_bn_bwd_reduce + hmf_bn_bwd_finalize (d gamma, d beta, coefficients)
       gy = a gz + b y + c                  hmf_bn_bwd_apply (also emits gz = the identity branch's gradient)
-      dW                                   hmf_conv_wgrad (MFMA GEMM over the pixel axis; the stem reads the NCHW input directly)
-      dx                                   the forward kernels with the flipped / transposed filter (stride-2 layers: zero-inserted gradient map);
+      dW                                   hmf_conv_wgrad_winograd (stride-1 3x3: Winograd F(3x3, 2x2), written in the parameter's own layout) |
+                                           hmf_conv_wgrad (MFMA GEMM over the pixel axis; the stem reads the NCHW input directly)
+      dx                                   stride 1: the forward kernels with the flipped / transposed filter; stride-2 3x3: hmf_conv_dgrad_s2
+                                           (four parity-class GEMMs in one launch, + the block's 1x1 downsample input gradient);
                                            the identity branch's gradient rides in that launch's residual epilogue
   max-pool: hmf_maxpool3x3s2_nhwc / hmf_maxpool3x3s2_nhwc_backward; global average pool: torch mean / broadcast (B x C values).
 Filter re-layouts (flip, transpose, channels_last) are small torch copies per step (the filters total 45-94 MB).
@@ -132,8 +135,17 @@ def _pack_all_winograd(enc, device):
     co = (C.c_int * n)(*[j[3] for j in jobs])
     dg = (C.c_int * n)(*[j[1] for j in jobs])
     _lib.check(lib.hmf_conv_winograd_pack_device_batch(wp, pp, ci, co, dg, n, _lib.current_stream()), 'hmf_conv_winograd_pack_device_batch')
-    for (w, d, _, _), v in zip(jobs, views):
-        _WINO_PACKS[(id(w), bool(d))] = (w._version, w.data_ptr(), v)
+    keys = [(id(w), bool(d)) for w, d, _, _ in jobs]
+    for k, (w, d, _, _), v in zip(keys, jobs, views):
+        _WINO_PACKS[k] = (w._version, w.data_ptr(), v)
+    if '_wino_finalizer' not in enc.__dict__:                        # the entries (and the buffer they view) go with the module
+        import weakref
+        enc.__dict__['_wino_finalizer'] = weakref.finalize(enc, _drop_wino_packs, keys)
+
+
+def _drop_wino_packs(keys):
+    for k in keys:
+        _WINO_PACKS.pop(k, None)
 
 
 def _conv3x3_winograd(x, native, residual=None):

@@ -349,8 +349,8 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
         ms, tag = ms[:n], tag[:n]
         t_w = float(ms[tag == 13].sum()) / P * 1e-3
         t_c = float(ms[(tag >= 8) & (tag <= 11)].sum()) / P * 1e-3
-        fam = {'weight gradients (k_stem_wgrad, k_conv_wgrad3, k_conv_wgrad)': (f_all, t_w, int((tag == 13).sum()) // P),
-               'forward + input-gradient convolutions (k_stem_conv, k_conv_winograd, k_conv_patch, k_conv_igemm)': (f_all + f_dgrad, t_c, int(((tag >= 8) & (tag <= 11)).sum()) // P)}
+        fam = {'weight gradients (k_stem_wgrad, k_wgw, k_conv_wgrad3, k_conv_wgrad)': (f_all, t_w, int((tag == 13).sum()) // P),
+               'forward + input-gradient convolutions (k_stem_conv, k_conv_winograd, k_conv_patch, k_conv_dgrad_s2, k_conv_gemm, k_conv_igemm)': (f_all + f_dgrad, t_c, int(((tag >= 8) & (tag <= 11)).sum()) // P)}
         name = max(fam, key=lambda k: fam[k][1])
         f, t, nl = fam[name]
         # HBM bytes per launch of that family from the separate rocprofv3 --pmc passes (tools/profile_round.sh), quoted only when the summary was
@@ -377,7 +377,8 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
                 'ms_per_step': round(t * 1e3, 3), 'algorithmic_gflop_per_step': round(f / 1e9, 1),
                 'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (HIP event pair around every launch of %d extra steps); '
                        'the stride-1 3x3 layers run as Winograd F(2x2,3x3) and are booked at direct-form FLOPs (the MFMA pipe executes 4/9 of them), '
-                       'the input gradients of stride-2 layers run on zero-inserted maps and are booked at the FLOPs of the layer' % P,
+                       'the input gradients of the stride-2 3x3 layers run as parity-class GEMMs (hmf_conv_dgrad_s2) and are booked at the FLOPs of the layer; the stride-1 3x3 '
+                       'weight gradients run as Winograd F(3x3,2x2) and are booked at direct-form FLOPs' % P,
                 'families': {k: {'gflop_per_step': round(v[0] / 1e9, 1), 'ms_per_step': round(v[1] * 1e3, 3), 'tflops': round(v[0] / v[1] / 1e12, 2),
                                  'launches_per_step': v[2]} for k, v in fam.items()}}
     except Exception as e:                                              # the measurement pass must not cost the bench line

@@ -52,6 +52,8 @@ int hmf_device_count(void);
 /* ------------------------------------------------------------------------------------------ */
 /* rot6d_to_rotmat :86-100.  x6: n x 6 (row-major pairs R11,R12,R21,R22,R31,R32) -> R: n x 9. */
 int hmf_rot6d_to_rotmat(const float* x6, int n, float* R, void* stream);
+/* Pull-back of that map (training): gx6 (n,6) = dL/dx6 from gR (n,3,3) = dL/dR, through both F.normalize calls and the cross product. */
+int hmf_rot6d_to_rotmat_backward(const float* x6, const float* gR, int n, float* gx6, void* stream);
 /* so3_exp :182-201 (fp64 Rodrigues incl. the theta<=1e-10 branch).  v: n x 3 -> R: n x 9.    */
 int hmf_so3_exp(const double* v, int n, double* R, void* stream);
 /* so3_vee(so3_log(R)) :204-279,168-179 incl. the near-pi sign search.  R: n x 9 -> v: n x 3.  */
@@ -387,9 +389,10 @@ int hmf_maxpool3x3s2_nhwc_backward(const float* x, const float* g_out, float* g_
 int hmf_conv_wgrad(const float* gy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int ks, int stride, int stem_nchw, void* stream);
 /* The same gradient for stride-1 3x3 layers as Winograd F(3x3, 2x2) (csrc/conv_wgrad_wino.hip: 16 instead of 36 multiplies per 2x2 tile of gy,
  * the sum over tiles as 16 MFMA GEMMs, one inverse transform at the end): gy (B,H,W,Cout), x (B,H,W,Cin) NHWC -> dw_native (Cout,Cin,3,3), the
- * parameter's own layout.  workspace: hmf_conv_wgrad_winograd_workspace_floats(Cin, Cout) floats of device memory (zeroed by the call).
- * Built for the shapes hmf_conv_wgrad_winograd_supported() accepts (H even; W a multiple of 32, or 16 with H % 4 == 0, or 8 with H % 8 == 0;
- * Cin % 64 == 0, Cout % 32 == 0); float atomics over slices of the tiles (run-to-run differences at rounding level).                       */
+ * parameter's own layout.  workspace: hmf_conv_wgrad_winograd_workspace_floats(Cin, Cout) floats of device memory (the work-groups' partial sums
+ * + the Winograd-domain accumulator; no initialisation needed).  Built for the shapes hmf_conv_wgrad_winograd_supported() accepts (W a multiple of
+ * 16 with H % 4 == 0, or W a multiple of 32 with H even, or W = 8 with H % 8 == 0; Cin % 64 == 0, Cout % 32 == 0).  The slices of the tile sum
+ * are added by a reduce kernel in a fixed order: no atomics, reproducible run to run.                                                          */
 size_t hmf_conv_wgrad_winograd_workspace_floats(int Cin, int Cout);
 int hmf_conv_wgrad_winograd_supported(int H, int W, int Cin, int Cout);
 int hmf_conv_wgrad_winograd(const float* gy, const float* x, float* dw_native, float* workspace, int B, int H, int W, int Cin, int Cout, void* stream);

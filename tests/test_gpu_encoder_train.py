@@ -112,7 +112,7 @@ def test_strided_dgrad_with_downsample_branch(cin, cout, B, H, W):
                                             (64, 96, 2, 4, 16), (128, 64, 1, 2, 96), (64, 32, 7, 8, 8)])
 def test_winograd_weight_gradient_matches_float64(cin, cout, B, H, W):
     """hmf_conv_wgrad_winograd (F(3x3, 2x2): Winograd-domain GEMMs + one inverse transform) vs torch autograd in float64, and vs the direct
-    weight-gradient kernel: every chunk geometry (1 x 16, 2 x 8, 4 x 4 tiles), image borders, two chunks per row (W = 64, 96), ragged slices."""
+    weight-gradient kernel: every chunk geometry (1 x 16, 2 x 8, 4 x 4 tiles), image borders, several chunks per row (W = 32, 64, 96), ragged slices; bitwise reproducible."""
     lib = _lib.load()
     assert lib.hmf_conv_wgrad_winograd_supported(H, W, cin, cout)
     torch.manual_seed(cin + cout + H)
@@ -126,12 +126,14 @@ def test_winograd_weight_gradient_matches_float64(cin, cout, B, H, W):
     s.conv, s.x, s.stride, s.stem = conv, x, 1, False
     with torch.no_grad():
         dw = et._wgrad(gy, s)
+        dw_again = et._wgrad(gy, s)
         et.WINOGRAD_WGRAD = False
         try:
             dw_direct = et._wgrad(gy, s)
         finally:
             et.WINOGRAD_WGRAD = True
     assert dw.shape == conv.weight.shape and dw.is_contiguous()
+    assert torch.equal(dw, dw_again)                                  # slices added by a reduce kernel in a fixed order: no atomics, reproducible
     assert _rel(dw, cr.weight.grad) < 5e-5, _rel(dw, cr.weight.grad)
     assert _rel(dw_direct, cr.weight.grad) < 5e-5
     assert not lib.hmf_conv_wgrad_winograd_supported(7, 16, 64, 64) and not lib.hmf_conv_wgrad_winograd_supported(16, 24, 64, 64)

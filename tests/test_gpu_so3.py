@@ -55,3 +55,27 @@ def test_batch_rodrigues_vs_oracle():
     g = torch.Generator().manual_seed(1)
     v = torch.cat([torch.randn(1000, 3, generator=g) * 0.8, torch.zeros(2, 3), torch.tensor([[1e-9, 0, 0], [3.1, 0.1, 0]])])
     assert (R.batch_rodrigues(v.to(d)).cpu() - batch_rodrigues(v)).abs().max() < 2e-6
+
+
+def test_rot6d_backward_matches_float64_autograd_of_the_gram_schmidt_map():
+    """hmf_rot6d_to_rotmat_backward (one launch) against torch autograd through the float64 restatement of utils/rigid_transform_utils.py:86-100:
+    random 6-vectors at several scales, nearly parallel column pairs, and the module-level Function (what the model calls under autograd)."""
+    from humaniflow_amd.autograd import Rot6dToRotmat, _rot6d_torch
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4096, 6, generator=g)
+    x[:1024] *= 10.0
+    x[1024:2048] *= 0.05
+    x[2048:2060, 1::2] = x[2048:2060, 0::2] * 1.5 + 1e-2 * torch.randn(12, 3, generator=g)      # a2 nearly parallel to a1
+    gR = torch.randn(4096, 3, 3, generator=g)
+    xr = x.double().requires_grad_(True)
+    (_rot6d_torch(xr) * gR.double()).sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    R = Rot6dToRotmat.apply(xd)
+    (R * gR.cuda()).sum().backward()
+    well = torch.ones(4096, dtype=torch.bool)
+    well[2048:2060] = False                                          # the nearly parallel pairs are ill-conditioned in fp32: looser bars
+    ferr = (R.detach().cpu().double() - _rot6d_torch(x.double())).abs().amax(dim=(1, 2))
+    assert ferr[well].max() < 1e-5 and ferr[~well].max() < 1e-3
+    err = ((xd.grad.cpu().double() - xr.grad).abs() / (1.0 + xr.grad.abs())).amax(dim=1)
+    assert err[well].max() < 2e-4, err[well].max()
+    assert err[~well].max() < 5e-2, err[~well].max()

@@ -10,29 +10,41 @@ mkdir -p "$OUT"
 STEPS=30; WARM=6
 # the profiled command = the default bench without its trailing measurement pass / CPU baseline, so that the timed region ends the process
 BENCH="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --profile-steps 0"
+# counter passes serialise every dispatch: a few steps carry every kernel of the step often enough
+PMCBENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-steps 0"
+stamp() { echo "[$(date +%H:%M:%S)] $*"; }
+PART=${HMF_PROFILE_PART:-all}          # all | main | flavours (two gpurun calls when one would exceed its time limit)
+if [ "$PART" != "flavours" ]; then
+stamp "kernel trace, timed region"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH > "$OUT/${R}_bench_under_rocprof.json" 2>/tmp/kt.log
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 python tools/rocpd_stats.py "$DB" 48 --steps $STEPS > "$OUT/${R}_kernel_stats.md"
 # the same steps on ONE stream, eagerly: kernel execution times without co-running kernels = what bench.py's measurement pass (roofline.frac) reports
 rocprofv3 --kernel-trace --stats -d /tmp/prof_k1 -o k1 -- $BENCH --streams 1 --no-graph > /dev/null 2>/tmp/k1.log
 python tools/rocpd_stats.py "$(find /tmp/prof_k1 -name '*.db' | head -1)" 48 --steps $STEPS > "$OUT/${R}_kernel_stats_1stream.md"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $BENCH >/dev/null 2>/tmp/f.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $BENCH >/dev/null 2>/tmp/w.log
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_m -o m -- $BENCH --streams 1 --no-graph >/dev/null 2>/tmp/m.log
+stamp "PMC FETCH_SIZE / WRITE_SIZE / MFMA busy"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $PMCBENCH >/dev/null 2>/tmp/f.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $PMCBENCH >/dev/null 2>/tmp/w.log
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_m -o m -- $PMCBENCH --streams 1 --no-graph >/dev/null 2>/tmp/m.log
 python tools/pmc_mfma.py "$(find /tmp/prof_m -name '*.db' | head -1)" > "$OUT/${R}_mfma_busy.txt"
 python tools/pmc_summary.py "$(find /tmp/prof_f -name '*.db' | head -1)" "$(find /tmp/prof_w -name '*.db' | head -1)" > "$OUT/${R}_pmc.json"
 cp "$OUT"/${R}_* profiles/
+stamp "headline bench line (quotes the PMC summary just written)"
+python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.log"
+cp "$OUT"/${R}_* profiles/ && python tools/roofline_table.py $R > "$OUT/${R}_roofline.md"
+fi
 # ---- the other BASELINE configurations: eval step (configs[3] per GPU), bf16 blend operands at B = 64 (configs[2]), training step (configs[4]):
 # two PMC passes each (FETCH_SIZE, WRITE_SIZE), then the bench line that quotes them
 pmc_pair() {   # $1 = tag, $2 = workload label, rest = bench flags
     tag=$1; wl=$2; shift 2
     rm -rf /tmp/pf_$tag /tmp/pw_$tag
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf_$tag -o f -- python bench.py --no-cpu-baseline --profile-steps 0 --steps 12 --warmup 4 "$@" >/dev/null 2>/tmp/pf_$tag.log
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw_$tag -o w -- python bench.py --no-cpu-baseline --profile-steps 0 --steps 12 --warmup 4 "$@" >/dev/null 2>/tmp/pw_$tag.log
+    stamp "PMC pair: $tag"
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf_$tag -o f -- python bench.py --no-cpu-baseline --profile-steps 0 --steps 6 --warmup 2 "$@" >/dev/null 2>/tmp/pf_$tag.log
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw_$tag -o w -- python bench.py --no-cpu-baseline --profile-steps 0 --steps 6 --warmup 2 "$@" >/dev/null 2>/tmp/pw_$tag.log
     HMF_PMC_WORKLOAD="$wl" python tools/pmc_summary.py "$(find /tmp/pf_$tag -name '*.db' | head -1)" "$(find /tmp/pw_$tag -name '*.db' | head -1)" > "$OUT/${R}_${tag}_pmc.json"
     cp "$OUT/${R}_${tag}_pmc.json" profiles/
 }
-if [ "${HMF_PROFILE_FLAVOURS:-1}" = "1" ]; then
+if [ "${HMF_PROFILE_FLAVOURS:-1}" = "1" ] && [ "$PART" != "main" ]; then
     pmc_pair eval "B=32,N=100,fp32,eval" --eval
     python bench.py --eval --no-cpu-baseline > "$OUT/${R}_bench_eval_configs3.json" 2> "$OUT/${R}_bench_eval.log"
     pmc_pair bf16 "B=64,N=100,bf16" --batch 64 --blend-dtype bf16
@@ -46,7 +58,5 @@ if [ "${HMF_PROFILE_FLAVOURS:-1}" = "1" ]; then
     python bench.py --gemm-terms 6 --no-cpu-baseline > "$OUT/${R}_bench_optin_gemm_terms6.json" 2> "$OUT/${R}_bench_terms6.log"
     python bench.py --gemm-terms 3 --no-cpu-baseline > "$OUT/${R}_bench_optin_gemm_terms3.json" 2> "$OUT/${R}_bench_terms3.log"
 fi
-# the headline line LAST: it quotes `traffic` from the PMC summary just written (same library source hash)
-python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.log"
-cp "$OUT"/${R}_* profiles/ && python tools/roofline_table.py $R > "$OUT/${R}_roofline.md"
+stamp done
 ls -la "$OUT"
