@@ -414,22 +414,28 @@ class HumaniflowModel(nn.Module):
                                          _lib.dptr(f32c(cam)), B, _lib.dptr(out), _lib.current_stream()), 'hmf_flow_isgc')
         return out
 
-    def _isgc_autograd(self, input_feats, shape, glob_R, cam):
+    def _isgc_feat_part(self, input_feats):
+        """W[:, :F] . feats + b of the layer below: the 2048-wide product that the sample path and the teacher-forced path of one training pass
+        share (same image features; round 3: computed once per pass, and on the aligned K = 2048 instead of K = 2060 of the concatenated input)."""
+        lin = self.fc_input_shape_glob_cam_feats
+        return torch.nn.functional.linear(input_feats, lin.weight[:, :self.input_feats_dim], lin.bias)
+
+    def _isgc_autograd(self, input_feats, shape, glob_R, cam, feat_part=None):
         """The same layer in torch ops (training: W.[f, shape, vec(R), cam] split so that per-sample shapes (B,N,nb) do not replicate the
         2048-wide feature product).  shape (B,nb) -> (B,256); shape (B,N,nb) -> (B,N,256)."""
         lin = self.fc_input_shape_glob_cam_feats
         Fd, nb = self.input_feats_dim, self.num_shape_params
         W = lin.weight
-        img = torch.nn.functional.linear(torch.cat([input_feats, glob_R.reshape(glob_R.shape[0], 9), cam], dim=1),
-                                         torch.cat([W[:, :Fd], W[:, Fd + nb:]], dim=1), lin.bias)
+        img = (feat_part if feat_part is not None else self._isgc_feat_part(input_feats)) \
+            + torch.nn.functional.linear(torch.cat([glob_R.reshape(glob_R.shape[0], 9), cam], dim=1), W[:, Fd + nb:])
         sh = torch.nn.functional.linear(shape, W[:, Fd:Fd + nb])
         return torch.nn.functional.elu(img[:, None] + sh if shape.dim() == 3 else img + sh)
 
-    def compute_input_shape_glob_cam_feats(self, input_feats, shape, glob_R, cam):
+    def compute_input_shape_glob_cam_feats(self, input_feats, shape, glob_R, cam, feat_part=None):
         """models/humaniflow_model.py:116-150.  (B,F),(B,nb),(B,3,3),(B,3) -> (B,256); the per-sample variant (B,N,nb) of the reference is
         fused into hmf_flow_forward on the inference path and only exists here in its differentiable (training) form."""
         if self._needs_grad(input_feats, shape, glob_R, cam):
-            return self._isgc_autograd(input_feats, shape, glob_R, cam)
+            return self._isgc_autograd(input_feats, shape, glob_R, cam, feat_part)
         if shape.dim() != 2:
             raise NotImplementedError('per-sample features are computed inside hmf_flow_forward')
         return self._isgc_kernel(input_feats, shape, glob_R, cam)
@@ -517,6 +523,7 @@ class HumaniflowModel(nn.Module):
         if grad_for_pose_point_est:
             raise NotImplementedError('humaniflow_amd: grad_for_pose_point_est=True (gradients through the z = 0 point-estimate chain) is not built')
         grad = torch.is_grad_enabled() and (input_feats.requires_grad or any(p.requires_grad for p in self.parameters()))
+        isgc_feat_part = None                   # W[:, :F] . feats of the isgc layer, once per differentiable pass
         flow_anchor = None                      # autograd.new_flow_anchor of this pass (made by the first differentiable flow consumer)
         if grad and not self.default_flow:
             raise NotImplementedError('humaniflow_amd: gradients are built for the default flow configuration (spline_coupling + permute); call the '
@@ -580,7 +587,8 @@ class HumaniflowModel(nn.Module):
                     shape_samples = shape_mode[:, None, :].expand(-1, N, -1)
                 else:
                     shape_samples = (shape_mode + eps_shape * torch.exp(shape_log_std)).transpose(0, 1)        # (B,N,nb), = the kernel's values
-                H = self._isgc_autograd(input_feats, shape_samples, glob_R, cam).reshape(BN, -1)
+                isgc_feat_part = self._isgc_feat_part(input_feats)          # shared with the teacher-forced path below
+                H = self._isgc_autograd(input_feats, shape_samples, glob_R, cam, isgc_feat_part).reshape(BN, -1)
                 rot_s = FlowSampleChain.apply(self, H, rot_s, eps_pose, *flow_anchor)
                 if packed:
                     rot_all = torch.cat([rot_s.reshape(BN, P, 3, 3), rot_p], dim=0)
@@ -596,7 +604,7 @@ class HumaniflowModel(nn.Module):
                                                 else shape_samples)
 
         if compute_for_loglik:
-            isgc = self.compute_input_shape_glob_cam_feats(input_feats, shape_for_loglik, glob_R_for_loglik, cam)    # :279-283
+            isgc = self.compute_input_shape_glob_cam_feats(input_feats, shape_for_loglik, glob_R_for_loglik, cam, isgc_feat_part)    # :279-283
             ctx = self.compute_flow_context_all(isgc, pose_R_for_loglik, anchor=flow_anchor)                          # :315-318
             return_dict['conditioned_pose_so3flow_dists_for_loglik'] = [
                 self.pose_so3flow_dists[j].condition(ctx[:, j], parent=(ctx, j)) for j in range(P)]
