@@ -33,7 +33,7 @@ struct WgwArgs {
     const float* x;      // [B][H][W][Cin]
     float* m;            // partial sums [slices][tiles][32768] (k_wgw) / [16][Cout][Cin] behind them (k_wgw_reduce)
     int B, H, W, Cin, Cout, chunks_per_img, chunks_per_row, nchunks, chunks_per_slice, ci_blocks;
-    int ablate;          // experiments only (tools/wgw_probe.py): 1 = no atomic pass (wrong result)
+    int ablate;          // experiments only (tools/wgw_probe.py): 1 = no accumulation pass, 2 = float atomics instead of partial stores (wrong results)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w;
@@ -231,7 +231,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // sustain = 40-47 us of a 134-143 us launch (tools/wgw_probe.py, atomic pass ablated: 94-100 us). ----
     if (c_begin >= c_end) return;
 #ifdef HMF_EXPERIMENTS
-    if (a.ablate == 1 && acc[0][0][0] != 12345.678f) return;
+    if (a.ablate == 1 && acc[0][0][0] != 12345.678f) return;        // tools/wgw_probe.py: no accumulation pass at all (timing only)
+    if (a.ablate == 2) {                                             // ... the round-3 first version: float atomics into one array (timing only: it is not zeroed)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float* mp = a.m + ((size_t)(wave * 4 + n) * a.Cout + co0) * a.Cin + ci0 + 32 * h + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(mp + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lq) * a.Cin, acc[n][h][r]);
+            }
+        return;
+    }
 #endif
     float* pp = a.m + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * (4 * 2 * 16 * 64) + lane;
 #pragma unroll
@@ -301,7 +312,7 @@ static int g_wgw_ablate = 0;
 static int g_wgw_single_stage = 0;       // 1: the single-staged 32-tile-chunk form (round 3 first version), for tools/wgw_probe.py
 #ifdef HMF_EXPERIMENTS
 extern "C" int hmf_debug_set_wgw_target_wgs(int n) { g_wgw_target_wgs = n > 0 ? n : 512; return HMF_OK; }      // tools/wgw_probe.py
-extern "C" int hmf_debug_set_wgw_single_stage(int on) { g_wgw_single_stage = on & 1; g_wgw_ablate = on >> 1; return HMF_OK; }      // bit 1: no atomic pass
+extern "C" int hmf_debug_set_wgw_single_stage(int on) { g_wgw_single_stage = on & 1; g_wgw_ablate = on >> 1; return HMF_OK; }      // bits 1..: ablate
 #endif
 
 // workspace: the work-groups' partial sums ((target work-groups + tiles) x 32 x 64 x 16 floats at most) + the 16 * Cout * Cin Winograd-domain

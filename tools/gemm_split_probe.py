@@ -32,7 +32,7 @@ SHAPES = [
     ('layer4.0 dual 512+1024->2048 @8', 8, 512, 2048, 1024, 16, 2, False),
 ]
 ABL = '--ablate' in sys.argv
-TILES = {3: [3064128, 9000001, 9000002, 9000003, 9000004, 9000007], 6: []} if ABL else {3: [3064128, 2064128, 2128128, 13064128, 14064128, 13128128, 14064064, 13064064, 13128064], 6: [2064128, 2128128, 13064128, 13128128, 14064064]}
+TILES = {3: [3064128, 9000001, 9000002, 9000003, 9000004, 9000007], 6: []} if ABL else {3: [2128128, 2064128, 3064064, 4064064, 3064128, 4064128, 3128128, 2128064, 3128064], 6: [2128128, 2064128, 3064064, 4064064, 3064128, 3128128, 2128064]}
 
 
 def timeit(fn, reps=20, rounds=5):

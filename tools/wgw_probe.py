@@ -36,16 +36,16 @@ for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256)
     line = '%s %3d ch @%2d, B=%d: %.1f GF direct' % (name, c, hw, B, fl / 1e9)
     t = timeit(lambda: _lib.check(lib.hmf_conv_wgrad(gy.data_ptr(), x.data_ptr(), dwd.data_ptr(), B, hw, hw, c, c, 3, 1, 0, st), 'direct'))
     line += ' | direct %.1f us (%.0f TF)' % (t, fl / t / 1e6)
-    for single in (1, 0, 2):
+    for single in (1, 0, 2, 4):
         lib.hmf_debug_set_wgw_single_stage(single)
-        for target in ((512,) if single == 2 else (256, 512, 768, 1024)):
+        for target in ((512,) if single >= 2 else (256, 512, 768, 1024)):
             lib.hmf_debug_set_wgw_target_wgs(target)
             t = timeit(lambda: _lib.check(lib.hmf_conv_wgrad_winograd(gy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, hw, hw, c, c, st), 'wino'))
-            line += ' | %s, %d WGs: %.1f us (%.0f TF)' % ('single-staged 32-tile chunks' if single == 1 else ('two stages of 16 tiles' if single == 0 else 'two stages, NO atomic pass (timing only)'), target, t, fl / t / 1e6)
+            line += ' | %s, %d WGs: %.1f us (%.0f TF)' % ({1: 'single-staged 32-tile chunks', 0: 'two stages of 16 tiles (product)', 2: 'two stages, NO accumulation pass (timing only)', 4: 'two stages, float ATOMICS instead of partial stores + reduce (timing only)'}[single], target, t, fl / t / 1e6)
     lib.hmf_debug_set_wgw_target_wgs(512)
     lib.hmf_debug_set_wgw_single_stage(0)
     # the zero fill of M and the inverse transform alone: one image's worth of tiles
     x1, g1 = x[:1].contiguous(memory_format=CL), gy[:1].contiguous(memory_format=CL)
     t1 = timeit(lambda: _lib.check(lib.hmf_conv_wgrad_winograd(g1.data_ptr(), x1.data_ptr(), dw.data_ptr(), ws.data_ptr(), 1, hw, hw, c, c, st), 'wino'))
-    line += ' | B=1 (zero fill + atomics + inverse transform floor): %.1f us' % t1
+    line += ' | B=1 (partial stores + reduce + inverse transform floor): %.1f us' % t1
     print(line, flush=True)
