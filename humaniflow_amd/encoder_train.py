@@ -26,6 +26,9 @@ from . import _lib
 
 CL = torch.channels_last
 WINOGRAD_WGRAD = True          # stride-1 3x3 weight gradients on hmf_conv_wgrad_winograd where the shape is built (False: hmf_conv_wgrad everywhere)
+WGRAD_SIDE_STREAM = False      # weight gradients on a second stream beside the BN-backward / input-gradient chain (they only need gy and the saved
+                               # input).  Measured on MI355X, B = 72, HIP-graph replay: 14.34 ms off, 15.12 ms on -- the co-running MFMA kernels
+                               # (k_wgw 72 KB + k_conv_winograd 49-55 KB of LDS) evict each other from the CUs; kept for other shapes / parts
 STRIDED_DGRAD = True           # stride-2 3x3 input gradients as parity-class GEMMs (hmf_conv_dgrad_s2); False: zero-inserted map + stride-1 convolution
 
 
@@ -318,6 +321,44 @@ def _folds_downsample(main0, ds):
             and w.shape[0] % 32 == 0 and w2.shape[0] % 32 == 0 and w.shape[1] % 64 == 0)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _WgradIssuer:
+    """Issues the weight-gradient launches of one backward pass on a side stream: dW of a unit depends on gy and the saved input only, while the
+    critical path of the pass is BN backward -> input gradient -> the next unit's BN backward.  Off by default (WGRAD_SIDE_STREAM: slower on
+    MI355X at the training batch).  Fork / join by stream
+    waits, which a HIP-graph capture of the step records as graph edges; `record_stream` keeps the allocator from recycling a tensor's
+    block before the other stream is done with it."""
+
+    def __init__(self, device):
+        self.on = WGRAD_SIDE_STREAM
+        self.main = torch.cuda.current_stream(device)
+        self.side = _side_stream(device) if self.on else None
+
+    def __call__(self, gy, s):
+        if not self.on:
+            return _wgrad(gy, s)
+        self.side.wait_stream(self.main)                              # gy was produced on the main stream
+        with torch.cuda.stream(self.side):
+            dw = _wgrad(gy, s)
+        gy.record_stream(self.side)
+        dw.record_stream(self.main)
+        return dw
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 class EncoderTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, x, *params):
@@ -392,6 +433,7 @@ class EncoderTrainFn(torch.autograd.Function):
         dev = g_feats.device
         with torch.cuda.device(dev), torch.no_grad():
             pool = _ZeroPool(enc, dev)
+            wgrad = _WgradIssuer(dev)
             B, C, H, W = ctx.final_shape
             g = (g_feats.detach().float() / (H * W))[:, :, None, None].expand(B, C, H, W).contiguous(memory_format=CL)
             for first, last, has_ds in reversed(plan):
@@ -402,7 +444,7 @@ class EncoderTrainFn(torch.autograd.Function):
                 s = main[-1]
                 gy, gz, gg, gb = _bn_backward(g, s, want_gz=True, pool=pool)
                 grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
-                grads[id(s.conv.weight)] = _wgrad(gy, s)
+                grads[id(s.conv.weight)] = wgrad(gy, s)
                 g_idt = gz                                            # gradient of the identity branch (masked by the block's ReLU)
                 only = len(main) == 1
                 g_h = _dgrad(gy, s, residual=g_idt if (only and ds is None) else None)
@@ -411,12 +453,12 @@ class EncoderTrainFn(torch.autograd.Function):
                 if fold:                                              # downsample branch first: its input gradient rides in the main path's launch
                     gy_ds, _, gg, gb = _bn_backward(g_idt, ds, want_gz=False, pool=pool)
                     grads[id(ds.bn.weight)], grads[id(ds.bn.bias)] = gg, gb
-                    grads[id(ds.conv.weight)] = _wgrad(gy_ds, ds)
+                    grads[id(ds.conv.weight)] = wgrad(gy_ds, ds)
                 for k in range(len(main) - 2, -1, -1):
                     s = main[k]
                     gy, _, gg, gb = _bn_backward(g_h, s, want_gz=False, pool=pool)
                     grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
-                    grads[id(s.conv.weight)] = _wgrad(gy, s)
+                    grads[id(s.conv.weight)] = wgrad(gy, s)
                     if k == 0 and fold:
                         g_h = _dgrad(gy, s, extra=(gy_ds, ds))
                     else:
@@ -424,7 +466,7 @@ class EncoderTrainFn(torch.autograd.Function):
                 if ds is not None and not fold:
                     gy, _, gg, gb = _bn_backward(g_idt, ds, want_gz=False, pool=pool)
                     grads[id(ds.bn.weight)], grads[id(ds.bn.bias)] = gg, gb
-                    grads[id(ds.conv.weight)] = _wgrad(gy, ds)
+                    grads[id(ds.conv.weight)] = wgrad(gy, ds)
                     g_h = _dgrad(gy, ds, residual=g_h)
                 g = g_h
             # max-pool and stem
@@ -436,7 +478,8 @@ class EncoderTrainFn(torch.autograd.Function):
             s = saved[0]
             gy, _, gg, gb = _bn_backward(g_a0, s, want_gz=False, pool=pool)
             grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
-            grads[id(s.conv.weight)] = _wgrad(gy, s)
+            grads[id(s.conv.weight)] = wgrad(gy, s)
+            wgrad.join()
         ctx.saved = None
         ctx.params_ref = None
         return (None, None) + tuple(grads.get(i) for i in ctx.param_ids)
