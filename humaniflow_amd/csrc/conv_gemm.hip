@@ -170,19 +170,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         if (c == 0) {
             if (nch >= S - 1) HMF_VMCNT((S - 2) * L);
             else HMF_VMCNT(0);
-        } else if (c + S - 2 <= nch - 1) {
-            HMF_VMCNT((S - 3) * L);
+        } else if (S > 2 && c + S - 2 <= nch - 1) {
+            HMF_VMCNT((S > 2 ? S - 3 : 0) * L);
         } else {
             HMF_VMCNT(0);
         }
         __builtin_amdgcn_s_barrier();
         if (c == 0) HMF_STAMP(1);
         const int stage = c % S;
-        if (c <= 1) frag(stage, 0, 0);
+        if (S == 2 || c <= 1) frag(stage, 0, 0);                // S = 2: the next chunk is still in flight during this one, no early fragments
         auto group = [&](auto G) {
             constexpr int g = decltype(G)::value;
             if (g < 3) frag(stage, g + 1, (g + 1) & 1);
-            else if (c >= 1 && c + 1 < nch) frag((c + 1) % S, 0, 0);       // first fragments of the next chunk under this chunk's last MFMAs
+            else if (S > 2 && c >= 1 && c + 1 < nch) frag((c + 1) % S, 0, 0);       // first fragments of the next chunk under this chunk's last MFMAs
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (KS == 2 && (u & 1)) {
@@ -290,7 +290,7 @@ extern "C" int hmf_debug_gemm_stamps(long long* out_host, int blocks) {
 
 // y = relu?(x . W[:, :K1]^T (+ x2[:, ::s, ::s, :] . W[:, K1:]^T) + bias (+ residual)).  x (B*OH*OW, K1), w (N, K1 + K2) row-major, y (B*OH*OW, N);
 // x2 (B, H2, W2, K2) or NULL (then K2, H2, W2, stride2 are ignored).  tile: 0 = chosen from the shape, else ring stages * 1000000 + BM * 1000 + BN of
-// {64064 (4 stages), 3064064, 3064128}.
+// {64064 (4 stages), 3064064, 3064128, 2064064, 2064128}.
 extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, int B, int OH, int OW,
                                 int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream) {
     if (!x || !w || !y || B <= 0 || OH <= 0 || OW <= 0) return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: bad args");
@@ -315,10 +315,16 @@ extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w,
         //   64 x 64 tile, 4-stage ring (64 KB, 2 per CU): the few-tile deep layers -- layer3 conv1 (512 tiles) 34.2 us vs 39.5, layer4 conv1 (256
         //     tiles: ONE wave per SIMD) 36.8 us vs 45.2.
         // 128 x 128 / 128 x 64 tiles (one work-group per CU) lose on every shape: one round of work-groups all fetching, then all storing.
+        // Round 3, later: TWO stages (32 / 48 KB of LDS: five / three work-groups per CU) beat the three-stage rings on every shape with enough
+        // tiles -- more co-resident work-groups in different phases hide more of each other's first fetch and epilogue than a deeper ring hides
+        // of a work-group's own fetch latency: layer2 conv3 45.6 -> 41.8 us, the 12.9 GFLOP downsample GEMMs 97-103 -> 93.5-98 us, layer1 conv1
+        // 39.2 -> 36.8 us.  The 128-wide tile where its work-group count fills the 768 slots evenly (<= 768 or >= 1536 work-groups; at 1,024 --
+        // layer3 conv3 / downsample -- it took 43.5 / 115 us against 36.4 / 98.0 us for the 64-wide one) and the reduction is not short.
         const long long w128 = ((M + 63) / 64) * (N / 128), w64 = ((M + 63) / 64) * (N / 64);
-        if (N % 128 == 0 && w128 >= 512 && K1 + K2 >= 384) tile = 3064128;
-        else if (w64 >= 768) tile = 3064064;
-        else tile = 64064;
+        const int K = K1 + K2;
+        if (w64 <= 512) tile = 64064;
+        else if (K <= 128 || (N % 128) || (w128 > 768 && w128 < 1536)) tile = 2064064;
+        else tile = 2064128;
     }
     hipStream_t st = (hipStream_t)stream;
     if ((tile % 1000) == 128 && N % 128) return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: a 128-channel tile needs N %% 128 == 0");
@@ -326,6 +332,8 @@ extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w,
         case 64064: launch_gemm<64, 64, 4, 2>(a, st); break;
         case 3064064: launch_gemm<64, 64, 3, 3>(a, st); break;
         case 3064128: launch_gemm<64, 128, 3, 2>(a, st); break;
+        case 2064064: launch_gemm<64, 64, 2, 5>(a, st); break;          // two stages (32 KB): five work-groups per CU
+        case 2064128: launch_gemm<64, 128, 2, 3>(a, st); break;          // 48 KB: three per CU
 #ifdef HMF_EXPERIMENTS           // tools/gemm1x1_probe.py: the tilings measured and not chosen, split accumulator chains
         case 128128: launch_gemm<128, 128, 4, 1>(a, st); break;
         case 64128: launch_gemm<64, 128, 4, 1>(a, st); break;
@@ -335,7 +343,7 @@ extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w,
         case 23064064: launch_gemm<64, 64, 3, 3, 2>(a, st); break;
         case 24064064: launch_gemm<64, 64, 4, 2, 2>(a, st); break;
 #endif
-        default: return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: unknown tile %d (0 = auto, 64064, 3064064, 3064128)", tile);
+        default: return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: unknown tile %d (0 = auto, 64064, 3064064, 3064128, 2064064, 2064128)", tile);
     }
     HMF_LAUNCH_CHECK();
     return HMF_OK;

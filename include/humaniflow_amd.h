@@ -271,7 +271,7 @@ int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const
  * downsample branch :111-127 as a second K range, + identity, + ReLU) as an LDS-DMA pipelined fp32-MFMA GEMM (csrc/conv_gemm.hip):
  * y = relu?(x . W[:, :K1]^T (+ x2[:, ::stride2, ::stride2, :] . W[:, K1:]^T) + bias (+ residual)).  x (B,OH,OW,K1) NHWC, x2 (B,H2,W2,K2) or
  * NULL, w (N, K1+K2) row-major, y / residual (B,OH,OW,N); K1, K2 % 32 == 0, N % 64 == 0, every pointer 16-byte aligned.
- * tile: 0 = from the shape, else [ring stages * 1000000 +] BM*1000+BN in {64064, 3064064, 3064128}.  Same results as hmf_conv2d_nhwc(ks=1) /
+ * tile: 0 = from the shape, else [ring stages * 1000000 +] BM*1000+BN in {64064, 3064064, 3064128, 2064064, 2064128}.  Same results as hmf_conv2d_nhwc(ks=1) /
  * hmf_conv1x1_dual_nhwc up to the fp32 accumulation order.  Profiler tag 8. */
 int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, int B, int OH, int OW,
                      int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream);

@@ -95,7 +95,7 @@ def _gemm_case(B, OH, OW, k1, n, tile, k2=0, stride2=1, res=False, relu=True, bi
     return y
 
 
-@pytest.mark.parametrize('tile', [0, 64064, 3064064, 3064128])
+@pytest.mark.parametrize('tile', [0, 64064, 3064064, 3064128, 2064064, 2064128])
 def test_conv1x1_gemm_matches_float64_reference(tile):
     _gemm_case(2, 16, 16, 256, 128, tile, res=True, relu=True)                                   # M = 512: whole tiles
     _gemm_case(3, 7, 7, 96, 256, tile, res=True, relu=False, seed=1)                             # M = 147: ragged last tile, 3 k-chunks (< pipeline depth)

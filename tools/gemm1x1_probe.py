@@ -10,7 +10,7 @@ import torch
 from humaniflow_amd import _lib
 
 lib = _lib.use_experiments_library()
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
 st = _lib.current_stream()
 CL = torch.channels_last
 # (name, HW, K1, N, K2, H2, stride2, residual)
@@ -32,7 +32,7 @@ SHAPES = [
     ('layer4.x.conv3  512->2048 @8+r', 8, 512, 2048, 0, 0, 1, True),
     ('layer4.0 dual 512+1024->2048 @8', 8, 512, 2048, 1024, 16, 2, False),
 ]
-TILES = [128128, 3128128, 3064128, 3128064, 64064, 3064064, 23064064, 24064064]
+TILES = [3064128, 2064128, 64064, 3064064, 2064064]
 
 
 def timeit(fn, reps=20, rounds=5):
