@@ -248,7 +248,7 @@ def dry_run_cpu(args):
         dist.destroy_process_group()
 
 
-KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc'}
+KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc', 13: 'k_heads_fc1 + k_heads_out'}
 CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_gemm + k_conv_pair (1x1)', 11: 'k_conv_winograd (3x3)'}
 
 
@@ -492,11 +492,19 @@ def main():
         pmc = load_pmc_traffic(source_hash(), 'B=%d,N=%d,%s%s%s' % (args.batch, args.samples, args.blend_dtype, ',eval' if args.eval else '',
                                                                      ',x%d' % args.gemm_terms if args.gemm_terms else ''))
 
-        def traffic_of(key):
+        def traffic_of(key, largest_grid=False):
+            """Mean HBM bytes per launch over the PMC rows of a kernel family.  The rows are keyed by (kernel, grid): `largest_grid` keeps only the
+            largest launch of a kernel name (the eval flavour also runs k_lbs_mfma on the M = B target bodies: averaging that small launch in made
+            `traffic` smaller than the full launch's own algorithmic bytes)."""
             if pmc is None:
                 return None
             keys = key if isinstance(key, tuple) else (key,)
-            cand = [v for k, v in pmc[1].get('kernels', {}).items() if any(kk in k for kk in keys)]
+            cand = [(k, v) for k, v in pmc[1].get('kernels', {}).items() if any(kk in k for kk in keys)]
+            if largest_grid and cand:
+                grid_of = lambda k: int(k.rsplit('[grid=', 1)[1].rstrip(']')) if '[grid=' in k else 0
+                gmax = max(grid_of(k) for k, _ in cand)
+                cand = [(k, v) for k, v in cand if grid_of(k) == gmax]
+            cand = [v for _, v in cand]
             if not cand:
                 return None
             return int(sum(c['hbm_bytes_per_launch'] * c['launches'] for c in cand) / sum(c['launches'] for c in cand))
@@ -538,7 +546,7 @@ def main():
             res['roofline_lbs'] = {'kernel': 'k_lbs_mfma16 (SMPL pose-blend GEMM in bf16 + fp32 skinning, M=%d rows)' % lbs_rows, 'bound': 'hbm',
                                    'achieved': round(ach, 1) if ach else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None}
-        res['roofline_lbs'].update({'avg_launch_us': round(lbs_ms * 1e3, 2) if lbs_ms == lbs_ms else None, 'traffic': traffic_of('k_lbs_mfma'),
+        res['roofline_lbs'].update({'avg_launch_us': round(lbs_ms * 1e3, 2) if lbs_ms == lbs_ms else None, 'traffic': traffic_of('k_lbs_mfma', largest_grid=True),
                                     'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * lbs_rows, 'algorithmic_bytes_per_launch': lbs_bytes})
         if res['roofline'] is None:
             res['roofline'] = res['roofline_lbs']

@@ -41,8 +41,13 @@ class FlowGradRecords(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('D1', 'D2', 'D3', 'D4', 'A1', 'A2', 'A3', 'XIN', 'ACTX', 'DCTX')] + [('rows', C.c_int)]
 
 
+class Rng(C.Structure):
+    """hmf_rng_t: where hmf_flow_forward's in-kernel base noise sits in the device generator's Philox stream."""
+    _fields_ = [('seed', C.c_uint64), ('offset', C.c_uint64), ('state_dev', C.c_void_p), ('grid_cap_blocks', C.c_int)]
+
+
 _VP = C.c_void_p
-HMF_FLOW_POINT_EST, HMF_FLOW_PACKED_ROWS = 1, 2          # flags of hmf_flow_forward (include/humaniflow_amd.h)
+HMF_FLOW_POINT_EST, HMF_FLOW_PACKED_ROWS, HMF_FLOW_SHAPE_MODE = 1, 2, 4          # flags of hmf_flow_forward (include/humaniflow_amd.h)
 _SIGS = {
     'hmf_abi_version': (C.c_int, []),
     'hmf_last_error': (C.c_char_p, []),
@@ -64,8 +69,15 @@ _SIGS = {
     'hmf_flow_update_from_device': (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     'hmf_flow_destroy': (None, [_VP]),
     'hmf_flow_forward_workspace_bytes': (C.c_size_t, [_VP, C.c_int, C.c_int, C.c_int]),
-    'hmf_flow_forward': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
+    'hmf_flow_forward': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(Rng), C.c_int, C.c_int, C.c_int,
                                    _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    'hmf_flow_draw_noise': (C.c_int, [C.POINTER(Rng), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
+    'hmf_flow_rng_increment': (C.c_ulonglong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
+    'hmf_smpl_lbs_packed': (C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, C.c_int, _VP]),
+    'hmf_conv1x1_gemm_avgpool': (C.c_int, [_VP] * 6 + [C.c_int] * 7 + [_VP]),
+    'hmf_avgpool_nhwc': (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    'hmf_heads_workspace_bytes': (C.c_size_t, [C.c_int] * 3),
+    'hmf_heads': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_int] + [_VP] * 8 + [C.c_int] + [_VP] * 6 + [C.c_size_t, _VP]),
     'hmf_flow_isgc': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_context': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_SO3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
@@ -146,7 +158,7 @@ def _bind(path, sigs, hint):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.hmf_abi_version() != 2:
+    if lib.hmf_abi_version() != 3:
         raise RuntimeError('humaniflow_amd: ABI version mismatch')
     return lib
 

@@ -89,15 +89,18 @@ def _anc_index(model, device):
     return cache[key]
 
 
-def _context_pullback(model, delta, isgc_rows, rot_rows):
+def _context_pullback(model, delta, isgc_rows, rot_rows, want_weight_grads=True):
     """delta (P, rows, 64) = d L / d (pre-activation of fc_flow_context[j]); isgc_rows (rows, 256); rot_rows (rows, 23, 9).
     Returns (g_full (P, 64, 256 + 207) = delta^T . [isgc | all rotations], db (P, 64), g_isgc (rows, 256)); the per-part weight gradient is a
-    column selection of g_full (`_context_weight_grads`), done once per backward pass in FlowParamAnchor."""
+    column selection of g_full (`_context_weight_grads`), done once per backward pass in FlowParamAnchor.  want_weight_grads=False (the flow is
+    frozen: the consumer's anchor token needs no gradient) skips the weight-gradient GEMM and returns (None, None, g_isgc)."""
     lib = _lib.load()
     P, R = delta.shape[0], delta.shape[1]
-    x_full = torch.cat([isgc_rows, rot_rows.reshape(rot_rows.shape[0], -1)], dim=1).float().contiguous()   # (rows, 256 + 207)
     delta = delta.float().contiguous()
-    g_full, db = _atb(delta, x_full, P, R, 64, x_full.shape[1], 64, x_full.shape[1], R * 64, 0, True)      # (P, 64, 463): one shared B operand
+    g_full = db = None
+    if want_weight_grads:
+        x_full = torch.cat([isgc_rows, rot_rows.reshape(rot_rows.shape[0], -1)], dim=1).float().contiguous()   # (rows, 256 + 207)
+        g_full, db = _atb(delta, x_full, P, R, 64, x_full.shape[1], 64, x_full.shape[1], R * 64, 0, True)      # (P, 64, 463): one shared B operand
     nin = isgc_rows.shape[1]
     # g_isgc[r] = sum_p delta[p, r] . W_p[:, :nin]: ONE GEMM (rows, P * 64) x (P * 64, nin) on the 1x1-convolution kernel (K = 1472, N = 256)
     d_rows = delta.permute(1, 0, 2).reshape(R, P * 64).contiguous()
@@ -219,7 +222,7 @@ class FlowContext(torch.autograd.Function):
             raise NotImplementedError('humaniflow_amd: gradient w.r.t. the teacher-forced rotations (pose_R_for_loglik) is not built')
         isgc, rot, out = ctx.saved_tensors
         delta = (g * torch.where(out > 0, torch.ones_like(out), out + 1.0)).transpose(0, 1).contiguous()   # ELU', (P, B, 64)
-        g_full, db, g_isgc = _context_pullback(ctx.model, delta, isgc, rot)
+        g_full, db, g_isgc = _context_pullback(ctx.model, delta, isgc, rot, want_weight_grads=ctx.needs_input_grad[3])
         if ctx.needs_input_grad[3]:                                   # the token: some flow parameter wants its gradient
             ctx.stash[(id(ctx), 'ctx')] = ('ctx', g_full, db)
         return None, g_isgc, None, g.new_zeros(()), None
@@ -279,7 +282,7 @@ class FlowSampleChain(torch.autograd.Function):
         with torch.cuda.device(H.device):
             _lib.check(lib.hmf_flow_sample_backward(model._flow_handle(H.device), _lib.dptr(H), _lib.dptr(rot), _lib.dptr(eps), B, N,
                                                     _lib.dptr(g_rot), C.byref(st), _lib.current_stream()), 'hmf_flow_sample_backward')
-        g_full, db, g_H = _context_pullback(model, rec.DCTX, H, rot.reshape(B * N, P, 9))
+        g_full, db, g_H = _context_pullback(model, rec.DCTX, H, rot.reshape(B * N, P, 9), want_weight_grads=ctx.needs_input_grad[4])
         if ctx.needs_input_grad[4]:                                   # the token
             ctx.stash[(id(ctx), 'ctx')] = ('ctx', g_full, db)
             ctx.stash[(id(ctx), 'hyper')] = ('hyper', 0, P, rec.hypernet_grads())

@@ -31,7 +31,8 @@ struct GemmArgs {
     const float* w;      // [N][K1 + K2]
     const float* bias;   // [N] or null
     const float* res;    // [M][N] or null
-    float* y;            // [M][N]
+    float* y;            // [M][N] (POOL: or null)
+    float* pool;         // POOL: [M / 64][N] mean over each run of 64 rows (= the 8 x 8 pixels of one image)
     int M, N, K1, K2, OH, OW, H2, W2, stride2, relu;
 };
 
@@ -63,7 +64,10 @@ static __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_pt
 
 // KS = 2 (wave tiles of ONE MFMA tile only): even / odd MFMA steps accumulate into two register sets that are added at the end, so the wave's
 // MFMAs form two independent chains instead of one dependent chain.
-template <int BM, int BN, int S, bool DUAL, int OCC, int KS>
+// POOL: the global average pool of models/resnet.py:214-215 rides in the epilogue of the encoder's last convolution: a 64-row tile is exactly one
+// image's 8 x 8 map, so the column means of the finished tile ARE that image's pooled features for the tile's channels -- no cross-work-group
+// reduction, a fixed summation order, and the 16.8 MB map is neither written nor re-read when the caller passes y = NULL.
+template <int BM, int BN, int S, bool DUAL, int OCC, int KS, bool POOL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_gemm(const GemmArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;            // 32 x 32 MFMA tiles per wave (2 x 2 waves)
     constexpr int NA = BM / 32, NB = BN / 32;            // DMA instructions per wave per chunk (8 rows of 128 B each)
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     const int rstep = RPI * a.N * 4;
     constexpr int HALF = NS > 8 ? NS / 2 : NS;                  // residual rows in flight at once (register budget)
     const float lo = a.relu ? 0.f : -INFINITY;
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < NS; h += HALF) {
         f32x4 rv[HALF];
@@ -258,9 +263,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             f32x4 v = *(const f32x4*)(tw + (row0 + (h + s) * RPI) * WN + col);
             v = v + bv + rv[s];
             v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), ry,
-                                                   (mb + (h + s) * RPI < a.M) ? vo + (h + s) * rstep : kOOB, 0, 0);
+            if (POOL) psum += v;
+            if (!POOL || a.y)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), ry,
+                                                       (mb + (h + s) * RPI < a.M) ? vo + (h + s) * rstep : kOOB, 0, 0);
         }
+    }
+    if (POOL) {
+        static_assert(!POOL || (BM == 64 && S * STAGE >= BM * BN + 2 * BN), "pool partials live behind the transposed tile");
+        // lanes l, l + LPR, ... hold the same 4 columns of different rows: butterfly over the row lanes, then the two row-halves (wm) through LDS
+#pragma unroll
+        for (int sft = LPR; sft < 64; sft <<= 1) {
+            psum[0] += __shfl_xor(psum[0], sft); psum[1] += __shfl_xor(psum[1], sft);
+            psum[2] += __shfl_xor(psum[2], sft); psum[3] += __shfl_xor(psum[3], sft);
+        }
+        float* sp = smem + BM * BN;
+        if (lane < LPR) *(f32x4*)(sp + wm * BN + wn * WN + col) = psum;
+        __syncthreads();
+        if (tid < BN) a.pool[(size_t)(m0 / 64) * a.N + n0 + tid] = (sp[tid] + sp[BN + tid]) * (1.0f / 64.0f);
     }
 #ifdef HMF_EXPERIMENTS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -272,6 +292,10 @@ template <int BM, int BN, int S, int OCC, int KS = 1>
 static void launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int T = ((a.M + BM - 1) / BM) * (a.N / BN);
     ProfScope ps(8, a.M, st);
+    if (a.pool) {
+        if constexpr (KS == 1 && BM == 64) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS, true>), dim3(T), dim3(256), 0, st, a);
+        return;
+    }
     if (a.x2) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, true, OCC, KS>), dim3(T), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS>), dim3(T), dim3(256), 0, st, a);
 }
@@ -291,9 +315,11 @@ extern "C" int hmf_debug_gemm_stamps(long long* out_host, int blocks) {
 // y = relu?(x . W[:, :K1]^T (+ x2[:, ::s, ::s, :] . W[:, K1:]^T) + bias (+ residual)).  x (B*OH*OW, K1), w (N, K1 + K2) row-major, y (B*OH*OW, N);
 // x2 (B, H2, W2, K2) or NULL (then K2, H2, W2, stride2 are ignored).  tile: 0 = chosen from the shape, else ring stages * 1000000 + BM * 1000 + BN of
 // {64064 (4 stages), 3064064, 3064128, 2064064, 2064128}.
-extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, int B, int OH, int OW,
-                                int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream) {
-    if (!x || !w || !y || B <= 0 || OH <= 0 || OW <= 0) return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: bad args");
+static int conv1x1_gemm_impl(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, float* pool, int B, int OH, int OW,
+                             int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream) {
+    if (!x || !w || (!y && !pool) || B <= 0 || OH <= 0 || OW <= 0) return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: bad args");
+    if (pool && (x2 || OH * OW != 64 || ((uintptr_t)pool & 15)))
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv1x1_gemm_avgpool: the fused pool is built for 64-pixel maps (one image per 64-row tile) without a second K range");
     if (!x2) K2 = 0;
     if (K1 <= 0 || K1 % 32 || K2 % 32 || N % 64) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv1x1_gemm: K1=%d, K2=%d must be multiples of 32 and N=%d of 64", K1, K2, N);
     if (x2 && (stride2 < 1 || (H2 - 1) / stride2 + 1 != OH || (W2 - 1) / stride2 + 1 != OW))
@@ -304,7 +330,7 @@ extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w,
     if (M * N >= (1LL << 29) || M * K1 >= (1LL << 29) || (x2 && (long long)B * H2 * W2 * K2 >= (1LL << 29)) || (long long)N * (K1 + K2) >= (1LL << 29))
         return fail(HMF_ERR_UNSUPPORTED, "hmf_conv1x1_gemm: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
     GemmArgs a;
-    a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.res = residual; a.y = y; a.pool = pool;
     a.M = (int)M; a.N = N; a.K1 = K1; a.K2 = K2; a.OH = OH; a.OW = OW; a.H2 = H2; a.W2 = W2; a.stride2 = stride2; a.relu = relu;
     if (tile == 0) {
         // Measured on MI355X at B = 32 (tools/gemm1x1_probe.py; every ResNet-50 1x1 shape x every tile).  What decides is how many work-groups a
@@ -347,4 +373,18 @@ extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w,
     }
     HMF_LAUNCH_CHECK();
     return HMF_OK;
+}
+
+extern "C" int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, int B, int OH, int OW,
+                                int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream) {
+    if (!y) return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: null y");
+    return conv1x1_gemm_impl(x, x2, w, bias, residual, y, nullptr, B, OH, OW, K1, H2, W2, K2, stride2, N, relu, tile, stream);
+}
+
+// The encoder's last 1x1 convolution with the global average pool of models/resnet.py:214-215 in its epilogue: pooled (B, N) = mean over the 8 x 8
+// pixels of relu?(x . W^T + bias (+ residual)).  y (B*64, N) receives the map itself when non-NULL (tests); the inference plan passes NULL.
+extern "C" int hmf_conv1x1_gemm_avgpool(const float* x, const float* w, const float* bias, const float* residual, float* y, float* pooled, int B, int OH, int OW,
+                                        int K1, int N, int relu, int tile, void* stream) {
+    if (!pooled) return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm_avgpool: null pooled");
+    return conv1x1_gemm_impl(x, nullptr, w, bias, residual, y, pooled, B, OH, OW, K1, 0, 0, 0, 1, N, relu, tile, stream);
 }

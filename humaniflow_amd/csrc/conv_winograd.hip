@@ -400,7 +400,8 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
                               int Cin, int Cout, int relu, int variant, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: bad args");
     if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: Cin=%d must be a multiple of 64 and Cout=%d of 32", Cin, Cout);
-    if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: x and w_packed must be 16-byte aligned");
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15) || ((uintptr_t)residual & 15) || ((uintptr_t)bias & 15))
+        return fail(HMF_ERR_INVALID, "hmf_conv_winograd: x, w_packed, y, residual and bias must be 16-byte aligned (16-byte buffer accesses in the output phase)");
     if ((long long)B * H * W * Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29))
         return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
     WinoArgs a;

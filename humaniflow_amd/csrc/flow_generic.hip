@@ -12,6 +12,7 @@
 #include "flow_common.h"
 #include "flow_handle.h"
 #include "so3_math.h"
+#include "rng_philox.h"
 
 namespace hmf {
 
@@ -130,8 +131,8 @@ __device__ __forceinline__ float gen_transform_inverse(const FlowDev& d, const G
 // sampling / point estimate: one wave per row (rows = B*N samples, then B point-estimate rows), 4 rows per work-group
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flow_generic_sample(FlowDev d, GenDev g, const float* __restrict__ G, const float* __restrict__ shape_mode,
-                                                             const float* __restrict__ shape_log_std, const float* __restrict__ eps_shape,
-                                                             const float* __restrict__ eps_pose, int B, int N, int Mtot, int packed_rows,
+                                                             const float* __restrict__ shape_log_std, NoiseSrc ns,
+                                                             int B, int N, int Mtot, int packed_rows,
                                                              float* __restrict__ shape_samples, float* __restrict__ rot_samples,
                                                              float* __restrict__ rot_point, float* __restrict__ so3_point) {
     __shared__ float sH[4][kIsgc];
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_flow_generic_sample(FlowDev d, GenDev g
     float beta = 0.f;
     if (lane < nb) {
         beta = shape_mode[(size_t)b * nb + lane];
-        if (!is_point && eps_shape) beta += eps_shape[((size_t)n * B + b) * nb + lane] * expf(shape_log_std[(size_t)b * nb + lane]);
+        if (!is_point && has_shape_noise(ns)) beta += shape_noise(ns, (unsigned int)((n * B + b) * nb + lane)) * expf(shape_log_std[(size_t)b * nb + lane]);
         if (live && shape_samples && (!is_point || packed_rows)) shape_samples[(size_t)row * nb + lane] = beta;
     }
     for (int i = 0; i < kIsgc / 64; ++i) {
@@ -171,8 +172,10 @@ __global__ __launch_bounds__(256) void k_flow_generic_sample(FlowDev d, GenDev g
         const float ctx = elu1(pre);
         float x[3] = {0.f, 0.f, 0.f};
         if (!is_point) {
-            const float* e = eps_pose + (((size_t)j * B + b) * N + n) * 3;
-            x[0] = e[0] * d.base_std; x[1] = e[1] * d.base_std; x[2] = e[2] * d.base_std;
+            const unsigned int e = (unsigned int)((b * N + n) * 3);
+            const unsigned long long per_part = (unsigned long long)B * N * 3;
+            x[0] = pose_noise(ns, j, e, per_part) * d.base_std; x[1] = pose_noise(ns, j, e + 1, per_part) * d.base_std;
+            x[2] = pose_noise(ns, j, e + 2, per_part) * d.base_std;
         }
         for (int t = 0; t < g.T; ++t) gen_transform_forward(d, g, gt, t, lane, ctx, x);
         float v[3] = {x[0], x[1], x[2]};
@@ -278,9 +281,9 @@ __global__ __launch_bounds__(256) void k_flow_generic_logprob(FlowDev d, GenDev 
 }
 
 // entry points used by flow_kernels.hip's dispatch
-int generic_forward(const hmf_flow* h, const float* G, const float* shape_mode, const float* shape_log_std, const float* eps_shape, const float* eps_pose,
+int generic_forward(const hmf_flow* h, const float* G, const float* shape_mode, const float* shape_log_std, const NoiseSrc& ns,
                     int B, int N, int Mtot, int packed_rows, float* shape_samples, float* rot_samples, float* rot_point, float* so3_point, hipStream_t st) {
-    hipLaunchKernelGGL(k_flow_generic_sample, dim3((Mtot + 3) / 4), dim3(256), 0, st, h->d, h->g, G, shape_mode, shape_log_std, eps_shape, eps_pose, B, N, Mtot,
+    hipLaunchKernelGGL(k_flow_generic_sample, dim3((Mtot + 3) / 4), dim3(256), 0, st, h->d, h->g, G, shape_mode, shape_log_std, ns, B, N, Mtot,
                        packed_rows, shape_samples, rot_samples, rot_point, so3_point);
     HMF_LAUNCH_CHECK();
     return HMF_OK;

@@ -15,6 +15,7 @@
 #include "flow_common.h"
 #include "flow_handle.h"
 #include "so3_math.h"
+#include "rng_philox.h"
 
 namespace hmf {
 
@@ -24,7 +25,19 @@ namespace hmf {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_isgc(FlowDev d, const float* __restrict__ feats, const float* __restrict__ shape,
                                               const float* __restrict__ glob_R, const float* __restrict__ cam, int B,
-                                              int apply_elu, float* __restrict__ out) {
+                                              int apply_elu, float* __restrict__ out, RngPass rng_imm, unsigned long long* __restrict__ rng_state,
+                                              unsigned long long rng_inc, RngPass* __restrict__ rng_pass) {
+    // First kernel of a sampling pass: fix the pass' position in the generator's stream for the kernels that follow.  Eager calls carry
+    // (seed, offset) as immediates (the host read them from the device generator and advances it); a pass captured into a HIP graph takes
+    // them from a device-resident state that every replay advances atomically (concurrent replays on other streams get disjoint ranges).
+    if (rng_pass && blockIdx.x == 0 && threadIdx.x == 0) {
+        RngPass p = rng_imm;
+        if (rng_state) {
+            p.seed = rng_state[0];
+            p.offset = atomicAdd(rng_state + 1, rng_inc);
+        }
+        *rng_pass = p;
+    }
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nchunk = (B + 7) / 8;
@@ -50,6 +63,27 @@ __global__ __launch_bounds__(256) void k_isgc(FlowDev d, const float* __restrict
             float v = acc + d.arena[d.o_bisgc + o];
             out[(size_t)bb * kIsgc + o] = apply_elu ? elu1(v) : v;
         }
+    }
+}
+
+// The pass' base noise as tensors (training keeps them for the reverse sweep; tests compare them with torch.randn): the same generator calls the
+// sampling kernels make in registers, materialised by one launch.
+__global__ void k_rng_snapshot(RngPass rng_imm, unsigned long long* __restrict__ rng_state, unsigned long long rng_inc, RngPass* __restrict__ rng_pass) {
+    RngPass p = rng_imm;
+    if (rng_state) {
+        p.seed = rng_state[0];
+        p.offset = atomicAdd(rng_state + 1, rng_inc);
+    }
+    *rng_pass = p;
+}
+__global__ __launch_bounds__(256) void k_draw_noise(NoiseSrc ns, unsigned int n_shape, unsigned int n_part, float* __restrict__ eps_shape,
+                                                    float* __restrict__ eps_pose) {
+    const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid < n_shape) {
+        eps_shape[gid] = shape_noise(ns, gid);
+    } else if (gid - n_shape < (unsigned int)kP * n_part) {
+        const unsigned int r = gid - n_shape, j = r / n_part, e = r - j * n_part;
+        eps_pose[r] = pose_noise(ns, (int)j, e, n_part);
     }
 }
 
@@ -136,7 +170,7 @@ constexpr int kPartsPerWave0 = 3;
 constexpr int kGroups0 = (kP + kPartsPerWave0 - 1) / kPartsPerWave0;   // 8
 
 __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __restrict__ G, const float* __restrict__ shape_mode,
-                                                      const float* __restrict__ shape_log_std, const float* __restrict__ eps_shape,
+                                                      const float* __restrict__ shape_log_std, NoiseSrc ns,
                                                       int B, int N, int Mtot, int ntiles, int packed_rows,
                                                       float* __restrict__ shape_samples, float* __restrict__ C0) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, q = lane >> 5;
@@ -152,8 +186,8 @@ __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __
         float v = 0.f;
         if (i < nb && ri.live) {
             v = shape_mode[(size_t)ri.b * nb + i];
-            if (!ri.is_point && eps_shape)
-                v = v + eps_shape[((size_t)ri.n * B + ri.b) * nb + i] * expf(shape_log_std[(size_t)ri.b * nb + i]);
+            if (!ri.is_point && has_shape_noise(ns))
+                v = v + shape_noise(ns, (unsigned int)((ri.n * B + ri.b) * nb + i)) * expf(shape_log_std[(size_t)ri.b * nb + i]);
         }
         beta[i] = v;
     }
@@ -283,7 +317,7 @@ __device__ __forceinline__ float tail_compute(const TailRegs& t, const f32x16 (&
 }
 
 __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, const float* __restrict__ C0,
-                                                                    const float* __restrict__ eps_pose, int B, int N, int Mtot,
+                                                                    NoiseSrc ns, int B, int N, int Mtot,
                                                                     float* __restrict__ rot_samples, float* __restrict__ rot_point,
                                                                     float* __restrict__ so3_point, long long* __restrict__ timeline) {
     __shared__ float sAnc[32 * kAncRow];
@@ -346,8 +380,10 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
             for (int to = 0; to < 4; ++to) w1e[to] = d.arena[pt.o_w1e + to * 64 + lane];
             float x0 = 0.f, x1 = 0.f, x2 = 0.f;            // base sample z = base_std * eps; point-estimate rows push z = 0
             if (ri.live && !ri.is_point) {
-                const float* e = eps_pose + (((size_t)j * B + ri.b) * N + ri.n) * 3;
-                x0 = e[0] * d.base_std; x1 = e[1] * d.base_std; x2 = e[2] * d.base_std;
+                const unsigned int e = (unsigned int)((ri.b * N + ri.n) * 3);
+                const unsigned long long per_part = (unsigned long long)B * N * 3;
+                x0 = pose_noise(ns, j, e, per_part) * d.base_std; x1 = pose_noise(ns, j, e + 1, per_part) * d.base_std;
+                x2 = pose_noise(ns, j, e + 2, per_part) * d.base_std;
             }
             TailRegs tr0, tr1;
             tail_fetch(d, pt, 0, lane, tr0);
@@ -617,7 +653,7 @@ __global__ __launch_bounds__(256) void k_flow_logprob(FlowDev d, const float* __
 
 namespace hmf {
 // flow_generic.hip: the non-default flow variants
-int generic_forward(const hmf_flow* h, const float* G, const float* shape_mode, const float* shape_log_std, const float* eps_shape, const float* eps_pose,
+int generic_forward(const hmf_flow* h, const float* G, const float* shape_mode, const float* shape_log_std, const NoiseSrc& ns,
                     int B, int N, int Mtot, int packed_rows, float* shape_samples, float* rot_samples, float* rot_point, float* so3_point, hipStream_t st);
 int generic_logprob(const hmf_flow* h, const float* ctx, const int* dev_ids, int P, const double* R, const float* v, int B, int mode, float* logp, hipStream_t st);
 }  // namespace hmf
@@ -639,23 +675,37 @@ size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int f
     (void)h;
     const size_t g = align_up((size_t)std::max(B, 1) * kIsgc * 4, 256);
     const size_t c0 = (size_t)std::max(n_tiles(B, N, flags), 1) * kP * 2 * 64 * 16 * 4;
-    return g + c0;
+    return g + c0 + 256;                 // + the pass' RngPass snapshot
+}
+
+unsigned long long hmf_flow_rng_increment(int B, int N, int num_betas, int draw_shape, unsigned int cap_blocks) {
+    if (B <= 0 || N <= 0) return 0;
+    return (draw_shape ? rng_call_increment((unsigned long long)N * B * num_betas, cap_blocks) : 0ull) +
+           (unsigned long long)kP * rng_call_increment((unsigned long long)B * N * 3, cap_blocks);
 }
 
 int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* cam, const float* shape_mode,
-                     const float* shape_log_std, const float* eps_shape, const float* eps_pose, int B, int N,
+                     const float* shape_log_std, const float* eps_shape, const float* eps_pose, const hmf_rng_t* rng, int B, int N,
                      int flags, float* shape_samples, float* rotmats_samples, float* rotmats_point, float* so3_point,
                      void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !feats || !glob_R || !cam || !shape_mode) return fail(HMF_ERR_INVALID, "hmf_flow_forward: null input");
     if (B <= 0 || N < 0) return fail(HMF_ERR_INVALID, "hmf_flow_forward: B=%d N=%d", B, N);
-    if (N > 0 && (!eps_pose || !rotmats_samples)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: N>0 needs eps_pose and rotmats_samples");
-    if (N > 0 && eps_shape && !shape_log_std) return fail(HMF_ERR_INVALID, "hmf_flow_forward: eps_shape needs shape_log_std");
+    if (N > 0 && !rotmats_samples) return fail(HMF_ERR_INVALID, "hmf_flow_forward: N>0 needs rotmats_samples");
+    if (N > 0 && !eps_pose && !rng) return fail(HMF_ERR_INVALID, "hmf_flow_forward: N>0 needs eps_pose or rng (the base noise: injected or drawn in the kernels)");
+    const int shape_mode_samples = (flags & HMF_FLOW_SHAPE_MODE) ? 1 : 0;
+    if (shape_mode_samples) eps_shape = nullptr;
+    // shape noise: injected (eps_shape), drawn (rng given, no eps_shape, not HMF_FLOW_SHAPE_MODE), or none (use_shape_mode_for_samples)
+    const int draw_shape = (N > 0 && rng && !eps_shape && !shape_mode_samples) ? 1 : 0;
+    const int draw_pose = (N > 0 && !eps_pose) ? 1 : 0;
+    if (N > 0 && (eps_shape || draw_shape) && !shape_log_std) return fail(HMF_ERR_INVALID, "hmf_flow_forward: shape noise needs shape_log_std");
     const int compute_point_est = flags & HMF_FLOW_POINT_EST;
     const int packed_rows = (flags & HMF_FLOW_PACKED_ROWS) ? 1 : 0;
     if (compute_point_est && (!rotmats_point || !so3_point)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: point-estimate outputs missing");
     if (packed_rows && (!compute_point_est || !shape_samples)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: HMF_FLOW_PACKED_ROWS needs the point estimate and shape_samples");
     if (N == 0 && !compute_point_est) return HMF_OK;
     if ((long long)B * N + B > (1LL << 30)) return fail(HMF_ERR_INVALID, "hmf_flow_forward: B*N too large");
+    if ((draw_shape || draw_pose) && ((long long)B * N * std::max(h->d.nb, 3) >= (1LL << 32) || rng->grid_cap_blocks < 1))
+        return fail(HMF_ERR_INVALID, "hmf_flow_forward: in-kernel noise needs B*N*max(nb,3) < 2^32 and rng->grid_cap_blocks >= 1");
     const size_t need = hmf_flow_forward_workspace_bytes(h, B, N, flags);
     if (!workspace || workspace_bytes < need) return fail(HMF_ERR_WORKSPACE, "hmf_flow_forward: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = (hipStream_t)stream;
@@ -663,27 +713,73 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
     float* C0 = (float*)((char*)workspace + align_up((size_t)B * kIsgc * 4, 256));
     const int Mtot = B * N + (compute_point_est ? B : 0);
     const int ntiles = (Mtot + 31) / 32;
+    RngPass* pass = (RngPass*)((char*)workspace + need - 256);
+    NoiseSrc ns{};
+    ns.eps_shape = eps_shape; ns.eps_pose = eps_pose;
+    RngPass imm{};
+    unsigned long long inc = 0;
+    const bool draws = draw_shape || draw_pose;
+    if (draws) {
+        const unsigned int cap = (unsigned int)rng->grid_cap_blocks;
+        ns.pass = pass;
+        ns.draw_shape = draw_shape;
+        ns.T_shape = rng_threads((unsigned long long)N * B * h->d.nb, cap);
+        ns.T_pose = rng_threads((unsigned long long)B * N * 3, cap);
+        ns.inc_shape = rng_call_increment((unsigned long long)N * B * h->d.nb, cap);
+        ns.inc_pose = rng_call_increment((unsigned long long)B * N * 3, cap);
+        imm.seed = rng->seed; imm.offset = rng->offset; imm.cap_blocks = cap;
+        if (rng->offset & 3) return fail(HMF_ERR_INVALID, "hmf_flow_forward: rng->offset must be a multiple of 4 (as the device generator keeps it)");
+        inc = (draw_shape ? ns.inc_shape : 0ull) + (draw_pose ? (unsigned long long)kP * ns.inc_pose : 0ull);
+    }
     {
         const int nw = kIsgc * ((B + 7) / 8);
         ProfScope ps(7, B, st);
-        hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, feats, (const float*)nullptr, glob_R, cam, B, 0, G);
+        hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, feats, (const float*)nullptr, glob_R, cam, B, 0, G, imm,
+                           draws ? (unsigned long long*)rng->state_dev : (unsigned long long*)nullptr, inc, draws ? pass : (RngPass*)nullptr);
         HMF_LAUNCH_CHECK();
     }
     if (h->g.enabled)
-        return generic_forward(h, G, shape_mode, shape_log_std, eps_shape, eps_pose, B, N, Mtot, packed_rows, shape_samples, rotmats_samples, rotmats_point,
+        return generic_forward(h, G, shape_mode, shape_log_std, ns, B, N, Mtot, packed_rows, shape_samples, rotmats_samples, rotmats_point,
                                so3_point, st);
     {
         const int nw = ntiles * kGroups0;
         ProfScope ps(5, Mtot, st);
-        hipLaunchKernelGGL(k_flow_ctx0, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, eps_shape, B, N, Mtot,
+        hipLaunchKernelGGL(k_flow_ctx0, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, ns, B, N, Mtot,
                            ntiles, packed_rows, shape_samples, C0);
         HMF_LAUNCH_CHECK();
     }
     {
         ProfScope ps(6, Mtot, st);
-        hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, eps_pose, B, N, Mtot, rotmats_samples,
+        hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, ns, B, N, Mtot, rotmats_samples,
                            rotmats_point, so3_point, g_timeline);
     }
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_draw_noise(const hmf_rng_t* rng, int B, int N, int num_betas, float* eps_shape, float* eps_pose, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    if (!rng || !eps_pose || B <= 0 || N <= 0 || num_betas < 1 || num_betas > 16) return fail(HMF_ERR_INVALID, "hmf_flow_draw_noise: bad args");
+    if (!workspace || workspace_bytes < 256) return fail(HMF_ERR_WORKSPACE, "hmf_flow_draw_noise: workspace of >= 256 bytes");
+    if ((long long)B * N * 3 * kP >= (1LL << 32) || (long long)B * N * num_betas >= (1LL << 31) || rng->grid_cap_blocks < 1 || (rng->offset & 3))
+        return fail(HMF_ERR_INVALID, "hmf_flow_draw_noise: B*N too large, grid_cap_blocks < 1 or offset not a multiple of 4");
+    const unsigned int cap = (unsigned int)rng->grid_cap_blocks;
+    NoiseSrc ns{};
+    ns.pass = (RngPass*)workspace;
+    ns.draw_shape = eps_shape ? 1 : 0;
+    ns.T_shape = rng_threads((unsigned long long)N * B * num_betas, cap);
+    ns.T_pose = rng_threads((unsigned long long)B * N * 3, cap);
+    ns.inc_shape = rng_call_increment((unsigned long long)N * B * num_betas, cap);
+    ns.inc_pose = rng_call_increment((unsigned long long)B * N * 3, cap);
+    RngPass imm{};
+    imm.seed = rng->seed; imm.offset = rng->offset; imm.cap_blocks = cap;
+    const unsigned long long inc = (ns.draw_shape ? ns.inc_shape : 0ull) + (unsigned long long)kP * ns.inc_pose;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rng_snapshot, dim3(1), dim3(1), 0, st, imm, (unsigned long long*)rng->state_dev, inc, (RngPass*)workspace);
+    HMF_LAUNCH_CHECK();
+    const unsigned int n_shape = ns.draw_shape ? (unsigned int)(N * B * num_betas) : 0u, n_part = (unsigned int)(B * N * 3);
+    const unsigned long long total = (unsigned long long)n_shape + (unsigned long long)kP * n_part;
+    hipLaunchKernelGGL(k_draw_noise, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, st, ns, n_shape, n_part, eps_shape, eps_pose);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }
@@ -692,7 +788,8 @@ int hmf_flow_isgc(const hmf_flow_t* h, const float* feats, const float* shape, c
                   float* isgc, void* stream) {
     if (!h || !feats || !shape || !glob_R || !cam || !isgc || B <= 0) return fail(HMF_ERR_INVALID, "hmf_flow_isgc: bad args");
     const int nw = kIsgc * ((B + 7) / 8);
-    hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, feats, shape, glob_R, cam, B, 1, isgc);
+    hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, feats, shape, glob_R, cam, B, 1, isgc, RngPass{},
+                       (unsigned long long*)nullptr, 0ull, (RngPass*)nullptr);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -1,0 +1,173 @@
+// The heads between the encoder and the flow (models/humaniflow_model.py:232-252, models/resnet.py:214-215):
+//
+//   hmf_avgpool_nhwc   F.adaptive_avg_pool2d(x, 1) + flatten for maps whose pooling is not already done in the last convolution's epilogue
+//                      (hmf_conv1x1_gemm with a pool output covers the 8 x 8 maps of the 256 x 256 input)
+//   hmf_heads          x1 = ELU(fc1 f);  cam = fc_cam x1 + init_cam;  glob_R = rot6d_to_rotmat(fc_glob x1 + init_glob);
+//                      (shape_mode | shape_log_std) = fc_shape x1;  shape_std = exp(shape_log_std)
+//
+// fc1 is the only layer with work in it: a (B x F) . (F x N1) product, F x N1 = 2048 x 1024 for ResNet-50: 8 MB of weights streamed once,
+// 134 MFLOP at B = 32 -- bound by how fast ~128 work-groups can pull 64 KB each out of HBM, not by arithmetic.  k_heads_fc1 runs it on the fp32
+// MFMA with the WEIGHT rows as the A operand straight from their natural (N1, F) layout (no packed copy: the parameters change under training
+// and the kernel reads the live tensors) and the feature rows as the B operand; the reduction axis is split over (4 waves x KS work-groups)
+// and combined in a fixed order, so results do not depend on scheduling.  k_heads_out finishes one image per work-group.
+#include <algorithm>
+#include "hmf_common.h"
+#include "flow_common.h"
+#include "so3_math.h"
+
+namespace hmf {
+
+// partial[ks][b][n] = sum over the ks-th K range of feats[b][k] * w1[n][k];   grid (N1 / 32, KS, ceil(B / 32)), 256 threads
+__global__ __launch_bounds__(256) void k_heads_fc1(const float* __restrict__ feats, const float* __restrict__ w1, int B, int F, int N1, int Kw,
+                                                   float* __restrict__ partial) {
+    __shared__ float sred[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, q = lane >> 5;
+    const int n0 = blockIdx.x * 32, ks = blockIdx.y, b0 = blockIdx.z * 32;
+    const int k0 = (ks * 4 + wave) * Kw;
+    const float* wr = w1 + (size_t)(n0 + i) * F + k0 + 4 * q;
+    const bool brow = b0 + i < B;
+    const float* fr = feats + (size_t)(brow ? b0 + i : 0) * F + k0 + 4 * q;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ng = Kw / 8;
+    f32x4 a = *(const f32x4*)wr, x = brow ? *(const f32x4*)fr : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < ng; ++g) {
+        f32x4 an = a, xn = x;
+        if (g + 1 < ng) {
+            an = *(const f32x4*)(wr + (g + 1) * 8);
+            if (brow) xn = *(const f32x4*)(fr + (g + 1) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], x[u], acc, 0, 0, 0);
+        a = an; x = xn;
+    }
+    // acc[r] of lane (b = i, q) is output channel n = 8 (r >> 2) + 4 q + (r & 3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sred[wave][8 * (r >> 2) + 4 * q + (r & 3)][i] = acc[r];
+    __syncthreads();
+    const int n = tid & 31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int b = (tid >> 5) + 8 * s;
+        if (b0 + b < B) {
+            const float v = ((sred[0][n][b] + sred[1][n][b]) + sred[2][n][b]) + sred[3][n][b];
+            partial[((size_t)ks * B + b0 + b) * N1 + n0 + n] = v;
+        }
+    }
+}
+
+struct HeadsOut {
+    const float *w_cam, *b_cam, *init_cam, *w_glob, *b_glob, *init_glob, *w_shape, *b_shape;
+    float *cam, *glob_R, *shape_mode, *shape_log_std, *shape_std;
+};
+
+// one work-group per image: x1 = ELU(sum of the K-split partials + b1) in LDS, then the 3 + 6 + 2 nb small outputs, one wave per output
+__global__ __launch_bounds__(256) void k_heads_out(const float* __restrict__ partial, const float* __restrict__ b1, int B, int N1, int KS, int nb, HeadsOut o) {
+    __shared__ __attribute__((aligned(16))) float sx[1024];
+    __shared__ float so[48];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    for (int n = tid; n < N1; n += 256) {
+        float v = partial[(size_t)b * N1 + n];
+        for (int ks = 1; ks < KS; ++ks) v += partial[((size_t)ks * B + b) * N1 + n];
+        sx[n] = elu1(v + b1[n]);
+    }
+    __syncthreads();
+    const int NO = 9 + 2 * nb;
+    for (int oi = wave; oi < NO; oi += 4) {
+        const float* wrow = oi < 3 ? o.w_cam + (size_t)oi * N1 : (oi < 9 ? o.w_glob + (size_t)(oi - 3) * N1 : o.w_shape + (size_t)(oi - 9) * N1);
+        float acc = 0.f;
+        for (int k4 = lane; k4 < N1 / 4; k4 += 64) {
+            const f32x4 w = *(const f32x4*)(wrow + 4 * k4), x = *(const f32x4*)(sx + 4 * k4);
+            acc = fmaf(w[0], x[0], acc); acc = fmaf(w[1], x[1], acc); acc = fmaf(w[2], x[2], acc); acc = fmaf(w[3], x[3], acc);
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+        if (lane == 0) so[oi] = acc;
+    }
+    __syncthreads();
+    if (tid < 3) o.cam[(size_t)b * 3 + tid] = (so[tid] + o.b_cam[tid]) + o.init_cam[tid];                    // :237-238
+    if (tid == 64) {                                                                                         // :243-245
+        float g6[6], R[9];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) g6[e] = (so[3 + e] + o.b_glob[e]) + o.init_glob[e];
+        rot6d_to_rotmat_f32(g6, R);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) o.glob_R[(size_t)b * 9 + e] = R[e];
+    }
+    if (tid >= 128 && tid < 128 + 2 * nb) {                                                                  // :250-253
+        const int e = tid - 128;
+        const float v = so[9 + e] + o.b_shape[e];
+        if (e < nb) {
+            o.shape_mode[(size_t)b * nb + e] = v;
+        } else {
+            o.shape_log_std[(size_t)b * nb + (e - nb)] = v;
+            o.shape_std[(size_t)b * nb + (e - nb)] = expf(v);
+        }
+    }
+}
+
+// (B, HW, C) NHWC -> (B, C) mean over the HW pixels; one thread per (image, 4 channels), fixed summation order
+__global__ __launch_bounds__(256) void k_avgpool_nhwc(const float* __restrict__ x, int B, int HW, int C, float* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C / 4;
+    if (gid >= B * c4n) return;
+    const int b = gid / c4n, c4 = gid - b * c4n;
+    const f32x4* p = (const f32x4*)(x + (size_t)b * HW * C) + c4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < HW; ++i) s += p[(size_t)i * c4n];
+    ((f32x4*)(out + (size_t)b * C))[c4] = s / (float)HW;
+}
+
+static int heads_ksplit(int F) {
+    for (int ks = 4; ks >= 1; ks >>= 1)
+        if (F % (ks * 4 * 8) == 0) return ks;
+    return 0;
+}
+
+}  // namespace hmf
+
+using namespace hmf;
+
+extern "C" {
+
+size_t hmf_heads_workspace_bytes(int B, int F, int N1) {
+    const int ks = heads_ksplit(F);
+    return (size_t)std::max(ks, 1) * std::max(B, 1) * N1 * sizeof(float);
+}
+
+int hmf_heads(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
+              const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
+              float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!feats || !w1 || !b1 || !w_cam || !b_cam || !init_cam || !w_glob || !b_glob || !init_glob || !w_shape || !b_shape || !cam || !glob_R || !shape_mode ||
+        !shape_log_std || !shape_std)
+        return fail(HMF_ERR_INVALID, "hmf_heads: null argument");
+    if (B <= 0 || nb < 1 || nb > 16) return fail(HMF_ERR_INVALID, "hmf_heads: B=%d nb=%d", B, nb);
+    const int KS = heads_ksplit(F);
+    if (KS == 0 || N1 % 32 || N1 > 1024 || N1 % 4)
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_heads: F=%d must be a multiple of 32 and N1=%d a multiple of 32, <= 1024", F, N1);
+    if (((uintptr_t)feats & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w_cam & 15) || ((uintptr_t)w_glob & 15) || ((uintptr_t)w_shape & 15))
+        return fail(HMF_ERR_INVALID, "hmf_heads: feats and the weight matrices must be 16-byte aligned");
+    const size_t need = hmf_heads_workspace_bytes(B, F, N1);
+    if (!workspace || workspace_bytes < need) return fail(HMF_ERR_WORKSPACE, "hmf_heads: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    ProfScope ps(13, B, st);
+    hipLaunchKernelGGL(k_heads_fc1, dim3(N1 / 32, KS, (B + 31) / 32), dim3(256), 0, st, feats, w1, B, F, N1, F / (KS * 4), partial);
+    HMF_LAUNCH_CHECK();
+    HeadsOut o{w_cam, b_cam, init_cam, w_glob, b_glob, init_glob, w_shape, b_shape, cam, glob_R, shape_mode, shape_log_std, shape_std};
+    hipLaunchKernelGGL(k_heads_out, dim3(B), dim3(256), 0, st, partial, b1, B, N1, KS, nb, o);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_avgpool_nhwc(const float* x, int B, int HW, int C, float* out, void* stream) {
+    if (!x || !out || B <= 0 || HW <= 0 || C <= 0 || C % 4) return fail(HMF_ERR_INVALID, "hmf_avgpool_nhwc: bad args (C %% 4 == 0)");
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return fail(HMF_ERR_INVALID, "hmf_avgpool_nhwc: pointers must be 16-byte aligned");
+    const int n = B * (C / 4);
+    hipLaunchKernelGGL(k_avgpool_nhwc, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, B, HW, C, out);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+}  // extern "C"

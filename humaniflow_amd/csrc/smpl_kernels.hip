@@ -110,7 +110,7 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
                                                      const float* __restrict__ body, const float* __restrict__ betas,
                                                      int Mb, int M, float* __restrict__ atr, float* __restrict__ joints,
                                                      float* __restrict__ panel, unsigned short* __restrict__ panel16,
-                                                     unsigned short* __restrict__ panel16_lo) {
+                                                     unsigned short* __restrict__ panel16_lo, int gN, float* __restrict__ full_pose) {
     __shared__ float sJ[8][kJ][3];
     __shared__ float sG[8][kJ][12];
     const int j = threadIdx.x % kJ, r = threadIdx.x / kJ;
@@ -129,7 +129,9 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
         }
         if (j == 0) {
             if (glob) {
-                const float* g = glob + (size_t)(Mg == 1 ? 0 : row) * 9;
+                // gN > 0: the packed rows of one HumaniflowModel.forward -- samples b * gN + n, then the point-estimate rows -- share image b's rotation
+                const int grow = Mg == 1 ? 0 : (gN > 0 ? (row < Mg * gN ? row / gN : row - Mg * gN) : row);
+                const float* g = glob + (size_t)grow * 9;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) R[e] = g[e];
             }
@@ -211,6 +213,11 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
         __syncthreads();
     }
     if (!live) return;
+    if (full_pose) {                                // smplx SMPL.forward: full_pose = cat([global_orient, body_pose], dim=1)
+        float* o = full_pose + ((size_t)row * kJ + j) * 9;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) o[e] = R[e];
+    }
     if (joints) {
         float* o = joints + ((size_t)row * kOutJ + j) * 3;
         o[0] = G[3]; o[1] = G[7]; o[2] = G[11];
@@ -1068,12 +1075,12 @@ static size_t ws_panel_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPer
 static size_t ws_panel16_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kRowsPerWG * kP16Stride * 2; }
 size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + 2 * ws_panel16_bytes(M); }
 
-int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose, const float* betas,
-                 int Mb, int M, float* verts, float* joints, void* workspace, size_t workspace_bytes, int impl,
-                 void* stream) {
+static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg, int gN, const float* body_pose, const float* betas,
+                         int Mb, int M, float* verts, float* joints, float* full_pose, void* workspace, size_t workspace_bytes, int impl,
+                         void* stream) {
     if (M == 0) return HMF_OK;                                       // empty batch: nothing to do, pointers may be null
     if (!h || !global_orient || !body_pose || !betas || !verts) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: null argument");
-    if (M < 0 || (Mb != 1 && Mb != M) || (Mg != 1 && Mg != M))
+    if (M < 0 || (Mb != 1 && Mb != M) || (gN == 0 && Mg != 1 && Mg != M))
         return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: M=%d Mb=%d Mg=%d (Mb, Mg must be 1 or M)", M, Mb, Mg);
     if (!workspace || workspace_bytes < hmf_smpl_lbs_workspace_bytes(M))
         return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
@@ -1092,7 +1099,7 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         ProfScope ps(2, M, st);      // grid padded to whole row groups: dead rows zero their slice of the panel
         hipLaunchKernelGGL(k_rigid_chain, dim3(nrg_all * (kRowsPerWG / 8)), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas,
                            Mb, M, atr, joints, bf16 ? (float*)nullptr : panel, bf16 ? panel16 : (unsigned short*)nullptr,
-                           split ? panel16_lo : (unsigned short*)nullptr);
+                           split ? panel16_lo : (unsigned short*)nullptr, gN, full_pose);
     }
     HMF_LAUNCH_CHECK();
     if ((impl & 15) == 1) {
@@ -1148,6 +1155,20 @@ int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const 
         HMF_LAUNCH_CHECK();
     }
     return HMF_OK;
+}
+
+int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose, const float* betas,
+                 int Mb, int M, float* verts, float* joints, void* workspace, size_t workspace_bytes, int impl,
+                 void* stream) {
+    return smpl_lbs_impl(h, global_orient, Mg, 0, body_pose, betas, Mb, M, verts, joints, nullptr, workspace, workspace_bytes, impl, stream);
+}
+
+int hmf_smpl_lbs_packed(const hmf_smpl_t* h, const float* glob_R, int B, int N, const float* body_pose, const float* betas, float* verts,
+                        float* joints, float* full_pose, void* workspace, size_t workspace_bytes, int impl, void* stream) {
+    if (B <= 0 || N <= 0) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs_packed: B=%d N=%d", B, N);
+    if ((long long)B * N + B > (1LL << 30)) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs_packed: B*N too large");
+    const int M = B * N + B;
+    return smpl_lbs_impl(h, glob_R, B, N, body_pose, betas, M, M, verts, joints, full_pose, workspace, workspace_bytes, impl, stream);
 }
 
 int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts, float* joints, void* stream) {

@@ -139,7 +139,7 @@ class ResNetEncoder(nn.Module):
         st['_plan_key'] = None
         st['_plan_tensors'] = None
         st.pop('_stem_map', None)
-        for k in [k for k in st if (k if isinstance(k, str) else k[0]).startswith('_wino')]:     # training-graph filter packs (encoder_train.py)
+        for k in [k for k in st if k.startswith('_wino')]:     # training-graph filter packs (encoder_train.py)
             st.pop(k)
         return st
 
@@ -298,14 +298,27 @@ class ResNetEncoder(nn.Module):
         _lib.check(lib.hmf_conv_winograd_pack_host(wh.data_ptr(), packed.data_ptr(), cin, cout), 'hmf_conv_winograd_pack_host')
         return packed.to(w.device)
 
-    def _conv_hip(self, x, w, bias, stride, residual, relu):
-        """y = relu?(conv(x, w) + bias + residual) in one launch; x / residual / y are channels_last (B,C,H,W) tensors."""
+    def _conv_hip(self, x, w, bias, stride, residual, relu, pool=False):
+        """y = relu?(conv(x, w) + bias + residual) in one launch; x / residual / y are channels_last (B,C,H,W) tensors.
+        pool=True (the encoder's last convolution): returns the (B, Cout) global average pool of y (models/resnet.py:214-215) -- from the GEMM's
+        own epilogue where built (1x1 layer on an 8x8 map: hmf_conv1x1_gemm_avgpool, the map never reaches HBM), else conv + hmf_avgpool_nhwc."""
         from . import _lib
         lib = _lib.load()
         B, Cin, H, W = x.shape
         Cout, _, ks, _ = w.shape
         pad = ks // 2
         OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        if pool:
+            feats = torch.empty((B, Cout), device=x.device, dtype=torch.float32)
+            split = self._plan is not None and self._plan['split'].get(id(w)) is not None
+            if ks == 1 and stride == 1 and self.gemm_1x1 and not split and OH * OW == 64 and Cin % 32 == 0 and Cout % 64 == 0:
+                _lib.check(lib.hmf_conv1x1_gemm_avgpool(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                        None if residual is None else residual.data_ptr(), None, feats.data_ptr(), B, OH, OW, Cin, Cout,
+                                                        int(relu), 0, _lib.current_stream()), 'hmf_conv1x1_gemm_avgpool')
+                return feats
+            y = self._conv_hip(x, w, bias, stride, residual, relu)
+            _lib.check(lib.hmf_avgpool_nhwc(y.data_ptr(), B, OH * OW, Cout, feats.data_ptr(), _lib.current_stream()), 'hmf_avgpool_nhwc')
+            return feats
         y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         wk = self._plan['wino'].get(id(w)) if self._plan is not None else None
         if wk is not None and stride == 1 and (W >= 16 or W == 8):
@@ -366,6 +379,7 @@ class ResNetEncoder(nn.Module):
         with torch.cuda.device(x.device):
             x = self._stem_hip(x.float().contiguous(), p['stem_packed'], p['stem'][1])
             pre = None                                   # the block's first 1x1 stage, when the previous seam launch already produced it
+            nblk = len(p['blocks'])
             for i, (stages, ds, dual) in enumerate(p['blocks']):
                 h = x if pre is None else pre
                 for w, b, s, pad in stages[(0 if pre is None else 1):-1]:
@@ -380,8 +394,13 @@ class ResNetEncoder(nn.Module):
                 else:
                     idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
                     w, b, s, pad = stages[-1]
-                    x = self._conv_hip(h, w, b, s[0], idt, True)
-            return x.mean(dim=(2, 3))
+                    x = self._conv_hip(h, w, b, s[0], idt, True, pool=(i == nblk - 1))       # the last convolution also pools (:214-215)
+            if x.dim() == 4:                                 # a plan whose last block ended in a fused launch: pool the map
+                B, C, H, W = x.shape
+                feats = torch.empty((B, C), device=x.device, dtype=torch.float32)
+                _lib.check(_lib.load().hmf_avgpool_nhwc(x.data_ptr(), B, H * W, C, feats.data_ptr(), _lib.current_stream()), 'hmf_avgpool_nhwc')
+                x = feats
+            return x
 
     def _stem_packed_from_device(self, w):
         """The stem kernel's packed filter operand from the live (64, 18, 7, 7) parameter without leaving the device: the host packer is a
@@ -398,6 +417,8 @@ class ResNetEncoder(nn.Module):
             m = self.__dict__['_stem_map'] = ((pm.clamp(min=1) - 1).to(w.device), (pm > 0).float().to(w.device))
         return w.reshape(-1).float()[m[0]] * m[1]
 
+    allow_module_fallback = False   # opt-in: the modes without a hand-written path (below) run forward_module() -- the plain nn.Module graph on ATen
+
     def forward(self, x):
         from . import _lib
         _lib.require_cuda(x, 'input')
@@ -411,10 +432,14 @@ class ResNetEncoder(nn.Module):
         # remaining combinations (train() without gradients, eval() with gradients = frozen statistics under autograd, gradients w.r.t. the
         # input) have no hand-written path and there is no vendor-library path in the product: fail loudly.  (`forward_module` is the plain
         # nn.Module graph; tests call it explicitly as the float64 reference.)
+        if self.allow_module_fallback:
+            return self.forward_module(x)
         raise NotImplementedError(
             'humaniflow_amd: ResNetEncoder.forward is built for inference (eval() under torch.no_grad()) and for the training step (train() with '
             'gradients w.r.t. the parameters, 18-channel input that does not require grad); got training=%s, grad=%s, input.requires_grad=%s, '
-            'in_channels=%d' % (self.training, wants_grad, x.requires_grad, self.conv1.in_channels))
+            'in_channels=%d.  Wrap inference in torch.no_grad(); for eval() under autograd (frozen BatchNorm fine-tuning, gradients w.r.t. the '
+            'input) call enc.forward_module(x) or set enc.allow_module_fallback = True (plain nn.Module graph on ATen, not the library kernels)'
+            % (self.training, wants_grad, x.requires_grad, self.conv1.in_channels))
 
 
 def resnet18(in_channels, pretrained=False):

@@ -122,7 +122,7 @@ def _pack_all_winograd(enc, device):
     if not jobs:
         return
     sizes = [int(lib.hmf_conv_winograd_packed_floats(ci, co)) for _, _, ci, co in jobs]
-    key = ('_wino_buf', str(device))
+    key = '_wino_buf:%s' % device                  # a STRING key: nn.Module.__dir__ sorts the __dict__ keys
     buf = enc.__dict__.get(key)
     if buf is None or buf.numel() != sum(sizes):
         buf = enc.__dict__[key] = torch.empty(sum(sizes), dtype=torch.float32, device=device)

@@ -195,9 +195,11 @@ class EvalMetricsTracker:
             names = [m for m in frames]                                       # same order on every rank (dict order of the constructor)
             n_local = max(len(v) for v in frames.values())
             present = torch.tensor([float(len(frames[m]) > 0) for m in names], dtype=sums.dtype, device=dev)
-            for m in names:
-                assert len(frames[m]) in (0, n_local), 'per-frame arrays of one rank must have one length (%s: %d vs %d)' % (m, len(frames[m]), n_local)
-            packed = torch.zeros(sums.numel() + len(names) + W + 2, dtype=sums.dtype, device=dev)
+            # per-frame arrays of one rank must have one length.  A rank that breaks this must not raise BEFORE the collective (the others would
+            # block in all_reduce for ever): it reports the fault in the packed vector and every rank raises together after collective 1.
+            bad = [m for m in names if len(frames[m]) not in (0, n_local)]
+            packed = torch.zeros(sums.numel() + len(names) + W + 3, dtype=sums.dtype, device=dev)
+            packed[-3] = float(len(bad) > 0)
             packed[:sums.numel()] = sums
             packed[sums.numel():sums.numel() + len(names)] = present           # a metric present on ANY rank is gathered (a rank may own zero frames)
             packed[sums.numel() + len(names) + rank] = n_local
@@ -207,7 +209,10 @@ class EvalMetricsTracker:
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)                       # collective 1
             sums = packed[:sums.numel()].clone()
             host = packed[sums.numel():].tolist()                               # one D2H of n_metrics + W + 2 numbers
-            have, counts = [h > 0 for h in host[:len(names)]], [int(c) for c in host[len(names):-2]]
+            if host[-3] > 0:
+                raise RuntimeError('EvalMetricsTracker.reduce: per-frame arrays of one rank must have one length (%d rank(s) report a mismatch%s)'
+                                   % (int(host[-3]), '; here: ' + ', '.join('%s=%d' % (m, len(frames[m])) for m in bad) + ' vs %d' % n_local if bad else ''))
+            have, counts = [h > 0 for h in host[:len(names)]], [int(c) for c in host[len(names):-3]]
             nmax = max(counts)
             with_data = sum(c > 0 for c in counts)
             if with_data:

@@ -262,6 +262,7 @@ class HumaniflowModel(nn.Module):
     def __getstate__(self):                       # handles and workspaces are device-side caches: never pickled / deep-copied
         st = self.__dict__.copy()
         st['_handles'], st['_ws'], st['_flow_tensors'], st['_flow_key'] = {}, {}, None, None
+        st.pop('_rng_dev', None)
         return st
 
     def train(self, mode=True):
@@ -270,6 +271,7 @@ class HumaniflowModel(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.invalidate_flow_weights()
+        self.__dict__.pop('_rng_dev', None)
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
@@ -385,14 +387,95 @@ class HumaniflowModel(nn.Module):
             self.__dict__['_flow_key'] = vkey
         return h
 
-    def _workspace(self, device, nbytes):
-        # one scratch buffer per (device, stream): steps issued on different streams may be in flight together
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    def _workspace(self, device, nbytes, tag='flow'):
+        # one scratch buffer per (device, stream, use): steps issued on different streams may be in flight together
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, tag)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self._ws[key] = ws
         return ws
+
+    # ---- heads + base noise ------------------------------------------------------------------------------------------
+    heads_kernel = True      # inference: fc1 + ELU + fc_cam / fc_glob / fc_shape + init adds + 6D->R + exp(log_std) on hmf_heads; False: torch ops
+
+    def _heads_kernel(self, input_feats):
+        """models/humaniflow_model.py:232-253 on hmf_heads (csrc/heads_kernels.hip): reads the live parameters, no packed copy."""
+        lib = _lib.load()
+        f = input_feats.detach().to(torch.float32).contiguous()
+        B, F = f.shape
+        dev = f.device
+        nb = self.num_shape_params
+        N1 = self.fc1.out_features
+        new = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        cam, glob_R, mode, lstd, std = new(B, 3), new(B, 3, 3), new(B, nb), new(B, nb), new(B, nb)
+        p32 = lambda t: t.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            ws = self._workspace(dev, int(lib.hmf_heads_workspace_bytes(B, F, N1)), tag='heads')
+            _lib.check(lib.hmf_heads(_lib.dptr(f), B, F, _lib.dptr(p32(self.fc1.weight)), _lib.dptr(p32(self.fc1.bias)), N1,
+                                     _lib.dptr(p32(self.fc_cam.weight)), _lib.dptr(p32(self.fc_cam.bias)), _lib.dptr(p32(self.init_cam)),
+                                     _lib.dptr(p32(self.fc_glob.weight)), _lib.dptr(p32(self.fc_glob.bias)), _lib.dptr(p32(self.init_glob)),
+                                     _lib.dptr(p32(self.fc_shape.weight)), _lib.dptr(p32(self.fc_shape.bias)), nb,
+                                     _lib.dptr(cam), _lib.dptr(glob_R), _lib.dptr(mode), _lib.dptr(lstd), _lib.dptr(std),
+                                     _lib.dptr(ws), ws.numel(), _lib.current_stream()), 'hmf_heads')
+        return cam, glob_R, mode, lstd, std
+
+    def _rng_for_pass(self, device, B, N, draw_shape):
+        """hmf_rng_t of one sampling pass: where the pass' 1 + 23 normal_() calls sit in the device generator's Philox stream.
+        Eager: (seed, offset) read from torch.cuda.default_generators[device] and the generator advanced by what the reference's calls would
+        consume -- torch.randn after the forward continues exactly where it would after the reference's forward.  Under HIP-graph capture the
+        host cannot touch the generator: the pass reads a device-resident (seed, offset) that every replay advances atomically; it is created by
+        the first eager pass on the device (capture without one raises) and re-based by reseed_captured_noise()."""
+        lib = _lib.load()
+        props = torch.cuda.get_device_properties(device)
+        cap = props.multi_processor_count * (props.max_threads_per_multi_processor // 256)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        r = _lib.Rng()
+        r.grid_cap_blocks = cap
+        st = self.__dict__.setdefault('_rng_dev', {})
+        if torch.cuda.is_current_stream_capturing():
+            if idx not in st:
+                raise RuntimeError('humaniflow_amd: run one eager forward(num_samples > 0) on this device before capturing it into a HIP graph '
+                                   '(the captured pass draws its noise from a device-resident generator state created by the first eager pass)')
+            r.state_dev = st[idx].data_ptr()
+            return r
+        gen = torch.cuda.default_generators[idx]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        inc = int(lib.hmf_flow_rng_increment(B, N, self.num_shape_params, int(draw_shape), cap))
+        gen.set_offset(off + inc)
+        r.seed, r.offset = seed & 0xFFFFFFFFFFFFFFFF, off
+        if idx not in st:           # the state captured passes will continue from: the generator right after this first eager pass
+            st[idx] = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off + inc], dtype=torch.int64).to(device)
+        return r
+
+    def draw_noise(self, device, B, N, draw_shape=True):
+        """The base noise of one forward(num_samples = N) as tensors, consuming the device generator exactly as the reference's draws do (and as the
+        inference path does inside its kernels): eps_shape (N,B,nb) = the pass' first normal_() call (None with draw_shape=False), eps_pose
+        (23,B,N,3) = one (B,N,3) call per body part.  `forward(..., noise={'shape': eps_shape, 'pose': eps_pose})` replays them."""
+        lib = _lib.load()
+        device = torch.device(device)
+        nb, P = self.num_shape_params, self.num_bodyparts
+        rng = self._rng_for_pass(device, B, N, draw_shape)
+        eps_shape = torch.empty(N, B, nb, dtype=torch.float32, device=device) if draw_shape else None
+        eps_pose = torch.empty(P, B, N, 3, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            ws = self._workspace(device, 256, tag='rng')
+            _lib.check(lib.hmf_flow_draw_noise(C.byref(rng), B, N, nb, _lib.dptr(eps_shape), _lib.dptr(eps_pose), _lib.dptr(ws), ws.numel(),
+                                               _lib.current_stream()), 'hmf_flow_draw_noise')
+        return eps_shape, eps_pose
+
+    def reseed_captured_noise(self, device=None):
+        """Re-base the device-resident generator state that HIP-graph-captured passes draw from on the device generator's current state."""
+        device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        gen = torch.cuda.default_generators[idx]
+        seed = gen.initial_seed()
+        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, gen.get_offset()], dtype=torch.int64).to(device)
+        st = self.__dict__.setdefault('_rng_dev', {})
+        if idx in st:
+            st[idx].copy_(t)
+        else:
+            st[idx] = t
 
     # ---- reference helper methods (kept for API parity; single calls into the library) -----------------------------
     def _needs_grad(self, *tensors):
@@ -531,14 +614,18 @@ class HumaniflowModel(nn.Module):
         lib = _lib.load()
         nb, P, N = self.num_shape_params, self.num_bodyparts, int(num_samples)
 
-        x = self.activation(self.fc1(input_feats))
-        cam = self.fc_cam(x) + self.init_cam                                         # :237-238
-        glob = self.fc_glob(x) + self.init_glob                                      # :243-244
-        glob_R = rot6d_to_rotmat(glob)                                               # :245  (hmf_rot6d_to_rotmat)
-        shape_params = self.fc_shape(x)
-        shape_mode = shape_params[:, :nb]
-        shape_log_std = shape_params[:, nb:]
-        shape_dist = Normal(loc=shape_mode, scale=torch.exp(shape_log_std), validate_args=False)
+        if grad or not self.heads_kernel:
+            x = self.activation(self.fc1(input_feats))
+            cam = self.fc_cam(x) + self.init_cam                                         # :237-238
+            glob = self.fc_glob(x) + self.init_glob                                      # :243-244
+            glob_R = rot6d_to_rotmat(glob)                                               # :245  (hmf_rot6d_to_rotmat)
+            shape_params = self.fc_shape(x)
+            shape_mode = shape_params[:, :nb]
+            shape_log_std = shape_params[:, nb:]
+            shape_std = torch.exp(shape_log_std)
+        else:
+            cam, glob_R, shape_mode, shape_log_std, shape_std = self._heads_kernel(input_feats)       # :232-253, two launches (hmf_heads)
+        shape_dist = Normal(loc=shape_mode, scale=shape_std, validate_args=False)
 
         return_dict = {'cam_wp': cam, 'glob_rotmat': glob_R, 'shape_mode': shape_mode, 'shape_log_std': shape_log_std,
                        'shape_dist_for_loglik': shape_dist}
@@ -546,23 +633,29 @@ class HumaniflowModel(nn.Module):
         if compute_point_est or N > 0:
             f32c = lambda t: t.detach().to(torch.float32).contiguous()
             feats_c, glob_c, cam_c, mode_c, lstd_c = f32c(input_feats), f32c(glob_R), f32c(cam), f32c(shape_mode), f32c(shape_log_std)
-            eps_shape = eps_pose = None
+            eps_shape = eps_pose = rng = None
+            flags0 = 0
             if N > 0:
+                if use_shape_mode_for_samples:
+                    flags0 = _lib.HMF_FLOW_SHAPE_MODE
                 if noise is not None:
                     eps_pose = f32c(noise['pose'])
                     assert tuple(eps_pose.shape) == (P, batch_size, N, 3)
                     if not use_shape_mode_for_samples:
                         eps_shape = f32c(noise['shape'])
                         assert tuple(eps_shape.shape) == (N, batch_size, nb)
+                elif grad:
+                    # training: the reparameterised-sample graph below needs the noise as tensors; same draw order as the reference (:258, :309)
+                    eps_shape, eps_pose = self.draw_noise(device, batch_size, N, draw_shape=not use_shape_mode_for_samples)
                 else:
-                    if not use_shape_mode_for_samples:
-                        eps_shape = torch.randn(N, batch_size, nb, device=device)          # :258 rsample([N])
-                    eps_pose = torch.randn(P, batch_size, N, 3, device=device)             # :309, parts 0..22 in order
+                    # inference: drawn inside the flow kernels from the device generator's Philox stream, call for call what the reference
+                    # draws -- (N,B,nb) for the shapes (:258), then one (B,N,3) per body part (:309); csrc/rng_philox.h
+                    rng = self._rng_for_pass(device, batch_size, N, draw_shape=not use_shape_mode_for_samples)
             # Sample rows (b*N + n) and point-estimate rows (B*N + b) share one buffer each, so that ONE SMPL launch of M = B*N + B
             # rows can consume them (SMPL.forward_samples_and_point_est); the reference's separate tensors are views of it.
             BN = batch_size * N
             packed = compute_point_est and N > 0
-            flags = (_lib.HMF_FLOW_POINT_EST if compute_point_est else 0) | (_lib.HMF_FLOW_PACKED_ROWS if packed else 0)
+            flags = (_lib.HMF_FLOW_POINT_EST if compute_point_est else 0) | (_lib.HMF_FLOW_PACKED_ROWS if packed else 0) | flags0
             rot_all = torch.empty(BN + (batch_size if compute_point_est else 0), P, 3, 3, dtype=torch.float32, device=device)
             shape_all = torch.empty(BN + (batch_size if packed else 0), nb, dtype=torch.float32, device=device) if N > 0 else None
             rot_s = rot_all[:BN].view(batch_size, N, P, 3, 3) if N > 0 else None
@@ -574,7 +667,8 @@ class HumaniflowModel(nn.Module):
                 nbytes = lib.hmf_flow_forward_workspace_bytes(h, batch_size, N, flags)
                 ws = self._workspace(device, nbytes)
                 _lib.check(lib.hmf_flow_forward(h, _lib.dptr(feats_c), _lib.dptr(glob_c), _lib.dptr(cam_c), _lib.dptr(mode_c),
-                                                _lib.dptr(lstd_c), _lib.dptr(eps_shape), _lib.dptr(eps_pose), batch_size, N,
+                                                _lib.dptr(lstd_c), _lib.dptr(eps_shape), _lib.dptr(eps_pose),
+                                                None if rng is None else C.byref(rng), batch_size, N,
                                                 flags, _lib.dptr(shape_all), _lib.dptr(rot_s), _lib.dptr(rot_p),
                                                 _lib.dptr(so3_p), _lib.dptr(ws), ws.numel(), _lib.current_stream()),
                            'hmf_flow_forward')

@@ -273,11 +273,36 @@ class SMPL(nn.Module):
         pk = pred['smpl_packed_inputs']
         g = pred['glob_rotmat']
         B, N = g.shape[0], pk['num_samples']
-        glob_all = torch.cat([g[:, None].expand(B, N, 3, 3).reshape(B * N, 1, 3, 3), g[:, None]], dim=0)
-        out = self(body_pose=pk['body_pose'], global_orient=glob_all, betas=pk['betas'], pose2rot=False)
-        BN = B * N
-        cut = lambda sl: SMPLOutput(vertices=out.vertices[sl], joints=out.joints[sl], full_pose=None, betas=pk['betas'][sl],
-                                    global_orient=glob_all[sl], body_pose=pk['body_pose'][sl])
+        BN, M = B * N, B * N + B
+        body, betas = pk['body_pose'], pk['betas']
+        wants_grad = torch.is_grad_enabled() and (body.requires_grad or betas.requires_grad or g.requires_grad)
+        if wants_grad or N == 0:
+            glob_all = torch.cat([g[:, None].expand(B, N, 3, 3).reshape(BN, 1, 3, 3), g[:, None]], dim=0)
+            out = self(body_pose=body, global_orient=glob_all, betas=betas, pose2rot=False)
+            verts, joints, full_pose = out.vertices, out.joints, out.full_pose
+        else:
+            # hmf_smpl_lbs_packed indexes image b's rotation for its N sample rows and its point-estimate row inside the kernel (the reference
+            # expands and concatenates a (B*N + B, 1, 3, 3) tensor first) and writes smplx's `full_pose` from the same launch
+            _lib.require_cuda(betas, 'betas')
+            _lib.require_cuda(body, 'body_pose')
+            _lib.require_cuda(g, 'global_orient')
+            lib = _lib.load()
+            dev = betas.device
+            gc, bc, bec = self._f32c(g).reshape(B, 9), self._f32c(body).reshape(M, 23 * 9), self._f32c(betas)
+            verts = torch.empty(M, NUM_VERTS, 3, dtype=torch.float32, device=dev)
+            joints = torch.empty(M, 90, 3, dtype=torch.float32, device=dev)
+            full_pose = torch.empty(M, 24, 3, 3, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                ws = self._workspace(dev, M)
+                _lib.check(lib.hmf_smpl_lbs_packed(self._handle(dev), _lib.dptr(gc), B, N, _lib.dptr(bc), _lib.dptr(bec), _lib.dptr(verts), _lib.dptr(joints),
+                                                   _lib.dptr(full_pose), _lib.dptr(ws), ws.numel(),
+                                                   int({'fp32': 0, 'bf16': 3, 'bf16_plain': 2}[self.blend_dtype]), _lib.current_stream()),
+                           'hmf_smpl_lbs_packed')
+            if hasattr(self, 'transl') and self.transl is not None:
+                joints = joints + self.transl.unsqueeze(1)
+                verts = verts + self.transl.unsqueeze(1)
+        cut = lambda sl: SMPLOutput(vertices=verts[sl], joints=joints[sl], full_pose=None if full_pose is None else full_pose[sl], betas=betas[sl],
+                                    global_orient=full_pose[sl, :1] if full_pose is not None else None, body_pose=body[sl])
         return cut(slice(BN, BN + B)), cut(slice(0, BN))
 
     def tpose(self, betas):

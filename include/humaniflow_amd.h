@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMF_ABI_VERSION 2
+#define HMF_ABI_VERSION 3
 
 #define HMF_OK 0
 #define HMF_ERR_INVALID (-1)     /* bad argument / shape                                  */
@@ -95,6 +95,13 @@ size_t hmf_smpl_lbs_workspace_bytes(int M);
 int hmf_smpl_lbs(const hmf_smpl_t* h, const float* global_orient, int Mg, const float* body_pose,
                  const float* betas, int Mb, int M, float* verts, float* joints, void* workspace,
                  size_t workspace_bytes, int impl, void* stream);
+/* The two SMPL calls of one HumaniflowModel.forward(num_samples = N) result as ONE launch (evaluate/evaluate_humaniflow.py:124-127,168-172;
+ * predict/predict_humaniflow.py:128-131,160-163): M = B*N + B rows = the B*N sampled bodies (row b*N + n), then the B point-estimate bodies,
+ * exactly the row order hmf_flow_forward writes with HMF_FLOW_PACKED_ROWS.  glob_R B x 9 is indexed per image inside the kernel (no expanded
+ * copy: the reference's `glob_rotmat[:, None].expand(-1, N, ...)`), body_pose M x 23 x 9, betas M x nb.  full_pose (nullable) M x 24 x 9 =
+ * smplx's `full_pose = cat([global_orient, body_pose], dim=1)`.                                                                          */
+int hmf_smpl_lbs_packed(const hmf_smpl_t* h, const float* glob_R, int B, int N, const float* body_pose, const float* betas, float* verts,
+                        float* joints, float* full_pose, void* workspace, size_t workspace_bytes, int impl, void* stream);
 /* T-pose bodies (evaluate/evaluate_humaniflow.py:131-133,186-192; predict_humaniflow.py:147):
  * v_template + shapedirs . beta.  joints nullable.                                                */
 int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts, float* joints,
@@ -161,18 +168,43 @@ void hmf_flow_destroy(hmf_flow_t* h);
 #define HMF_FLOW_POINT_EST 1    /* also push z = 0 through every flow (compute_point_est, :294-300)                      */
 #define HMF_FLOW_PACKED_ROWS 2  /* shape_samples has B*N + B rows: the point-estimate rows' shape (= shape_mode) is appended, so that
                                  * (rotmats_samples | rotmats_point) and shape_samples feed ONE hmf_smpl_lbs call of M = B*N + B rows */
+#define HMF_FLOW_SHAPE_MODE 4   /* use_shape_mode_for_samples (:255-256): no shape noise, whatever eps_shape / rng say                  */
 size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int flags);
+
+/* Base noise drawn INSIDE the kernels from the device generator's Philox4x32-10 stream, in the reference's draw order (SURVEY 8b "RNG
+ * contract"; models/humaniflow_model.py:258 then :309): one normal_() call of shape (N, B, nb), then one of shape (B, N, 3) per body part --
+ * bit for bit what torch.randn would have written on the same generator state (csrc/rng_philox.h restates ATen's launch geometry).
+ *   seed, offset    the generator's state at the start of the pass (torch.cuda.default_generators[i]: initial_seed(), get_offset()); the caller
+ *                   advances its generator by hmf_flow_rng_increment(...) afterwards;
+ *   state_dev       NULL, or a DEVICE pointer to {uint64 seed, uint64 offset}: then seed / offset above are ignored, the pass takes them from
+ *                   there and advances the offset itself with one atomic add (a pass captured into a HIP graph: every replay draws fresh noise);
+ *   grid_cap_blocks #CU * (max threads per CU / 256): the grid cap of ATen's launch on this device (2048 on MI355X).                       */
+typedef struct {
+    uint64_t seed, offset;
+    void* state_dev;
+    int grid_cap_blocks;
+} hmf_rng_t;
+/* generator offset one sampling pass consumes (draw_shape = 0 with use_shape_mode_for_samples or injected shape noise) */
+unsigned long long hmf_flow_rng_increment(int B, int N, int num_betas, int draw_shape, unsigned int grid_cap_blocks);
+
+/* The same generator calls materialised as tensors by one launch (training keeps the noise for its reverse sweep, train/train_humaniflow.py:248-256;
+ * tests compare with torch.randn): eps_shape N x B x nb (NULL = not drawn: use_shape_mode_for_samples), eps_pose 23 x B x N x 3.
+ * workspace: >= 256 bytes of device memory.                                                                                               */
+int hmf_flow_draw_noise(const hmf_rng_t* rng, int B, int N, int num_betas, float* eps_shape, float* eps_pose, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* Kinematic-chain pass: N pose samples per image and/or the z=0 point estimate, all 23 parts in
  * dependency order inside one launch sequence (replaces the Python loop :286-311).
  *   feats B x feat_dim; glob_R B x 9; cam B x 3; shape_mode/shape_log_std B x nb;
- *   eps_shape N x B x nb standard normal (NULL = use_shape_mode_for_samples, :255-256);
- *   eps_pose 23 x B x N x 3 standard normal, in the reference's draw order (:309);
+ *   base noise, either INJECTED (exact-parity tests): eps_shape N x B x nb, eps_pose 23 x B x N x 3 standard normals in the reference's
+ *   draw order (:258, :309), or DRAWN in the kernels: eps_pose = NULL and rng != NULL (then eps_shape = NULL draws the shape noise too,
+ *   unless HMF_FLOW_SHAPE_MODE).  Without rng, eps_shape = NULL means use_shape_mode_for_samples (:255-256).
  * outputs (nullable when not requested):
  *   shape_samples B x N x nb (+ B x nb with HMF_FLOW_PACKED_ROWS); rotmats_samples B x N x 23 x 9 (fp64 exp rounded to fp32, :311);
  *   rotmats_point B x 23 x 9 (batch_rodrigues, :299); so3_point B x 23 x 3 (:300).               */
 int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* cam,
                      const float* shape_mode, const float* shape_log_std, const float* eps_shape,
-                     const float* eps_pose, int B, int N, int flags, float* shape_samples,
+                     const float* eps_pose, const hmf_rng_t* rng, int B, int N, int flags, float* shape_samples,
                      float* rotmats_samples, float* rotmats_point, float* so3_point, void* workspace,
                      size_t workspace_bytes, void* stream);
 
@@ -275,6 +307,27 @@ int hmf_conv1x1_dual_nhwc(const float* x, const float* x2, const float* w, const
  * hmf_conv1x1_dual_nhwc up to the fp32 accumulation order.  Profiler tag 8. */
 int hmf_conv1x1_gemm(const float* x, const float* x2, const float* w, const float* bias, const float* residual, float* y, int B, int OH, int OW,
                      int K1, int H2, int W2, int K2, int stride2, int N, int relu, int tile, void* stream);
+/* The encoder's last 1x1 convolution with the global average pool of models/resnet.py:214-215 (`avgpool` + flatten) in its epilogue:
+ * pooled (B, N) = mean over the OH*OW = 64 pixels of relu?(x . W^T + bias (+ residual)); a 64-row GEMM tile is one image's 8 x 8 map, so the
+ * pooled features are column means of finished tiles: no cross-work-group reduction, fixed summation order.  y (B,8,8,N) also receives the map
+ * when non-NULL; the inference plan passes NULL (the map is neither written nor re-read).  Other arguments as hmf_conv1x1_gemm. */
+int hmf_conv1x1_gemm_avgpool(const float* x, const float* w, const float* bias, const float* residual, float* y, float* pooled, int B, int OH,
+                             int OW, int K1, int N, int relu, int tile, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Heads between the encoder and the flow (models/humaniflow_model.py:232-252, models/resnet.py:214-215)                              */
+/* ------------------------------------------------------------------------------------------ */
+/* F.adaptive_avg_pool2d(x, 1) + flatten (models/resnet.py:214-215) for maps the fused epilogue above does not cover: x (B, HW, C) NHWC -> (B, C). */
+int hmf_avgpool_nhwc(const float* x, int B, int HW, int C, float* out, void* stream);
+size_t hmf_heads_workspace_bytes(int B, int F, int N1);
+/* models/humaniflow_model.py:232-253 in two launches and no vendor GEMM: x1 = ELU(fc1 feats) (fp32 MFMA over the live (N1, F) weight, K split in a
+ * fixed order); cam = fc_cam x1 + init_cam (:237-238); glob_R = rot6d_to_rotmat(fc_glob x1 + init_glob) (:243-245); (shape_mode | shape_log_std) =
+ * fc_shape x1 (:250-252); shape_std = exp(shape_log_std) (the scale of :253's Normal).  feats B x F; w1 N1 x F, b1 N1;
+ * w_cam 3 x N1, w_glob 6 x N1, w_shape 2nb x N1 (+ biases); init_cam 3, init_glob 6.  Outputs cam B x 3, glob_R B x 9, shape_mode / shape_log_std /
+ * shape_std B x nb each.  F % 32 == 0, N1 % 32 == 0, N1 <= 1024; feats and weight matrices 16-byte aligned.  Profiler tag 13. */
+int hmf_heads(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
+              const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
+              float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, void* workspace, size_t workspace_bytes, void* stream);
 
 /* OPT-IN: the same GEMM on the bf16 matrix pipe with split fp32 operands (csrc/conv_gemm_split.hip; not the default of any plan).  Every fp32
  * value x = p0 + p1 (+ p2) in bf16 pieces (round-to-nearest remainders); terms = 3: x*w ~ p0 q0 + p0 q1 + p1 q0 (product error ~2^-16 relative),
@@ -312,7 +365,8 @@ int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, con
 /* Winograd F(2x2,3x3) variant for stride-1 3x3 layers (same result as hmf_conv2d_nhwc with ks = 3, 2.25x fewer MFMA k-steps): 8x16-pixel
  * tiles x 32 channels (maps at most 8 pixels wide: 8x8 pixels of two consecutive images), input transform in registers, output transform through LDS, same fused epilogue.  w_packed =
  * hmf_conv_winograd_pack_host(w (Cout,3,3,Cin) channels_last, ...) [the transformed weights G g G^T in MFMA lane order,
- * hmf_conv_winograd_packed_floats = 16*Cout*Cin floats] uploaded to the device.  Cin % 64 == 0, Cout % 32 == 0.  Profiler tag 11. */
+ * hmf_conv_winograd_packed_floats = 16*Cout*Cin floats] uploaded to the device.  Cin % 64 == 0, Cout % 32 == 0; x, w_packed, y, residual and
+ * bias 16-byte aligned (the output phase uses 16-byte buffer accesses).  Profiler tag 11. */
 long long hmf_conv_winograd_packed_floats(int Cin, int Cout);
 int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout);
 int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
