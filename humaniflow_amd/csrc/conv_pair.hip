@@ -32,7 +32,11 @@ struct PairArgs {
     int y_nt;             // y does not fit the L2s anyway: store it non-temporal (measured on layer1: 102 -> 84 us per seam)
 };
 
-constexpr int kPairYS = 64 + 4;          // LDS row stride of a Y chunk
+// LDS image of a 64 x 64 chunk of Y: dense rows of sixteen 16-byte slots, slot c of row r stored at c ^ f(r), f(r) = ((r & 1) << 3) | ((r >> 1) & 7).
+// One image serves three access patterns without bank conflicts: the accumulator spill (ds_write_b32, lane = channel: 32 consecutive floats of one
+// row), the epilogue's row pieces (ds_read/write_b128, 8 lanes per 128-byte half row, two rows per 16-lane group: f flips bit 3 between adjacent
+// rows) and the second GEMM's A fragments (ds_read_b128, lane = row: f is a bijection on 16 consecutive rows).
+__device__ __forceinline__ int pair_swz(int r) { return ((r & 1) << 3) | ((r >> 1) & 7); }
 
 // ABL (tools/pair_probe.py, timing only; & 7 give wrong results): & 1 = y is not stored, & 2 = the residual is not loaded, & 4 = no chunk barrier,
 // & 8 = residual loads streaming (nt), & 16 = y stores NOT non-temporal.
@@ -40,7 +44,7 @@ template <int KT, int N2, int OCC, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_pair(const PairArgs a) {
     constexpr int XS = KT + 4, G3 = KT / 8, TN2 = N2 / 64, NT2 = N2 / 32, V4 = KT / 4, NX = 64 * V4 / 256;
     __shared__ float sX[64 * XS];
-    __shared__ float sY[2][64 * kPairYS];
+    __shared__ __attribute__((aligned(16))) float sY[2][64 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: scalar offsets below
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lq = lane >> 5;
     const int m0 = blockIdx.x * 64;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     const int nchunk = a.C / 64;
     const int pxb = 32 * wm + 4 * lq;                       // accumulator register r of this lane: pixel pxb + (r & 3) + 8 (r >> 2), channel li of the tile
     const float* pa1 = sX + (32 * wm + li) * XS + 4 * lq;
-    const int ya = (32 * wm + li) * kPairYS + 4 * lq;
+    const int arow = 32 * wm + li, aswz = pair_swz(arow);    // this lane's A-fragment row of the second GEMM
 
     // Every global access below is a raw buffer access: one per-lane 32-bit offset + a scalar offset (chunk, k-group, accumulator row), so no
     // 64-bit per-row address lives in registers across the chunk loop.  M is a multiple of 64 (checked by the host wrapper): no row tails.
@@ -86,15 +90,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.M * a.C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.z, 0, a.M * N2 * 4, 0x00020000);
     const int vlane = lane * 16;
-    const int vy = ((m0 + 4 * lq) * a.C + li) * 4;          // + scalar ((32 wm + row(r)) C + 64 c + 32 wn) * 4
     const int vz = ((m0 + 4 * lq) * N2 + li) * 4;
     const int rowC = a.C * 4;
+    // Round 4: the wave finishes its own 32 x 32 tile of Y with 16-byte accesses (round 2 stored 16 scalars per lane and loaded the residual
+    // the same way: 32 memory instructions per lane and chunk, now 8).  Lane l takes the 16-byte piece e4 = l & 7 of rows (l >> 3) + 8 i, i = 0..3,
+    // of the tile: 8 lanes cover the 128 contiguous bytes of a pixel's 32 channels.  The tile passes through the chunk's own LDS image
+    // (accumulators + bias in, relu(. + residual) back), which the second GEMM reads anyway; the pass is wave-local, so it needs no barrier.
+    const int er = lane >> 3, e4 = lane & 7;
+    const int vy16 = ((m0 + 32 * wm + er) * a.C + 32 * wn + 4 * e4) * 4;       // + scalar (8 i C + 64 c) * 4
+    // float offsets into a chunk image (see pair_swz): accumulator spill of register class cls (cr = 0, 1, 4, 5) and the two half-row flips ...
+    int spill[4];
+    {
+        constexpr int kCr[4] = {0, 1, 4, 5};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) spill[k] = pxb * 64 + ((((li >> 2) ^ ((2 * lq + kCr[k]) & 7))) << 2) + (li & 3);
+    }
+    const int hflip0 = (8 * wn) << 2, hflip1 = ((8 * wn) ^ 8) << 2;
+    // ... and the epilogue's row pieces: rows 32 wm + er + 8 i; the swizzle of row + 8 differs from the row's by bit 2 of the slot
+    const int rowe = 32 * wm + er;
+    const int piece0 = rowe * 64 + (((8 * wn + e4) ^ pair_swz(rowe)) << 2), piece1 = rowe * 64 + (((8 * wn + e4) ^ pair_swz(rowe) ^ 4) << 2);
 
     // W1 fragments of a chunk: all 8 k-groups in registers for N2 <= 128; for N2 = 256 (four 32-channel tiles per wave: 64 accumulator registers)
     // they stream through a two-stage ring, one k-group ahead
     constexpr bool kRing1 = TN2 > 2;
     f32x4 b3[G3], b1[TN2][kRing1 ? 2 : 8];
-    float rva[16], rvb[16];
+    f32x4 rva[4], rvb[4];
     auto load_b3 = [&](int c) {
         const int so = (c * 2 + wn) * G3 * 1024;
 #pragma unroll
@@ -113,14 +133,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             for (int g = 0; g < 8; ++g) load_b1g(c, g, g);
         }
     };
-    auto load_res = [&](int c, float (&rv)[16]) {
+    auto load_res = [&](int c, f32x4 (&rv)[4]) {
         if (a.res && !(ABL & 2)) {
-            const int so = 32 * wm * rowC + (64 * c + 32 * wn) * 4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vy, so + ((r & 3) + 8 * (r >> 2)) * rowC, (ABL & 8) ? 2 : 0));
+            for (int i = 0; i < 4; ++i) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, vy16, (8 * i * a.C + 64 * c) * 4, (ABL & 8) ? 2 : 0));
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            for (int i = 0; i < 4; ++i) rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 
     // One chunk.  Order of the memory operations: vmcnt retires in order, so everything a later MFMA phase waits for is requested BEFORE the y stores of
     // this chunk (a store is acknowledged late): W3 fragments + residual of chunk c + 1 right after phase 1, W1 fragments of c at the top.
-    auto chunk = [&](int c, float (&rv)[16], float (&rvn)[16]) {
+    auto chunk = [&](int c, f32x4 (&rv)[4], f32x4 (&rvn)[4]) {
         load_b1(c);
         // ---- phase 1: a 32 x 32 tile of Y, K = KT ----
         f32x16 accy;
@@ -152,30 +171,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             load_b3(c + 1);
             load_res(c + 1, rvn);
         }
+        float* yc = sY[c & 1];
         {
             const float bv = a.bias3[64 * c + 32 * wn + li];
-            float* ys = sY[c & 1] + pxb * kPairYS + 32 * wn + li;
-            const int so = 32 * wm * rowC + (64 * c + 32 * wn) * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2);
-                const float v = fmaxf(accy[r] + bv + rv[r], 0.f);
+                // row = pxb + (r & 3) + 8 (r >> 2): the swizzle's bit 3 is r & 1, its low bits (2 lq + cr) & 7 with cr = ((r & 3) >> 1) + 4 (r >> 2) mod 8
+                // in {0, 1, 4, 5}: four per-lane offsets + a wave-uniform half-row flip instead of sixteen address computations
+                constexpr int kCls[4] = {0, 1, 4, 5};
+                const int cls = ((r & 3) >> 1) | (((r >> 2) & 1) << 1);
+                (void)kCls;
+                yc[spill[cls] + ((r & 1) ? hflip1 : hflip0) + ((r & 3) + 8 * (r >> 2)) * 64] = accy[r] + bv;
+            }
+        }
+        {   // wave-local: the tile this wave just spilled, finished row piece by row piece
+            const int so = 64 * c * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* p = yc + ((i & 1) ? piece1 : piece0) + 8 * i * 64;
+                f32x4 v = *(const f32x4*)p + rv[i];
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
                 if (ABL & 1) {
                 } else if (a.y_nt && !(ABL & 16)) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, vy, so + row * rowC, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, vy16, so + 8 * i * rowC, 2);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, vy, so + row * rowC, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, vy16, so + 8 * i * rowC, 0);
                 }
-                ys[row * kPairYS] = v;
+                *(f32x4*)p = v;
             }
         }
         if (!(ABL & 4)) __syncthreads();
         // ---- phase 2: Z += chunk . W1[:, chunk]^T ----
-        const float* pa2 = sY[c & 1] + ya;
+        const float* pa2 = yc + arow * 64;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             if (kRing1 && g + 1 < 8) load_b1g(c, g + 1, (g + 1) & 1);
-            const f32x4 fa = *(const f32x4*)(pa2 + 8 * g);
+            const f32x4 fa = *(const f32x4*)(pa2 + (((2 * g + lq) ^ aswz) << 2));
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll

@@ -179,21 +179,32 @@ __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __
     if (tile >= ntiles) return;
     const int nb = d.nb;
     const RowInfo ri = row_info(tile * 32 + l31, B, N, Mtot);
-    // shape vector of this lane's row (models/humaniflow_model.py:250-258)
-    float beta[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    // shape vectors of the tile's 32 rows (models/humaniflow_model.py:250-258), computed ONCE per work-group: its four waves work on the same
+    // tile (gw = 4 * block + wave, 8 part groups per tile), so thread (wave, q) takes the elements i = 2 * wave + q (+ 8) of its lane's row
+    // and the rows are exchanged through LDS (row pitch 17: conflict-free).  Round 3 kept `float beta[16]` per thread and indexed it with a
+    // run-time bound, which the compiler turned into a 16 KB LDS array with a 64-byte lane stride: the 93.6 % LDS bank-conflict cycles of the
+    // round-1..3 profiles.  With the noise drawn in the kernel a lane now also pays for 1-2 Philox blocks instead of 10.
+    __shared__ float sbeta[32][17];
+    const int wv = threadIdx.x >> 6;
+    for (int i = 2 * wv + q; i < 16; i += 8) {
         float v = 0.f;
         if (i < nb && ri.live) {
             v = shape_mode[(size_t)ri.b * nb + i];
             if (!ri.is_point && has_shape_noise(ns))
                 v = v + shape_noise(ns, (unsigned int)((ri.n * B + ri.b) * nb + i)) * expf(shape_log_std[(size_t)ri.b * nb + i]);
         }
-        beta[i] = v;
+        sbeta[l31][i] = v;
     }
+    __syncthreads();
+    float beta[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) beta[i] = sbeta[l31][i];
     // row id = b*N + n for samples, B*N + b for point-estimate rows: with HMF_FLOW_PACKED_ROWS the shape buffer carries both
-    if (pg == 0 && q == 0 && ri.live && shape_samples && (!ri.is_point || packed_rows))
-        for (int i = 0; i < nb; ++i) shape_samples[((size_t)tile * 32 + l31) * nb + i] = beta[i];
+    if (pg == 0 && q == 0 && ri.live && shape_samples && (!ri.is_point || packed_rows)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nb) shape_samples[((size_t)tile * 32 + l31) * nb + i] = beta[i];
+    }
     // h = ELU(G[b] + W_beta . beta) for the 256 isgc channels, produced directly in ARL registers: the rank-nb
     // update is itself an MFMA (A = packed W_beta, B = this lane's beta pair), G[b] is gathered as float4.
     f32x16 h[8];

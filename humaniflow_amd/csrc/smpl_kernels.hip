@@ -7,7 +7,8 @@
 //                      transforms A (M x 24 x 3x4) -> workspace; posed joints -> joints[:, :24]
 //   2. k_lbs_mfma      v_posed = [R-I | beta | 1] (M x 224) . Bpack (224 x 3V) on fp32 MFMA 32x32x2,
 //                      skinning transform blended from LDS and applied in-register, vertices written once
-//   3. k_joints        21 vertex picks + 45 sparse regressed joints gathered from the written vertices
+//   3. k_joints_compact  21 vertex picks + 45 sparse regressed joints from the compact (M, <= 276, 3) copy of the vertices they touch, which the
+//                      skinning epilogue of step 2 writes next to the vertices (round 4; k_joints gathers from the vertices themselves: T-pose bodies)
 // Data layout and roofline: DESIGN.md "hmf_smpl_lbs".
 #include <vector>
 #include <utility>
@@ -49,6 +50,10 @@ struct SmplDev {
     int* ju_ptr;                     // [n_ju + 1]
     int* ju_out;                     // output joint index 0..65 (joint 24 + i)
     float* ju_w;
+    // joints 24..89 without re-reading the vertices: the <= kMaxJU vertices they touch leave the skinning epilogue a second time, into a compact
+    // (M, n_ju, 3) buffer, and k_joints_compact finishes the 66 joints from it
+    int* ju_slot;                    // [kVT * 32]: compact slot of vertex v, or -1
+    int* jr_slot;                    // CSR column of jr_ptr in compact slots (= slot of jr_idx[e])
 };
 constexpr int kMaxJU = 320;          // >= 21 picks + 255 regressor non-zeros of the reference's tables
 
@@ -238,6 +243,10 @@ struct EpiCtx {
     float* obase;                    // verts + ((row0 + 4*half) * V + v) * 3
     bool ok_v, full_rows;
     int row_lim;                     // M - row0 - 4*half
+    float* cj;                       // compact joint-vertex buffer + ((row0 + 4*half) * n_ju + slot of this lane's vertex) * 3, or null
+    int cj_row;                      // n_ju * 3
+    bool tile_has_ju;                // wave-uniform: some vertex of this tile feeds a gathered joint
+    bool lane_has_ju;
 };
 
 template <int SLOTS>
@@ -275,6 +284,12 @@ __device__ __forceinline__ void skin_element(const SmplDev& d, const char* __res
         // 2.3 MB operand range that each XCD's L2 is supposed to hold (r01 PMC: the operand was re-fetched ~9x)
         __builtin_nontemporal_store(x, o); __builtin_nontemporal_store(y, o + 1); __builtin_nontemporal_store(z, o + 2);
     }
+    if (e.tile_has_ju) {                                  // wave-uniform; ~150 of the 216 vertex tiles hold one of the <= 276 joint vertices
+        if (e.lane_has_ju && (e.full_rows || rc < e.row_lim)) {
+            float* q = e.cj + rc * e.cj_row;
+            q[0] = x; q[1] = y; q[2] = z;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -291,7 +306,7 @@ __device__ __forceinline__ void skin_element(const SmplDev& d, const char* __res
 template <int SLOTS, int ABL>
 __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, int wpx, const float* __restrict__ panel,
                                                    const float* __restrict__ atr, float* __restrict__ verts,
-                                                   long long* __restrict__ cycles) {
+                                                   long long* __restrict__ cycles, float* __restrict__ cjv) {
     const long long c_start = cycles ? (long long)__builtin_readcyclecounter() : 0;
     __shared__ __attribute__((aligned(16))) float smem[kKpad * kRowsPerWG + kRowsPerWG * kAtr];  // 56 + 72 KB
     float* sPF = smem;
@@ -313,7 +328,10 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
             const f32x4* src = (const f32x4*)(panel + (size_t)rg * (kKpad * 64));
             f32x4* dst = (f32x4*)sPF;
 #pragma unroll
-            for (int i = 0; i < kKpad * 64 / 4 / 512; ++i) dst[tid + i * 512] = src[tid + i * 512];
+            // (round 4, measured and rejected: streaming / non-temporal loads for this once-per-segment copy, meant to keep the 2.3 MB operand range
+            // of the XCD in its L2: +15 us at M = 3,232 (tools/lbs_tune.py 0 8) -- the copy sits on the critical path of every segment and the
+            // non-temporal path is slower to first data; ABL & 8 keeps the variant in the experiments build)
+            for (int i = 0; i < kKpad * 64 / 4 / 512; ++i) dst[tid + i * 512] = (ABL & 8) ? __builtin_nontemporal_load(src + tid + i * 512) : src[tid + i * 512];
             const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
             f32x4* dst2 = (f32x4*)sA;
             const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
             for (int i = 0; i < kRowsPerWG * (kAtr / 4) / 512; ++i) {
                 const int ii = tid + i * 512;
                 f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                dst2[ii] = (ii < n4) ? src2[ii] : z;
+                dst2[ii] = (ii < n4) ? ((ABL & 8) ? __builtin_nontemporal_load(src2 + ii) : src2[ii]) : z;
             }
         }
         __syncthreads();
@@ -356,10 +374,12 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
         f32x4 b0, b1, b2;
         int off[SLOTS > 0 ? SLOTS : 1];
         float w[SLOTS > 0 ? SLOTS : 1];
+        int jslot = -1;
         if (tt >= 0) {
             const int vt = xr * kVTperX + (tt - rg * kVTperX);
             const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
             b0 = bp[0]; b1 = bp[64]; b2 = bp[128];
+            if (cjv) jslot = d.ju_slot[vt * 32 + l31];
             if (SLOTS > 0) {
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) {
@@ -417,10 +437,12 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
             const int ntt = item(kitem + 1, nrh);
             int noff[SLOTS > 0 ? SLOTS : 1];
             float nw[SLOTS > 0 ? SLOTS : 1];
+            int njslot = -1;
             if (ntt >= 0) {
                 const int nvt = xr * kVTperX + (ntt - rg * kVTperX);
                 const f32x4* nbp = (const f32x4*)(d.blend + (size_t)nvt * kKG * 3 * 64 * 4) + lane;
                 b0 = nbp[0]; b1 = nbp[64]; b2 = nbp[128];
+                if (cjv) njslot = d.ju_slot[nvt * 32 + l31];
                 if (SLOTS > 0) {
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
@@ -443,6 +465,10 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
                 const int rsh = rh > 0 ? 32 : 0;
                 e.row_lim = M - row0 - 4 * half - rsh;
                 e.obase = verts + ((size_t)(row0 + 4 * half + rsh) * kV + v) * 3;
+                e.lane_has_ju = jslot >= 0;
+                e.tile_has_ju = __builtin_amdgcn_ballot_w64(e.lane_has_ju) != 0;
+                e.cj_row = d.n_ju * 3;
+                e.cj = cjv + ((size_t)(row0 + 4 * half + rsh) * d.n_ju + (jslot >= 0 ? jslot : 0)) * 3;
                 const char* lbase = (const char*)(sA + (4 * half + rsh) * kAtr);
 #pragma unroll
                 for (int el = 0; el < 32; ++el) {
@@ -454,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) { off[s] = noff[s]; w[s] = nw[s]; }
             }
+            jslot = njslot;
             tt = ntt;
             rh = nrh;
             ++kitem;
@@ -507,6 +534,24 @@ __global__ void k_joints(SmplDev d, const float* __restrict__ verts, int M, floa
     for (int e = d.jr_ptr[i]; e < d.jr_ptr[i + 1]; ++e) {
         const float w = d.jr_w[e];
         const float* p = vr + (size_t)d.jr_idx[e] * 3;
+        x = fmaf(w, p[0], x); y = fmaf(w, p[1], y); z = fmaf(w, p[2], z);
+    }
+    float* o = joints + ((size_t)row * kOutJ + kJ + i) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+// The same 66 joints from the compact (M, n_ju, 3) copy of the <= 276 vertices they touch, written by the skinning epilogue: the same fma chain
+// per joint as k_joints (bit-identical results), 3.3 KB per body instead of a gather over its 82.7 KB of vertices.
+__global__ void k_joints_compact(SmplDev d, const float* __restrict__ cjv, int M, float* __restrict__ joints) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nextra = kOutJ - kJ;
+    if (gid >= M * nextra) return;
+    const int row = gid / nextra, i = gid % nextra;
+    const float* vr = cjv + (size_t)row * d.n_ju * 3;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int e = d.jr_ptr[i]; e < d.jr_ptr[i + 1]; ++e) {
+        const float w = d.jr_w[e];
+        const float* p = vr + (size_t)d.jr_slot[e] * 3;
         x = fmaf(w, p[0], x); y = fmaf(w, p[1], y); z = fmaf(w, p[2], z);
     }
     float* o = joints + ((size_t)row * kOutJ + kJ + i) * 3;
@@ -587,7 +632,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // 1e-4 m of the fp32 oracle -- the north-star tolerance -- at 3/16 of the fp32 MFMA time: still bound by the vertex write.
 template <int SLOTS, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
-                                                     const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts) {
+                                                     const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts,
+                                                     float* __restrict__ cjv) {
     constexpr int kPanelF = kRowsPerWG * kP16Stride / 2;                     // floats of one bf16 panel
     __shared__ __attribute__((aligned(16))) float smem[(SPLIT ? 2 : 1) * kPanelF + kRowsPerWG * kAtr];   // 29 (+ 29) + 72 KB
     const unsigned short* sP = (const unsigned short*)smem;
@@ -702,6 +748,11 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
             e.full_rows = row0 + kRowsPerWG <= M;
             e.row_lim = M - row0 - 4 * half;
             e.obase = verts + ((size_t)(row0 + 4 * half) * kV + v) * 3;
+            const int jslot = cjv ? d.ju_slot[vt * 32 + l31] : -1;
+            e.lane_has_ju = jslot >= 0;
+            e.tile_has_ju = __builtin_amdgcn_ballot_w64(e.lane_has_ju) != 0;
+            e.cj_row = d.n_ju * 3;
+            e.cj = cjv + ((size_t)(row0 + 4 * half) * d.n_ju + (jslot >= 0 ? jslot : 0)) * 3;
             const char* lbase = (const char*)(sA + 4 * half * kAtr);
 #pragma unroll
             for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
@@ -989,6 +1040,9 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
         }
         if ((int)ju_vid.size() > kMaxJU) return fail(HMF_ERR_UNSUPPORTED, "hmf_smpl_create: %zu vertices feed the gathered joints (> %d)", ju_vid.size(), kMaxJU);
     }
+    std::vector<int> ju_slot((size_t)kVT * 32, -1), jr_slot(idx.size());
+    for (size_t u = 0; u < ju_vid.size(); ++u) ju_slot[ju_vid[u]] = (int)u;
+    for (size_t e = 0; e < idx.size(); ++e) jr_slot[e] = ju_slot[idx[e]];
     // --- T-pose basis [nb][3V] -----------------------------------------------------------------------
     std::vector<float> tpd((size_t)nb * kV * 3);
     for (int v = 0; v < kV; ++v)
@@ -1008,6 +1062,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     const size_t o_idx = place(idx.size() * 4), o_w = place(wts.size() * 4), o_tpd = place(tpd.size() * 4);
     const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2), o_b16l = place(blend16l.size() * 2);
     const size_t o_jv = place(ju_vid.size() * 4 + 4), o_jp = place(ju_ptr.size() * 4), o_jo = place(ju_out.size() * 4 + 4), o_jw = place(ju_w.size() * 4 + 4);
+    const size_t o_jsl = place(ju_slot.size() * 4), o_jrs = place(jr_slot.size() * 4 + 4);
     void* arena = nullptr;
     HMF_HIP(hipMalloc(&arena, off));
     char* base = (char*)arena;
@@ -1028,6 +1083,8 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     if (e == hipSuccess) e = up(o_jp, ju_ptr.data(), ju_ptr.size() * 4);
     if (e == hipSuccess && !ju_out.empty()) e = up(o_jo, ju_out.data(), ju_out.size() * 4);
     if (e == hipSuccess && !ju_w.empty()) e = up(o_jw, ju_w.data(), ju_w.size() * 4);
+    if (e == hipSuccess) e = up(o_jsl, ju_slot.data(), ju_slot.size() * 4);
+    if (e == hipSuccess && !jr_slot.empty()) e = up(o_jrs, jr_slot.data(), jr_slot.size() * 4);
     if (e != hipSuccess) {
         (void)hipFree(arena);
         return fail(HMF_ERR_HIP, "hmf_smpl_create: upload failed: %s", hipGetErrorString(e));
@@ -1060,6 +1117,8 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     d.ju_ptr = (int*)(base + o_jp);
     d.ju_out = (int*)(base + o_jo);
     d.ju_w = (float*)(base + o_jw);
+    d.ju_slot = (int*)(base + o_jsl);
+    d.jr_slot = (int*)(base + o_jrs);
     *out = h;
     return HMF_OK;
 }
@@ -1073,7 +1132,8 @@ void hmf_smpl_destroy(hmf_smpl_t* h) {
 static size_t ws_atr_bytes(int M) { return align_up((size_t)std::max(M, 1) * kAtr * sizeof(float), 256); }
 static size_t ws_panel_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kKpad * 64 * sizeof(float); }
 static size_t ws_panel16_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kRowsPerWG * kP16Stride * 2; }
-size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + 2 * ws_panel16_bytes(M); }
+static size_t ws_cj_bytes(int M) { return align_up((size_t)std::max(M, 1) * kMaxJU * 3 * sizeof(float), 256); }
+size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + 2 * ws_panel16_bytes(M) + ws_cj_bytes(M); }
 
 static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg, int gN, const float* body_pose, const float* betas,
                          int Mb, int M, float* verts, float* joints, float* full_pose, void* workspace, size_t workspace_bytes, int impl,
@@ -1092,6 +1152,7 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
     float* panel = (float*)((char*)workspace + ws_atr_bytes(M));
     unsigned short* panel16 = (unsigned short*)((char*)workspace + ws_atr_bytes(M) + ws_panel_bytes(M));
     unsigned short* panel16_lo = (unsigned short*)((char*)panel16 + ws_panel16_bytes(M));
+    float* cjv = (joints && (impl & 15) != 1) ? (float*)((char*)panel16_lo + ws_panel16_bytes(M)) : nullptr;      // the scalar cross-check kernel keeps k_joints
     const bool split = (impl & 15) == 3;
     const bool bf16 = (impl & 15) == 2 || split;
     const int nrg_all = (M + kRowsPerWG - 1) / kRowsPerWG;
@@ -1114,8 +1175,8 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
         const dim3 grid(8 * wpx), block(512);
 #define HMF_LBS16(S)                                                                                                                       \
     do {                                                                                                                                   \
-        if (split) hipLaunchKernelGGL((k_lbs_mfma16<S, true>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts);     \
-        else hipLaunchKernelGGL((k_lbs_mfma16<S, false>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts);          \
+        if (split) hipLaunchKernelGGL((k_lbs_mfma16<S, true>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv);     \
+        else hipLaunchKernelGGL((k_lbs_mfma16<S, false>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv);          \
     } while (0)
         if (h->d.skin_slots == 4) HMF_LBS16(4);
         else if (h->d.skin_slots == 8) HMF_LBS16(8);
@@ -1128,13 +1189,18 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
         int wpx = (T + 7) / 8;                      // at least one tile per wave
         wpx = std::max(1, std::min(32, wpx));       // 32 CUs per XCD
         const dim3 grid(8 * wpx), block(512);
-#define HMF_LBS(S, ABL) hipLaunchKernelGGL((k_lbs_mfma<S, ABL>), grid, block, 0, st, h->d, M, nrg, wpx, panel, atr, verts, g_lbs_cycles)
+#define HMF_LBS(S, ABL) hipLaunchKernelGGL((k_lbs_mfma<S, ABL>), grid, block, 0, st, h->d, M, nrg, wpx, panel, atr, verts, g_lbs_cycles, lbs_cjv)
+        float* lbs_cjv = cjv;
+#ifdef HMF_EXPERIMENTS
+        if ((impl >> 4) & 16) lbs_cjv = nullptr;            // timing: no compact joint-vertex stores in the epilogue (joints are then stale)
+#endif
         if (h->d.skin_slots == 4) {
 #ifdef HMF_EXPERIMENTS
             switch (impl >> 4) {          // impl = 16 * ABL: ablation variants for tools/lbs_tune.py; 0 = product kernel
                 case 1: HMF_LBS(4, 1); break;        // no skinning epilogue
                 case 3: HMF_LBS(4, 3); break;        // ... and no B-operand stream
                 case 7: HMF_LBS(4, 7); break;        // ... and no A-operand LDS reads: bare MFMA loop
+                case 8: case 24: HMF_LBS(4, 8); break;   // non-temporal staging loads of the panel + transforms (rejected)
                 default: HMF_LBS(4, 0); break;
             }
 #else
@@ -1151,7 +1217,8 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
     if (joints) {
         const int n = M * (kOutJ - kJ);
         ProfScope ps(3, M, st);
-        hipLaunchKernelGGL(k_joints, dim3((n + 255) / 256), dim3(256), 0, st, h->d, verts, M, joints);
+        if (cjv) hipLaunchKernelGGL(k_joints_compact, dim3((n + 255) / 256), dim3(256), 0, st, h->d, cjv, M, joints);
+        else hipLaunchKernelGGL(k_joints, dim3((n + 255) / 256), dim3(256), 0, st, h->d, verts, M, joints);
         HMF_LAUNCH_CHECK();
     }
     return HMF_OK;

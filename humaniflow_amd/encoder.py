@@ -378,29 +378,35 @@ class ResNetEncoder(nn.Module):
         p = self._plan
         with torch.cuda.device(x.device):
             x = self._stem_hip(x.float().contiguous(), p['stem_packed'], p['stem'][1])
-            pre = None                                   # the block's first 1x1 stage, when the previous seam launch already produced it
-            nblk = len(p['blocks'])
-            for i, (stages, ds, dual) in enumerate(p['blocks']):
-                h = x if pre is None else pre
-                for w, b, s, pad in stages[(0 if pre is None else 1):-1]:
-                    h = self._conv_hip(h, w, b, s[0], None, True)
-                pre = None
-                pk = p['pair'].get(i)
-                if pk is not None and (h.shape[0] * h.shape[2] * h.shape[3]) % 64 == 0:
-                    nb1 = p['blocks'][i + 1][0][0][1]
-                    x, pre = self._conv_pair(h, x if dual is not None else None, None if dual is not None else x, pk, stages[-1][1], nb1)
-                elif dual is not None:
-                    x = self._conv_dual(h, x, dual[0], dual[1], dual[2])
-                else:
-                    idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
-                    w, b, s, pad = stages[-1]
-                    x = self._conv_hip(h, w, b, s[0], idt, True, pool=(i == nblk - 1))       # the last convolution also pools (:214-215)
+            x, _ = self._run_blocks(p, x, None, 0, len(p['blocks']))
             if x.dim() == 4:                                 # a plan whose last block ended in a fused launch: pool the map
                 B, C, H, W = x.shape
                 feats = torch.empty((B, C), device=x.device, dtype=torch.float32)
                 _lib.check(_lib.load().hmf_avgpool_nhwc(x.data_ptr(), B, H * W, C, feats.data_ptr(), _lib.current_stream()), 'hmf_avgpool_nhwc')
                 x = feats
             return x
+
+    def _run_blocks(self, p, x, pre, i0, i1):
+        """Residual blocks i0 .. i1-1 of the plan on x; `pre` = the first block's first 1x1 stage when a seam launch already produced it.
+        Returns (x, pre) in the same sense for block i1."""
+        nblk = len(p['blocks'])
+        for i in range(i0, i1):
+            stages, ds, dual = p['blocks'][i]
+            h = x if pre is None else pre
+            for w, b, s, pad in stages[(0 if pre is None else 1):-1]:
+                h = self._conv_hip(h, w, b, s[0], None, True)
+            pre = None
+            pk = p['pair'].get(i)
+            if pk is not None and (h.shape[0] * h.shape[2] * h.shape[3]) % 64 == 0:
+                nb1 = p['blocks'][i + 1][0][0][1]
+                x, pre = self._conv_pair(h, x if dual is not None else None, None if dual is not None else x, pk, stages[-1][1], nb1)
+            elif dual is not None:
+                x = self._conv_dual(h, x, dual[0], dual[1], dual[2])
+            else:
+                idt = x if ds is None else self._conv_hip(x, ds[0], None, ds[2][0], None, False)
+                w, b, s, pad = stages[-1]
+                x = self._conv_hip(h, w, b, s[0], idt, True, pool=(i == nblk - 1))       # the last convolution also pools (:214-215)
+        return x, pre
 
     def _stem_packed_from_device(self, w):
         """The stem kernel's packed filter operand from the live (64, 18, 7, 7) parameter without leaving the device: the host packer is a
@@ -417,8 +423,6 @@ class ResNetEncoder(nn.Module):
             m = self.__dict__['_stem_map'] = ((pm.clamp(min=1) - 1).to(w.device), (pm > 0).float().to(w.device))
         return w.reshape(-1).float()[m[0]] * m[1]
 
-    allow_module_fallback = False   # opt-in: the modes without a hand-written path (below) run forward_module() -- the plain nn.Module graph on ATen
-
     def forward(self, x):
         from . import _lib
         _lib.require_cuda(x, 'input')
@@ -432,13 +436,11 @@ class ResNetEncoder(nn.Module):
         # remaining combinations (train() without gradients, eval() with gradients = frozen statistics under autograd, gradients w.r.t. the
         # input) have no hand-written path and there is no vendor-library path in the product: fail loudly.  (`forward_module` is the plain
         # nn.Module graph; tests call it explicitly as the float64 reference.)
-        if self.allow_module_fallback:
-            return self.forward_module(x)
         raise NotImplementedError(
             'humaniflow_amd: ResNetEncoder.forward is built for inference (eval() under torch.no_grad()) and for the training step (train() with '
             'gradients w.r.t. the parameters, 18-channel input that does not require grad); got training=%s, grad=%s, input.requires_grad=%s, '
             'in_channels=%d.  Wrap inference in torch.no_grad(); for eval() under autograd (frozen BatchNorm fine-tuning, gradients w.r.t. the '
-            'input) call enc.forward_module(x) or set enc.allow_module_fallback = True (plain nn.Module graph on ATen, not the library kernels)'
+            'input) call `forward_module` on the encoder explicitly (the plain nn.Module graph on ATen: not the library kernels, never chosen silently)'
             % (self.training, wants_grad, x.requires_grad, self.conv1.in_channels))
 
 

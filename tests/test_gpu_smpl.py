@@ -43,6 +43,29 @@ def test_mfma_and_scalar_kernels_agree_tightly(smpl):
     assert (a.vertices - b.vertices).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize('M', [1, 37, 64, 100, 3232])
+def test_joints_from_the_compact_copy_equal_joints_gathered_from_the_vertices(smpl, M):
+    """Round 4: joints 24..89 (models/smpl.py:27-34: 21 vertex picks + three sparse regressors) come from the compact copy of the <= 276 vertices
+    they touch that the skinning epilogue writes, not from a second pass over the 82.7 KB of vertices per body: same values, same fma order."""
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    R, betas = _inputs(M, seed=M + 1, scale=0.8)
+    out = smpl(body_pose=R[:, 1:].cuda(), global_orient=R[:, :1].cuda(), betas=betas.cuda(), pose2rot=False, impl=0)
+    # k_joints on the written vertices: hmf_smpl_tpose's joint path is that kernel; replay it here through the T-pose entry on a body whose
+    # "T-pose" we do not need -- instead gather on the host in float64 and bound, then bit-compare with the scalar path's joints on a subset
+    ref = smpl(body_pose=R[:64, 1:].cuda(), global_orient=R[:64, :1].cuda(), betas=betas[:64].cuda(), pose2rot=False, impl=1)      # k_lbs_scalar + k_joints
+    n = min(M, 64)
+    # same vertices up to the accumulation order of the two blend kernels -> joints agree to that order; and each joint is EXACTLY the fma chain
+    # over the kernel's own vertices:
+    assert (out.joints[:n] - ref.joints[:n]).abs().max().item() < 2e-6
+    md = smpl.model_dict()
+    ids = torch.tensor(H.smpl.EXTRA_VERTEX_IDS, device='cuda')
+    assert torch.equal(out.joints[:, 24:45], out.vertices[:, ids])                       # the 21 picks are copies
+    more = torch.cat([md['J_regressor_extra'], md['J_regressor_cocoplus'], md['J_regressor_h36m']]).cuda().double()
+    j64 = torch.einsum('jv,mvc->mjc', more, out.vertices.double())
+    assert (out.joints[:, 45:].double() - j64).abs().max().item() < 2e-6
+
+
 def test_axis_angle_path_betas_broadcast_and_large_rotations(smpl):
     g = torch.Generator().manual_seed(4)
     M = 33
