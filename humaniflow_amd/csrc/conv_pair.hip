@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 
     // W1 fragments of a chunk: all 8 k-groups in registers for N2 <= 128; for N2 = 256 (four 32-channel tiles per wave: 64 accumulator registers)
     // they stream through a two-stage ring, one k-group ahead
-    constexpr bool kRing1 = TN2 > 2;
+    constexpr bool kRing1 = (TN2 > 1 && OCC > 2) || TN2 > 2;      // N2 = 128 at three work-groups per CU: the ring frees 48 registers
     f32x4 b3[G3], b1[TN2][kRing1 ? 2 : 8];
     f32x4 rva[4], rvb[4];
     auto load_b3 = [&](int c) {
@@ -279,7 +279,7 @@ extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_p
     ProfScope ps(8, (int)M, st);               // booked with the 1x1 family (it replaces two of its launches)
     if (variant == 0) {
         if (Kt == 64 && N2 == 64) hipLaunchKernelGGL((k_conv_pair<64, 64, 3>), dim3(grid), dim3(256), 0, st, a);
-        else if (Kt == 64 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<64, 128, 2>), dim3(grid), dim3(256), 0, st, a);
+        else if (Kt == 64 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<64, 128, 3>), dim3(grid), dim3(256), 0, st, a);
         else if (Kt == 128 && N2 == 64) hipLaunchKernelGGL((k_conv_pair<128, 64, 2>), dim3(grid), dim3(256), 0, st, a);
         else if (Kt == 128 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<128, 128, 2>), dim3(grid), dim3(256), 0, st, a);
         else if (Kt == 64 && N2 == 256) hipLaunchKernelGGL((k_conv_pair<64, 256, 2>), dim3(grid), dim3(256), 0, st, a);

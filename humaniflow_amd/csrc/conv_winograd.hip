@@ -281,6 +281,222 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #endif
 }
 
+
+#ifdef HMF_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Round 4 EXPERIMENT (measured, not faster: see the dispatch comment in conv_winograd_impl): the same convolution with the patch fetch taken off the critical path.  Stamps (tools/wino_probe.py) show a work-group of
+// k_conv_winograd as  first patch 6-11 k cycles | per slab: global fetch + two barriers, then 8 k-groups of MFMAs | output 2.5-6 k:  every
+// slab's global -> register -> LDS copy is exposed (only co-resident work-groups hide it), and on the one-slab layers (layer1 / layer2) the
+// first fetch is a third of the work-group's life.  Here a work-group walks a list of STAGES = (pixel tile, slab), TPW tiles per work-group,
+// and the patch of stage i + 1 is requested WHILE stage i's MFMAs issue: one or two 16-byte loads per k-group, placed after that group's weight
+// loads so that the counted vmcnt wait for the weights does not cover them (vmcnt retires in order: a patch load issued BEFORE a weight load
+// would stall the next k-group on HBM latency).  The data waits in registers until the MFMA loop is done, then goes to LDS between two barriers.
+// Same arithmetic, same k order, same output transform as k_conv_winograd: bitwise the same results.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+template <int NIMG, int PIPE, int OCC, int TPW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_winograd_pf(const WinoArgs a, const int ptiles) {
+    constexpr int kWPW = NIMG == 1 ? kWTW + 2 : 20, kWRP = NIMG == 1 ? (kWPW * kWCS + 8) : (kWPW * kWCS + 24);
+    constexpr int NV = kWPH * kWPW * (kWSC / 4), NIT = (NV + 255) / 256;
+    __shared__ float lds[kWPH * kWRP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lq = lane >> 5;
+
+    const int T = gridDim.x;
+    int L = blockIdx.x;
+    if ((T & 7) == 0) L = (blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    const int nt = L % a.n_tiles, pt0 = (L / a.n_tiles) * TPW;
+    const int ntl = min(TPW, ptiles - pt0);                     // pixel tiles of this work-group
+    const int nslab = a.Cin / kWSC, nstage = ntl * nslab;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.H * a.W * a.Cin * 4, 0x00020000);
+    constexpr int kOOB = (int)0x80000000;
+    // patch element k of this thread: LDS offset (tile-invariant) and global offset (per tile)
+    int loff[NIT], goff[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int e = tid + 256 * k;
+        const int p = e / (kWSC / 4), c4 = e - p * (kWSC / 4);
+        const int r = p / kWPW, col = p - r * kWPW;
+        const int img = NIMG == 1 ? 0 : col / 10;
+        const int cl = col - img * 10;
+        loff[k] = r * kWRP + (NIMG == 1 ? (col & 1) * 9 + (col >> 1) : img * 10 + (cl & 1) * 5 + (cl >> 1)) * kWCS + 4 * c4;
+    }
+    auto tile_geom = [&](int pt, int& b, int& oh0, int& ow0) {
+        b = (pt / a.tiles_hw) * NIMG;
+        const int trem = pt - (pt / a.tiles_hw) * a.tiles_hw;
+        oh0 = (trem / a.tiles_w) * kWTH;
+        ow0 = NIMG == 1 ? (trem % a.tiles_w) * kWTW : 0;
+    };
+    auto tile_goff = [&](int pt) {
+        int b, oh0, ow0;
+        tile_geom(pt, b, oh0, ow0);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + 256 * k;
+            const int p = e / (kWSC / 4), c4 = e - p * (kWSC / 4);
+            const int r = p / kWPW, col = p - r * kWPW;
+            const int img = NIMG == 1 ? 0 : col / 10;
+            const int ih = oh0 + r - 1, iw = NIMG == 1 ? ow0 + col - 1 : col - img * 10 - 1;
+            const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (b + img < a.B);
+            goff[k] = ok ? ((((b + img) * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
+        }
+    };
+    f32x4 pv[NIT];
+    auto fetch = [&](int k, int slab) {
+        pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, goff[k] == kOOB ? kOOB : goff[k] + slab * kWSC * 4, 0, 0));
+    };
+
+    // weight stream of this wave: [n-tile][wave xi][slab][g][nu][lane][4]
+    const f32x4* wbase = a.wp + (long long)(nt * 4 + wave) * nslab * kWNG * 4 * 64 + lane;
+    const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1), a2 = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float sg = wave == 1 ? 1.f : -1.f;
+    auto row_tile = [](int i) {
+        return NIMG == 1 ? i : (i & ~4) | ((((i >> 2) ^ (((i >> 3) + 1) >> 1)) & 1) << 2);
+    };
+    const int tl = row_tile(li);
+    const int ti = tl >> 3, tj = tl & 7;
+    const float* pbase = lds + (2 * ti) * kWRP + (NIMG == 1 ? tj : (tj >> 2) * 10 + (tj & 3)) * kWCS + 4 * lq;
+    const float* p1 = pbase + a1 * kWRP;
+    const float* p2 = pbase + a2 * kWRP;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    f32x4 bw[2][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bw[0][n] = wbase[n * 64];
+
+    // first stage's patch
+    tile_goff(pt0);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) fetch(k, 0);
+
+    // output-phase constants
+    const int otile = tid >> 3, oq = tid & 7;
+    const int otl = row_tile(otile);
+    constexpr int kOOBo = (int)0x80000000;
+    const int ybytes = a.B * a.H * a.W * a.Cout * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.y), 0, ybytes, 0x00020000);
+    const float lo = a.relu ? 0.f : -INFINITY;
+    const int n_out = nt * 32 + 4 * oq;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *(const f32x4*)(a.bias + n_out);
+
+    int stage = 0;
+    for (int k_tile = 0; k_tile < ntl; ++k_tile) {
+        for (int s = 0; s < nslab; ++s, ++stage) {
+            if (stage) __syncthreads();                  // the previous stage's readers (MFMA operands or the output exchange) are done with the LDS buffer
+#pragma unroll
+            for (int k = 0; k < NIT; ++k)
+                if (NV % 256 == 0 || k < NIT - 1 || tid + 256 * k < NV) *(f32x4*)&lds[loff[k]] = pv[k];
+            __syncthreads();
+            const bool has_next = stage + 1 < nstage;
+            const bool next_new_tile = s + 1 == nslab;
+            const int ns = next_new_tile ? 0 : s + 1;
+            if (has_next && next_new_tile) tile_goff(pt0 + k_tile + 1);
+
+            auto xform = [&](int g, f32x4 (&v)[4]) {
+                f32x4 t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int co = ((c & 1) * (NIMG == 1 ? 9 : 5) + (c >> 1)) * kWCS;
+                    const f32x4 d1 = *(const f32x4*)(p1 + co + 8 * g);
+                    const f32x4 d2 = *(const f32x4*)(p2 + co + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sg, d2[e], d1[e]);
+                }
+                v[0] = t[0] - t[2];
+                v[1] = t[1] + t[2];
+                v[2] = t[2] - t[1];
+                v[3] = t[1] - t[3];
+            };
+            f32x4 v[2][4];
+            if (PIPE) xform(0, v[0]);
+            const f32x4* ws = wbase + (long long)s * kWNG * 4 * 64;
+            const f32x4* wn = wbase + (long long)ns * kWNG * 4 * 64;
+#pragma clang loop unroll(full)
+            for (int g = 0; g < kWNG; ++g) {
+                if (g + 1 < kWNG) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bw[(g + 1) & 1][n] = ws[((g + 1) * 4 + n) * 64];
+                } else if (has_next) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bw[(g + 1) & 1][n] = wn[n * 64];
+                }
+                // next stage's patch: NIT requests spread over the first k-groups, AFTER this group's weight requests
+                if (has_next) {
+                    constexpr int PER = (NIT + 5) / 6;           // 2 per group for NIT = 12 / 13: done by group 5 or 6
+#pragma unroll
+                    for (int k = g * PER; k < (g + 1) * PER && k < NIT; ++k) fetch(k, ns);
+                }
+                if (PIPE) {
+                    if (g + 1 < kWNG) xform(g + 1, v[(g + 1) & 1]);
+                } else {
+                    xform(g, v[g & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[g & 1][n][u], bw[g & 1][n][u], acc[n], 0, 0, 0);
+                if (!PIPE) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- output transform of this pixel tile (as k_conv_winograd) ----
+        int b, oh0, ow0;
+        tile_geom(pt0 + k_tile, b, oh0, ow0);
+        const int oh = oh0 + 2 * (otl >> 3), ow = NIMG == 1 ? ow0 + 2 * (otl & 7) : 2 * (otl & 3);
+        const int bi = b + (NIMG == 1 ? 0 : (otl >> 2) & 1);
+        int off[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                off[dy][dx] = (oh + dy < a.H && ow + dx < a.W && bi < a.B) ? ((((bi * a.H + oh + dy) * a.W + ow + dx) * a.Cout) + n_out) * 4 : kOOBo;
+        f32x4 rv[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                rv[dy][dx] = a.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[dy][dx], 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tile = (r & 3) + 8 * (r >> 2) + 4 * lq;
+            const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+            lds[((wave * 2 + 0) * 32 + tile) * 32 + li] = m0 + m1 + m2;
+            lds[((wave * 2 + 1) * 32 + tile) * 32 + li] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        __syncthreads();
+        f32x4 pm[4][2];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) pm[xi][dx] = *(const f32x4*)&lds[((xi * 2 + dx) * 32 + otile) * 32 + 4 * oq];
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            f32x4 y0 = pm[0][dx] + pm[1][dx] + pm[2][dx] + bv + rv[0][dx];
+            f32x4 y1 = pm[1][dx] - pm[2][dx] - pm[3][dx] + bv + rv[1][dx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y0[e] = fmaxf(y0[e], lo);
+                y1[e] = fmaxf(y1[e], lo);
+            }
+            typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y0), ry, off[0][dx], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y1), ry, off[1][dx], 0, 0);
+        }
+    }
+}
+#endif  // HMF_EXPERIMENTS
+
 }  // namespace hmf
 
 using namespace hmf;
@@ -422,16 +638,36 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
         if (pair) hipLaunchKernelGGL((k_conv_winograd<1, 2, MODE, PIPE, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((k_conv_winograd<1, 1, MODE, PIPE, OCC>), dim3((unsigned)blocks), dim3(256), 0, st, a);    \
     } while (0)
+#ifdef HMF_EXPERIMENTS
+    const int ptiles = (pair ? (B + 1) / 2 : B) * a.tiles_hw;
+#endif
+#define HMF_WINO_PF(NIMG, PIPE, OCC, TPW)                                                                                                     \
+    hipLaunchKernelGGL((k_conv_winograd_pf<NIMG, PIPE, OCC, TPW>), dim3((unsigned)(((ptiles + TPW - 1) / TPW) * a.n_tiles)), dim3(256), 0, st, a, ptiles)
     switch (variant) {
         case 0:
             // Measured round-robin, median of 7 (tools/winograd_ablate.py, B = 32): with one or two 64-channel slabs (layer1 / layer2) a work-group is
             // mostly its first patch fetch and its output phase, so a third work-group per CU and the transform of group g + 1 issued under the MFMAs of
             // group g pay (52.4 -> 47.7 us, 51.3 -> 44.6 us); with 4+ slabs they do not (layer3 43.2 vs 44.3 us) and on 8-pixel maps (one wave per
             // SIMD) the pipelined transform loses outright (49.3 vs 62.7 us).
+            // Round 4, measured and rejected (tools/winograd_ablate.py --pf; bitwise the same results): the stage-pipelined k_conv_winograd_pf -- the next
+            // slab's / next pixel tile's patch requested under the current MFMA loop -- is no faster where it fits the register file (layer3 45.2 vs 45.5 us,
+            // layer4 52.5 vs 51.1, layer1 at two waves per SIMD 49.6 vs 47.0) and spills at three waves per SIMD (+48 prefetch registers on 163): the
+            // co-resident work-groups already hide the fetch; the kernel stays in the experiments build.
             if (!pair && Cin <= 128) hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 1, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a);
             else HMF_WINO_LAUNCH(0, 0, 2);
             break;
 #ifdef HMF_EXPERIMENTS
+        case 300:           // = the product dispatch, for A/B against the stage-pipelined kernel
+            if (!pair && Cin <= 128) hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 1, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else HMF_WINO_LAUNCH(0, 0, 2);
+            break;
+        case 301: if (pair) HMF_WINO_PF(2, 0, 2, 1); else if (Cin <= 128) HMF_WINO_PF(1, 1, 3, 2); else HMF_WINO_PF(1, 0, 2, 1); break;
+        case 311: if (pair) HMF_WINO_PF(2, 0, 2, 1); else HMF_WINO_PF(1, 1, 3, 1); break;      // stage-pipelined variants: PIPE / OCC / tiles per work-group
+        case 312: if (pair) HMF_WINO_PF(2, 0, 2, 2); else HMF_WINO_PF(1, 1, 3, 2); break;
+        case 314: if (pair) HMF_WINO_PF(2, 0, 2, 2); else HMF_WINO_PF(1, 1, 3, 4); break;
+        case 321: if (pair) HMF_WINO_PF(2, 0, 2, 1); else HMF_WINO_PF(1, 0, 2, 1); break;
+        case 322: if (pair) HMF_WINO_PF(2, 0, 2, 2); else HMF_WINO_PF(1, 0, 2, 2); break;
+        case 332: if (pair) HMF_WINO_PF(2, 1, 2, 2); else HMF_WINO_PF(1, 1, 2, 2); break;
         case 100: HMF_WINO_LAUNCH(0, 0, 2); break;          // tools: the round-2 configuration on every shape
         case 1: HMF_WINO_LAUNCH(1, 0, 2); break;       // 1..3, 10.., 20..: tools/winograd_ablate.py only
         case 2: HMF_WINO_LAUNCH(2, 0, 2); break;
@@ -455,6 +691,7 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
         default: return fail(HMF_ERR_INVALID, "hmf_conv_winograd_variant: unknown variant %d", variant);
     }
 #undef HMF_WINO_LAUNCH
+#undef HMF_WINO_PF
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -32,6 +32,12 @@ struct PartTab {
     int o_wctxT;           // [(256 + 9a)][64]  natural transposed, for the teacher-forced kernels
     int o_nnT[2][4];       // [K][N] transposed hyper-network layers
     int o_nnb[2][4];
+    // ---- round 4: the same layers packed for 16-row tiles on v_mfma_f32_16x16x4_f32 (k_flow_chain16, "ARL16" below) ----
+    int kas16, kag16;      // ancestor k-steps ceil(9a/4) and float4 groups ceil(kas16/4)
+    int o16_wa;            // ancestor half of the context layer: [4 tiles][kag16][64][4]
+    int o16_w1, o16_w1e;   // first hyper-net layer of both couplings [8 tiles][4][64][4]; extra k-step [8][64]: (x1 column | bias | 0 | 0)
+    int o16_w2[2], o16_w3[2], o16_w4[2];     // [2][4][64][4], [2][2][64][4], [4][2][64][4]
+    int o16_we[2];         // bias k-steps of layers 2 (2 tiles), 3 (2 tiles), 4 (4 tiles): [8][64], lane group 0 -> bias, others 0
 };
 constexpr int kPartTabInts = sizeof(PartTab) / sizeof(int);
 
@@ -73,6 +79,22 @@ struct GenDev {
 };
 
 __host__ __device__ inline int arl_channel(int t, int reg, int q) { return 32 * t + 8 * (reg >> 2) + 4 * q + (reg & 3); }
+
+// "ARL16": the same idea on v_mfma_f32_16x16x4_f32 for tiles of 16 sample rows (round 4: twice the work-groups, half the MFMA time per part).
+// D(16 out-channels x 16 rows) += A(16 x 4) . B(4 x 16 rows); lane (row = l & 15, g = l >> 4), register r of output tile t holds channel
+//        ch16(t, r, g) = 16 t + 4 g + r ,
+// and that register across the wave is the B operand of k-step s = 4 t + r of the next layer (k index within the step = g).
+__host__ __device__ inline int arl16_channel(int s, int g) { return 16 * (s >> 2) + 4 * g + (s & 3); }
+// Last hyper-network layer, 16-row form: output (tile t, A row i) lands in lane group g = i >> 2, register r = i & 3.  Lane groups 0, 1 hold the
+// spline parameters of coordinate 0, groups 2, 3 those of coordinate 1; within a coordinate the even group holds slot m = 4 t + r: widths [0,8),
+// heights [8,16), the odd group derivatives [0,7), pad 7, lambdas [8,16).  Returns the index into pyro's 62-vector (w 16 | h 16 | d 14 | l 16), -1 = pad.
+__host__ __device__ inline int spline_orig_index16(int t, int i) {
+    const int g = i >> 2, r = i & 3, q = g >> 1, m = 4 * t + r;
+    if ((g & 1) == 0) return m < 8 ? q * 8 + m : 16 + q * 8 + (m - 8);
+    if (m < 7) return 32 + q * 7 + m;
+    if (m == 7) return -1;
+    return 46 + q * 8 + (m - 8);
+}
 
 // packed spline-parameter channel -> index into pyro's 62-vector (w 16 | h 16 | d 14 | l 16), -1 = pad.
 // Lane q owns dimension q; its local slot m = 16 t + reg: [0,8) widths, [8,16) heights, [16,23) derivatives,

@@ -166,21 +166,23 @@ __device__ __forceinline__ void dense_layer_pf(const f32x4* __restrict__ wp, con
 // ---------------------------------------------------------------------------------------------------
 // k_flow_ctx0: image/shape half of every part's context layer.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kPartsPerWave0 = 3;
-constexpr int kGroups0 = (kP + kPartsPerWave0 - 1) / kPartsPerWave0;   // 8
+// PPW parts per wave, four waves per work-group.  PPW = 3 (two work-groups per 32-row tile: 808 waves at B = 32, N = 100) is the throughput form;
+// PPW = 1 (six work-groups per tile) the latency form for a handful of tiles (predict: one image, 11 rows -> 25 us instead of 49 us).  At full
+// size one part per wave loses, 65 us vs 52-59 us: every wave rebuilds h, 64 MFMAs + 128 ELUs, for a 256-MFMA layer (round 4, measured).
+constexpr int ctx0_groups(int ppw) { return ((kP + ppw - 1) / ppw + 3) / 4; }     // work-groups per tile
 
+template <int PPW>
 __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __restrict__ G, const float* __restrict__ shape_mode,
                                                       const float* __restrict__ shape_log_std, NoiseSrc ns,
                                                       int B, int N, int Mtot, int ntiles, int packed_rows,
                                                       float* __restrict__ shape_samples, float* __restrict__ C0) {
+    constexpr int kPartsPerWave0 = PPW, kGroups0 = ctx0_groups(PPW);
     const int lane = threadIdx.x & 63, l31 = lane & 31, q = lane >> 5;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int tile = gw / kGroups0, pg = gw % kGroups0;
-    if (tile >= ntiles) return;
+    const int tile = blockIdx.x / kGroups0, pg = (blockIdx.x % kGroups0) * 4 + (threadIdx.x >> 6);      // pg = the wave's part (>= kP: idle after the barrier)
     const int nb = d.nb;
     const RowInfo ri = row_info(tile * 32 + l31, B, N, Mtot);
     // shape vectors of the tile's 32 rows (models/humaniflow_model.py:250-258), computed ONCE per work-group: its four waves work on the same
-    // tile (gw = 4 * block + wave, 8 part groups per tile), so thread (wave, q) takes the elements i = 2 * wave + q (+ 8) of its lane's row
+    // tile (block = (tile, 4 consecutive parts)), so thread (wave, q) takes the elements i = 2 * wave + q (+ 8) of its lane's row
     // and the rows are exchanged through LDS (row pitch 17: conflict-free).  Round 3 kept `float beta[16]` per thread and indexed it with a
     // run-time bound, which the compiler turned into a 16 KB LDS array with a 64-byte lane stride: the 93.6 % LDS bank-conflict cycles of the
     // round-1..3 profiles.  With the noise drawn in the kernel a lane now also pays for 1-2 Philox blocks instead of 10.
@@ -245,13 +247,15 @@ __global__ __launch_bounds__(256, 1) void k_flow_ctx0(FlowDev d, const float* __
         f32x16 acc[2];
         bias_init<2>(d.arena + pt.o_bctx, q, acc);
         dense_layer_pf<2, 8, 6>((const f32x4*)(d.arena + pt.o_wc0) + lane, h, acc);
-        f32x4* out = (f32x4*)(C0 + (((size_t)tile * kP + j) * 2) * 64 * 16) + lane * 4;
+        // C0 is row-major [row][part][64 channels] (round 4: the 16-row chain kernel and the 32-row one read it through their own register
+        // layouts): register 4 g + r of tile t of lane (row, q) is channel 32 t + 8 g + 4 q + r
+        float* out = C0 + (((size_t)tile * 32 + l31) * kP + j) * kCtx + 4 * q;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                out[t * 64 * 4 + g] = v;
+                *(f32x4*)(out + 32 * t + 8 * g) = v;
             }
     }
 }
@@ -363,12 +367,12 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
             }
             f32x16 cx[2];                                   // context accumulators <- C0 (image/shape half, k_flow_ctx0)
             {
-                const f32x4* src = (const f32x4*)(C0 + (((size_t)tile * kP + j) * 2) * 64 * 16) + lane * 4;
+                const float* src = C0 + (((size_t)tile * 32 + l31) * kP + j) * kCtx + 4 * q;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = src[t * 64 * 4 + g];
+                        const f32x4 v = *(const f32x4*)(src + 32 * t + 8 * g);
                         cx[t][4 * g] = v[0]; cx[t][4 * g + 1] = v[1]; cx[t][4 * g + 2] = v[2]; cx[t][4 * g + 3] = v[3];
                     }
             }
@@ -508,6 +512,319 @@ __global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain(FlowDev d, c
             HMF_STAMP(7);
 #undef HMF_STAMP
         }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_flow_chain16 (round 4): the same kinematic loop on 16-row tiles and v_mfma_f32_16x16x4_f32 (flow_common.h "ARL16").  k_flow_chain ran 101
+// work-groups on 256 CUs at B = 32, N = 100, each a latency-bound stream of ~430 64-cycle MFMAs per part and round: half the rows per tile =
+// the same number of 32-cycle MFMAs = half the time per part, on 202 work-groups; a single image (predict: one tile either way) halves its
+// chain latency.  Lane (row j = l & 15, g = l >> 4).  Spline parameters of coordinate q sit in lane groups 2q (widths | heights) and 2q + 1
+// (derivatives | lambdas); the two halves of a spline evaluation meet through four cross-lane reads.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+struct TailRegs16 {
+    f32x4 w2[2][4], w3[2][2], w4[4][2];
+    float we[8];
+};
+__device__ __forceinline__ void tail_fetch16(const FlowDev& d, const PartTab& pt, int c, int lane, TailRegs16& t) {
+    const f32x4* p2 = (const f32x4*)(d.arena + pt.o16_w2[c]) + lane;
+    const f32x4* p3 = (const f32x4*)(d.arena + pt.o16_w3[c]) + lane;
+    const f32x4* p4 = (const f32x4*)(d.arena + pt.o16_w4[c]) + lane;
+    const float* pe = d.arena + pt.o16_we[c] + lane;
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.w2[to][i] = p2[(to * 4 + i) * 64];
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) t.w3[to][i] = p3[(to * 2 + i) * 64];
+#pragma unroll
+    for (int to = 0; to < 4; ++to)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) t.w4[to][i] = p4[(to * 2 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.we[i] = pe[i * 64];
+}
+
+// layers 2..4 of one coupling + the spline of this lane's coordinate; h1: the four ReLU'd tiles of layer 1; returns the transformed coordinate
+// (valid in the even lane group of the coordinate)
+__device__ __forceinline__ float tail_compute16(const TailRegs16& t, const f32x4 (&h1)[4], float x, float bound, float one_g0, int g) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a2[2] = {mfma16(t.we[0], one_g0, z), mfma16(t.we[1], one_g0, z)};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int to = 0; to < 2; ++to) a2[to] = mfma16(t.w2[to][s >> 2][s & 3], h1[s >> 2][s & 3], a2[to]);
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a2[to][e] = fmaxf(a2[to][e], 0.f);
+    f32x4 a3[2] = {mfma16(t.we[2], one_g0, z), mfma16(t.we[3], one_g0, z)};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int to = 0; to < 2; ++to) a3[to] = mfma16(t.w3[to][s >> 2][s & 3], a2[s >> 2][s & 3], a3[to]);
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a3[to][e] = fmaxf(a3[to][e], 0.f);
+    f32x4 a4[4] = {mfma16(t.we[4], one_g0, z), mfma16(t.we[5], one_g0, z), mfma16(t.we[6], one_g0, z), mfma16(t.we[7], one_g0, z)};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int to = 0; to < 4; ++to) a4[to] = mfma16(t.w4[to][s >> 2][s & 3], a3[s >> 2][s & 3], a4[to]);
+    // slots m = 4 t + r.  Even lane group: widths [0,8) | heights [8,16).  Odd group: derivatives [0,7) | pad | lambdas [8,16).
+    float p[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) p[m] = a4[m >> 2][m & 3];
+    // ---- role A (meaningful in the even group): knots and the bin of x  (spline_forward_fast, first half) ----
+    float w[8], h[8], cw[9], chh[9];
+    {
+        float mx = p[0], nx = p[8];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { mx = fmaxf(mx, p[i]); nx = fmaxf(nx, p[8 + i]); }
+        float sw = 0.f, sh = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w[i] = __expf(p[i] - mx); sw += w[i]; h[i] = __expf(p[8 + i] - nx); sh += h[i]; }
+        const float is = (1.0f - 1e-3f * 8) / sw, it = (1.0f - 1e-3f * 8) / sh;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w[i] = fmaf(w[i], is, 1e-3f); h[i] = fmaf(h[i], it, 1e-3f); }
+        float a = 0.f, b = 0.f;
+        cw[0] = -bound; chh[0] = -bound;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a += w[i]; b += h[i];
+            cw[i + 1] = fmaf(2.f * bound, a, -bound);
+            chh[i + 1] = fmaf(2.f * bound, b, -bound);
+        }
+        cw[8] = bound; chh[8] = bound;
+    }
+    int bin = -1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bin += (x >= cw[i] + 1e-6f) ? 1 : 0;
+    bin = min(max(bin, 0), 7);
+    float k_lo = cw[0], k_hi = cw[1], c_lo = chh[0], c_hi = chh[1];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const bool sel = bin == i;
+        k_lo = sel ? cw[i] : k_lo; k_hi = sel ? cw[i + 1] : k_hi; c_lo = sel ? chh[i] : c_lo; c_hi = sel ? chh[i + 1] : c_hi;
+    }
+    // ---- role B (meaningful in the odd group): the selected bin's raw derivatives and lambda, from the partner's bin ----
+    const int lane_id = (int)(threadIdx.x & 63);
+    const int pbin = __shfl(bin, lane_id ^ 16);
+    float lamr = p[8], rd0 = 0.f, rd1 = p[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const bool sel = pbin == i;
+        lamr = sel ? p[8 + i] : lamr; rd0 = sel ? p[i - 1] : rd0;
+        if (i < 7) rd1 = sel ? p[i] : rd1;
+    }
+    float in_d = pbin == 0 ? 1.0f - 1e-3f : 1e-3f + softplus1(rd0);
+    float in_d1 = pbin == 7 ? 1.0f - 1e-3f : 1e-3f + softplus1(rd1);
+    float lam = (1.f - 2.f * 0.025f) * sigmoid1(lamr) + 0.025f;
+    // back to the even group
+    in_d = __shfl(in_d, lane_id ^ 16); in_d1 = __shfl(in_d1, lane_id ^ 16); lam = __shfl(lam, lane_id ^ 16);
+    (void)g;
+    const float in_w = k_hi - k_lo, in_h = c_hi - c_lo;
+    const float delta = in_h / in_w;
+    const float wb = sqrtf(in_d / in_d1);
+    const float wc = (lam * in_d + (1.f - lam) * wb * in_d1) / delta;
+    const float ya = c_lo, yb = c_hi;
+    const float yc = ((1.f - lam) * ya + lam * wb * yb) / ((1.f - lam) + lam * wb);
+    const float th = (x - k_lo) / in_w;
+    const bool lo = th <= lam;
+    const float num = lo ? (ya * (lam - th) + wc * yc * th) : (wc * yc * (1.f - th) + wb * yb * (th - lam));
+    const float den = lo ? ((lam - th) + wc * th) : (wc * (1.f - th) + wb * (th - lam));
+    const bool inside = (x >= -bound) && (x <= bound);
+    return inside ? num / den : x;
+}
+
+__global__ __launch_bounds__(kChainWaves * 64, 1) void k_flow_chain16(FlowDev d, const float* __restrict__ C0, NoiseSrc ns, int B, int N, int Mtot,
+                                                                      float* __restrict__ rot_samples, float* __restrict__ rot_point,
+                                                                      float* __restrict__ so3_point, long long* __restrict__ timeline) {
+    __shared__ float sAnc[16 * kAncRow];
+    __shared__ int sOff[kP * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j16 = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x;
+    // The base samples z = base_std * eps of all 23 parts x 16 rows, once per work-group: 1,104 generator elements over 256 threads (4-5 Philox
+    // blocks + Box-Muller each) instead of 3 per lane and part inside the dependent rounds (timeline: ~2.4 k of a part's ~30 k cycles).
+    __shared__ float sZ[kP * 16 * 3];
+    for (int i = tid; i < 16 * kAncRow; i += kChainWaves * 64) sAnc[i] = 0.f;
+    for (int i = tid; i < kP * 64; i += kChainWaves * 64) sOff[i] = d.anc_off[i];
+    for (int i = tid; i < kP * 16 * 3; i += kChainWaves * 64) {
+        const int jp = i / 48, rem = i - jp * 48, rw = rem / 3, c = rem - rw * 3;
+        const RowInfo rr = row_info(tile * 16 + rw, B, N, Mtot);
+        float zv = 0.f;
+        if (rr.live && !rr.is_point) zv = pose_noise(ns, jp, (unsigned int)((rr.b * N + rr.n) * 3 + c), (unsigned long long)B * N * 3) * d.base_std;
+        sZ[i] = zv;
+    }
+    __syncthreads();
+    const int rowid = tile * 16 + j16;
+    const RowInfo ri = row_info(rowid, B, N, Mtot);
+    const float bound = d.radius;
+    const float one_g0 = g == 0 ? 1.f : 0.f;
+    float* myAnc = sAnc + j16 * kAncRow;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    // Global operands of a part's first stages: requested for the wave's part of round r + 1 BEFORE round r's tanh / exp / store phase and the
+    // round barrier (timeline: a round used to start with 6-8 k cycles of load issue + first-use latency; the registers are free by then).
+    f32x4 cx[4], wa[4][4], w1[8][4];
+    float w1e[8];
+    TailRegs16 tr0, tr1;
+    auto load_part = [&](int j) {
+        const PartTab& pt = d.tab[j];
+        const float* src = C0 + ((size_t)rowid * kP + j) * kCtx + 4 * g;     // context accumulators <- C0 (image/shape half, k_flow_ctx0): channel 16 t + 4 g + r
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cx[t] = *(const f32x4*)(src + 16 * t);
+        const int kag = pt.kag16;
+        const f32x4* wp = (const f32x4*)(d.arena + pt.o16_wa) + lane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                if (s4 < kag) wa[t][s4] = wp[(t * kag + s4) * 64];
+        const f32x4* w1p = (const f32x4*)(d.arena + pt.o16_w1) + lane;      // first layer of both couplings: 8 tiles x 16 k-steps
+#pragma unroll
+        for (int to = 0; to < 8; ++to)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w1[to][i] = w1p[(to * 4 + i) * 64];
+#pragma unroll
+        for (int to = 0; to < 8; ++to) w1e[to] = d.arena[pt.o16_w1e + to * 64 + lane];
+        tail_fetch16(d, pt, 0, lane, tr0);
+    };
+    auto part_of = [&](int lev, int& j) -> bool {
+        if (lev >= d.lev.nlev) return false;
+        const int pi = d.lev.start[lev] + wave;
+        if (pi >= d.lev.start[lev + 1]) return false;
+        j = d.lev.parts[pi];
+        return true;
+    };
+    int j = 0, jn = 0;
+    bool have = part_of(0, j);
+    if (have) load_part(j);
+
+    for (int lev = 0; lev < d.lev.nlev; ++lev) {
+        const bool have_n = part_of(lev + 1, jn);
+        if (have) {
+            const PartTab& pt = d.tab[j];
+            // diagnostic timeline (hmf_debug_set_timeline, experiments build): shader-clock stamps of tile 0's phases, 8 per part
+            long long* tl = (timeline && tile == 0 && lane == 0) ? timeline + j * 8 : nullptr;
+#define HMF_STAMP(i) do { if (tl) tl[i] = (long long)__builtin_readcyclecounter(); } while (0)
+            HMF_STAMP(0);
+            // ================= stage 0: ancestor entries 4 s + g of this lane's row (B operands of the ancestor half), base sample =================
+            float bv[16];
+            {
+                const int* off = sOff + j * 64 + g;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bv[s] = myAnc[off[4 * s]];
+            }
+            const int kag = pt.kag16;
+            // base sample z = base_std * eps; point-estimate rows push z = 0
+            const float x0 = sZ[(j * 16 + j16) * 3], x1 = sZ[(j * 16 + j16) * 3 + 1], x2 = sZ[(j * 16 + j16) * 3 + 2];
+            __builtin_amdgcn_sched_barrier(0);
+            HMF_STAMP(1);
+            // ================= stage 1: ancestor half of the context layer, ELU =================
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 < kag) {                                           // wave-uniform
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) cx[t] = mfma16(wa[t][s4][u], bv[s4 * 4 + u], cx[t]);
+                }
+            }
+            tail_fetch16(d, pt, 1, lane, tr1);
+            __builtin_amdgcn_sched_barrier(0);
+            HMF_STAMP(2);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cx[t][e] = elu_fast(cx[t][e]);
+            HMF_STAMP(3);
+            // ================= stage 2: first hyper-network layer of both couplings =================
+            // extra k-step: (x1 column | bias | 0 | 0) . (x0 | 1 | 0 | 0) for coupling 0 now; coupling 1's needs y0 and comes later
+            const float bx0 = g == 0 ? x0 : (g == 1 ? 1.f : 0.f);
+            f32x4 a1[8];
+#pragma unroll
+            for (int to = 0; to < 4; ++to) a1[to] = mfma16(w1e[to], bx0, z4);
+#pragma unroll
+            for (int to = 4; to < 8; ++to) a1[to] = z4;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int to = 0; to < 8; ++to) a1[to] = mfma16(w1[to][s >> 2][s & 3], cx[s >> 2][s & 3], a1[to]);
+            HMF_STAMP(4);
+            // ================= stage 3: coupling 0 (Permute [0,1,2]): x0 passes, the lane's coordinate x_{1 + (g >> 1)} is transformed =================
+            f32x4 h1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h1[t][e] = fmaxf(a1[t][e], 0.f);
+            const float xn = tail_compute16(tr0, h1, (g >> 1) ? x2 : x1, bound, one_g0, g);
+            const float x1n = __shfl(xn, j16), x2n = __shfl(xn, 32 + j16);
+            HMF_STAMP(5);
+            // ================= stage 4: coupling 1 (Permute [1,2,0]): y = (x1', x2', x0); y0 passes =================
+            const float y0 = x1n;
+            const float by0 = g == 0 ? y0 : (g == 1 ? 1.f : 0.f);
+#pragma unroll
+            for (int to = 4; to < 8; ++to) a1[to] = mfma16(w1e[to], by0, a1[to]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h1[t][e] = fmaxf(a1[4 + t][e], 0.f);
+            const float yn = tail_compute16(tr1, h1, (g >> 1) ? x0 : x2n, bound, one_g0, g);
+            const float y1 = __shfl(yn, j16), y2 = __shfl(yn, 32 + j16);
+            HMF_STAMP(6);
+            if (have_n) load_part(jn);                      // next round's operands: in flight during stage 5 and the barrier
+            // ================= stage 5: ScaledRadialTanh (scaled_radial_tanh_transform.py:28-35) + exp map =================
+            float v[3] = {y0, y1, y2};
+            {
+                const float nrm = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+                if (nrm > 1e-7f) {
+                    const float tt = tanhf(nrm / bound);
+                    v[0] = tt * (y0 / nrm) * bound; v[1] = tt * (y1 / nrm) * bound; v[2] = tt * (y2 / nrm) * bound;
+                }
+            }
+            if (g == 0) {
+                // fp64 Rodrigues rounded to fp32 for samples (:311), smplx Rodrigues for point rows (:299)
+                float R[9];
+                if (ri.is_point) {
+                    batch_rodrigues_f32(v, R);
+                } else {
+                    const double vd[3] = {(double)v[0], (double)v[1], (double)v[2]};
+                    double Rd[9];
+                    so3_exp_f64(vd, Rd);
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) R[e] = (float)Rd[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 9; ++e) myAnc[j * 9 + e] = R[e];
+                if (ri.live) {
+                    if (ri.is_point) {
+                        float* o = rot_point + ((size_t)ri.b * kP + j) * 9;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) o[e] = R[e];
+                        float* a = so3_point + ((size_t)ri.b * kP + j) * 3;
+                        a[0] = v[0]; a[1] = v[1]; a[2] = v[2];
+                    } else {
+                        float* o = rot_samples + ((size_t)rowid * kP + j) * 9;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) o[e] = R[e];
+                    }
+                }
+            }
+            HMF_STAMP(7);
+#undef HMF_STAMP
+        } else if (have_n) {
+            load_part(jn);
+        }
+        have = have_n;
+        j = jn;
         __syncthreads();
     }
 }
@@ -685,7 +1002,7 @@ static int n_tiles(int B, int N, int flags) { return ((B * N + ((flags & HMF_FLO
 size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int flags) {
     (void)h;
     const size_t g = align_up((size_t)std::max(B, 1) * kIsgc * 4, 256);
-    const size_t c0 = (size_t)std::max(n_tiles(B, N, flags), 1) * kP * 2 * 64 * 16 * 4;
+    const size_t c0 = (size_t)std::max(n_tiles(B, N, flags), 1) * 32 * kP * kCtx * 4;          // [rows padded to 32][part][64]
     return g + c0 + 256;                 // + the pass' RngPass snapshot
 }
 
@@ -753,16 +1070,23 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
         return generic_forward(h, G, shape_mode, shape_log_std, ns, B, N, Mtot, packed_rows, shape_samples, rotmats_samples, rotmats_point,
                                so3_point, st);
     {
-        const int nw = ntiles * kGroups0;
         ProfScope ps(5, Mtot, st);
-        hipLaunchKernelGGL(k_flow_ctx0, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, ns, B, N, Mtot,
-                           ntiles, packed_rows, shape_samples, C0);
+        if (ntiles <= 16)
+            hipLaunchKernelGGL(k_flow_ctx0<1>, dim3(ntiles * ctx0_groups(1)), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, ns, B, N, Mtot,
+                               ntiles, packed_rows, shape_samples, C0);
+        else
+            hipLaunchKernelGGL(k_flow_ctx0<3>, dim3(ntiles * ctx0_groups(3)), dim3(256), 0, st, h->d, G, shape_mode, shape_log_std, ns, B, N, Mtot,
+                               ntiles, packed_rows, shape_samples, C0);
         HMF_LAUNCH_CHECK();
     }
     {
         ProfScope ps(6, Mtot, st);
-        hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, ns, B, N, Mtot, rotmats_samples,
-                           rotmats_point, so3_point, g_timeline);
+        if (flags & HMF_FLOW_CHAIN32)           // the round-1..3 kernel: 32-row tiles on v_mfma_f32_32x32x2_f32 (cross-check; tools/flow_timeline.py)
+            hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, ns, B, N, Mtot, rotmats_samples,
+                               rotmats_point, so3_point, g_timeline);
+        else
+            hipLaunchKernelGGL(k_flow_chain16, dim3((Mtot + 15) / 16), dim3(kChainWaves * 64), 0, st, h->d, C0, ns, B, N, Mtot, rotmats_samples,
+                               rotmats_point, so3_point, g_timeline);
     }
     HMF_LAUNCH_CHECK();
     return HMF_OK;

@@ -185,6 +185,48 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
                 }
             }
         }
+        // ---- the same layers for 16-row tiles (flow_common.h "ARL16"): A operand lane = (i = lane & 15 out channel of the 16-tile, g = lane >> 4 the
+        // k index inside the step)
+        {
+            t.kas16 = (ka + 3) / 4;
+            t.kag16 = (t.kas16 + 3) / 4;
+            t.o16_wa = (int)pack_a(P, 4, t.kas16, [&](int tl, int s, int lane) {
+                const int k = 4 * s + (lane >> 4);
+                return k < ka ? wc[(size_t)(16 * tl + (lane & 15)) * kin + kIsgc + k] : 0.f;
+            });
+            t.o16_w1 = (int)pack_a(P, 8, 16, [&](int tl, int s, int lane) {
+                const float* W = wn[(tl >> 2) * 4 + 0];   // (64 x 65), input = [context(64), x1]
+                return W[(size_t)(16 * (tl & 3) + (lane & 15)) * 65 + arl16_channel(s, lane >> 4)];
+            });
+            t.o16_w1e = (int)P.place(8 * 64);
+            for (int tl = 0; tl < 8; ++tl)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int c = tl >> 2, n = 16 * (tl & 3) + (lane & 15), g = lane >> 4;
+                    P.buf[t.o16_w1e + tl * 64 + lane] = g == 0 ? wn[c * 4 + 0][(size_t)n * 65 + 64] : (g == 1 ? bn[c * 4 + 0][n] : 0.f);
+                }
+            for (int c = 0; c < 2; ++c) {
+                const float* W2 = wn[c * 4 + 1];   // (32 x 64)
+                const float* W3 = wn[c * 4 + 2];   // (32 x 32)
+                const float* W4 = wn[c * 4 + 3];   // (62 x 32)
+                t.o16_w2[c] = (int)pack_a(P, 2, 16, [&](int tl, int s, int lane) { return W2[(size_t)(16 * tl + (lane & 15)) * 64 + arl16_channel(s, lane >> 4)]; });
+                t.o16_w3[c] = (int)pack_a(P, 2, 8, [&](int tl, int s, int lane) { return W3[(size_t)(16 * tl + (lane & 15)) * 32 + arl16_channel(s, lane >> 4)]; });
+                t.o16_w4[c] = (int)pack_a(P, 4, 8, [&](int tl, int s, int lane) {
+                    const int o = spline_orig_index16(tl, lane & 15);
+                    return o < 0 ? 0.f : W4[(size_t)o * 32 + arl16_channel(s, lane >> 4)];
+                });
+                t.o16_we[c] = (int)P.place(8 * 64);
+                for (int lane = 0; lane < 16; ++lane) {                                   // lane group 0 carries the bias (B operand = 1 there, 0 elsewhere)
+                    for (int tl = 0; tl < 2; ++tl) {
+                        P.buf[t.o16_we[c] + (0 + tl) * 64 + lane] = bn[c * 4 + 1][16 * tl + lane];
+                        P.buf[t.o16_we[c] + (2 + tl) * 64 + lane] = bn[c * 4 + 2][16 * tl + lane];
+                    }
+                    for (int tl = 0; tl < 4; ++tl) {
+                        const int o = spline_orig_index16(tl, lane);
+                        P.buf[t.o16_we[c] + (4 + tl) * 64 + lane] = o < 0 ? 0.f : bn[c * 4 + 3][o];
+                    }
+                }
+            }
+        }
         // natural transposed copies of the hyper-networks for the teacher-forced / backward kernels (lane = output channel)
         static const int Kd[4] = {65, 64, 32, 32}, Nd[4] = {64, 32, 32, 62};
         for (int c = 0; c < 2; ++c)

@@ -18,7 +18,8 @@ Q = LANES >> 5
 D_ROW = (np.arange(16)[:, None] & 3) + 8 * (np.arange(16)[:, None] >> 2) + 4 * Q[None, :]     # (16, 64)
 
 PART_FIELDS = [('n_anc', 1), ('anc', 7), ('kas', 1), ('kag', 1), ('o_wc0', 1), ('o_bctx', 1), ('o_wa', 1), ('o_w1', 1),
-               ('o_w1e', 1), ('o_w2', 2), ('o_w3', 2), ('o_w4', 2), ('o_we', 2), ('o_wctxT', 1), ('o_nnT', 8), ('o_nnb', 8)]
+               ('o_w1e', 1), ('o_w2', 2), ('o_w3', 2), ('o_w4', 2), ('o_we', 2), ('o_wctxT', 1), ('o_nnT', 8), ('o_nnb', 8),
+               ('kas16', 1), ('kag16', 1), ('o16_wa', 1), ('o16_w1', 1), ('o16_w1e', 1), ('o16_w2', 2), ('o16_w3', 2), ('o16_w4', 2), ('o16_we', 2)]
 LEVEL_INTS = 1 + 24 + 23
 PART_INTS = sum(n for _, n in PART_FIELDS)
 

@@ -1,4 +1,5 @@
-"""Phase timeline of k_flow_chain (tile 0) from in-kernel shader-clock stamps: where do the 8 dependency levels spend time?"""
+"""Phase timeline of k_flow_chain16 (tile 0; `--chain32`: the 32-row kernel of rounds 1-3) from in-kernel shader-clock stamps: where do the 8
+dependency levels spend time?"""
 import sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +10,7 @@ lib = _lib.use_experiments_library()      # tools/libhumaniflow_amd_experiments.
 dev = torch.device('cuda:0')
 model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), H.get_benchmark_cfg().MODEL, H.SMPL_PARENTS)).eval().to(dev)
 feats = torch.randn(32, 2048, device=dev) * 0.3
+model.flow_chain32 = '--chain32' in sys.argv
 tl = torch.zeros(23, 8, dtype=torch.int64, device=dev)
 with torch.no_grad():
     for _ in range(3):
@@ -19,7 +21,7 @@ with torch.no_grad():
     lib.hmf_debug_set_timeline(None)
 t = tl.cpu().double()
 t0 = t[:, 0].min()
-names = ['C0 load', 'anc mfma', 'elu', 'L1(128 mfma)', 'coupling0', 'coupling1', 'tanh+exp', 'store']
+names = ['issue loads', 'anc mfma', 'elu', 'L1 mfma', 'coupling0', 'coupling1', 'tanh+exp+store']
 anc = H.immediate_parent_to_all_ancestors(H.SMPL_PARENTS)
 print('part depth start(cyc)  ' + '  '.join('%12s' % n for n in names) + '   total')
 for j in sorted(range(23), key=lambda j: (len(anc[j]), j)):

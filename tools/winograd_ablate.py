@@ -25,7 +25,10 @@ def timeit(fn, iters=100):
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 VARIANTS = ((100, 'fenced transform, 2 waves/SIMD'), (30, 'pipelined + 3 waves/SIMD'), (40, '64 channels per work-group'), (41, '64 channels, pipelined'), (10, '3 waves/SIMD'), (20, 'pipelined transform'), (1, 'no-fetch'), (2, 'no-epilogue'), (3, 'bare loop'))
-if '--full' not in sys.argv:
+if '--pf' in sys.argv:            # round 4: k_conv_winograd (300 = the round-3 defaults) vs the stage-pipelined k_conv_winograd_pf
+    VARIANTS = ((300, 'product (round-3 kernel)'), (301, 'pf: 3 waves/SIMD + 2 tiles | 2 waves/SIMD'), (311, 'pf pipe occ3 1 tile'), (312, 'pf pipe occ3 2 tiles'), (314, 'pf pipe occ3 4 tiles'),
+                (321, 'pf fenced occ2 1 tile'), (322, 'pf fenced occ2 2 tiles'), (332, 'pf pipe occ2 2 tiles'))
+elif '--full' not in sys.argv:
     VARIANTS = VARIANTS[:4]
 ROUNDS = 7           # variants are timed round-robin and the median over rounds is reported: a single pass is dominated by clock ramp / order effects (+-15 %)
 for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256), ('layer4', 8, 512)):
@@ -37,6 +40,14 @@ for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256)
     bias = torch.randn(c, device=dev)
     y = torch.empty(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     st = _lib.current_stream()
+    if '--pf' in sys.argv:        # the variants compute the same convolution: check them bit for bit against the round-3 kernel first
+        res = torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+        ref = torch.empty_like(y)
+        _lib.check(lib.hmf_conv_winograd_variant(x.data_ptr(), wk.data_ptr(), bias.data_ptr(), res.data_ptr(), ref.data_ptr(), B, hw, hw, c, c, 1, 300, st), 'wino')
+        for var, lab in VARIANTS[1:]:
+            y.zero_()
+            _lib.check(lib.hmf_conv_winograd_variant(x.data_ptr(), wk.data_ptr(), bias.data_ptr(), res.data_ptr(), y.data_ptr(), B, hw, hw, c, c, 1, var, st), 'wino')
+            assert torch.equal(y, ref), (name, var, (y - ref).abs().max().item())
     fl = 2.0 * B * hw * hw * c * c * 9
     line = '%-6s %5.2f GF direct (%.2f executed)' % (name, fl / 1e9, fl / 1e9 * 4 / 9)
     import statistics
