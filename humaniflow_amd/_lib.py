@@ -47,7 +47,7 @@ class Rng(C.Structure):
 
 
 _VP = C.c_void_p
-HMF_FLOW_POINT_EST, HMF_FLOW_PACKED_ROWS, HMF_FLOW_SHAPE_MODE, HMF_FLOW_CHAIN32 = 1, 2, 4, 8          # flags of hmf_flow_forward (include/humaniflow_amd.h)
+HMF_FLOW_POINT_EST, HMF_FLOW_PACKED_ROWS, HMF_FLOW_SHAPE_MODE, HMF_FLOW_CHAIN32, HMF_FLOW_CHAIN16 = 1, 2, 4, 8, 16          # flags of hmf_flow_forward (include/humaniflow_amd.h)
 _SIGS = {
     'hmf_abi_version': (C.c_int, []),
     'hmf_last_error': (C.c_char_p, []),

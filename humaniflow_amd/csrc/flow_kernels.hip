@@ -1081,7 +1081,13 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
     }
     {
         ProfScope ps(6, Mtot, st);
-        if (flags & HMF_FLOW_CHAIN32)           // the round-1..3 kernel: 32-row tiles on v_mfma_f32_32x32x2_f32 (cross-check; tools/flow_timeline.py)
+        // Two forms of the same loop.  16-row tiles (k_flow_chain16) finish a tile in 0.73x the time -- 117 vs 159 us alone at B = 32, N = 100, and
+        // for a single image -- but hold twice the SIMDs (a wave of either kernel owns its SIMD's register file): 808 x 117 us = 94 k SIMD-us against
+        // 404 x 159 us = 64 k.  With other batches' encoders co-running (bench.py: three streams) the step went 3.14 -> 3.18 ms with the 16-row form.
+        // So: the latency form up to 1,024 rows (predict: one image x 10 samples; small evaluation batches), the 32-row form beyond;
+        // HMF_FLOW_CHAIN32 / HMF_FLOW_CHAIN16 force one (cross-checks, tools/flow_timeline.py).
+        const bool use32 = (flags & HMF_FLOW_CHAIN32) || (!(flags & HMF_FLOW_CHAIN16) && Mtot > 1024);
+        if (use32)
             hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, ns, B, N, Mtot, rotmats_samples,
                                rotmats_point, so3_point, g_timeline);
         else

@@ -96,6 +96,8 @@ class ResNetEncoder(nn.Module):
     # downsample branch's bias is added to the block's last bias so that branch needs no pass of its own.
     fuse_stem_pool = True    # stem convolution + max-pool as one launch (hmf_stem_conv_pool)
     fuse_pairs = True        # a bottleneck's last 1x1 + the next bottleneck's first 1x1 as one launch where built (hmf_conv_pair: layer1 / layer2)
+    fuse_pairs_wide = False  # also the seams with a 128-channel input (layer1.0's K-concatenated downsample branch, layer2): slower than two launches
+                             # of hmf_conv1x1_gemm when run alone (5-12 us per seam); see _build_plan
     fuse_downsample = True   # bottleneck conv3 + downsample branch as one K-concatenated GEMM (hmf_conv1x1_gemm with a second K range)
     gemm_1x1 = True          # stride-1 1x1 layers on the LDS-DMA pipelined GEMM (hmf_conv1x1_gemm); False: the implicit-GEMM kernel (hmf_conv2d_nhwc)
     gemm_terms = 0           # OPT-IN: 3 / 6 = the 1x1 GEMMs on the bf16 matrix pipe with split fp32 operands (hmf_conv1x1_gemm_split: 3 = hi/lo
@@ -195,7 +197,7 @@ class ResNetEncoder(nn.Module):
                 C, Kt, N2 = wk.shape[0], wk.shape[1], w1.shape[0]
                 if Kt not in (64, 128) or C % 64 or N2 not in (64, 128, 256) or C > 512 or (dual is not None and dual[2] != 1):
                     continue
-                if self.gemm_1x1 and Kt != 64:
+                if self.gemm_1x1 and Kt != 64 and not self.fuse_pairs_wide:
                     # measured at B = 32 against two launches of hmf_conv1x1_gemm (tools/gemm1x1_probe.py, tools/encoder_layers.py): the seam
                     # launch wins only where the wide tensor between the two layers bounds them through HBM (layer1: conv3 64 -> 256 + identity
                     # at 64x64, 73.8 + 39.3 us as two launches vs 103 us fused); with a 128-channel input (layer1.0's K-concatenated downsample

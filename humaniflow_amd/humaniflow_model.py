@@ -397,7 +397,7 @@ class HumaniflowModel(nn.Module):
         return ws
 
     # ---- heads + base noise ------------------------------------------------------------------------------------------
-    flow_chain32 = False     # True: the kinematic loop on the 32-row-tile kernel of rounds 1-3 (k_flow_chain) instead of k_flow_chain16: cross-checks, tools
+    flow_chain32 = None      # None: by size (k_flow_chain16 up to 1,024 rows, the 32-row k_flow_chain beyond); True / False force one: cross-checks, tools
     heads_kernel = True      # inference: fc1 + ELU + fc_cam / fc_glob / fc_shape + init adds + 6D->R + exp(log_std) on hmf_heads; False: torch ops
 
     def _heads_kernel(self, input_feats):
@@ -657,7 +657,7 @@ class HumaniflowModel(nn.Module):
             BN = batch_size * N
             packed = compute_point_est and N > 0
             flags = ((_lib.HMF_FLOW_POINT_EST if compute_point_est else 0) | (_lib.HMF_FLOW_PACKED_ROWS if packed else 0) | flags0
-                     | (_lib.HMF_FLOW_CHAIN32 if self.flow_chain32 else 0))
+                     | (_lib.HMF_FLOW_CHAIN32 if self.flow_chain32 is True else (_lib.HMF_FLOW_CHAIN16 if self.flow_chain32 is False else 0)))
             rot_all = torch.empty(BN + (batch_size if compute_point_est else 0), P, 3, 3, dtype=torch.float32, device=device)
             shape_all = torch.empty(BN + (batch_size if packed else 0), nb, dtype=torch.float32, device=device) if N > 0 else None
             rot_s = rot_all[:BN].view(batch_size, N, P, 3, 3) if N > 0 else None

@@ -169,7 +169,8 @@ void hmf_flow_destroy(hmf_flow_t* h);
 #define HMF_FLOW_PACKED_ROWS 2  /* shape_samples has B*N + B rows: the point-estimate rows' shape (= shape_mode) is appended, so that
                                  * (rotmats_samples | rotmats_point) and shape_samples feed ONE hmf_smpl_lbs call of M = B*N + B rows */
 #define HMF_FLOW_SHAPE_MODE 4   /* use_shape_mode_for_samples (:255-256): no shape noise, whatever eps_shape / rng say                  */
-#define HMF_FLOW_CHAIN32 8      /* run the kinematic loop on the 32-row-tile kernel of rounds 1-3 (cross-check of the 16-row product kernel) */
+#define HMF_FLOW_CHAIN32 8      /* force the kinematic loop onto the 32-row-tile kernel (k_flow_chain; the default above 1,024 rows: throughput form) */
+#define HMF_FLOW_CHAIN16 16     /* force it onto the 16-row-tile kernel (k_flow_chain16; the default up to 1,024 rows: latency form)             */
 size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int flags);
 
 /* Base noise drawn INSIDE the kernels from the device generator's Philox4x32-10 stream, in the reference's draw order (SURVEY 8b "RNG

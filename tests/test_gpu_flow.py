@@ -55,17 +55,19 @@ def test_flow_forward_matches_oracle(layers, B, N, use_mode):
 
 @pytest.mark.parametrize('layers,B,N', [(18, 1, 10), (18, 3, 21), (50, 32, 100)])
 def test_16_row_chain_kernel_agrees_with_the_32_row_kernel_and_the_oracle(layers, B, N):
-    """Round 4: the kinematic loop runs on 16-row tiles (k_flow_chain16, v_mfma_f32_16x16x4_f32); the 32-row kernel of rounds 1-3 stays selectable
-    (HMF_FLOW_CHAIN32).  Two independent register layouts, packings and spline-parameter exchanges of the same arithmetic."""
+    """Round 4: the kinematic loop exists on 16-row tiles (k_flow_chain16, v_mfma_f32_16x16x4_f32: the latency form, default up to 1,024 rows) and
+    on 32-row tiles (k_flow_chain: the throughput form).  Two independent register layouts, packings and spline-parameter exchanges of the same
+    arithmetic."""
     model, sd, cfg = _model(layers)
     F = 512 if layers == 18 else 2048
     feats = (torch.randn(B, F, generator=torch.Generator().manual_seed(B + N)) * 0.5).cuda()
     noise = _cuda(_noise(B, N, seed=B))
     with torch.no_grad():
+        model.flow_chain32 = False
         a = model(None, input_feats=feats, num_samples=N, noise=noise)
         model.flow_chain32 = True
         b = model(None, input_feats=feats, num_samples=N, noise=noise)
-        model.flow_chain32 = False
+        model.flow_chain32 = None
     for k in ('pose_rotmats_samples', 'pose_rotmats_point_est', 'pose_axisangle_point_est'):
         assert (a[k] - b[k]).abs().max().item() < 2e-5, k
     assert torch.equal(a['shape_samples'], b['shape_samples'])

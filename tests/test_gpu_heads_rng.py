@@ -102,6 +102,24 @@ def test_in_kernel_noise_is_the_device_generators_stream_in_the_reference_order(
     assert s2 is None and (p2 - ref_pose2).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize('B,N', [(2, 5), (32, 100)])
+def test_in_kernel_noise_equals_the_oracle_restatement_of_the_generator(B, N):
+    """The third leg: csrc/rng_philox.h vs oracle/rng.py (numpy Philox4x32-10 pinned by the Random123 known-answer vectors + rocrand's Box-Muller
+    in float32) from the generator's (seed, offset) -- independent of torch's own kernel."""
+    from oracle import rng as orng
+    model, sd, cfg = _model(18)
+    torch.manual_seed(99)
+    torch.randn(3, device='cuda')
+    gen = torch.cuda.default_generators[0]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    props = torch.cuda.get_device_properties(0)
+    cap = props.multi_processor_count * (props.max_threads_per_multi_processor // 256)
+    eps_shape, eps_pose = model.draw_noise(torch.device('cuda:0'), B, N)
+    ref_shape, ref_pose, off_after = orng.flow_noise(seed, off, B, N, 10, cap)
+    assert gen.get_offset() == off_after
+    assert (eps_shape.cpu().numpy() - ref_shape).__abs__().max() < 2e-6 and (eps_pose.cpu().numpy() - ref_pose).__abs__().max() < 2e-6
+
+
 @pytest.mark.parametrize('layers,B,N,use_mode', [(18, 3, 17, False), (50, 2, 100, False), (18, 4, 9, True)])
 def test_seeded_forward_equals_forward_with_the_reference_draws_injected(layers, B, N, use_mode):
     model, sd, cfg = _model(layers)

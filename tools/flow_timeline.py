@@ -10,7 +10,7 @@ lib = _lib.use_experiments_library()      # tools/libhumaniflow_amd_experiments.
 dev = torch.device('cuda:0')
 model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), H.get_benchmark_cfg().MODEL, H.SMPL_PARENTS)).eval().to(dev)
 feats = torch.randn(32, 2048, device=dev) * 0.3
-model.flow_chain32 = '--chain32' in sys.argv
+model.flow_chain32 = '--chain32' in sys.argv        # False: force the 16-row kernel at this size
 tl = torch.zeros(23, 8, dtype=torch.int64, device=dev)
 with torch.no_grad():
     for _ in range(3):
