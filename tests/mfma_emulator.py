@@ -208,3 +208,116 @@ def emulate_flow_tile(arena, parts, anc_off, glob, levels, nb, G, shape_mode, sh
         if live[lane]:
             res[int(rowid[lane])] = (out_R[lane], out_v[lane], beta[:nb, lane].copy())
     return res
+
+
+# ---- round 4: k_flow_chain16 -- 16-row tiles on v_mfma_f32_16x16x4_f32 (flow_common.h "ARL16") ------------------------------------------------------
+J16 = LANES & 15
+G16 = LANES >> 4
+
+
+def mfma16(a, b, acc):
+    """acc (4, 64) += A(16x4) . B(4x16): lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D register r of lane (j, g) is row 4 g + r."""
+    A = a.reshape(4, 16).T.astype(np.float32)          # [i][k]
+    Bm = b.reshape(4, 16).astype(np.float32)           # [k][j]
+    D = np.zeros((16, 16), np.float32)
+    for k in range(4):
+        D = (D + A[:, k:k + 1] * Bm[k:k + 1, :]).astype(np.float32)
+    for r in range(4):
+        acc[r] += D[4 * G16 + r, J16]
+    return acc
+
+
+def a_block16(arena, off, ntiles, g4):
+    return arena[off:off + ntiles * g4 * 64 * 4].reshape(ntiles, g4, 64, 4)
+
+
+def emulate_flow_tile16(arena, parts, anc_off, levels, C0_rows, z_rows, is_point_rows, radius):
+    """One 16-row tile through k_flow_chain16, lane by lane on the packed `o16_*` blocks.  C0_rows (16, 23, 64): the image/shape half of every
+    context layer (k_flow_ctx0's row-major output); z_rows (23, 16, 3): base samples; is_point_rows (16,) bool.  Returns (R (16,23,9), v (16,23,3))."""
+    from oracle import so3
+    from oracle.flow import radial_tanh_forward
+    from oracle.spline import rational_linear_spline
+    import torch.nn.functional as F
+    sAnc = np.zeros((16, 209), np.float32)
+    out_R = np.zeros((16, 23, 9), np.float32)
+    out_v = np.zeros((16, 23, 3), np.float32)
+    one_g0 = np.where(G16 == 0, 1.0, 0.0).astype(np.float32)
+    for lev in levels:
+        for j in lev:
+            pt = parts[j]
+            cx = np.zeros((4, 4, 64), np.float32)                      # [tile][reg][lane]: channel 16 t + 4 g + r
+            for t in range(4):
+                for r in range(4):
+                    cx[t, r] = C0_rows[J16, j, 16 * t + 4 * G16 + r]
+            kag = pt['kag16']
+            if kag > 0:
+                wa = a_block16(arena, pt['o16_wa'], 4, kag)
+                for s4 in range(kag):
+                    for u in range(4):
+                        s = s4 * 4 + u
+                        bval = sAnc[J16, anc_off[j, 4 * s + G16]]
+                        for t in range(4):
+                            mfma16(wa[t, s4, :, u], bval, cx[t])
+            cx = elu(cx)
+            x0, x1, x2 = z_rows[j, J16, 0], z_rows[j, J16, 1], z_rows[j, J16, 2]
+            w1 = a_block16(arena, pt['o16_w1'], 8, 4)
+            w1e = arena[pt['o16_w1e']:pt['o16_w1e'] + 512].reshape(8, 64)
+            a1 = np.zeros((8, 4, 64), np.float32)
+            bx0 = np.where(G16 == 0, x0, np.where(G16 == 1, 1.0, 0.0)).astype(np.float32)
+            for to in range(4):
+                mfma16(w1e[to], bx0, a1[to])
+            for s in range(16):
+                for to in range(8):
+                    mfma16(w1[to, s >> 2, :, s & 3], cx[s >> 2, s & 3], a1[to])
+
+            def tail(c, h1, xin):
+                we = arena[pt['o16_we'][c]:pt['o16_we'][c] + 512].reshape(8, 64)
+                w2, w3, w4 = a_block16(arena, pt['o16_w2'][c], 2, 4), a_block16(arena, pt['o16_w3'][c], 2, 2), a_block16(arena, pt['o16_w4'][c], 4, 2)
+                a2 = np.zeros((2, 4, 64), np.float32)
+                for to in range(2):
+                    mfma16(we[to], one_g0, a2[to])
+                for s in range(16):
+                    for to in range(2):
+                        mfma16(w2[to, s >> 2, :, s & 3], h1[s >> 2, s & 3], a2[to])
+                a2 = np.maximum(a2, 0)
+                a3 = np.zeros((2, 4, 64), np.float32)
+                for to in range(2):
+                    mfma16(we[2 + to], one_g0, a3[to])
+                for s in range(8):
+                    for to in range(2):
+                        mfma16(w3[to, s >> 2, :, s & 3], a2[s >> 2, s & 3], a3[to])
+                a3 = np.maximum(a3, 0)
+                a4 = np.zeros((4, 4, 64), np.float32)
+                for to in range(4):
+                    mfma16(we[4 + to], one_g0, a4[to])
+                for s in range(8):
+                    for to in range(4):
+                        mfma16(w4[to, s >> 2, :, s & 3], a3[s >> 2, s & 3], a4[to])
+                p = a4.reshape(16, 64)                                     # slot m = 4 t + r
+                # the even lane group of a coordinate holds widths | heights, its partner (lane ^ 16) derivatives | pad | lambdas
+                partner = LANES ^ 16
+                rw, rh = p[0:8].T, p[8:16].T                               # (64, 8) each: meaningful in the even groups
+                rd, rl = p[0:7][:, partner].T, p[8:16][:, partner].T       # the partner's registers as seen from the even group
+                w, h, d, l = F.softmax(torch.from_numpy(rw.copy()), -1), F.softmax(torch.from_numpy(rh.copy()), -1), F.softplus(torch.from_numpy(rd.copy())), \
+                    torch.sigmoid(torch.from_numpy(rl.copy()))
+                y, _ = rational_linear_spline(torch.from_numpy(xin.astype(np.float32)), w, h, d, l, radius)
+                return y.numpy()
+            h1 = np.maximum(a1[0:4], 0).astype(np.float32)
+            xn = tail(0, h1, np.where((G16 >> 1) == 1, x2, x1))
+            x1n, x2n = xn[J16], xn[32 + J16]
+            y0 = x1n
+            by0 = np.where(G16 == 0, y0, np.where(G16 == 1, 1.0, 0.0)).astype(np.float32)
+            for to in range(4, 8):
+                mfma16(w1e[to], by0, a1[to])
+            h1 = np.maximum(a1[4:8], 0).astype(np.float32)
+            yn = tail(1, h1, np.where((G16 >> 1) == 1, x0, x2n))
+            y1, y2 = yn[J16], yn[32 + J16]
+            yv = torch.from_numpy(np.stack([y0, y1, y2], -1).astype(np.float32)[:16])
+            v = radial_tanh_forward(yv, radius)
+            R_s = so3.so3_exp(v.double()).float().reshape(16, 9).numpy()
+            R_p = so3.batch_rodrigues(v).reshape(16, 9).numpy()
+            R = np.where(is_point_rows[:, None], R_p, R_s)
+            sAnc[:, j * 9:(j + 1) * 9] = R
+            out_R[:, j] = R
+            out_v[:, j] = v.numpy()
+    return out_R, out_v

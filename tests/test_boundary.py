@@ -226,6 +226,39 @@ def test_flow_operand_pack_and_kernel_dataflow_match_oracle(lib, use_mode):
     assert np.abs(Rs - np.eye(3).reshape(9)).max() > 0.3
 
 
+def test_flow_16_row_operand_pack_and_kernel_dataflow_match_oracle(lib):
+    """The same replay for k_flow_chain16 (round 4: 16-row tiles on v_mfma_f32_16x16x4_f32): the `o16_*` operand blocks of the C++ packer, the ARL16
+    register layout, the spline-parameter placement across lane groups, against the oracle's reference-mode forward."""
+    from oracle import model as omodel
+    cfg = H.get_humaniflow_cfg_defaults()
+    model = init_model_for_tests(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=3).eval()
+    arena, parts, anc_off, glob = E.parse_flow_pack(_flow_pack(model, lib))
+    B, N, nb = 2, 7, 10                                        # 14 sample rows + 2 point-estimate rows = one 16-row tile
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(B, 512, generator=g)
+    noise = {'shape': torch.randn(N, B, nb, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    ref = omodel.forward(sd, ocfg, input_feats=feats, num_samples=N, noise=noise)
+    # rows of the tile: samples b * N + n, then the point-estimate rows; C0 = the image/shape half of every context layer (k_flow_ctx0), dense here
+    isgc_s = omodel.isgc_feats(sd, feats, ref['shape_samples'], ref['glob_rotmat'], ref['cam_wp']).reshape(B * N, 256)
+    isgc_p = omodel.isgc_feats(sd, feats, ref['shape_mode'], ref['glob_rotmat'], ref['cam_wp'])
+    hrows = torch.cat([isgc_s, isgc_p])                                                    # (16, 256)
+    C0 = np.zeros((16, 23, 64), np.float32)
+    for j in range(23):
+        W, bias = sd['fc_flow_context.%d.weight' % j], sd['fc_flow_context.%d.bias' % j]
+        C0[:, j] = (hrows @ W[:, :256].T + bias).numpy()
+    z = np.zeros((23, 16, 3), np.float32)
+    z[:, :B * N] = (noise['pose'].reshape(23, B * N, 3) * ocfg.base_std).numpy()
+    is_point = np.arange(16) >= B * N
+    R, v = E.emulate_flow_tile16(arena, parts, anc_off, glob['rounds'], C0, z, is_point, ocfg.radius)
+    Rs = ref['pose_rotmats_samples'].reshape(B * N, 23, 9).numpy()
+    assert np.abs(R[:B * N] - Rs).max() < 2e-5
+    assert np.abs(R[B * N:] - ref['pose_rotmats_point_est'].reshape(B, 23, 9).numpy()).max() < 2e-5
+    assert np.abs(v[B * N:] - ref['pose_axisangle_point_est'].numpy()).max() < 2e-5
+    assert np.abs(Rs - np.eye(3).reshape(9)).max() > 0.3
+
+
 def test_encoder_bn_fold_host_logic():
     """Host side of the encoder's inference plan (no GPU): eval-mode BatchNorm folded into (weight, bias) reproduces bn(conv(x)); the
     downsample branch concatenated along K reproduces conv3 + downsample; the plan is dropped when parameters can have changed."""
