@@ -248,7 +248,7 @@ def dry_run_cpu(args):
         dist.destroy_process_group()
 
 
-KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc', 13: 'k_heads_fc1 + k_heads_out'}
+KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc', 15: 'k_heads_fc1 + k_heads_out'}
 CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_gemm + k_conv_pair (1x1)', 11: 'k_conv_winograd (3x3)'}
 
 

@@ -326,7 +326,7 @@ size_t hmf_heads_workspace_bytes(int B, int F, int N1);
  * fixed order); cam = fc_cam x1 + init_cam (:237-238); glob_R = rot6d_to_rotmat(fc_glob x1 + init_glob) (:243-245); (shape_mode | shape_log_std) =
  * fc_shape x1 (:250-252); shape_std = exp(shape_log_std) (the scale of :253's Normal).  feats B x F; w1 N1 x F, b1 N1;
  * w_cam 3 x N1, w_glob 6 x N1, w_shape 2nb x N1 (+ biases); init_cam 3, init_glob 6.  Outputs cam B x 3, glob_R B x 9, shape_mode / shape_log_std /
- * shape_std B x nb each.  F % 32 == 0, N1 % 32 == 0, N1 <= 1024; feats and weight matrices 16-byte aligned.  Profiler tag 13. */
+ * shape_std B x nb each.  F % 32 == 0, N1 % 32 == 0, N1 <= 1024; feats and weight matrices 16-byte aligned.  Profiler tag 15. */
 int hmf_heads(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
               const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
               float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, void* workspace, size_t workspace_bytes, void* stream);
