@@ -35,6 +35,8 @@ cp "$OUT"/${R}_* profiles/ && python tools/roofline_table.py $R > "$OUT/${R}_roo
 stamp "predict-shape latency (B = 1, N = 10), flow kernel timeline"
 python tools/predict_latency.py 1 10 > "$OUT/${R}_predict_latency.txt" 2>/dev/null
 python tools/flow_time.py > "$OUT/${R}_flow_time.txt" 2>/dev/null
+stamp "issue-pipe counters of the one-stream step (MFMA busy / VALU active / waits per kernel)"
+tools/pipe_profile.sh $R > /dev/null 2>&1
 fi
 # ---- the other BASELINE configurations: eval step (configs[3] per GPU), bf16 blend operands at B = 64 (configs[2]), training step (configs[4]):
 # two PMC passes each (FETCH_SIZE, WRITE_SIZE), then the bench line that quotes them
