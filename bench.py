@@ -117,8 +117,6 @@ def parse():
     ap.add_argument('--dry-run-cpu', action='store_true', help='exercise only the rank plumbing (gloo, CPU, stand-in step): used by the CPU tests')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the steps are round-robined over (batches are independent: the '
                     'low-occupancy flow kernels of step i overlap the encoder convolutions of step i+1)')
-    ap.add_argument('--split-tail', action='store_true', help='experiment: encoder and heads+flow+SMPL of a batch as two graphs on two streams of a pipeline '
-                    '(the latency-bound tail of batch i overlaps the encoder of batch i + streams)')
     ap.add_argument('--batches', type=int, default=3, help='distinct input batches rotated through (>= 3: the inputs do not sit in the 256 MB Infinity Cache)')
     ap.add_argument('--no-graph', action='store_true', help='issue the steps eagerly instead of replaying one captured HIP graph per batch')
     ap.add_argument('--profile-steps', type=int, default=5, help='steps of the per-kernel measurement pass after the timed region (0 = skip)')
@@ -389,58 +387,6 @@ def main():
                     outs[i] = step(i)
         for s_ in streams:
             cur.wait_stream(s_)
-
-    if args.split_tail and use_graph and not args.eval:
-        tails = [torch.cuda.Stream(device=dev) for _ in range(S)]
-        feats, gA, gB = [None] * NB, [None] * NB, [None] * NB
-
-        def enc(i):
-            with torch.no_grad():
-                return model.image_encoder(batches[i]['input'])
-
-        def tail(i):
-            with torch.no_grad():
-                pred = model(batches[i]['input'], num_samples=N, input_feats=feats[i])
-                pe, sa = smpl.forward_samples_and_point_est(pred)
-                return sa.vertices, sa.joints, pe.vertices, pred['pose_rotmats_samples']
-
-        for i in range(NB):
-            with torch.cuda.stream(streams[i % S]):
-                feats[i] = enc(i)
-            torch.cuda.synchronize()
-            with torch.cuda.stream(tails[i % S]):
-                outs[i] = tail(i)
-            torch.cuda.synchronize()
-        for i in range(NB):
-            gA[i], gB[i] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gA[i], stream=streams[i % S], capture_error_mode='thread_local'):
-                feats[i] = enc(i)
-            with torch.cuda.graph(gB[i], stream=tails[i % S], capture_error_mode='thread_local'):
-                outs[i] = tail(i)
-        torch.cuda.synchronize()
-        enc_done = [torch.cuda.Event() for _ in range(NB)]
-        tail_done = [None] * NB
-
-        def issue(k0, n):                                                            # noqa: F811
-            cur = torch.cuda.current_stream()
-            for s_ in streams + tails:
-                s_.wait_stream(cur)
-            for k in range(k0, k0 + n):
-                i = k % NB
-                e_, t_ = streams[i % S], tails[i % S]
-                if tail_done[i] is not None:
-                    e_.wait_event(tail_done[i])
-                with torch.cuda.stream(e_):
-                    gA[i].replay()
-                enc_done[i].record(e_)
-                t_.wait_event(enc_done[i])
-                with torch.cuda.stream(t_):
-                    gB[i].replay()
-                tail_done[i] = torch.cuda.Event()
-                tail_done[i].record(t_)
-            for s_ in streams + tails:
-                cur.wait_stream(s_)
-        log('split-tail: %d encoder + %d tail streams' % (S, S))
 
     issue(0, args.warmup)
     dist_sync(dist, dev)

@@ -4,7 +4,8 @@
 
 --steps K restricts the table to the bench's TIMED region: one hmf::k_isgc is launched per step, so the window opens at the end of
 the k_isgc that precedes the last K of them (= the last warm-up step's; with 2 streams the first timed step's encoder may already
-be running, i.e. the window holds K steps' worth of every kernel, shifted by at most one encoder) and closes at the last dispatch.
+be running, i.e. the window holds K steps' worth of every kernel, shifted by at most one encoder) and closes at the end of the last hmf:: kernel
+(what follows is the bench's checksum of the outputs).
 Run the bench with --profile-steps 0 --no-cpu-baseline so that the timed region is the end of the process.
 """
 import sqlite3
@@ -22,8 +23,12 @@ if steps:
     marks = con.execute("select end from kernels where name like '%hmf::k_isgc%' order by start").fetchall()
     if len(marks) > steps:
         t0 = marks[len(marks) - steps - 1][0]
-        where = ' where start >= %d' % t0
-        note = 'timed region: the last %d steps of the process (run bench.py with --profile-steps 0 so that nothing follows the timed region; window opens at the end of the last warm-up step\'s k_isgc)' % steps
+        t1 = con.execute("select max(end) from kernels where name like '%hmf::%'").fetchone()[0]      # the last step's last kernel
+        where = ' where start >= %d and start <= %d' % (t0, t1)
+        after = con.execute("select count(*), coalesce(sum(duration), 0) from kernels where start > %d" % t1).fetchone()
+        note = ('timed region: the last %d steps of the process (run bench.py with --profile-steps 0 so that nothing follows the timed region; window opens at the '
+                'end of the last warm-up step\'s k_isgc and closes with the last step\'s last kernel; the %d dispatches after it, %.3f ms, are bench.py\'s checksum '
+                'of the outputs -- abs / mean / stack on torch -- not part of a step)' % (steps, after[0], after[1] / 1e6))
 rows = con.execute("select name || case when name like '%hmf::%' then ' [grid ' || grid_x || ']' else '' end as nm, count(*), sum(duration), "
                    "avg(duration), min(duration), max(duration), max(vgpr_count), max(accum_vgpr_count), max(lds_size), max(scratch_size), "
                    "max(grid_x), max(workgroup_x) from kernels" + where + " group by nm order by sum(duration) desc").fetchall()
@@ -49,4 +54,4 @@ if steps:
         v = con.execute("select coalesce(sum(duration), 0) from kernels" + where + " and " + cond).fetchone()[0]
         acc += v
         print('| %s | %.3f | %.1f |' % (label, v / 1e6 / steps, 100.0 * v / total))
-    print('| everything else (torch glue: feature mean, heads GEMMs, copies, RNG) | %.3f | %.1f |' % ((total - acc) / 1e6 / steps, 100.0 * (total - acc) / total))
+    print('| everything else (hmf::k_heads_fc1, k_heads_out, k_zero; any torch / vendor kernel inside a step would be counted here) | %.3f | %.1f |' % ((total - acc) / 1e6 / steps, 100.0 * (total - acc) / total))
