@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0                  # guides/MI355X_MICROARCH.md: HBM3E ~8 TB
 FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2516.6         # v_mfma_f32_32x32x16_bf16: 16x the k per instruction at half the issue time (the guide's ~2.5 PFLOP/s dense)
 WINOGRAD_MFMA_FRACTION = 4.0 / 9.0     # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed MFMA FLOPs = 4/9 of direct
+STEM_POLYPHASE_MFMA_FRACTION = 100.0 / 196.0   # csrc/stem_wino.hip: 100 products per 2x2 outputs and channel instead of 4 * 49
 
 
 def encoder_conv_flops(enc, B, size, with_bytes=False):
@@ -249,7 +250,7 @@ def dry_run_cpu(args):
 
 
 KERNEL_TAGS = {1: 'k_lbs_mfma', 12: 'k_lbs_mfma16', 2: 'k_rigid_chain', 3: 'k_joints', 4: 'k_tpose', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc', 15: 'k_heads_fc1 + k_heads_out'}
-CONV_TAGS = {9: 'k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_gemm + k_conv_pair (1x1)', 11: 'k_conv_winograd (3x3)'}
+CONV_TAGS = {9: 'k_stem_wino | k_stem_conv (7x7/2)', 10: 'k_conv_patch (3x3)', 8: 'k_conv_gemm + k_conv_pair (1x1)', 11: 'k_conv_winograd (3x3)'}
 
 
 def collect_profile(lib, _lib, cap=65536):
@@ -260,7 +261,7 @@ def collect_profile(lib, _lib, cap=65536):
     return ms[:n], tag[:n], rows[:n]
 
 
-def conv_families(ms_, tag_, reps, conv_flops, conv_bytes=None):
+def conv_families(ms_, tag_, reps, conv_flops, conv_bytes=None, stem_polyphase=False):
     """Per-family table of the encoder convolutions from `reps` recorded encoder passes (one record per launch, plan order)."""
     csel = (tag_ >= 8) & (tag_ <= 11)
     if csel.sum() != reps * len(conv_flops) or reps == 0:
@@ -278,6 +279,8 @@ def conv_families(ms_, tag_, reps, conv_flops, conv_bytes=None):
         d['tflops'] = round(d['flop'] / (d['us_per_step'] * 1e-6) / 1e12, 2)
         if 'winograd' in name:               # what the MFMA pipe executes: 4/9 of the direct-form multiplies
             d['tflops_executed_mfma'] = round(d['tflops'] * WINOGRAD_MFMA_FRACTION, 2)
+        if 'stem' in name and stem_polyphase:
+            d['tflops_executed_mfma'] = round(d['tflops'] * STEM_POLYPHASE_MFMA_FRACTION, 2)
         d['us_per_step'] = round(d['us_per_step'], 1)
         d['gflop_per_step'] = round(d.pop('flop') / 1e9, 2)
     return fam
@@ -439,7 +442,7 @@ def main():
             for r in sorted(set(rows[tag == tg].tolist())):
                 sel = (tag == tg) & (rows == r)
                 kern['%s[M=%d]' % (nm, r)] = {'us': round(float(ms[sel].mean()) * 1e3, 2), 'launches_per_step': int(sel.sum()) // P}
-        conv = conv_families(ms, tag, P, conv_flops, conv_bytes)
+        conv = conv_families(ms, tag, P, conv_flops, conv_bytes, stem_polyphase=getattr(model.image_encoder, 'stem_polyphase', False))
         ltag = 12 if args.blend_dtype == 'bf16' else 1
         lsel = (tag == ltag) & (rows == lbs_rows)
         lbs_ms = float(ms[lsel].mean()) if lsel.any() else float('nan')
@@ -499,7 +502,8 @@ def main():
             2.0 * B * (256 // (4 * 2 ** li)) ** 2 * c.out_channels * c.in_channels * 9
             for li, l in enumerate([enc_.layer1, enc_.layer2, enc_.layer3, enc_.layer4]) for blk in l for c, _ in blk.stages()
             if c.kernel_size[0] == 3 and c.stride[0] == 2)
-        agg_exec = (step_flops - wino_flops * (1.0 - WINOGRAD_MFMA_FRACTION)) / (elapsed / args.steps) / 1e12
+        stem_flops = conv_flops[0] if getattr(enc_, 'stem_polyphase', False) else 0.0          # the polyphase stem executes 100/196 of its direct-form multiplies
+        agg_exec = (step_flops - wino_flops * (1.0 - WINOGRAD_MFMA_FRACTION) - stem_flops * (1.0 - STEM_POLYPHASE_MFMA_FRACTION)) / (elapsed / args.steps) / 1e12
         pmc = load_pmc_traffic(source_hash(), 'B=%d,N=%d,%s%s%s' % (args.batch, args.samples, args.blend_dtype, ',eval' if args.eval else '',
                                                                      ',x%d' % args.gemm_terms if args.gemm_terms else ''))
 
@@ -524,7 +528,7 @@ def main():
             dom = conv[dom_name]
             per_launch_flop = dom['gflop_per_step'] * 1e9 / dom['launches_per_step']
             key = {'k_conv_gemm + k_conv_pair (1x1)': ('k_conv_gemm', 'k_conv_igemm', 'k_conv_pair'), 'k_conv_patch (3x3)': 'k_conv_patch', 'k_conv_winograd (3x3)': 'k_conv_winograd',
-                   'k_stem_conv (7x7/2)': 'k_stem_conv'}[dom_name]
+                   'k_stem_wino | k_stem_conv (7x7/2)': ('k_stem_wino', 'k_stem_conv')}[dom_name]
             res['roofline'] = {
                 'kernel': '%s convolutions of the encoder: %d launches/step, the kernel family with the largest share of the step' % (dom_name, dom['launches_per_step']),
                 'bound': 'mfma', 'achieved': dom['tflops'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -539,7 +543,7 @@ def main():
                 'how': 'algorithmic 2*M*N*K FLOPs of the family / its kernel execution time (measurement pass: HIP events on the launch stream, one stream)',
                 'step_aggregate': {'what': 'algorithmic FLOPs of every convolution (Winograd layers at direct-form FLOPs) + SMPL blend GEMMs of a step / step time of the timed region',
                                    'achieved': round(agg, 2), 'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                                   'executed_mfma': {'what': 'the same with the Winograd layers at the FLOPs the matrix pipe executes (4/9 of direct form)',
+                                   'executed_mfma': {'what': 'the same with the Winograd layers (4/9 of direct form) and the polyphase stem (100/196) at the FLOPs the matrix pipe executes',
                                                      'achieved': round(agg_exec, 2), 'frac': round(agg_exec / FP32_MFMA_PEAK_TFLOPS, 4)}}}
             if args.gemm_terms:
                 res['roofline']['step_aggregate']['peak_note'] = ('OPT-IN split-operand flavour: the 1x1 GEMMs run on the bf16 matrix pipe, so `frac` against the fp32 MFMA '

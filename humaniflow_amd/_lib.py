@@ -103,6 +103,11 @@ _SIGS = {
     'hmf_stem_pack_host': (C.c_int, [_VP, _VP]),
     'hmf_stem_conv': (C.c_int, [_VP] * 4 + [C.c_int] * 5 + [_VP]),
     'hmf_stem_conv_pool': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
+    'hmf_stem_wino_packed_floats': (C.c_longlong, []),
+    'hmf_stem_wino_pack_host': (C.c_int, [_VP, _VP]),
+    'hmf_stem_wino_pack_device': (C.c_int, [_VP, _VP, _VP]),
+    'hmf_stem_wino': (C.c_int, [_VP] * 4 + [C.c_int] * 5 + [_VP]),
+    'hmf_stem_wino_pool': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
     'hmf_maxpool3x3s2_nhwc': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP]),
     'hmf_conv_patch_packed_floats': (C.c_longlong, [C.c_int] * 3),
     'hmf_conv_patch_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 4),

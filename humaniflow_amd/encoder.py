@@ -94,7 +94,9 @@ class ResNetEncoder(nn.Module):
     # ---- folded inference plan ----------------------------------------------------------
     # eval-mode BatchNorm folded into the conv weight + a per-channel bias that the convolution kernel adds in its epilogue; a
     # downsample branch's bias is added to the block's last bias so that branch needs no pass of its own.
-    fuse_stem_pool = True    # stem convolution + max-pool as one launch (hmf_stem_conv_pool)
+    fuse_stem_pool = True    # stem convolution + max-pool as one launch (hmf_stem_conv_pool / hmf_stem_wino_pool)
+    stem_polyphase = True    # the stem as a polyphase fast convolution (csrc/stem_wino.hip: 100 instead of 196 products per 2 x 2 outputs and channel,
+                             # F(2,3)-class arithmetic); False: the direct form (csrc/stem_conv.hip)
     fuse_pairs = True        # a bottleneck's last 1x1 + the next bottleneck's first 1x1 as one launch where built (hmf_conv_pair: layer1 / layer2)
     fuse_pairs_wide = False  # also the seams with a 128-channel input (layer1.0's K-concatenated downsample branch, layer2): slower than two launches
                              # of hmf_conv1x1_gemm when run alone (5-12 us per seam); see _build_plan
@@ -158,6 +160,9 @@ class ResNetEncoder(nn.Module):
             packed = torch.empty(int(lib.hmf_stem_packed_floats()), dtype=torch.float32)
             _lib.check(lib.hmf_stem_pack_host(w.data_ptr(), packed.data_ptr()), 'hmf_stem_pack_host')
             plan['stem_packed'] = packed.to(self.conv1.weight.device)
+            packed = torch.empty(int(lib.hmf_stem_wino_packed_floats()), dtype=torch.float32)
+            _lib.check(lib.hmf_stem_wino_pack_host(w.data_ptr(), packed.data_ptr()), 'hmf_stem_wino_pack_host')
+            plan['stem_packed_polyphase'] = packed.to(self.conv1.weight.device)
         for li in range(1, 5):
             for blk in getattr(self, 'layer%d' % li):
                 stages = [self._fold(c, b) for c, b in blk.stages()]
@@ -361,11 +366,12 @@ class ResNetEncoder(nn.Module):
         PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
         st = _lib.current_stream()
         z = torch.empty((B, 64, PH, PW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        conv, conv_pool = (lib.hmf_stem_wino, lib.hmf_stem_wino_pool) if self.stem_polyphase else (lib.hmf_stem_conv, lib.hmf_stem_conv_pool)
         if self.fuse_stem_pool:
-            _lib.check(lib.hmf_stem_conv_pool(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), z.data_ptr(), B, C, H, W, st), 'hmf_stem_conv_pool')
+            _lib.check(conv_pool(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), z.data_ptr(), B, C, H, W, st), 'hmf_stem_conv_pool')
             return z
         y = torch.empty((B, 64, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _lib.check(lib.hmf_stem_conv(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), 'hmf_stem_conv')
+        _lib.check(conv(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), 'hmf_stem_conv')
         _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
         return z
 
@@ -379,7 +385,7 @@ class ResNetEncoder(nn.Module):
             self._plan, self._plan_key = self._build_plan(), key
         p = self._plan
         with torch.cuda.device(x.device):
-            x = self._stem_hip(x.float().contiguous(), p['stem_packed'], p['stem'][1])
+            x = self._stem_hip(x.float().contiguous(), p['stem_packed_polyphase' if self.stem_polyphase else 'stem_packed'], p['stem'][1])
             x, _ = self._run_blocks(p, x, None, 0, len(p['blocks']))
             if x.dim() == 4:                                 # a plan whose last block ended in a fused launch: pool the map
                 B, C, H, W = x.shape

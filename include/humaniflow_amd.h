@@ -399,6 +399,18 @@ int hmf_stem_conv(const float* x, const float* w_packed, const float* bias, floa
 int hmf_stem_conv_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* stream);
 int hmf_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);
 
+/* The same stem (same arguments, same outputs as hmf_stem_conv / hmf_stem_conv_pool) as a polyphase fast convolution (csrc/stem_wino.hip): the 7 taps of
+ * a stride-2 filter split into a 4-tap and a 3-tap stride-1 filter on the even / odd samples, each evaluated with Winograd F(2,3) arithmetic (constants
+ * 0, +-1, 1/2) -- 100 products per 2 x 2 output tile and input channel instead of 196, chained into 16 class accumulators on the MFMA pipe.  Results
+ * differ from the direct form by fp32 rounding only (held to the same 2e-5 x scale bar against a float64 convolution).  The inference plan's stem.
+ * w_packed: hmf_stem_wino_pack_host / hmf_stem_wino_pack_device(w (64,18,7,7) row-major, packed[hmf_stem_wino_packed_floats()]); the device form packs the
+ * live parameter (training re-packs every step).  Profiler tag 9. */
+long long hmf_stem_wino_packed_floats(void);
+int hmf_stem_wino_pack_host(const float* w, float* packed);
+int hmf_stem_wino_pack_device(const float* w, float* packed, void* stream);
+int hmf_stem_wino(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, void* stream);
+int hmf_stem_wino_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Evaluation epilogue (metrics/eval_metrics_tracker.py:95-280,398-410; utils/eval_utils.py)     */
 /* ------------------------------------------------------------------------------------------ */

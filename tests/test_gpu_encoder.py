@@ -331,25 +331,31 @@ def test_conv_rejects_unsupported_shapes():
         assert rc < 0 and lib.hmf_last_error()
 
 
+STEM_FORMS = {'direct': ('hmf_stem_packed_floats', 'hmf_stem_pack_host', 'hmf_stem_conv', 'hmf_stem_conv_pool'),
+              'polyphase': ('hmf_stem_wino_packed_floats', 'hmf_stem_wino_pack_host', 'hmf_stem_wino', 'hmf_stem_wino_pool')}
+
+
+@pytest.mark.parametrize('form', ['direct', 'polyphase'])
 @pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 48, 80), (3, 30, 22)])
-def test_stem_conv_and_maxpool_match_float64_reference(B, H, W):
-    """hmf_stem_conv (NCHW in, NHWC out, bias + ReLU fused) and hmf_maxpool3x3s2_nhwc vs float64 torch; odd sizes exercise partial tiles
-    and the zero-padded patch borders."""
+def test_stem_conv_and_maxpool_match_float64_reference(B, H, W, form):
+    """hmf_stem_conv / hmf_stem_wino (NCHW in, NHWC out, bias + ReLU fused) and hmf_maxpool3x3s2_nhwc vs float64 torch; odd sizes exercise partial
+    tiles and the zero-padded patch borders."""
     from humaniflow_amd import _lib
     lib = _lib.load()
+    f_floats, f_pack, f_conv, _ = (getattr(lib, nm) for nm in STEM_FORMS[form])
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.randn(B, 18, H, W, generator=g)
     w = torch.randn(64, 18, 7, 7, generator=g) / 30.0
     bias = torch.randn(64, generator=g) * 0.1
     ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), 2, 3))
     refp = F.max_pool2d(ref, 3, 2, 1)
-    packed = torch.empty(int(lib.hmf_stem_packed_floats()))
-    _lib.check(lib.hmf_stem_pack_host(w.contiguous().data_ptr(), packed.data_ptr()), 'pack')
+    packed = torch.empty(int(f_floats()))
+    _lib.check(f_pack(w.contiguous().data_ptr(), packed.data_ptr()), 'pack')
     xd, pd, bd = x.cuda(), packed.cuda(), bias.cuda()
     OH, OW = ref.shape[2:]
     y = torch.full((B, 64, OH, OW), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
     st = _lib.current_stream()
-    _lib.check(lib.hmf_stem_conv(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'hmf_stem_conv')
+    _lib.check(f_conv(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'stem')
     z = torch.full(tuple(refp.shape), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
     _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'hmf_maxpool3x3s2_nhwc')
     torch.cuda.synchronize()
@@ -358,18 +364,20 @@ def test_stem_conv_and_maxpool_match_float64_reference(B, H, W):
     assert torch.equal(z, F.max_pool2d(y, 3, 2, 1))              # the pool itself is exact
 
 
+@pytest.mark.parametrize('form', ['direct', 'polyphase'])
 @pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 100, 76), (3, 34, 130), (1, 256, 256)])
-def test_stem_with_fused_maxpool_equals_the_two_launches(B, H, W):
-    """hmf_stem_conv_pool (pool applied per tile, shared windows by atomic max) == hmf_stem_conv + hmf_maxpool3x3s2_nhwc, bit for bit
+def test_stem_with_fused_maxpool_equals_the_two_launches(B, H, W, form):
+    """hmf_stem_conv_pool / hmf_stem_wino_pool (pool applied per tile, shared windows by atomic max) == the stem + hmf_maxpool3x3s2_nhwc, bit for bit
     (ragged tiles, odd pooled sizes, several images)."""
     from humaniflow_amd import _lib
     lib = _lib.load()
+    f_floats, f_pack, f_conv, f_pool = (getattr(lib, nm) for nm in STEM_FORMS[form])
     g = torch.Generator().manual_seed(H + W)
     x = torch.randn(B, 18, H, W, generator=g).cuda()
     w = (torch.randn(64, 18, 7, 7, generator=g) / 30).contiguous()
     bias = torch.randn(64, generator=g).cuda()
-    packed = torch.empty(int(lib.hmf_stem_packed_floats()))
-    _lib.check(lib.hmf_stem_pack_host(w.data_ptr(), packed.data_ptr()), 'pack')
+    packed = torch.empty(int(f_floats()))
+    _lib.check(f_pack(w.data_ptr(), packed.data_ptr()), 'pack')
     pk = packed.cuda()
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
@@ -377,11 +385,38 @@ def test_stem_with_fused_maxpool_equals_the_two_launches(B, H, W):
     y = torch.empty(B, OH, OW, 64, device='cuda')
     z = torch.empty(B, PH, PW, 64, device='cuda')
     zf = torch.full((B, PH, PW, 64), float('nan'), device='cuda')
-    _lib.check(lib.hmf_stem_conv(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'stem')
+    _lib.check(f_conv(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'stem')
     _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'pool')
-    _lib.check(lib.hmf_stem_conv_pool(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), zf.data_ptr(), B, 18, H, W, st), 'stem+pool')
+    _lib.check(f_pool(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), zf.data_ptr(), B, 18, H, W, st), 'stem+pool')
     torch.cuda.synchronize()
     assert torch.equal(z, zf)
+
+
+def test_polyphase_stem_filters_packed_on_the_device_equal_the_host_packer_and_no_relu_no_bias_form():
+    """hmf_stem_wino_pack_device (training re-packs the live filter every step) == hmf_stem_wino_pack_host bit for bit; the relu = 0 / bias = NULL
+    form (the training graph's stem) against float64."""
+    from humaniflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    w = (torch.randn(64, 18, 7, 7, generator=g) / 30).contiguous()
+    n = int(lib.hmf_stem_wino_packed_floats())
+    host = torch.empty(n)
+    _lib.check(lib.hmf_stem_wino_pack_host(w.data_ptr(), host.data_ptr()), 'pack')
+    dev = torch.full((n,), float('nan'), device='cuda')
+    wd = w.cuda()
+    st = _lib.current_stream()
+    _lib.check(lib.hmf_stem_wino_pack_device(wd.data_ptr(), dev.data_ptr(), st), 'pack device')
+    torch.cuda.synchronize()
+    assert torch.equal(dev.cpu(), host)
+    B, H, W = 2, 96, 64
+    x = torch.randn(B, 18, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    y = torch.full((B, 64, H // 2, W // 2), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    xd = x.cuda()
+    _lib.check(lib.hmf_stem_wino(xd.data_ptr(), dev.data_ptr(), None, y.data_ptr(), B, 18, H, W, 0, st), 'stem')
+    torch.cuda.synchronize()
+    assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert (y < 0).any()                                          # no ReLU was applied
 
 
 def test_folded_encoder_matches_module_path():

@@ -34,7 +34,7 @@ print('Peaks: fp32 MFMA %.1f TFLOP/s, HBM %.0f TB/s.  Durations: HIP events on t
 print('MfmaUtil: SQ_VALU_MFMA_BUSY_CYCLES (%s_mfma_busy.txt).  HBM bytes: FETCH_SIZE x2 + WRITE_SIZE (%s_pmc.json).\n' % (R, R))
 print('| kernel | launches/step | us/step | algorithmic work/step | achieved | bound | frac of peak | MfmaUtil | HBM MB/launch (PMC) |')
 print('|---|---|---|---|---|---|---|---|---|')
-keys = {'k_stem_conv (7x7/2)': 'k_stem_conv', 'k_conv_igemm (1x1)': 'k_conv_igemm', 'k_conv_igemm + k_conv_pair (1x1)': ('k_conv_igemm', 'k_conv_pair'), 'k_conv_gemm + k_conv_pair (1x1)': ('k_conv_gemm', 'k_conv_igemm', 'k_conv_pair'), 'k_conv_winograd (3x3)': 'k_conv_winograd', 'k_conv_patch (3x3)': 'k_conv_patch'}
+keys = {'k_stem_wino | k_stem_conv (7x7/2)': ('k_stem_wino', 'k_stem_conv'), 'k_stem_conv (7x7/2)': 'k_stem_conv', 'k_conv_igemm (1x1)': 'k_conv_igemm', 'k_conv_igemm + k_conv_pair (1x1)': ('k_conv_igemm', 'k_conv_pair'), 'k_conv_gemm + k_conv_pair (1x1)': ('k_conv_gemm', 'k_conv_igemm', 'k_conv_pair'), 'k_conv_winograd (3x3)': 'k_conv_winograd', 'k_conv_patch (3x3)': 'k_conv_patch'}
 tot_us = 0.0
 for name, d in b['conv_kernels'].items():
     t = traffic(keys[name])
