@@ -107,7 +107,8 @@ _SIGS = {
     'hmf_stem_wino_pack_host': (C.c_int, [_VP, _VP]),
     'hmf_stem_wino_pack_device': (C.c_int, [_VP, _VP, _VP]),
     'hmf_stem_wino': (C.c_int, [_VP] * 4 + [C.c_int] * 5 + [_VP]),
-    'hmf_stem_wino_pool': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
+    'hmf_stem_wino_pool_workspace_bytes': (C.c_longlong, [C.c_int] * 3),
+    'hmf_stem_wino_pool': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP, C.c_longlong, _VP]),
     'hmf_maxpool3x3s2_nhwc': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP]),
     'hmf_conv_patch_packed_floats': (C.c_longlong, [C.c_int] * 3),
     'hmf_conv_patch_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 4),
@@ -147,7 +148,8 @@ _EXPERIMENT_SIGS = {
     'hmf_debug_gemm_stamps': (C.c_int, [_VP, C.c_int]),
     'hmf_debug_set_wgw_target_wgs': (C.c_int, [C.c_int]),
     'hmf_debug_set_wgw_single_stage': (C.c_int, [C.c_int]),                            # tools/wgw_probe.py
-    'hmf_debug_stem_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/stem_probe.py
+    'hmf_debug_stem_stamps': (C.c_int, [_VP, C.c_int]),
+    'hmf_debug_stem_wino_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/stem_probe.py
     'hmf_debug_wino_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/wino_probe.py                             # tools/gemm1x1_probe.py
 }
 

@@ -25,11 +25,27 @@
 
 namespace hmf {
 
+#ifdef HMF_EXPERIMENTS           // tools/stem_probe.py --polyphase: per work-group stamps (shader clock: start, patch in LDS, main loop done, tile in LDS, end; 100 MHz counter at start / end)
+__device__ long long g_sw_stamps[12 * 4096];
+#define HMF_SWSTAMP(k, v)                                                                \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_sw_stamps[blockIdx.x * 12 + (k)] = (long long)(v); \
+    } while (0)
+#else
+#define HMF_SWSTAMP(k, v) \
+    do {                  \
+    } while (0)
+#endif
+
 constexpr int kSwC = 18, kSwN = 64;
 constexpr int kSwTH = 8, kSwTW = 16;
 constexpr int kSwRows = 21;
 constexpr int kSwP = 42, kSwQ = 10, kSwPlane = 1024;
 constexpr int kSwPairs = kSwC / 2;                 // 9 channel pairs = MFMA k-steps per product
+constexpr int kSwRing = 4;                         // channel-pair slots of the patch ring in LDS
+constexpr int kSwRim = 24;                         // pooled positions on the rim of a tile's 5 x 9 (shared with neighbour tiles)
+// rim slot of tile-relative pooled position (a, c): top row, bottom row, left column, right column
+__host__ __device__ constexpr int sw_rim_slot(int a, int c) { return a == 0 ? c : a == 4 ? 9 + c : c == 0 ? 17 + a : 20 + a; }
 constexpr int kSwGroups = 13;                      // 16-byte weight groups per channel pair and wave role (50 products + 2 zero slots)
 constexpr int kSwTotalGroups = kSwPairs * kSwGroups;   // 117
 
@@ -61,8 +77,8 @@ static inline double sw_gcoef(int v, int k) {
 }
 
 typedef __attribute__((address_space(3))) void* sw_lds_ptr_t;
-static __device__ __forceinline__ void sw_dma4(__amdgpu_buffer_rsrc_t rsrc, sw_lds_ptr_t dst, int voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 4, voff, 0, 0, 0);
+static __device__ __forceinline__ void sw_dma4(__amdgpu_buffer_rsrc_t rsrc, sw_lds_ptr_t dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 4, voff, soff, 0, 0);
 }
 
 __device__ __forceinline__ constexpr int sw_off(int j, int b) { return j * kSwP + (b & 3) * kSwQ + (b >> 2); }
@@ -74,15 +90,24 @@ __device__ __forceinline__ constexpr int sw_off(int j, int b) { return j * kSwP 
         op[5] = t[8];        op[6] = t[1] - t[5]; op[7] = t[3] + t[5]; op[8] = t[5] - t[3]; op[9] = t[7] - t[3];      \
     } while (0)
 
-// raw patch rows of vertical product vi of channel pair s (9 or 18 LDS reads), and their combination into the 10 MFMA A operands
+// raw patch rows of vertical product vi of a channel pair (9 or 18 LDS reads), and their combination into the 10 MFMA A operands.
+// The row base goes through an opaque register: the compiler then addresses the row's samples as base + small constant (ds_read2_b32 pairs), one
+// VALU add per row -- left to itself it rebuilt `lane base + large constant` for every pair (9 adds per product row instead of 2).
+typedef const __attribute__((address_space(3))) float* sw_ldsf_t;
+__device__ __forceinline__ sw_ldsf_t sw_opaque(sw_ldsf_t p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
 template <int VH>
-__device__ __forceinline__ void sw_load(const float* __restrict__ pa, int s, int vi, float (&raw)[18]) {
+__device__ __forceinline__ void sw_load(sw_ldsf_t pa, int slot, int vi, float (&raw)[18]) {
     const SwProd pr = sw_prod(sw_vlist(VH, vi));
-    const float* p = pa + s * 2 * kSwPlane;
+    const sw_ldsf_t pa_ = sw_opaque(pa + slot * 2 * kSwPlane + pr.ja * kSwP);
 #pragma unroll
-    for (int b = 0; b < 9; ++b) {
-        raw[b] = p[sw_off(pr.ja, b)];
-        if (pr.mode != 0) raw[9 + b] = p[sw_off(pr.jb, b)];
+    for (int b = 0; b < 9; ++b) raw[b] = pa_[sw_off(0, b)];
+    if (pr.mode != 0) {
+        const sw_ldsf_t pb_ = sw_opaque(pa + slot * 2 * kSwPlane + pr.jb * kSwP);
+#pragma unroll
+        for (int b = 0; b < 9; ++b) raw[9 + b] = pb_[sw_off(0, b)];
     }
 }
 template <int VH>
@@ -94,76 +119,109 @@ __device__ __forceinline__ void sw_combine(int vi, const float (&raw)[18], float
     HMF_SW_HOPS(op, t);
 }
 
+#define HMF_SW_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// The input patch streams through a ring of kSwRing channel-pair slots (2 planes of 1,024 floats each): pair s + 3 is requested (LDS-DMA, this wave's
+// quarter of the 32 requests) while pair s is consumed, so no phase of the work-group waits for the whole patch.
+struct SwFetch {
+    __amdgpu_buffer_rsrc_t rx;       // the image's 18 planes
+    int plane_bytes;                 // H * W * 4
+    int vo[4];                       // lane offsets of this wave's requests j = 4 jj + wave of a plane (out of range where the slot is padding / outside the image)
+    int wv;                          // wave index (scalar)
+    float* ring;                     // LDS
+};
+static __device__ __forceinline__ void sw_fetch_pair(const SwFetch& f, int s) {
+    const int slot = s % kSwRing;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            sw_dma4(f.rx, (sw_lds_ptr_t)((__attribute__((address_space(3))) float*)f.ring + (slot * 2 + k) * kSwPlane + 64 * (4 * jj + f.wv)), f.vo[jj],
+                    (2 * s + k) * f.plane_bytes);
+}
+
 // main loop of one wave role: 9 channel pairs x 5 vertical x 10 horizontal products, each chained into its class accumulator
-// acc[vertical class][horizontal class].  Software pipeline: the patch rows of the next vertical product are requested before the 10 MFMAs of the
-// current one and combined after them; filter groups arrive kPF groups (16 MFMAs) ahead in a register ring.
+// acc[vertical class][horizontal class].  Software pipeline inside a pair: the patch rows of the next vertical product are requested before the 10
+// MFMAs of the current one and combined after them; filter groups arrive kPF groups (4 kPF MFMAs) ahead in a register ring, as buffer loads whose
+// group offset is a scalar (no address arithmetic on the vector pipe).  vmcnt is in-order: by the time a wave reaches the barrier of pair s it has
+// consumed filter groups requested after its share of pair s, so that share has landed; the counted wait only makes this explicit.
 template <int VH>
-__device__ __forceinline__ void sw_main(const float* __restrict__ pa, const f32x4* __restrict__ pw, f32x16 (&acc)[2][4]) {
-    constexpr int kPF = 4, kRing = kPF + 1, kIters = kSwPairs * 5;
+__device__ __forceinline__ void sw_main(sw_ldsf_t pa, __amdgpu_buffer_rsrc_t rw, int wvo, const SwFetch& f, f32x16 (&acc)[2][4]) {
+    constexpr int kPF = 6, kRing = kPF + 1;
     f32x4 bw[kRing];
 #pragma unroll
-    for (int g = 0; g < kPF; ++g) bw[g] = pw[g * 64];
-    float raw[18], op[2][10];
-    sw_load<VH>(pa, 0, 0, raw);
-    sw_combine<VH>(0, raw, op[0]);
-#pragma clang loop unroll(full)
-    for (int it = 0; it < kIters; ++it) {
-        const int s = it / 5, vi = it - 5 * s;
-        if (it + 1 < kIters) sw_load<VH>(pa, (it + 1) / 5, (it + 1) % 5, raw);
-        __builtin_amdgcn_sched_barrier(0);
-        const int vc = vi < 3 ? 0 : 1;
+    for (int g = 0; g < kPF; ++g) bw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wvo, g * 1024, 0));
 #pragma unroll
-        for (int h = 0; h < 10; ++h) {
-            const int p = vi * 10 + h, g = s * kSwGroups + (p >> 2), u = p & 3;
-            if (u == 0 && g + kPF < kSwTotalGroups) bw[(g + kPF) % kRing] = pw[(g + kPF) * 64];
-            acc[vc][sw_prod(h).cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(op[it & 1][h], bw[g % kRing][u], acc[vc][sw_prod(h).cls], 0, 0, 0);
+    for (int s = 0; s < kSwRing - 1; ++s) sw_fetch_pair(f, s);
+    float raw[18], op[2][10];
+#pragma clang loop unroll(full)
+    for (int s = 0; s < kSwPairs; ++s) {
+        // own requests of pair s complete (everything but the requests of the up to two later pairs and the filter groups in flight) ...
+        if (s + 2 < kSwPairs) HMF_SW_VMCNT(16 + (s == 0 ? 0 : kPF));
+        else if (s + 1 < kSwPairs) HMF_SW_VMCNT(8 + kPF);
+        else HMF_SW_VMCNT(kPF);
+        __builtin_amdgcn_s_barrier();                                // ... everybody's, and every wave is past its reads of pair s - 1
+        if (s + kSwRing - 1 < kSwPairs) sw_fetch_pair(f, s + kSwRing - 1);
+        const int slot = s % kSwRing;
+        sw_load<VH>(pa, slot, 0, raw);
+        sw_combine<VH>(0, raw, op[0]);
+#pragma unroll
+        for (int vi = 0; vi < 5; ++vi) {
+            if (vi + 1 < 5) sw_load<VH>(pa, slot, vi + 1, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            const int vc = vi < 3 ? 0 : 1;
+#pragma unroll
+            for (int h = 0; h < 10; ++h) {
+                const int p = vi * 10 + h, g = s * kSwGroups + (p >> 2), u = p & 3;
+                if (u == 0 && g + kPF < kSwTotalGroups)
+                    bw[(g + kPF) % kRing] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wvo, (g + kPF) * 1024, 0));
+                acc[vc][sw_prod(h).cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(op[vi & 1][h], bw[g % kRing][u], acc[vc][sw_prod(h).cls], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (vi + 1 < 5) sw_combine<VH>(vi + 1, raw, op[(vi + 1) & 1]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < kIters) sw_combine<VH>((it + 1) % 5, raw, op[(it + 1) & 1]);
     }
 }
 
 template <bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_stem_wino(
-    const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
-    int OH, int OW, int tiles_w, int tiles_hw, int relu) {
-    __shared__ __attribute__((aligned(16))) float patch[kSwC * kSwPlane];           // 72 KB: two work-groups per CU
+    const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ halo, int B, int H,
+    int W, int OH, int OW, int tiles_w, int tiles_hw, int relu) {
+    // ring of 4 channel-pair slots (32 KB; after the main loop: the exchange buffer of the wave pairs) + the finished 8 x 16 x 64 tile (32 KB): two work-groups per CU
+    __shared__ __attribute__((aligned(16))) float lds[kSwRing * 2 * kSwPlane + kSwTH * kSwTW * kSwN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
     const int b = blockIdx.x / tiles_hw, trem = blockIdx.x - b * tiles_hw;
     const int oh0 = (trem / tiles_w) * kSwTH, ow0 = (trem % tiles_w) * kSwTW;
     const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+    HMF_SWSTAMP(0, __builtin_readcyclecounter());
+    HMF_SWSTAMP(5, wall_clock64());
+    HMF_SWSTAMP(8, __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));                    // HW_ID
+    HMF_SWSTAMP(9, __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)));                   // XCC_ID
 
-    // ---- input patch -> LDS by LDS-DMA: request (channel, j) fills plane floats [64 j, 64 j + 64); lane offsets computed once (16 VGPRs), the
-    // channel enters through the buffer descriptor's base.  Unused slots, rows >= 21 and pixels outside the image read out of range: the DMA
-    // writes the 0 the buffer load returns (= the zero padding of the convolution). ----
+    // ---- patch requests: request j of a plane fills plane floats [64 j, 64 j + 64): row = f / 42, slot = f % 42 -> column 4 (slot % 10) + slot / 10.
+    // Unused slots, rows >= 21 and pixels outside the image get an out-of-range offset: the DMA writes the 0 the buffer load returns (= the zero
+    // padding of the convolution).  Wave w issues requests w, w + 4, w + 8, w + 12 of every plane: four lane offsets, computed once. ----
     constexpr int kOOBs = 0x40000000;
-    int vo[16];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    SwFetch f;
+    f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * kSwC * H * W), 0, kSwC * H * W * 4, 0x00020000);
+    f.plane_bytes = H * W * 4;
+    f.wv = wv;
+    f.ring = lds;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int f = 64 * j + lane, row = f / kSwP, slot = f - row * kSwP;
+    for (int jj = 0; jj < 4; ++jj) {
+        const int fl = 64 * (4 * jj + wv) + lane, row = fl / kSwP, slot = fl - row * kSwP;
         const int grp = slot / kSwQ, idx = slot - grp * kSwQ, col = 4 * idx + grp;
         const bool ok = (row < kSwRows) & (slot < 4 * kSwQ) & (col <= 2 * kSwTW + 4) & ((unsigned)(ih0 + row) < (unsigned)H) & ((unsigned)(iw0 + col) < (unsigned)W);
-        vo[j] = ok ? ((ih0 + row) * W + iw0 + col) * 4 : kOOBs;
+        f.vo[jj] = ok ? ((ih0 + row) * W + iw0 + col) * 4 : kOOBs;
     }
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const float* ximg = x + (long long)b * kSwC * H * W;
-    for (int ch = 0; ch < kSwC; ++ch) {
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(ximg + (long long)ch * H * W), 0, H * W * 4, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if ((j & 3) != wv) continue;                              // wave-uniform: wave w issues requests w, w + 4, ... of every plane
-            sw_dma4(rc, (sw_lds_ptr_t)((__attribute__((address_space(3))) float*)patch + ch * kSwPlane + 64 * j), vo[j]);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     // ---- 450 products per wave ----
     const int nh = wv >> 1, vh = wv & 1;
     const int tr = li >> 3, tc = li & 7;                              // the lane's 2 x 2 tile: output rows 2 tr, 2 tr + 1, columns 2 tc, 2 tc + 1
-    const float* pa = patch + lq * kSwPlane + (4 * tr) * kSwP + tc;
-    const f32x4* pw = wp + (long long)(nh * 2 + vh) * kSwTotalGroups * 64 + lane;
+    const sw_ldsf_t pa = (sw_ldsf_t)lds + lq * kSwPlane + (4 * tr) * kSwP + tc;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wp + (long long)(nh * 2 + vh) * kSwTotalGroups * 64), 0, kSwTotalGroups * 1024, 0x00020000);
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -171,85 +229,128 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-    if (vh == 0) sw_main<0>(pa, pw, acc); else sw_main<1>(pa, pw, acc);
+    if (vh == 0) sw_main<0>(pa, rw, lane * 16, f, acc); else sw_main<1>(pa, rw, lane * 16, f, acc);
+    HMF_SWSTAMP(2, __builtin_readcyclecounter());
+#ifdef HMF_EXPERIMENTS
+    if (threadIdx.x == 64 && blockIdx.x < 4096) g_sw_stamps[blockIdx.x * 12 + 7] = (long long)__builtin_readcyclecounter();      // wave 1 (vh = 1)
+#endif
 
     // ---- class sums -> the wave's share of the four outputs of every tile.  Horizontal: C0 = A0 + P + Q, C1 = A1 + P - Q per vertical class;
-    // vertical: wave vh = 0 holds E = A0v and P = Pv: rows (E + P, P); wave vh = 1 holds F = A1v and Q = Qv: rows (Q, F - Q). ----
-    f32x16 part[2][2];                                               // [output row][output column]
+    // vertical: wave vh = 0 holds E = A0v and P = Pv: output rows (E + P, P); wave vh = 1 holds F = A1v and Q = Qv: rows (Q, F - Q).
+    // Wave vh finishes output row vh of its tiles: it hands its share of the other row to its partner through LDS (8 x 16-byte writes per lane). ----
+    f32x16 mine[2], give[2];                                         // [output column]
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const f32x16 c0 = c == 0 ? acc[0][0] + acc[0][2] + acc[0][3] : acc[0][1] + acc[0][2] - acc[0][3];     // vertical class 0 of this wave
         const f32x16 c1 = c == 0 ? acc[1][0] + acc[1][2] + acc[1][3] : acc[1][1] + acc[1][2] - acc[1][3];     // vertical class 1
-        if (vh == 0) { part[0][c] = c0 + c1; part[1][c] = c1; }
-        else         { part[0][c] = c1;      part[1][c] = c0 - c1; }
+        if (vh == 0) { mine[c] = c0 + c1; give[c] = c1; }
+        else         { mine[c] = c0 - c1; give[c] = c1; }
     }
-    __syncthreads();                                                 // every wave is done with the patch
-    float* tl = patch;                                               // [row 8][col 16][ch 64]
-    const int n = 32 * nh + li;
-    if (vh == 0) {
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
+    f32x4* xb = (f32x4*)lds;                                         // [wave][column][quad][lane]
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lq;
-                    tl[((2 * (i >> 3) + rr) * 16 + 2 * (i & 7) + c) * 64 + n] = part[rr][c][r];
-                }
-    }
+        for (int q = 0; q < 4; ++q) xb[((wv * 2 + c) * 4 + q) * 64 + lane] = f32x4{give[c][4 * q], give[c][4 * q + 1], give[c][4 * q + 2], give[c][4 * q + 3]};
     __syncthreads();
-    if (vh == 1) {
+    float* tl = lds + kSwRing * 2 * kSwPlane;                        // [row 8][col 16][ch 64]
+    const int n = 32 * nh + li;
+    {
         const float bv = bias ? bias[n] : 0.f;
+        f32x4 got[2][4];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int q = 0; q < 4; ++q) got[c][q] = xb[(((wv ^ 1) * 2 + c) * 4 + q) * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lq;
-                    const int row = 2 * (i >> 3) + rr, col = 2 * (i & 7) + c;
-                    const float v = tl[(row * 16 + col) * 64 + n] + part[rr][c][r] + bv;
-                    const bool in = (oh0 + row < OH) & (ow0 + col < OW);
-                    if (POOL) {
-                        tl[(row * 16 + col) * 64 + n] = in ? fmaxf(v, 0.f) + 0.f : 0.f;          // + 0.f: never -0 (its bit pattern would win the max)
-                    } else if (in) {
-                        y[(((long long)b * OH + oh0 + row) * OW + ow0 + col) * kSwN + n] = relu ? fmaxf(v, 0.f) : v;
-                    }
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lq;
+                const int row = 2 * (i >> 3) + vh, col = 2 * (i & 7) + c;
+                // row 0: (E + P) + Q, row 1: P + (F - Q) -- the order of the two-launch form's sums is kept (vh = 0's share first)
+                const float v = (vh == 0 ? mine[c][r] + got[c][r >> 2][r & 3] : got[c][r >> 2][r & 3] + mine[c][r]) + bv;
+                const bool in = (oh0 + row < OH) & (ow0 + col < OW);
+                if (POOL) {
+                    tl[(row * 16 + col) * 64 + n] = in ? fmaxf(v, 0.f) + 0.f : 0.f;              // + 0.f: never -0 (its bit pattern would win the max)
+                } else if (in) {
+                    y[(((long long)b * OH + oh0 + row) * OW + ow0 + col) * kSwN + n] = relu ? fmaxf(v, 0.f) : v;
                 }
+            }
     }
     if (!POOL) return;
     __syncthreads();
-    // ---- max-pool 3x3 / stride 2 / pad 1 of the tile (as k_stem_conv<true>): windows inside the tile are stored, windows shared with a neighbour tile
-    // are combined with an integer atomic max (post-ReLU values are >= +0); y is the POOLED map, zeroed by the caller ----
+    HMF_SWSTAMP(3, __builtin_readcyclecounter());
+    // ---- max-pool 3x3 / stride 2 / pad 1 of the tile.  The tile touches 5 x 9 pooled positions: the 3 x 7 whose windows lie inside it are final and
+    // stored; the 24 on its rim also take rows / columns of a neighbour tile: their PARTIAL maxima go to the tile's halo record (plain stores) and
+    // k_stem_pool_rim combines the two to four records of a rim position afterwards.  No atomics, no zero-filled map: every pooled value is written
+    // exactly once.  (k_stem_conv<true> combines the rim with integer atomic maxima on a pre-zeroed map: 28 us of a 315-us launch here, mostly the
+    // acknowledgement latency at the end of every work-group.)  A wave takes whole positions (lane = channel): nine conflict-free LDS reads and one
+    // 256-byte store per position. ----
     const int PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;
     const int pr0 = oh0 >> 1, pc0 = ow0 >> 1;
-    for (int it = tid; it < 45 * 16; it += 256) {
-        const int p = it >> 4, cq = (it & 15) * 4;
-        const int a = p / 9, c = p - a * 9;
+    float* hrec = halo + (long long)blockIdx.x * (kSwRim * kSwN);
+#pragma unroll 4
+    for (int p = wv; p < 45; p += 4) {
+        const int a = p / 9, c = p - a * 9;                          // wave-uniform
         if (pr0 + a >= PH || pc0 + c >= PW) continue;
-        f32x4 m = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+        float m = 0.f;                                               // window rows / columns clamped into the tile: a duplicate does not change a maximum,
+#pragma unroll                                                       // and nine unconditional reads can be in flight together
         for (int dr = -1; dr <= 1; ++dr) {
-            const int rr = 2 * a + dr;
-            if ((unsigned)rr >= 8u) continue;
+            const int rr = min(max(2 * a + dr, 0), 7);
 #pragma unroll
             for (int dc = -1; dc <= 1; ++dc) {
-                const int cc = 2 * c + dc;
-                if ((unsigned)cc < 16u) {
-                    const f32x4 v = *(const f32x4*)&tl[(rr * 16 + cc) * 64 + cq];
-                    m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
-                }
+                const int cc = min(max(2 * c + dc, 0), 15);
+                m = fmaxf(m, tl[(rr * 16 + cc) * 64 + lane]);
             }
         }
-        float* dst = y + (((long long)b * PH + pr0 + a) * PW + pc0 + c) * kSwN + cq;
         const bool whole = (a >= 1) & (a <= 3) & (c >= 1) & (c <= 7);
-        if (whole) {
-            *(f32x4*)dst = m;
-        } else {
+        if (whole) y[(((long long)b * PH + pr0 + a) * PW + pc0 + c) * kSwN + lane] = m;
+        else hrec[sw_rim_slot(a, c) * kSwN + lane] = m;
+    }
+#ifdef HMF_EXPERIMENTS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HMF_SWSTAMP(4, __builtin_readcyclecounter());
+    HMF_SWSTAMP(6, wall_clock64());
+#endif
+}
+
+// Rim positions of the pooled map (pooled row % 4 == 0 or pooled column % 8 == 0): the maximum over the halo records of the up to four tiles
+// whose 5 x 9 ranges contain the position.  One thread per (position, channel).
+__global__ __launch_bounds__(256) void k_stem_pool_rim(const float* __restrict__ halo, float* __restrict__ y, int B, int PH, int PW, int tiles_h, int tiles_w,
+                                                       int rows_rim, int cols_plain) {
+    // enumeration: first the rim rows (every column), then the rim columns of the other rows
+    const long long per_img = (long long)rows_rim * PW + (long long)(PH - rows_rim) * cols_plain;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ch = (int)(e & 63);
+    const long long q = e >> 6;
+    if (q >= per_img * B) return;
+    const int b = (int)(q / per_img);
+    long long r = q - (long long)b * per_img;
+    int pr, pc;
+    if (r < (long long)rows_rim * PW) {
+        pr = (int)(r / PW) * 4;
+        pc = (int)(r % PW);
+    } else {
+        r -= (long long)rows_rim * PW;
+        const int rowi = (int)(r / cols_plain);                       // index among the rows with pr % 4 != 0
+        pr = rowi + rowi / 3 + 1;
+        pc = (int)(r % cols_plain) * 8;
+    }
+    float m = 0.f;                                                     // post-ReLU values are >= 0
+    const int ty1 = pr >> 2, tx1 = pc >> 3;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicMax((unsigned int*)dst + e, __float_as_uint(m[e]));
+    for (int dy = 0; dy < 2; ++dy) {
+        const int ty = ty1 - dy, a = pr - 4 * ty;
+        if (ty < 0 || ty >= tiles_h || a > 4) continue;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int tx = tx1 - dx, c = pc - 8 * tx;
+            if (tx < 0 || tx >= tiles_w || c > 8) continue;
+            m = fmaxf(m, halo[(((long long)b * tiles_h + ty) * tiles_w + tx) * (kSwRim * kSwN) + sw_rim_slot(a, c) * kSwN + ch]);
         }
     }
+    y[(((long long)b * PH + pr) * PW + pc) * kSwN + ch] = m;
 }
 
 // transformed filters of wave role (nh, vh), group g = pair * 13 + q, lane, slot u:  product p = 4 q + u -> (vertical vi = p / 10, horizontal h = p % 10)
@@ -307,7 +408,22 @@ __global__ __launch_bounds__(256) void k_stem_wino_pack(const float* __restrict_
 
 using namespace hmf;
 
+#ifdef HMF_EXPERIMENTS
+extern "C" int hmf_debug_stem_wino_stamps(long long* out_host, int blocks) {
+    if (!out_host || blocks < 1 || blocks > 4096) return fail(HMF_ERR_INVALID, "hmf_debug_stem_wino_stamps: bad args");
+    HMF_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sw_stamps), (size_t)blocks * 12 * sizeof(long long)));
+    return HMF_OK;
+}
+#endif
+
 extern "C" long long hmf_stem_wino_packed_floats(void) { return 4LL * kSwTotalGroups * 64 * 4; }
+
+extern "C" long long hmf_stem_wino_pool_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long th = (OH + kSwTH - 1) / kSwTH, tw = (OW + kSwTW - 1) / kSwTW;
+    return (long long)B * th * tw * kSwRim * kSwN * (long long)sizeof(float);
+}
 
 extern "C" int hmf_stem_wino_pack_host(const float* w /*64x18x7x7*/, float* packed) {
     if (!w || !packed) return fail(HMF_ERR_INVALID, "hmf_stem_wino_pack_host: null pointer");
@@ -341,31 +457,38 @@ extern "C" int hmf_stem_wino_pack_device(const float* w, float* packed, void* st
     return HMF_OK;
 }
 
-static int stem_wino_launch(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, bool pool, void* stream,
-                            const char* who) {
+static int stem_wino_launch(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, bool pool, void* ws,
+                            long long ws_bytes, void* stream, const char* who) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "%s: bad args", who);
     if (C != kSwC) return fail(HMF_ERR_UNSUPPORTED, "%s: %d input channels (the 18-channel proxy representation is built)", who, C);
     if ((uintptr_t)w_packed & 15) return fail(HMF_ERR_INVALID, "%s: packed weights must be 16-byte aligned", who);
-    if ((long long)H * W * 4 >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "%s: image plane too large for a buffer descriptor", who);
+    if ((long long)H * W * 4 * kSwC >= (1LL << 30)) return fail(HMF_ERR_UNSUPPORTED, "%s: image too large for a buffer descriptor", who);
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1, PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;
     const int th = (OH + kSwTH - 1) / kSwTH, tw = (OW + kSwTW - 1) / kSwTW;
     const long long blocks = (long long)B * th * tw;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "%s: too many tiles", who);
+    if (pool && (!ws || ws_bytes < hmf_stem_wino_pool_workspace_bytes(B, H, W) || ((uintptr_t)ws & 15)))
+        return fail(HMF_ERR_INVALID, "%s: workspace missing, unaligned or smaller than hmf_stem_wino_pool_workspace_bytes", who);
     hipStream_t st = (hipStream_t)stream;
-    if (pool) {
-        if (int zr = zero_async(y, (size_t)B * PH * PW * kSwN * sizeof(float), st)) return zr;       // the identity of the max over post-ReLU values
-    }
     ProfScope ps(9, B, st);
-    if (pool) hipLaunchKernelGGL(k_stem_wino<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw, 1);
-    else hipLaunchKernelGGL(k_stem_wino<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, B, H, W, OH, OW, tw, th * tw, relu);
+    if (pool) {
+        hipLaunchKernelGGL(k_stem_wino<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, (float*)ws, B, H, W, OH, OW, tw, th * tw, 1);
+        HMF_LAUNCH_CHECK();
+        const int rows_rim = (PH + 3) / 4, cols_plain = (PW + 7) / 8;                    // pooled rows with pr % 4 == 0; rim columns (pc % 8 == 0) of the other rows
+        const long long n = ((long long)rows_rim * PW + (long long)(PH - rows_rim) * cols_plain) * B * 64;
+        hipLaunchKernelGGL(k_stem_pool_rim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, y, B, PH, PW, th, tw, rows_rim, cols_plain);
+    } else {
+        hipLaunchKernelGGL(k_stem_wino<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, (float*)nullptr, B, H, W, OH, OW, tw, th * tw, relu);
+    }
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }
 
 extern "C" int hmf_stem_wino(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, void* stream) {
-    return stem_wino_launch(x, w_packed, bias, y, B, C, H, W, relu, false, stream, "hmf_stem_wino");
+    return stem_wino_launch(x, w_packed, bias, y, B, C, H, W, relu, false, nullptr, 0, stream, "hmf_stem_wino");
 }
 
-extern "C" int hmf_stem_wino_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* stream) {
-    return stem_wino_launch(x, w_packed, bias, y_pooled, B, C, H, W, 1, true, stream, "hmf_stem_wino_pool");
+extern "C" int hmf_stem_wino_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* ws, long long ws_bytes,
+                                  void* stream) {
+    return stem_wino_launch(x, w_packed, bias, y_pooled, B, C, H, W, 1, true, ws, ws_bytes, stream, "hmf_stem_wino_pool");
 }

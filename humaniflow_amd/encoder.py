@@ -83,6 +83,7 @@ class ResNetEncoder(nn.Module):
         self._plan = None
         self._plan_key = None
         self.__dict__['_plan_tensors'] = None
+        self.__dict__['_stem_ws'] = {}
 
     # ---- plain module graph: batch-statistics BatchNorm under autograd (training), and the float64 reference of the tests ----
     def forward_module(self, x):
@@ -143,6 +144,7 @@ class ResNetEncoder(nn.Module):
         st['_plan_key'] = None
         st['_plan_tensors'] = None
         st.pop('_stem_map', None)
+        st['_stem_ws'] = {}
         for k in [k for k in st if k.startswith('_wino')]:     # training-graph filter packs (encoder_train.py)
             st.pop(k)
         return st
@@ -366,9 +368,18 @@ class ResNetEncoder(nn.Module):
         PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
         st = _lib.current_stream()
         z = torch.empty((B, 64, PH, PW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-        conv, conv_pool = (lib.hmf_stem_wino, lib.hmf_stem_wino_pool) if self.stem_polyphase else (lib.hmf_stem_conv, lib.hmf_stem_conv_pool)
+        conv = lib.hmf_stem_wino if self.stem_polyphase else lib.hmf_stem_conv
+        if self.fuse_stem_pool and self.stem_polyphase:
+            nbytes = int(lib.hmf_stem_wino_pool_workspace_bytes(B, H, W))
+            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+            ws = self._stem_ws.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = self._stem_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)     # per stream: overlapped batches must not share it
+            _lib.check(lib.hmf_stem_wino_pool(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), z.data_ptr(), B, C, H, W, ws.data_ptr(), ws.numel(), st),
+                       'hmf_stem_wino_pool')
+            return z
         if self.fuse_stem_pool:
-            _lib.check(conv_pool(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), z.data_ptr(), B, C, H, W, st), 'hmf_stem_conv_pool')
+            _lib.check(lib.hmf_stem_conv_pool(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), z.data_ptr(), B, C, H, W, st), 'hmf_stem_conv_pool')
             return z
         y = torch.empty((B, 64, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         _lib.check(conv(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), 'hmf_stem_conv')

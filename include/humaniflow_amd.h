@@ -409,7 +409,12 @@ long long hmf_stem_wino_packed_floats(void);
 int hmf_stem_wino_pack_host(const float* w, float* packed);
 int hmf_stem_wino_pack_device(const float* w, float* packed, void* stream);
 int hmf_stem_wino(const float* x, const float* w_packed, const float* bias, float* y, int B, int C, int H, int W, int relu, void* stream);
-int hmf_stem_wino_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* stream);
+/* hmf_stem_wino_pool: the max-pool is applied to each work-group's tile before it leaves the CU; pooled positions on a tile's rim go through per-tile
+ * halo records in `ws` (hmf_stem_wino_pool_workspace_bytes(B, H, W) bytes, 16-byte aligned) and a second, small launch combines them -- no atomics and
+ * no zero-filled map, every pooled value is written exactly once (hmf_stem_conv_pool uses integer atomic maxima on a pre-zeroed map instead). */
+long long hmf_stem_wino_pool_workspace_bytes(int B, int H, int W);
+int hmf_stem_wino_pool(const float* x, const float* w_packed, const float* bias, float* y_pooled, int B, int C, int H, int W, void* ws, long long ws_bytes,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Evaluation epilogue (metrics/eval_metrics_tracker.py:95-280,398-410; utils/eval_utils.py)     */

@@ -33,6 +33,9 @@ int hmf_debug_set_wgw_single_stage(int on);     /* 1: the single-staged 32-tile-
 /* Diagnostic (tools/stem_probe.py): stamps of the last k_stem_conv<POOL> launch, 6 int64 per work-group (shader clock at start, patch in LDS, main
  * loop done, end; the 100 MHz counter at start and end). */
 int hmf_debug_stem_stamps(long long* out_host, int blocks);
+/* the same for the polyphase stem (csrc/stem_wino.hip): 12 values per work-group -- shader clock at start, -, main loop done, tile in LDS, end; 100 MHz counter at
+ * start / end; wave 1 main loop done; HW_ID; XCC_ID */
+int hmf_debug_stem_wino_stamps(long long* out_host, int blocks);
 
 /* Diagnostic (tools/gemm1x1_probe.py --timeline): stamps of the last k_conv_gemm launch, 6 int64 per work-group: shader clock at start, first
  * chunk visible, main loop done, stores retired; the constant 100 MHz counter at start and end.  Work-groups 0 .. blocks-1 (<= 4096). */

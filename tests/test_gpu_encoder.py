@@ -365,7 +365,7 @@ def test_stem_conv_and_maxpool_match_float64_reference(B, H, W, form):
 
 
 @pytest.mark.parametrize('form', ['direct', 'polyphase'])
-@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 100, 76), (3, 34, 130), (1, 256, 256)])
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 100, 76), (3, 34, 130), (1, 256, 256), (2, 18, 22), (1, 130, 258)])
 def test_stem_with_fused_maxpool_equals_the_two_launches(B, H, W, form):
     """hmf_stem_conv_pool / hmf_stem_wino_pool (pool applied per tile, shared windows by atomic max) == the stem + hmf_maxpool3x3s2_nhwc, bit for bit
     (ragged tiles, odd pooled sizes, several images)."""
@@ -387,7 +387,12 @@ def test_stem_with_fused_maxpool_equals_the_two_launches(B, H, W, form):
     zf = torch.full((B, PH, PW, 64), float('nan'), device='cuda')
     _lib.check(f_conv(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), y.data_ptr(), B, 18, H, W, 1, st), 'stem')
     _lib.check(lib.hmf_maxpool3x3s2_nhwc(y.data_ptr(), z.data_ptr(), B, OH, OW, 64, st), 'pool')
-    _lib.check(f_pool(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), zf.data_ptr(), B, 18, H, W, st), 'stem+pool')
+    if form == 'polyphase':
+        ws = torch.empty(int(lib.hmf_stem_wino_pool_workspace_bytes(B, H, W)), dtype=torch.uint8, device='cuda')
+        _lib.check(f_pool(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), zf.data_ptr(), B, 18, H, W, ws.data_ptr(), ws.numel(), st), 'stem+pool')
+        assert lib.hmf_stem_wino_pool(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), zf.data_ptr(), B, 18, H, W, ws.data_ptr(), ws.numel() - 1, st) < 0      # too small
+    else:
+        _lib.check(f_pool(x.data_ptr(), pk.data_ptr(), bias.data_ptr(), zf.data_ptr(), B, 18, H, W, st), 'stem+pool')
     torch.cuda.synchronize()
     assert torch.equal(z, zf)
 
