@@ -373,9 +373,14 @@ class EncoderTrainFn(torch.autograd.Function):
             if stem:
                 B, C, H, W = xin.shape
                 OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-                packed = enc._stem_packed_from_device(conv.weight.detach())
                 s.y = _cl_empty(B, 64, OH, OW, dev)
-                _lib.check(lib.hmf_stem_conv(xin.data_ptr(), packed.data_ptr(), None, s.y.data_ptr(), B, C, H, W, 0, _lib.current_stream()), 'hmf_stem_conv')
+                if enc.stem_polyphase:                                # csrc/stem_wino.hip: transformed filters rebuilt from the live parameter by one small launch
+                    packed = torch.empty(int(lib.hmf_stem_wino_packed_floats()), dtype=torch.float32, device=dev)
+                    _lib.check(lib.hmf_stem_wino_pack_device(conv.weight.detach().data_ptr(), packed.data_ptr(), _lib.current_stream()), 'hmf_stem_wino_pack_device')
+                    _lib.check(lib.hmf_stem_wino(xin.data_ptr(), packed.data_ptr(), None, s.y.data_ptr(), B, C, H, W, 0, _lib.current_stream()), 'hmf_stem_wino')
+                else:
+                    packed = enc._stem_packed_from_device(conv.weight.detach())
+                    _lib.check(lib.hmf_stem_conv(xin.data_ptr(), packed.data_ptr(), None, s.y.data_ptr(), B, C, H, W, 0, _lib.current_stream()), 'hmf_stem_conv')
             else:
                 s.y = _conv_any(xin, conv.weight.detach(), s.stride, native=(conv.weight, False))
             s.out, s.mean, s.rstd = _bn_forward(s.y, bn, residual, relu, pool, tracked)
