@@ -191,7 +191,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     __shared__ __attribute__((aligned(16))) float lds[kSwRing * 2 * kSwPlane + kSwTH * kSwTW * kSwN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
-    const int b = blockIdx.x / tiles_hw, trem = blockIdx.x - b * tiles_hw;
+    // Work-groups are dealt to the 8 XCDs round-robin: give each XCD a contiguous run of tiles, so that the horizontally adjacent tiles that share
+    // 128-byte lines of the input rows (and the vertically adjacent ones that share 5 of their 21 rows) meet in ONE L2 at the same time.
+    int L = blockIdx.x;
+    if ((gridDim.x & 7) == 0) L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int b = L / tiles_hw, trem = L - b * tiles_hw;
     const int oh0 = (trem / tiles_w) * kSwTH, ow0 = (trem % tiles_w) * kSwTW;
     const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
     HMF_SWSTAMP(0, __builtin_readcyclecounter());
@@ -285,28 +289,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // stored; the 24 on its rim also take rows / columns of a neighbour tile: their PARTIAL maxima go to the tile's halo record (plain stores) and
     // k_stem_pool_rim combines the two to four records of a rim position afterwards.  No atomics, no zero-filled map: every pooled value is written
     // exactly once.  (k_stem_conv<true> combines the rim with integer atomic maxima on a pre-zeroed map: 28 us of a 315-us launch here, mostly the
-    // acknowledgement latency at the end of every work-group.)  A wave takes whole positions (lane = channel): nine conflict-free LDS reads and one
-    // 256-byte store per position. ----
+    // acknowledgement latency at the end of every work-group.) ----
     const int PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;
     const int pr0 = oh0 >> 1, pc0 = ow0 >> 1;
-    float* hrec = halo + (long long)blockIdx.x * (kSwRim * kSwN);
-#pragma unroll 4
-    for (int p = wv; p < 45; p += 4) {
-        const int a = p / 9, c = p - a * 9;                          // wave-uniform
+    float* hrec = halo + (long long)L * (kSwRim * kSwN);
+    for (int it = tid; it < 45 * 16; it += 256) {                    // item = (pooled position, 4 channels): nine 16-byte LDS reads, one 16-byte store
+        const int p = it >> 4, cq = (it & 15) * 4;
+        const int a = p / 9, c = p - a * 9;
         if (pr0 + a >= PH || pc0 + c >= PW) continue;
-        float m = 0.f;                                               // window rows / columns clamped into the tile: a duplicate does not change a maximum,
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};                              // window rows / columns clamped into the tile: a duplicate does not change a maximum,
 #pragma unroll                                                       // and nine unconditional reads can be in flight together
         for (int dr = -1; dr <= 1; ++dr) {
             const int rr = min(max(2 * a + dr, 0), 7);
 #pragma unroll
             for (int dc = -1; dc <= 1; ++dc) {
                 const int cc = min(max(2 * c + dc, 0), 15);
-                m = fmaxf(m, tl[(rr * 16 + cc) * 64 + lane]);
+                const f32x4 v = *(const f32x4*)&tl[(rr * 16 + cc) * 64 + cq];
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
             }
         }
         const bool whole = (a >= 1) & (a <= 3) & (c >= 1) & (c <= 7);
-        if (whole) y[(((long long)b * PH + pr0 + a) * PW + pc0 + c) * kSwN + lane] = m;
-        else hrec[sw_rim_slot(a, c) * kSwN + lane] = m;
+        float* dst = whole ? y + (((long long)b * PH + pr0 + a) * PW + pc0 + c) * kSwN + cq : hrec + sw_rim_slot(a, c) * kSwN + cq;
+        *(f32x4*)dst = m;
     }
 #ifdef HMF_EXPERIMENTS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -316,28 +320,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 }
 
 // Rim positions of the pooled map (pooled row % 4 == 0 or pooled column % 8 == 0): the maximum over the halo records of the up to four tiles
-// whose 5 x 9 ranges contain the position.  One thread per (position, channel).
+// whose 5 x 9 ranges contain the position.  One thread per (position, 4 channels).
 __global__ __launch_bounds__(256) void k_stem_pool_rim(const float* __restrict__ halo, float* __restrict__ y, int B, int PH, int PW, int tiles_h, int tiles_w,
                                                        int rows_rim, int cols_plain) {
-    // enumeration: first the rim rows (every column), then the rim columns of the other rows
-    const long long per_img = (long long)rows_rim * PW + (long long)(PH - rows_rim) * cols_plain;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int ch = (int)(e & 63);
-    const long long q = e >> 6;
-    if (q >= per_img * B) return;
-    const int b = (int)(q / per_img);
-    long long r = q - (long long)b * per_img;
+    // enumeration per image: first the rim rows (every column), then the rim columns of the other rows
+    const int per_img = rows_rim * PW + (PH - rows_rim) * cols_plain;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const int cq = (int)(e & 15) * 4;
+    const unsigned q = e >> 4;
+    if (q >= (unsigned)per_img * (unsigned)B) return;
+    const int b = (int)(q / (unsigned)per_img);
+    int r = (int)(q - (unsigned)b * (unsigned)per_img);
     int pr, pc;
-    if (r < (long long)rows_rim * PW) {
-        pr = (int)(r / PW) * 4;
-        pc = (int)(r % PW);
+    if (r < rows_rim * PW) {
+        pr = (r / PW) * 4;
+        pc = r % PW;
     } else {
-        r -= (long long)rows_rim * PW;
-        const int rowi = (int)(r / cols_plain);                       // index among the rows with pr % 4 != 0
+        r -= rows_rim * PW;
+        const int rowi = r / cols_plain;                              // index among the rows with pr % 4 != 0
         pr = rowi + rowi / 3 + 1;
-        pc = (int)(r % cols_plain) * 8;
+        pc = (r % cols_plain) * 8;
     }
-    float m = 0.f;                                                     // post-ReLU values are >= 0
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};                                    // post-ReLU values are >= 0
     const int ty1 = pr >> 2, tx1 = pc >> 3;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
@@ -347,10 +351,11 @@ __global__ __launch_bounds__(256) void k_stem_pool_rim(const float* __restrict__
         for (int dx = 0; dx < 2; ++dx) {
             const int tx = tx1 - dx, c = pc - 8 * tx;
             if (tx < 0 || tx >= tiles_w || c > 8) continue;
-            m = fmaxf(m, halo[(((long long)b * tiles_h + ty) * tiles_w + tx) * (kSwRim * kSwN) + sw_rim_slot(a, c) * kSwN + ch]);
+            const f32x4 v = *(const f32x4*)&halo[(((long long)b * tiles_h + ty) * tiles_w + tx) * (kSwRim * kSwN) + sw_rim_slot(a, c) * kSwN + cq];
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
         }
     }
-    y[(((long long)b * PH + pr) * PW + pc) * kSwN + ch] = m;
+    *(f32x4*)&y[(((long long)b * PH + pr) * PW + pc) * kSwN + cq] = m;
 }
 
 // transformed filters of wave role (nh, vh), group g = pair * 13 + q, lane, slot u:  product p = 4 q + u -> (vertical vi = p / 10, horizontal h = p % 10)
@@ -475,7 +480,8 @@ static int stem_wino_launch(const float* x, const float* w_packed, const float* 
         hipLaunchKernelGGL(k_stem_wino<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, (float*)ws, B, H, W, OH, OW, tw, th * tw, 1);
         HMF_LAUNCH_CHECK();
         const int rows_rim = (PH + 3) / 4, cols_plain = (PW + 7) / 8;                    // pooled rows with pr % 4 == 0; rim columns (pc % 8 == 0) of the other rows
-        const long long n = ((long long)rows_rim * PW + (long long)(PH - rows_rim) * cols_plain) * B * 64;
+        const long long n = ((long long)rows_rim * PW + (long long)(PH - rows_rim) * cols_plain) * B * 16;
+        if (n >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "%s: pooled map too large", who);
         hipLaunchKernelGGL(k_stem_pool_rim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, y, B, PH, PW, th, tw, rows_rim, cols_plain);
     } else {
         hipLaunchKernelGGL(k_stem_wino<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, (const f32x4*)w_packed, bias, y, (float*)nullptr, B, H, W, OH, OW, tw, th * tw, relu);
