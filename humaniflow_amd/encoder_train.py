@@ -299,8 +299,13 @@ def _dgrad(gy, s, residual=None, extra=None):
                    'hmf_conv_dgrad_s2')
         return gx
     assert extra is None
-    wt = w.flip(2, 3).transpose(0, 1) if ks > 1 else w.transpose(0, 1)          # (Cin, Cout, k, k) view: flipped, in/out swapped
     nat = (s.conv.weight, True)
+    if (s.stride == 1 and ks == 3 and s.conv.weight.is_contiguous() and gy.shape[1] % 64 == 0 and Cin % 32 == 0
+            and (gy.shape[3] >= 16 or gy.shape[3] == 8)):
+        return _conv3x3_winograd(gy, nat, residual)                    # the Winograd pack reads the parameter itself: no flipped copy (torch.flip is a launch)
+    if s.stride == 1 and ks == 3 and s.conv.weight.is_contiguous() and gy.shape[1] % 64 == 0 and Cin % 64 == 0:
+        return _conv3x3_patch(gy, w.transpose(0, 1), 1, residual, nat)  # the gather map is composed with the flip: only the view's shape is read
+    wt = w.flip(2, 3).transpose(0, 1) if ks > 1 else w.transpose(0, 1)          # (Cin, Cout, k, k) view: flipped, in/out swapped
     if s.stride == 1:
         return _conv_any(gy, wt, 1, residual, native=nat)
     if ks == 1:                                                       # strided 1x1 (downsample branch): only the sampled pixels receive gradient
