@@ -58,7 +58,7 @@ if [ "${HMF_PROFILE_FLAVOURS:-1}" = "1" ] && [ "$PART" != "main" ]; then
     python bench.py --train --no-cpu-baseline > "$OUT/${R}_bench_train_configs4.json" 2> "$OUT/${R}_bench_train.log"
     rocprofv3 --kernel-trace --stats -d /tmp/prof_tr -o tr -- python bench.py --train --no-cpu-baseline --steps 12 --warmup 4 --profile-steps 0 > /dev/null 2>/tmp/tr.log
     python tools/rocpd_stats.py "$(find /tmp/prof_tr -name '*.db' | head -1)" 60 > "$OUT/${R}_train_kernel_stats.md"
-    python tools/step_sequence.py "$(find /tmp/prof_tr -name '*.db' | head -1)" k_stem_conv 8 > "$OUT/${R}_train_step_sequence.txt"
+    python tools/step_sequence.py "$(find /tmp/prof_tr -name '*.db' | head -1)" k_stem_wino_pack 8 > "$OUT/${R}_train_step_sequence.txt"
     # opt-in flavours of the headline workload (never the headline line): 1x1 GEMMs on the bf16 pipe with split fp32 operands
     python bench.py --gemm-terms 6 --no-cpu-baseline > "$OUT/${R}_bench_optin_gemm_terms6.json" 2> "$OUT/${R}_bench_terms6.log"
     python bench.py --gemm-terms 3 --no-cpu-baseline > "$OUT/${R}_bench_optin_gemm_terms3.json" 2> "$OUT/${R}_bench_terms3.log"
