@@ -34,6 +34,7 @@ struct GemmArgs {
     float* y;            // [M][N] (POOL: or null)
     float* pool;         // POOL: [M / 64][N] mean over each run of 64 rows (= the 8 x 8 pixels of one image)
     int M, N, K1, K2, OH, OW, H2, W2, stride2, relu;
+    int xb;              // XCD split along n (hmf_common.h xcd_n_split)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 
     // ---- XCD-aware tile assignment: the ids of one XCD cover a contiguous run of tiles, n fastest (the N / BN tiles sharing an activation panel share an L2)
     const int NT = a.N / BN, MT = (a.M + BM - 1) / BM, T = MT * NT;
-    int t = blockIdx.x;
-    if ((T & 7) == 0) t = (blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    const int t = xcd_tile(blockIdx.x, MT, NT, a.xb);
+    (void)T;
     const int m0 = (t / NT) * BM, n0 = (t % NT) * BN;
     const int K = a.K1 + a.K2;
 
@@ -289,8 +290,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 }
 
 template <int BM, int BN, int S, int OCC, int KS = 1>
-static void launch_gemm(const GemmArgs& a, hipStream_t st) {
-    const int T = ((a.M + BM - 1) / BM) * (a.N / BN);
+static void launch_gemm(GemmArgs a, hipStream_t st) {
+    const int MT = (a.M + BM - 1) / BM, NT = a.N / BN, T = MT * NT;
+    // activation bytes: the x panel (+ the strided second source) once per m-tile; filter bytes once per n-tile (residual / output go to one XCD either way)
+    a.xb = xcd_n_split(4LL * a.M * (a.K1 + a.K2), 4LL * a.N * (a.K1 + a.K2), MT, NT);
     ProfScope ps(8, a.M, st);
     if (a.pool) {
         if constexpr (KS == 1 && BM == 64) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS, true>), dim3(T), dim3(256), 0, st, a);

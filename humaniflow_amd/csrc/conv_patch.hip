@@ -26,6 +26,7 @@ struct PatchArgs {
     const float* res;
     float* y;             // [B][OH][OW][Cout]
     int B, H, W, Cin, OH, OW, Cout, stride, relu, tiles_w, tiles_hw, n_tiles;
+    int xb;               // XCD split along the channel tiles (hmf_common.h xcd_n_split)
 };
 
 template <int KS, int TW, int PG, int TN, int SC, int ST>
@@ -57,9 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
     // block -> (image, pixel tile, channel tile); channel tile fastest so the blocks sharing an input patch are neighbours
     // and XCD-aware (work-group ids round-robin over the 8 XCDs: give each XCD a contiguous run of logical tiles -> one L2 per patch)
-    const int T = gridDim.x;
-    int L = blockIdx.x;
-    if ((T & 7) == 0) L = (blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    const int L = xcd_tile(blockIdx.x, gridDim.x / a.n_tiles, a.n_tiles, a.xb);
     const int nt = L % a.n_tiles, pt = L / a.n_tiles;
     const int b = pt / a.tiles_hw, trem = pt - b * a.tiles_hw;
     const int oh0 = (trem / a.tiles_w) * TH, ow0 = (trem % a.tiles_w) * TW;
@@ -194,6 +193,7 @@ static void launch_patch(PatchArgs a, hipStream_t st) {
     a.tiles_hw = a.tiles_w * ((a.OH + TH - 1) / TH);
     a.n_tiles = a.Cout / BN;
     const long long blocks = (long long)a.B * a.tiles_hw * a.n_tiles;
+    a.xb = xcd_n_split(4LL * a.B * a.H * a.W * a.Cin, 4LL * KS * KS * a.Cin * a.Cout, a.B * a.tiles_hw, a.n_tiles);
     ProfScope ps(10, a.B * a.OH * a.OW, st);
     hipLaunchKernelGGL((k_conv_patch<KS, TW, PG, TN, SC, ST>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }

@@ -23,6 +23,7 @@ struct WinoArgs {
     const float* res;
     float* y;             // [B][H][W][Cout]
     int B, H, W, Cin, Cout, relu, tiles_w, tiles_hw, n_tiles;
+    int xb;               // XCD split along the channel tiles (hmf_common.h xcd_n_split)
 };
 
 #ifdef HMF_EXPERIMENTS           // tools/wino_probe.py: per work-group stamps (shader clock: start, first patch in LDS, main loop done, end; the cycles
@@ -72,9 +73,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     long long fetch_cyc = 0;
 #endif
 
-    const int T = gridDim.x;
-    int L = blockIdx.x;
-    if ((T & 7) == 0) L = (blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    const int L = xcd_tile(blockIdx.x, gridDim.x / a.n_tiles, a.n_tiles, a.xb);
     const int nt = L % a.n_tiles, pt = L / a.n_tiles;
     const int b = (pt / a.tiles_hw) * NIMG, trem = pt - (pt / a.tiles_hw) * a.tiles_hw;
     const int oh0 = (trem / a.tiles_w) * kWTH, ow0 = NIMG == 1 ? (trem % a.tiles_w) * kWTW : 0;
@@ -631,6 +630,7 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
     a.n_tiles = Cout / 32;
     const long long blocks = (long long)(pair ? (B + 1) / 2 : B) * a.tiles_hw * a.n_tiles;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: too many tiles");
+    a.xb = xcd_n_split(4LL * B * H * W * Cin, 64LL * Cin * Cout, (int)(blocks / a.n_tiles), a.n_tiles);
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, B * H * W, st);
 #define HMF_WINO_LAUNCH(MODE, PIPE, OCC)                                                                                   \
@@ -680,6 +680,7 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
         case 41:
             if (pair || Cout % 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_variant: variant 40/41 needs Cout %% 64 == 0 and maps wider than 8");
             a.n_tiles = Cout / 64;
+            a.xb = 1;
             if (variant == 40) hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 0, 2>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 1, 2>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
             break;

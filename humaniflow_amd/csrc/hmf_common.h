@@ -41,6 +41,24 @@ struct ProfScope {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Work-group ids are dealt to the 8 XCDs round-robin (id & 7), each XCD with its own L2.  A GEMM-shaped launch of MT x NT tiles reads an
+// activation panel per m-tile and a filter panel per n-tile; splitting the XCDs a x b (a b = 8) over (m, n) makes every activation byte cross into
+// b L2s and every filter byte into a: HBM reads ~ b * act + a * filt.  The all-m split (b = 1: every XCD streams ALL filters) is right while
+// activations dominate (layers 1-3) and 3-7x too much traffic for the deep layers on small maps (layer4: 138 MB read for 21 MB of operands).
+// Returns b in {1, 2, 4, 8}; 1 keeps the contiguous-run order.
+static inline int xcd_n_split(long long act_bytes, long long filt_bytes, int MT, int NT) {
+    if ((((long long)MT * NT) & 7) != 0) return 1;
+    int best = 1;
+    long long cost = act_bytes + 8 * filt_bytes;
+    for (int b = 2; b <= 8; b *= 2) {
+        const int a = 8 / b;
+        if (NT % b || MT % a) continue;
+        const long long c = b * act_bytes + a * filt_bytes;
+        if (c < cost) { cost = c; best = b; }
+    }
+    return best;
+}
+
 // Zero `bytes` (a multiple of 4, pointer 4-byte aligned) on `st` with a KERNEL.  hipMemsetAsync is not used by this library: captured into a HIP
 // graph (torch.cuda.graph) its memset node was observed not to clear the buffer on later replays (ROCm 7.2) -- the pooled stem map and the
 // weight-gradient accumulators then carried the previous replay's values into their atomic updates.
@@ -53,5 +71,18 @@ constexpr int kV = HMF_NUM_VERTS;          // 6890
 constexpr int kJ = HMF_NUM_SMPL_JOINTS;    // 24
 constexpr int kP = HMF_NUM_PARTS;          // 23
 constexpr int kOutJ = HMF_NUM_OUT_JOINTS;  // 90
+
+#ifdef __HIPCC__
+// logical tile (t = mt * NT + nt, n fastest) of work-group `bid` under an a x xb split of the XCDs (xcd_n_split); xb = 1: one contiguous run per XCD
+__device__ __forceinline__ int xcd_tile(int bid, int MT, int NT, int xb) {
+    const int T = MT * NT;
+    if ((T & 7) != 0) return bid;
+    if (xb <= 1) return (bid & 7) * (T >> 3) + (bid >> 3);
+    const int x = bid & 7, j = bid >> 3, a = 8 / xb;
+    const int npg = NT / xb, mpg = MT / a;
+    (void)mpg;
+    return ((x / xb) * (MT / a) + j / npg) * NT + (x % xb) * npg + j % npg;
+}
+#endif
 
 }  // namespace hmf
