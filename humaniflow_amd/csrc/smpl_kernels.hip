@@ -282,7 +282,10 @@ __device__ __forceinline__ void skin_element(const SmplDev& d, const char* __res
         float* o = e.obase + rc * (kV * 3);
         // streaming stores: the 267 MB of vertices are written once and never re-read by this kernel; keeping them out of the way of the
         // 2.3 MB operand range that each XCD's L2 is supposed to hold (r01 PMC: the operand was re-fetched ~9x)
-        __builtin_nontemporal_store(x, o); __builtin_nontemporal_store(y, o + 1); __builtin_nontemporal_store(z, o + 2);
+        // ONE 12-byte store per lane: the 32 vertices of a row are then one dense 384-byte run per instruction.  (Three dword stores at a 12-byte lane
+        // stride left the three partial passes over every line to the write combiner: PMC counted 318 MB written for 267 MB of vertices.)
+        typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+        __builtin_nontemporal_store(f32x3u{x, y, z}, (f32x3u*)o);
     }
     if (e.tile_has_ju) {                                  // wave-uniform; ~150 of the 216 vertex tiles hold one of the <= 276 joint vertices
         if (e.lane_has_ju && (e.full_rows || rc < e.row_lim)) {
