@@ -120,6 +120,8 @@ _SIGS = {
     'hmf_conv_winograd_packed_floats': (C.c_longlong, [C.c_int] * 2),
     'hmf_conv_winograd_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 2),
     'hmf_conv_winograd': (C.c_int, [_VP] * 5 + [C.c_int] * 6 + [_VP]),
+    'hmf_conv_winograd_workspace_bytes': (C.c_longlong, [C.c_int] * 5),
+    'hmf_conv_winograd_ws': (C.c_int, [_VP] * 5 + [C.c_int] * 6 + [_VP, C.c_longlong, _VP]),
     'hmf_conv_winograd_pack_device': (C.c_int, [_VP] * 2 + [C.c_int] * 3 + [_VP]),
     'hmf_conv_winograd_pack_device_batch': (C.c_int, [_VP] * 5 + [C.c_int, _VP]),
     'hmf_conv1x1_dual_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 10 + [_VP]),

@@ -24,6 +24,8 @@ struct WinoArgs {
     float* y;             // [B][H][W][Cout]
     int B, H, W, Cin, Cout, relu, tiles_w, tiles_hw, n_tiles;
     int xb;               // XCD split along the channel tiles (hmf_common.h xcd_n_split)
+    int ksplit;           // > 1: blockIdx.y walks Cin / 64 / ksplit slabs and stores its raw 2 x 2 outputs to part[blockIdx.y] (k_wino_splitk_finish adds them up)
+    float* part;          // [ksplit][B][H][W][Cout]
 };
 
 #ifdef HMF_EXPERIMENTS           // tools/wino_probe.py: per work-group stamps (shader clock: start, first patch in LDS, main loop done, end; the cycles
@@ -94,10 +96,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         loff[k] = r * kWRP + (NIMG == 1 ? (col & 1) * 9 + (col >> 1) : img * 10 + (cl & 1) * 5 + (cl >> 1)) * kWCS + 4 * c4;
     }
     const int nslab = a.Cin / kWSC;
+    const int s_per = nslab / a.ksplit, s_begin = (int)blockIdx.y * s_per, s_end = s_begin + s_per;       // ksplit = 1: all slabs
     // weight stream of this wave: [n-tile][wave xi][slab][g][nu][lane][4]
     const f32x4* pw[TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((MODE & 8) ? 0LL : (long long)((nt * TN + t) * 4 + wave) * nslab * kWNG * 4) * 64 + lane;   // MODE & 8: every wave streams the SAME weights (L1 hits)
+    for (int t = 0; t < TN; ++t)
+        pw[t] = a.wp + ((MODE & 8) ? 0LL : ((long long)((nt * TN + t) * 4 + wave) * nslab + s_begin) * kWNG * 4) * 64 + lane;   // MODE & 8: every wave streams the SAME weights (L1 hits)
 
     // row transform of this wave: t[b] = d[a1][b] + sg * d[a2][b]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3): one fma per element, the sign is wave-uniform
     const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1), a2 = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #pragma unroll
         for (int n = 0; n < 4; ++n) bw[0][t][n] = pw[t][n * 64];
 
-    for (int s = 0; s < nslab; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
 #ifdef HMF_EXPERIMENTS
         const long long tA = HMF_WCLK();
 #endif
@@ -138,17 +142,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             else pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s) __syncthreads();
+        if (s != s_begin) __syncthreads();
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
             if (NV % 256 == 0 || k < NIT - 1 || tid + 256 * k < NV) *(f32x4*)&lds[loff[k]] = pv[k];
         __syncthreads();
 #ifdef HMF_EXPERIMENTS
         fetch_cyc += HMF_WCLK() - tA;
-        if (s == 0) HMF_WSTAMP(1, HMF_WCLK());
+        if (s == s_begin) HMF_WSTAMP(1, HMF_WCLK());
 #endif
 
-        const bool last = (s + 1 == nslab);
+        const bool last = (s + 1 == s_end);
         auto xform = [&](int g, f32x4 (&v)[4]) {
             f32x4 t[4];
 #pragma unroll
@@ -223,14 +227,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     const int bi = b + (NIMG == 1 ? 0 : (otl >> 2) & 1);
     constexpr int kOOBo = (int)0x80000000;
     const int ybytes = a.B * a.H * a.W * a.Cout * 4;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.y), 0, ybytes, 0x00020000);
-    const float lo = a.relu ? 0.f : -INFINITY;
+    // split reduction: raw sums of this slab range into part[blockIdx.y] -- no bias, no residual, no ReLU (k_wino_splitk_finish applies them to the total)
+    const bool partial = a.ksplit > 1;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(partial ? (void*)(a.part + (size_t)blockIdx.y * (ybytes / 4)) : (void*)a.y, 0, ybytes, 0x00020000);
+    const float* resp = partial ? nullptr : a.res;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(resp ? resp : a.y), 0, ybytes, 0x00020000);
+    const float lo = (a.relu && !partial) ? 0.f : -INFINITY;
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int n_out = (nt * TN + t) * 32 + 4 * oq;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) bv = *(const f32x4*)(a.bias + n_out);
+        if (a.bias && !partial) bv = *(const f32x4*)(a.bias + n_out);
         int off[2][2];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx)
-                rv[dy][dx] = a.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[dy][dx], 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rv[dy][dx] = resp ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[dy][dx], 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -280,6 +287,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #endif
 }
 
+
+// Small batches (the predict shape: one image): a launch has 16-64 work-groups, each walking all Cin / 64 slabs -- 256 CUs wait for 16 long loops.
+// With ksplit > 1 blockIdx.y takes a slab range and k_conv_winograd stores raw sums; this kernel adds the ranges in a FIXED order (deterministic) and
+// applies bias, residual and ReLU: y = relu?(sum_s part[s] + bias + residual).  One thread per 4 channels.
+__global__ __launch_bounds__(256) void k_wino_splitk_finish(const f32x4* __restrict__ part, int ksplit, long long n4, const float* __restrict__ bias,
+                                                            const f32x4* __restrict__ res, f32x4* __restrict__ y, int cout4, int relu) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    f32x4 acc = part[e];
+    for (int s = 1; s < ksplit; ++s) acc += part[(long long)s * n4 + e];
+    if (bias) acc += *(const f32x4*)(bias + 4 * (int)(e % cout4));
+    if (res) acc += res[e];
+    if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+    y[e] = acc;
+}
 
 #ifdef HMF_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------------------------------
@@ -611,8 +633,25 @@ extern "C" int hmf_conv_winograd_pack_device(const float* w_native, float* packe
 
 extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }
 
+// slab ranges for a launch of `blocks` work-groups: only when the launch leaves most CUs idle (< 128 work-groups) and has slabs to split; the largest
+// divisor of the slab count that keeps blocks * ksplit <= 512
+static int wino_ksplit(long long blocks, int Cin) {
+    const int nslab = Cin / kWSC;
+    if (blocks >= 128 || nslab < 2) return 1;
+    int best = 1;
+    for (int k = 2; k <= nslab; ++k)
+        if (nslab % k == 0 && blocks * k <= 512) best = k;
+    return best;
+}
+
+static long long wino_blocks(int B, int H, int W, int Cout) {
+    const bool pair = W <= 8;
+    const int tiles_w = pair ? 1 : (W + kWTW - 1) / kWTW;
+    return (long long)(pair ? (B + 1) / 2 : B) * tiles_w * ((H + kWTH - 1) / kWTH) * (Cout / 32);
+}
+
 static int conv_winograd_impl(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
-                              int Cin, int Cout, int relu, int variant, void* stream) {
+                              int Cin, int Cout, int relu, int variant, void* stream, void* ws = nullptr, long long ws_bytes = 0) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_winograd: bad args");
     if (Cin % kWSC || Cout % 32) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: Cin=%d must be a multiple of 64 and Cout=%d of 32", Cin, Cout);
     if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15) || ((uintptr_t)residual & 15) || ((uintptr_t)bias & 15))
@@ -631,6 +670,17 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
     const long long blocks = (long long)(pair ? (B + 1) / 2 : B) * a.tiles_hw * a.n_tiles;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_winograd: too many tiles");
     a.xb = xcd_n_split(4LL * B * H * W * Cin, 64LL * Cin * Cout, (int)(blocks / a.n_tiles), a.n_tiles);
+    a.ksplit = 1;
+    a.part = nullptr;
+    const long long out_bytes = 4LL * B * H * W * Cout;
+    if (variant == 0 && ws) {
+        const int ks = wino_ksplit(blocks, Cin);
+        if (ks > 1) {
+            if (ws_bytes < ks * out_bytes || ((uintptr_t)ws & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_ws: workspace smaller than hmf_conv_winograd_workspace_bytes or unaligned");
+            a.ksplit = ks;
+            a.part = (float*)ws;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, B * H * W, st);
 #define HMF_WINO_LAUNCH(MODE, PIPE, OCC)                                                                                   \
@@ -653,8 +703,15 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
             // slab's / next pixel tile's patch requested under the current MFMA loop -- is no faster where it fits the register file (layer3 45.2 vs 45.5 us,
             // layer4 52.5 vs 51.1, layer1 at two waves per SIMD 49.6 vs 47.0) and spills at three waves per SIMD (+48 prefetch registers on 163): the
             // co-resident work-groups already hide the fetch; the kernel stays in the experiments build.
-            if (!pair && Cin <= 128) hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 1, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-            else HMF_WINO_LAUNCH(0, 0, 2);
+            if (!pair && Cin <= 128) hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 1, 3>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
+            else if (pair) hipLaunchKernelGGL((k_conv_winograd<1, 2, 0, 0, 2>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 0, 2>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
+            if (a.ksplit > 1) {
+                HMF_LAUNCH_CHECK();
+                const long long n4 = out_bytes / 16;
+                hipLaunchKernelGGL(k_wino_splitk_finish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const f32x4*)a.part, a.ksplit, n4, bias,
+                                   (const f32x4*)residual, (f32x4*)y, Cout / 4, relu);
+            }
             break;
 #ifdef HMF_EXPERIMENTS
         case 300:           // = the product dispatch, for A/B against the stage-pipelined kernel
@@ -695,6 +752,17 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
 #undef HMF_WINO_PF
     HMF_LAUNCH_CHECK();
     return HMF_OK;
+}
+
+extern "C" long long hmf_conv_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kWSC || Cout % 32) return 0;
+    const int ks = wino_ksplit(wino_blocks(B, H, W, Cout), Cin);
+    return ks > 1 ? ks * 4LL * B * H * W * Cout : 0;
+}
+
+extern "C" int hmf_conv_winograd_ws(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                                    int Cin, int Cout, int relu, void* ws, long long ws_bytes, void* stream) {
+    return conv_winograd_impl(x, w_packed, bias, residual, y, B, H, W, Cin, Cout, relu, 0, stream, ws, ws_bytes);
 }
 
 extern "C" int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,

@@ -66,7 +66,7 @@ struct HeadsOut {
 __global__ __launch_bounds__(256) void k_heads_out(const float* __restrict__ partial, const float* __restrict__ b1, int B, int N1, int KS, int nb, HeadsOut o) {
     __shared__ __attribute__((aligned(16))) float sx[1024];
     __shared__ float so[48];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x;
     for (int n = tid; n < N1; n += 256) {
         float v = partial[(size_t)b * N1 + n];
         for (int ks = 1; ks < KS; ++ks) v += partial[((size_t)ks * B + b) * N1 + n];

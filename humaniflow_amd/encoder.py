@@ -331,9 +331,17 @@ class ResNetEncoder(nn.Module):
         y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         wk = self._plan['wino'].get(id(w)) if self._plan is not None else None
         if wk is not None and stride == 1 and (W >= 16 or W == 8):
-            _lib.check(lib.hmf_conv_winograd(x.data_ptr(), wk.data_ptr(), None if bias is None else bias.data_ptr(),
-                                             None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout,
-                                             int(relu), _lib.current_stream()), 'hmf_conv_winograd')
+            nbytes = int(lib.hmf_conv_winograd_workspace_bytes(B, H, W, Cin, Cout))          # > 0: a small batch, the slab loop is split over work-groups
+            ws = None
+            if nbytes:
+                key = ('wino', x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+                ws = self._stem_ws.get(key)
+                if ws is None or ws.numel() < nbytes:
+                    ws = self._stem_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.hmf_conv_winograd_ws(x.data_ptr(), wk.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout,
+                                                int(relu), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _lib.current_stream()),
+                       'hmf_conv_winograd')
             return y
         pk = self._plan['packed'].get(id(w)) if self._plan is not None else None
         if pk is not None:

@@ -218,6 +218,25 @@ def _wino_case(B, H, W, cin, cout, res, relu, seed=0):
     torch.cuda.synchronize()
     err = (y.cpu().double() - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, res, relu, err)      # Winograd: a few more roundings than direct
+    # the small-batch form (slab loop split over work-groups, partial sums added in a fixed order): same bar, deterministic, and the unsplit entry's
+    # result when the shape is not split
+    nbytes = int(lib.hmf_conv_winograd_workspace_bytes(B, H, W, cin, cout))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device='cuda')
+    y2 = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    y3 = torch.full(ref.shape, float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    for out in (y2, y3):
+        ws.fill_(255)
+        _lib.check(lib.hmf_conv_winograd_ws(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), None if rd is None else rd.data_ptr(), out.data_ptr(),
+                                            B, H, W, cin, cout, int(relu), ws.data_ptr() if nbytes else None, nbytes, _lib.current_stream()), 'hmf_conv_winograd_ws')
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3)
+    if nbytes:
+        assert (y2.cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, 'split')
+        assert lib.hmf_conv_winograd_ws(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), None, y3.data_ptr(), B, H, W, cin, cout, int(relu), ws.data_ptr(), nbytes - 16,
+                                        _lib.current_stream()) < 0
+    else:
+        assert torch.equal(y2, y)
+    return nbytes
 
 
 def test_winograd_conv3x3_matches_float64_reference():
@@ -229,6 +248,12 @@ def test_winograd_conv3x3_matches_float64_reference():
     _wino_case(3, 8, 8, 64, 32, False, False, seed=7)           # ... odd batch: the last tile holds one image
     _wino_case(2, 5, 7, 64, 32, True, True, seed=8)             # ... ragged narrow map
     _wino_case(2, 11, 19, 64, 128, True, False, seed=5)
+    # the predict shape's deep layers (one image): split over 2 / 4 / 8 slab ranges
+    assert _wino_case(1, 32, 32, 128, 128, True, True, seed=9) > 0
+    assert _wino_case(1, 16, 16, 256, 256, True, True, seed=10) > 0
+    assert _wino_case(1, 8, 8, 512, 512, True, True, seed=11) > 0
+    assert _wino_case(2, 8, 8, 512, 512, False, False, seed=12) > 0
+    assert _wino_case(1, 64, 64, 64, 64, True, True, seed=13) == 0           # one slab: nothing to split
 
 
 def test_dual_1x1_matches_float64_reference():
