@@ -113,6 +113,8 @@ _SIGS = {
     'hmf_conv_patch_packed_floats': (C.c_longlong, [C.c_int] * 3),
     'hmf_conv_patch_pack_host': (C.c_int, [_VP, _VP] + [C.c_int] * 4),
     'hmf_conv_patch': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP]),
+    'hmf_conv_patch_workspace_bytes': (C.c_longlong, [C.c_int] * 8),
+    'hmf_conv_patch_ws': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP, C.c_longlong, _VP]),
     'hmf_pointset_errors': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP, _VP]),
     'hmf_sample_diversity': (C.c_int, [_VP] + [C.c_int] * 3 + [_VP, _VP]),
     'hmf_conv_pair_pack_host': (C.c_int, [_VP] * 4 + [C.c_int] * 3),

@@ -27,6 +27,8 @@ struct PatchArgs {
     float* y;             // [B][OH][OW][Cout]
     int B, H, W, Cin, OH, OW, Cout, stride, relu, tiles_w, tiles_hw, n_tiles;
     int xb;               // XCD split along the channel tiles (hmf_common.h xcd_n_split)
+    int ksplit;           // > 1: blockIdx.y walks Cin / SC / ksplit slabs and stores raw sums to part[blockIdx.y] (hmf_common.h small_launch_ksplit)
+    float* part;          // [ksplit][B][OH][OW][Cout]
 };
 
 template <int KS, int TW, int PG, int TN, int SC, int ST>
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr int GPS = KS * KS * NG;               // groups per slab
     // this wave's weight stream: [n-tile][slab][tap][g][lane][4]; n-tile index = (nt * CG + cg) * TN + t
     const f32x4* pw[TN];
+    const int s_per = nslab / a.ksplit, s_begin = (int)blockIdx.y * s_per, s_end = s_begin + s_per;      // ksplit = 1: all slabs
 #pragma unroll
-    for (int t = 0; t < TN; ++t) pw[t] = a.wp + ((long long)((nt * CG + cg) * TN + t) * nslab * GPS) * 64 + lane;
+    for (int t = 0; t < TN; ++t) pw[t] = a.wp + (((long long)((nt * CG + cg) * TN + t) * nslab + s_begin) * GPS) * 64 + lane;
 
     const int prow = pg * RPG + li / TW, pcol = li % TW;
     const float* pa = patch + prow * ST * RPF + pcol * (ST == 2 ? 1 : ST) * CS + 4 * lq;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int t = 0; t < TN; ++t) bw[g][t] = pw[t][g * 64];
 
-    for (int s = 0; s < nslab; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
         // ---- slab patch: global -> registers -> LDS ----
         f32x4 pv[NIT];
 #pragma unroll
@@ -108,14 +111,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s) __syncthreads();                      // everyone is done reading the previous slab
+        if (s != s_begin) __syncthreads();           // everyone is done reading the previous slab
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
             if (NV % 256 == 0 || k < NIT - 1 || tid + 256 * k < NV) *(f32x4*)&patch[loff[k]] = pv[k];
         __syncthreads();
 
         // ---- barrier-free MFMA run over the slab ----
-        const bool last = (s + 1 == nslab);
+        const bool last = (s + 1 == s_end);
         f32x4 fa[2];
         fa[0] = *(const f32x4*)pa;
 #pragma clang loop unroll(full)
@@ -155,11 +158,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
     }
 
-    // ---- epilogue ----
+    // ---- epilogue (split reduction: raw sums of this slab range, no bias / residual / ReLU: splitk_finish applies them to the total) ----
+    const bool partial = a.ksplit > 1;
+    float* const yout = partial ? a.part + (size_t)blockIdx.y * ((size_t)a.B * a.OH * a.OW * a.Cout) : a.y;
+    const float* const resp = partial ? nullptr : a.res;
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int n = ((nt * CG + cg) * TN + t) * 32 + li;
-        const float bv = a.bias ? a.bias[n] : 0.f;
+        const float bv = (a.bias && !partial) ? a.bias[n] : 0.f;
         long long yoff[16];
         bool okp[16];
 #pragma unroll
@@ -170,9 +176,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             yoff[r] = (((long long)b * a.OH + min(oh, a.OH - 1)) * a.OW + min(ow, a.OW - 1)) * a.Cout + n;
         }
         float rv[16];
-        if (a.res) {
+        if (resp) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = a.res[yoff[r]];
+            for (int r = 0; r < 16; ++r) rv[r] = resp[yoff[r]];
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) rv[r] = 0.f;
@@ -180,22 +186,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[t][r] + bv + rv[r];
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (okp[r]) a.y[yoff[r]] = v;
+            if (a.relu && !partial) v = fmaxf(v, 0.f);
+            if (okp[r]) yout[yoff[r]] = v;
         }
     }
 }
 
 template <int KS, int TW, int PG, int TN, int SC, int ST>
-static void launch_patch(PatchArgs a, hipStream_t st) {
+static int launch_patch(PatchArgs a, hipStream_t st) {
     constexpr int TH = PG * (32 / TW), BN = (4 / PG) * TN * 32;
     a.tiles_w = (a.OW + TW - 1) / TW;
     a.tiles_hw = a.tiles_w * ((a.OH + TH - 1) / TH);
     a.n_tiles = a.Cout / BN;
     const long long blocks = (long long)a.B * a.tiles_hw * a.n_tiles;
     a.xb = xcd_n_split(4LL * a.B * a.H * a.W * a.Cin, 4LL * KS * KS * a.Cin * a.Cout, a.B * a.tiles_hw, a.n_tiles);
+    a.ksplit = a.part ? small_launch_ksplit(blocks, a.Cin / SC) : 1;
     ProfScope ps(10, a.B * a.OH * a.OW, st);
-    hipLaunchKernelGGL((k_conv_patch<KS, TW, PG, TN, SC, ST>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_patch<KS, TW, PG, TN, SC, ST>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
+    HMF_LAUNCH_CHECK();
+    if (a.ksplit > 1) return splitk_finish(a.part, a.ksplit, (long long)a.B * a.OH * a.OW * a.Cout, a.bias, a.res, a.y, a.Cout, a.relu, st);
+    return HMF_OK;
+}
+
+// work-groups of a launch before any split (for the workspace size)
+static long long patch_blocks(int B, int OH, int OW, int Cout, int TW, int TH, int BN) {
+    return (long long)B * ((OW + TW - 1) / TW) * ((OH + TH - 1) / TH) * (Cout / BN);
 }
 
 }  // namespace hmf
@@ -229,8 +244,40 @@ extern "C" int hmf_conv_patch_pack_host(const float* w, float* packed, int Cin, 
     return HMF_OK;
 }
 
+// tile geometry of a cfg: pixel tile TW x TH, channel tile BN (the 3x3 / stride 2 layers always run cfg 8210's 8 x 8 x 64)
+static void patch_cfg_tile(int cfg, int stride, int& TW, int& TH, int& BN) {
+    if (stride == 2) cfg = 8210;
+    TW = cfg / 1000;
+    const int pg = (cfg / 100) % 10;
+    TH = pg * (32 / TW);
+    BN = patch_cfg_bn(cfg);
+}
+
+static int conv_patch_impl(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int ks,
+                           int stride, int relu, int cfg, void* ws, long long ws_bytes, void* stream);
+
+extern "C" long long hmf_conv_patch_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ks, int stride, int cfg) {
+    if (B <= 0 || H <= 0 || W <= 0 || ks != 3 || (stride != 1 && stride != 2) || !patch_cfg_ok(cfg) || Cin % 64) return 0;
+    int TW, TH, BN;
+    patch_cfg_tile(cfg, stride, TW, TH, BN);
+    if (Cout % BN) return 0;
+    const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    const int ks_ = small_launch_ksplit(patch_blocks(B, OH, OW, Cout, TW, TH, BN), Cin / 64);
+    return ks_ > 1 ? ks_ * 4LL * B * OH * OW * Cout : 0;
+}
+
+extern "C" int hmf_conv_patch_ws(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
+                                 int ks, int stride, int relu, int cfg, void* ws, long long ws_bytes, void* stream) {
+    return conv_patch_impl(x, w_packed, bias, residual, y, B, H, W, Cin, Cout, ks, stride, relu, cfg, ws, ws_bytes, stream);
+}
+
 extern "C" int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                               int Cin, int Cout, int ks, int stride, int relu, int cfg, void* stream) {
+    return conv_patch_impl(x, w_packed, bias, residual, y, B, H, W, Cin, Cout, ks, stride, relu, cfg, nullptr, 0, stream);
+}
+
+static int conv_patch_impl(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int ks,
+                           int stride, int relu, int cfg, void* ws, long long ws_bytes, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_patch: bad args");
     if (!patch_cfg_ok(cfg)) return fail(HMF_ERR_INVALID, "hmf_conv_patch: unknown cfg %d", cfg);
     if (ks != 3 || (stride != 1 && stride != 2)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: ks=%d stride=%d (3x3, stride 1 or 2)", ks, stride);
@@ -246,9 +293,19 @@ extern "C" int hmf_conv_patch(const float* x, const float* w_packed, const float
     if ((long long)B * a.OH * a.OW * Cout >= (1LL << 29) || (long long)B * H * W * Cin >= (1LL << 29))
         return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: tensor exceeds 2^29 elements (32-bit byte offsets of the buffer loads)");
     hipStream_t st = (hipStream_t)stream;
+    a.part = nullptr;
+    a.ksplit = 1;
+    if (ws) {                                                     // the small-launch form: raw partial sums in ws, finished by splitk_finish
+        const long long need = hmf_conv_patch_workspace_bytes(B, H, W, Cin, Cout, ks, stride, cfg);
+        if (need) {
+            if (ws_bytes < need || ((uintptr_t)ws & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15))
+                return fail(HMF_ERR_INVALID, "hmf_conv_patch_ws: workspace smaller than hmf_conv_patch_workspace_bytes, or ws / y / bias / residual not 16-byte aligned");
+            a.part = (float*)ws;
+        }
+    }
 #define PCASE(CFG, KS_, TW_, PG_, TN_, SC_) \
-    if (cfg == CFG && ks == KS_) { launch_patch<KS_, TW_, PG_, TN_, SC_, 1>(a, st); HMF_LAUNCH_CHECK(); return HMF_OK; }
-    if (ks == 3 && stride == 2) { launch_patch<3, 8, 2, 1, 64, 2>(a, st); HMF_LAUNCH_CHECK(); return HMF_OK; }
+    if (cfg == CFG && ks == KS_) return launch_patch<KS_, TW_, PG_, TN_, SC_, 1>(a, st);
+    if (ks == 3 && stride == 2) return launch_patch<3, 8, 2, 1, 64, 2>(a, st);
     PCASE(16420, 3, 16, 4, 2, 64) PCASE(16410, 3, 16, 4, 1, 64) PCASE(8210, 3, 8, 2, 1, 64)
     // 1x1 layers were measured on this kernel as well (64- and 128-channel slabs, single- and double-buffered patches): equal to or slower than
     // k_conv_igemm on every ResNet shape, so those instantiations are not built

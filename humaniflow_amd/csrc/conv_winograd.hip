@@ -303,6 +303,17 @@ __global__ __launch_bounds__(256) void k_wino_splitk_finish(const f32x4* __restr
     y[e] = acc;
 }
 
+int splitk_finish(const float* part, int ksplit, long long n, const float* bias, const float* res, float* y, int Cout, int relu, hipStream_t st) {
+    if (!part || !y || ksplit < 1 || n <= 0 || (n & 3) || (Cout & 3) || (((uintptr_t)part | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)res) & 15))
+        return fail(HMF_ERR_INVALID, "splitk_finish: bad args");
+    const long long n4 = n / 4;
+    if ((n4 + 255) / 256 >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "splitk_finish: too many elements");
+    hipLaunchKernelGGL(k_wino_splitk_finish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const f32x4*)part, ksplit, n4, bias, (const f32x4*)res, (f32x4*)y,
+                       Cout / 4, relu);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
 #ifdef HMF_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // Round 4 EXPERIMENT (measured, not faster: see the dispatch comment in conv_winograd_impl): the same convolution with the patch fetch taken off the critical path.  Stamps (tools/wino_probe.py) show a work-group of
@@ -633,16 +644,7 @@ extern "C" int hmf_conv_winograd_pack_device(const float* w_native, float* packe
 
 extern "C" long long hmf_conv_winograd_packed_floats(int Cin, int Cout) { return (long long)Cout * 16 * Cin; }
 
-// slab ranges for a launch of `blocks` work-groups: only when the launch leaves most CUs idle (< 128 work-groups) and has slabs to split; the largest
-// divisor of the slab count that keeps blocks * ksplit <= 512
-static int wino_ksplit(long long blocks, int Cin) {
-    const int nslab = Cin / kWSC;
-    if (blocks >= 128 || nslab < 2) return 1;
-    int best = 1;
-    for (int k = 2; k <= nslab; ++k)
-        if (nslab % k == 0 && blocks * k <= 512) best = k;
-    return best;
-}
+static int wino_ksplit(long long blocks, int Cin) { return small_launch_ksplit(blocks, Cin / kWSC); }
 
 static long long wino_blocks(int B, int H, int W, int Cout) {
     const bool pair = W <= 8;
@@ -708,9 +710,7 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
             else hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 0, 2>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
             if (a.ksplit > 1) {
                 HMF_LAUNCH_CHECK();
-                const long long n4 = out_bytes / 16;
-                hipLaunchKernelGGL(k_wino_splitk_finish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const f32x4*)a.part, a.ksplit, n4, bias,
-                                   (const f32x4*)residual, (f32x4*)y, Cout / 4, relu);
+                if (int rc = splitk_finish(a.part, a.ksplit, out_bytes / 4, bias, residual, y, Cout, relu, st)) return rc;
             }
             break;
 #ifdef HMF_EXPERIMENTS

@@ -72,6 +72,19 @@ constexpr int kJ = HMF_NUM_SMPL_JOINTS;    // 24
 constexpr int kP = HMF_NUM_PARTS;          // 23
 constexpr int kOutJ = HMF_NUM_OUT_JOINTS;  // 90
 
+// Small launches (the predict shape: one image): with fewer than 128 work-groups on 256 CUs the reduction loop of a convolution (slabs of 64 input
+// channels) is split over up to 8 work-groups per tile; the raw partial outputs are added in a fixed order by splitk_finish (conv_winograd.hip),
+// which also applies bias / residual / ReLU.  Returns the number of slab ranges (a divisor of nslab; 1 = no split).
+static inline int small_launch_ksplit(long long blocks, int nslab) {
+    if (blocks >= 128 || nslab < 2) return 1;
+    int best = 1;
+    for (int k = 2; k <= nslab; ++k)
+        if (nslab % k == 0 && blocks * k <= 512) best = k;
+    return best;
+}
+// y[n] = relu?(sum_s part[s][n] + bias[n % Cout] + res[n]); n and Cout multiples of 4, all pointers 16-byte aligned
+int splitk_finish(const float* part, int ksplit, long long n, const float* bias, const float* res, float* y, int Cout, int relu, hipStream_t st);
+
 #ifdef __HIPCC__
 // logical tile (t = mt * NT + nt, n fastest) of work-group `bid` under an a x xb split of the XCDs (xcd_n_split); xb = 1: one contiguous run per XCD
 __device__ __forceinline__ int xcd_tile(int bid, int MT, int NT, int xb) {

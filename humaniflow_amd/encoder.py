@@ -332,12 +332,7 @@ class ResNetEncoder(nn.Module):
         wk = self._plan['wino'].get(id(w)) if self._plan is not None else None
         if wk is not None and stride == 1 and (W >= 16 or W == 8):
             nbytes = int(lib.hmf_conv_winograd_workspace_bytes(B, H, W, Cin, Cout))          # > 0: a small batch, the slab loop is split over work-groups
-            ws = None
-            if nbytes:
-                key = ('wino', x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-                ws = self._stem_ws.get(key)
-                if ws is None or ws.numel() < nbytes:
-                    ws = self._stem_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            ws = self._small_launch_ws(x.device, nbytes) if nbytes else None
             _lib.check(lib.hmf_conv_winograd_ws(x.data_ptr(), wk.data_ptr(), None if bias is None else bias.data_ptr(),
                                                 None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout,
                                                 int(relu), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _lib.current_stream()),
@@ -346,9 +341,12 @@ class ResNetEncoder(nn.Module):
         pk = self._plan['packed'].get(id(w)) if self._plan is not None else None
         if pk is not None:
             cfg = 8210 if stride == 2 else pk[0]                            # the stride-2 3x3 variant is built for the 8x8 tile
-            _lib.check(lib.hmf_conv_patch(x.data_ptr(), pk[1].data_ptr(), None if bias is None else bias.data_ptr(),
-                                          None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
-                                          int(relu), cfg, _lib.current_stream()), 'hmf_conv_patch')
+            nbytes = int(lib.hmf_conv_patch_workspace_bytes(B, H, W, Cin, Cout, ks, stride, cfg))      # > 0: a small batch, the slab loop is split
+            ws = self._small_launch_ws(x.device, nbytes) if nbytes else None
+            _lib.check(lib.hmf_conv_patch_ws(x.data_ptr(), pk[1].data_ptr(), None if bias is None else bias.data_ptr(),
+                                             None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
+                                             int(relu), cfg, None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _lib.current_stream()),
+                       'hmf_conv_patch')
             return y
         sp = self._plan['split'].get(id(w)) if (self._plan is not None and ks == 1 and stride == 1) else None
         if sp is not None:
@@ -365,6 +363,14 @@ class ResNetEncoder(nn.Module):
                                        None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, ks, stride,
                                        int(relu), 0, _lib.current_stream()), 'hmf_conv2d_nhwc')
         return y
+
+    def _small_launch_ws(self, device, nbytes):
+        """Partial-sum workspace of the split small-batch convolutions, one per stream (launches of a stream run in order and consume it at once)."""
+        key = ('splitk', device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._stem_ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._stem_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return ws
 
     def _stem_hip(self, x, w_packed, bias):
         """NCHW proxy input -> conv7x7/2 + bias + ReLU + max-pool 3x3/2 (NHWC): one launch (the pool is applied to the tiles before they leave

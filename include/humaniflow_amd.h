@@ -363,6 +363,12 @@ long long hmf_conv_patch_packed_floats(int Cin, int Cout, int ks);
 int hmf_conv_patch_pack_host(const float* w, float* packed, int Cin, int Cout, int ks, int cfg);
 int hmf_conv_patch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                    int Cin, int Cout, int ks, int stride, int relu, int cfg, void* stream);
+/* Small launches (one image per call): as hmf_conv_winograd_ws below -- with fewer than 128 work-groups the slab loop (Cin / 64) is split over up to 8
+ * work-groups per tile, raw partial sums go to `ws` (hmf_conv_patch_workspace_bytes: 0 = the shape is not split, ws may be NULL) and a second small launch
+ * adds them in a fixed order and applies bias / residual / ReLU.  With a split, y, bias and residual must be 16-byte aligned. */
+long long hmf_conv_patch_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ks, int stride, int cfg);
+int hmf_conv_patch_ws(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                      int Cin, int Cout, int ks, int stride, int relu, int cfg, void* ws, long long ws_bytes, void* stream);
 
 /* Winograd F(2x2,3x3) variant for stride-1 3x3 layers (same result as hmf_conv2d_nhwc with ks = 3, 2.25x fewer MFMA k-steps): 8x16-pixel
  * tiles x 32 channels (maps at most 8 pixels wide: 8x8 pixels of two consecutive images), input transform in registers, output transform through LDS, same fused epilogue.  w_packed =

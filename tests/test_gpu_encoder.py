@@ -181,6 +181,21 @@ def _patch_case(B, H, W, cin, cout, ks, stride, res, relu, cfg, seed=0):
     torch.cuda.synchronize()
     err = (y.cpu().double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, ks, stride, res, relu, cfg, err)
+    # the small-launch form (slab loop split over work-groups, partial sums added in a fixed order)
+    nbytes = int(lib.hmf_conv_patch_workspace_bytes(B, H, W, cin, cout, ks, stride, cfg))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device='cuda')
+    y2, y3 = torch.full_like(y, float('nan')), torch.full_like(y, float('nan'))
+    for out in (y2, y3):
+        ws.fill_(255)
+        _lib.check(lib.hmf_conv_patch_ws(xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), None if rd is None else rd.data_ptr(), out.data_ptr(), B, H, W, cin, cout, ks,
+                                         stride, int(relu), cfg, ws.data_ptr() if nbytes else None, nbytes, _lib.current_stream()), 'hmf_conv_patch_ws')
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3)
+    if nbytes:
+        assert (y2.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (B, H, W, cin, cout, 'split')
+    else:
+        assert torch.equal(y2, y)
+    return nbytes
 
 
 @pytest.mark.parametrize('cfg', [16420, 16410, 8210])
@@ -192,6 +207,9 @@ def test_patch_conv3x3_matches_float64_reference(cfg):
 def test_patch_conv3x3_stride2():
     _patch_case(2, 16, 16, 128, 64, 3, 2, False, True, 8210)
     _patch_case(1, 13, 9, 64, 128, 3, 2, True, False, 8210, seed=3)
+    # the predict shape (one image): layer3.0 / layer4.0 sized reductions split over 4 / 8 slab ranges
+    assert _patch_case(1, 32, 32, 256, 256, 3, 2, False, True, 8210, seed=4) > 0
+    assert _patch_case(1, 16, 16, 512, 512, 3, 2, True, True, 8210, seed=5) > 0
 
 
 def _wino_case(B, H, W, cin, cout, res, relu, seed=0):
