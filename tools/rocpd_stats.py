@@ -44,7 +44,7 @@ for r in rows[:int(args[1]) if len(args) > 1 else 40]:
 print('\ntotal kernel time: %.3f ms over %d dispatches; wall span of the window %.3f ms' % (total / 1e6, sum(r[1] for r in rows), span / 1e6))
 if steps:
     print('per step: %.3f ms of kernel time, %.3f ms of wall span' % (total / 1e6 / steps, span / 1e6 / steps))
-    groups = [('encoder convolutions (hmf::k_stem_conv, k_conv_winograd, k_conv_patch, k_conv_igemm, k_conv_pair)', "(name like '%hmf::k_stem_conv%' or name like '%hmf::k_conv_%')"),
+    groups = [('encoder convolutions (hmf::k_stem_wino + k_stem_pool_rim | k_stem_conv, k_conv_winograd + k_wino_splitk_finish, k_conv_patch, k_conv_gemm, k_conv_igemm, k_conv_pair)', "(name like '%hmf::k_stem_%' or name like '%hmf::k_conv_%' or name like '%hmf::k_wino_%')"),
               ('encoder max-pool (hmf::k_maxpool_nhwc)', "name like '%k_maxpool_nhwc%'"),
               ('flow (hmf::k_isgc, k_flow_*)', "(name like '%hmf::k_isgc%' or name like '%hmf::k_flow%')"),
               ('SMPL (hmf::k_lbs_mfma, k_rigid_chain, k_joints, k_tpose)', "(name like '%hmf::k_lbs%' or name like '%hmf::k_rigid%' or name like '%hmf::k_joints%' or name like '%hmf::k_tpose%')")]
