@@ -1,5 +1,7 @@
 """Which torch (ATen) operators does one training step still launch, and from which source lines?  CPU-side operator profile of two eager
-training steps at the configs[4] shape (torch.profiler, CPU activity with stacks: every leaf operator below launches one or more device kernels).
+training steps at the configs[4] shape (torch.profiler, CPU activity, grouped by input shapes: every leaf operator below launches one or more device
+kernels; Python stacks are not recorded by this torch build, the shapes are what identifies the source: (72, 10) = the shape prior / Normal log-prob of the loss,
+(256, 534) = the isgc layer's weight gradient assembled from slices, (72, 9, 17, 2) = the 2D-joint loss over point estimate + 8 samples, ...).
     python tools/train_glue_profile.py [B] > gpurun_out/train_glue.txt"""
 import os
 import sys
@@ -44,19 +46,22 @@ LEAF = ('aten::fill_', 'aten::zero_', 'aten::add', 'aten::add_', 'aten::copy_', 
         'aten::tanh', 'aten::cos', 'aten::sin', 'aten::rsqrt', 'aten::reciprocal', 'aten::square', 'aten::all', 'aten::any', 'aten::max', 'aten::min', 'aten::normal_',
         'aten::_to_copy', 'aten::sum_to_size', 'aten::threshold_backward', 'aten::linalg_norm', 'aten::nll_loss', 'aten::mse_loss')
 counts = collections.Counter()
-for ev in prof.events():
-    if ev.name not in LEAF:
+for ev in prof.key_averages(group_by_stack_n=12, group_by_input_shape=True):
+    if ev.key not in LEAF:
         continue
     where = 'autograd engine / unknown'
     for fr in (ev.stack or []):
-        if ROOT in fr and '/tools/' not in fr:
-            where = fr.replace(ROOT + '/', '').strip()
+        if ('humaniflow_amd/' in fr or 'bench.py' in fr) and '/tools/' not in fr:
+            where = fr[fr.index('humaniflow_amd/'):] if 'humaniflow_amd/' in fr else fr
             break
-    shp = str(ev.input_shapes)[:70] if ev.input_shapes else ''
-    counts[(ev.name, where, shp)] += 1
-print('leaf ATen operators per training step (B = %d, N = %d, ResNet-18), by the first frame inside the repository:' % (B, N))
+    shp = str(ev.input_shapes)[:60] if ev.input_shapes else ''
+    counts[(ev.key, where.strip(), shp)] += ev.count
+print('leaf ATen operators per training step (B = %d, N = %d, ResNet-18), by the first frame inside the package:' % (B, N))
 tot = 0
+by_where = collections.Counter()
 for (name, where, shp), c in sorted(counts.items(), key=lambda kv: -kv[1]):
-    print('%6.1f  %-26s %-90s %s' % (c / STEPS, name, where[:90], shp))
+    print('%6.1f  %-24s %-80s %s' % (c / STEPS, name, where[:80], shp))
     tot += c
+    by_where[where.split('(')[0]] += c
 print('total %.1f leaf operators per step' % (tot / STEPS))
+print('by file:', [(k, round(v / STEPS, 1)) for k, v in by_where.most_common(12)])
