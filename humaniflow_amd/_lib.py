@@ -103,6 +103,8 @@ _SIGS = {
     'hmf_stem_pack_host': (C.c_int, [_VP, _VP]),
     'hmf_stem_conv': (C.c_int, [_VP] * 4 + [C.c_int] * 5 + [_VP]),
     'hmf_stem_conv_pool': (C.c_int, [_VP] * 4 + [C.c_int] * 4 + [_VP]),
+    'hmf_train_loss_workspace_bytes': (C.c_longlong, [C.c_int]),
+    'hmf_train_loss': (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_int] + [_VP] * 8 + [C.c_longlong, _VP]),
     'hmf_stem_wino_packed_floats': (C.c_longlong, []),
     'hmf_stem_wino_pack_host': (C.c_int, [_VP, _VP]),
     'hmf_stem_wino_pack_device': (C.c_int, [_VP, _VP, _VP]),

@@ -353,3 +353,41 @@ class Rot6dToRotmat(torch.autograd.Function):
             _lib.check(lib.hmf_rot6d_to_rotmat_backward(x6.data_ptr(), gR.data_ptr(), x6.shape[0], gx.data_ptr(), _lib.current_stream()),
                        'hmf_rot6d_to_rotmat_backward')
         return gx.reshape(x.shape).to(x.dtype)
+
+
+class FusedTrainLoss(torch.autograd.Function):
+    """HumaniflowLoss on the training step's own quantities (losses/humaniflow_loss.py:25-79, J2D_LOSS_ON = 'point_est+samples', no 3D point-estimate
+    terms) with the joint selection / flip / projection of train/train_humaniflow.py:283-318 folded in: hmf_train_loss computes the scalar AND its
+    gradients in two launches; backward scales the stored gradients by the incoming one (one multi-tensor launch)."""
+
+    @staticmethod
+    def forward(ctx, lp, shape_mode, shape_log_std, joints, cam, glob_R, shape_t, j2d_t, vis, glob_t, N, coco, img_wh, weights, mean):
+        lib = _lib.load()
+        dev = lp.device
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        lp_, mode_, ls_, j_, cam_, g_ = f(lp), f(shape_mode), f(shape_log_std), f(joints), f(cam), f(glob_R).reshape(-1, 9)
+        st_, jt_, gt_ = f(shape_t), f(j2d_t), f(glob_t).reshape(-1, 9)
+        vis_ = vis.detach().to(torch.uint8).contiguous()
+        B, P, nb = lp_.shape[0], lp_.shape[1], mode_.shape[1]
+        assert j_.shape == (B * N + B, 90, 3) and cam_.shape == (B, 3) and jt_.shape == (B, 17, 2) and vis_.shape == (B, 17)
+        new = lambda t: torch.empty_like(t)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        grads = [new(lp_), new(mode_), new(ls_), new(j_), new(cam_), new(g_)]
+        import ctypes as C
+        ws = torch.empty(int(lib.hmf_train_loss_workspace_bytes(B)), dtype=torch.uint8, device=dev)
+        idx = (C.c_int * 17)(*[int(i) for i in coco])
+        with torch.cuda.device(dev):
+            _lib.check(lib.hmf_train_loss(_lib.dptr(lp_), P, _lib.dptr(mode_), _lib.dptr(ls_), _lib.dptr(st_), nb, _lib.dptr(j_), _lib.dptr(cam_), idx, _lib.dptr(jt_),
+                                          vis_.data_ptr(), _lib.dptr(g_), _lib.dptr(gt_), B, N, float(img_wh), float(weights[0]), float(weights[1]), float(weights[2]),
+                                          float(weights[3]), int(mean), _lib.dptr(loss), *[_lib.dptr(t) for t in grads], ws.data_ptr(), ws.numel(),
+                                          _lib.current_stream()), 'hmf_train_loss')
+        ctx.grads = grads
+        ctx.glob_shape = glob_R.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = list(torch._foreach_mul(ctx.grads, g.to(torch.float32)))
+        ctx.grads = None
+        grads[5] = grads[5].reshape(ctx.glob_shape)
+        return tuple(grads) + (None,) * 9

@@ -265,7 +265,7 @@ class SMPL(nn.Module):
         return SMPLOutput(vertices=verts, joints=joints, full_pose=full_pose, betas=betas, global_orient=global_orient,
                           body_pose=body_pose)
 
-    def forward_samples_and_point_est(self, pred):
+    def forward_samples_and_point_est(self, pred, return_packed=False):
         """One launch for what the reference does with two SMPL calls (evaluate/evaluate_humaniflow.py:124-127,168-172,
         predict/predict_humaniflow.py:128-131,160-163): the B point-estimate bodies and the B*N sampled bodies of a
         HumaniflowModel.forward(num_samples=N) result, M = B*N + B rows -- the M = B launch alone fills 1/8 of the GPU for 1 % of the work.
@@ -303,6 +303,8 @@ class SMPL(nn.Module):
                 verts = verts + self.transl.unsqueeze(1)
         cut = lambda sl: SMPLOutput(vertices=verts[sl], joints=joints[sl], full_pose=None if full_pose is None else full_pose[sl], betas=betas[sl],
                                     global_orient=full_pose[sl, :1] if full_pose is not None else None, body_pose=body[sl])
+        if return_packed:
+            return cut(slice(BN, BN + B)), cut(slice(0, BN)), joints
         return cut(slice(BN, BN + B)), cut(slice(0, BN))
 
     def tpose(self, betas):

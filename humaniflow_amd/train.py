@@ -17,11 +17,12 @@ import time
 import torch
 
 from . import _lib
-from .evaluate import flip_about_x, joint_index, orthographic_project_torch, select_joints
+from .evaluate import ALL_JOINTS_TO_COCO_MAP, flip_about_x, joint_index, orthographic_project_torch, select_joints
 from .losses import HumaniflowLoss
 
 
 _XY_SIGN = {}
+FUSED_LOSS = True               # the step's loss and its gradients on hmf_train_loss (two launches); False: HumaniflowLoss on torch operators
 
 
 def _xy_sign(t):
@@ -40,6 +41,20 @@ def train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples
     pred = model(proxy_input, compute_point_est=True, num_samples=N, compute_for_loglik=True, shape_for_loglik=targets['shape'],
                  pose_R_for_loglik=targets['pose_rotmats'], glob_R_for_loglik=targets['glob_rotmats'], noise=noise, input_feats=input_feats)
     B = pred['glob_rotmat'].shape[0]
+    cfg_l = criterion.loss_cfg
+    dists = pred['conditioned_pose_SO3flow_dists_for_loglik']
+    if (FUSED_LOSS and N > 0 and cfg_l.J2D_LOSS_ON == 'point_est+samples' and not cfg_l.APPLY_POINT_EST_LOSS and cfg_l.REDUCTION in ('mean', 'sum')
+            and pred['glob_rotmat'].is_cuda and getattr(dists[0], 'parent', None) is not None):
+        # :283-343 in two launches (csrc/train_loss.hip): joint selection, flip, projection and the four loss terms with their gradients; as torch
+        # operators the same arithmetic is ~150 launches of a few hundred elements each (and the reference's own loop)
+        from .autograd import FusedTrainLoss
+        pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True)
+        lp = criterion.pose_log_probs(dists, targets['pose_rotmats'].double())
+        W = cfg_l.WEIGHTS
+        loss = FusedTrainLoss.apply(lp, pred['shape_mode'], pred['shape_log_std'], joints, pred['cam_wp'], pred['glob_rotmat'], targets['shape'],
+                                    targets['joints2D'], targets['joints2D_vis'], targets['glob_rotmats'], N, ALL_JOINTS_TO_COCO_MAP, criterion.img_wh,
+                                    (W.POSE, W.SHAPE, W.JOINTS2D, W.GLOB_ROTMATS), cfg_l.REDUCTION == 'mean')
+        return loss, pred
     pe, sa = smpl.forward_samples_and_point_est(pred)                                   # :283-287 and :300-304 in one launch
     cam = pred['cam_wp']
     # :289-297: orthographic_project_torch(flip_about_x(select_joints(joints, 'coco')), cam) = s * ((x, -y) + t) of the 17 COCO joints, written

@@ -112,6 +112,20 @@ int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts,
 int hmf_smpl_joints_backward(const hmf_smpl_t* h, const float* global_orient, const float* body_pose, const float* betas, int M,
                              const float* g_joints, float* g_global_orient, float* g_body_pose, float* g_betas, void* stream);
 
+/* The training loss of one step and its gradients in two launches (train/train_humaniflow.py:283-343 through losses/humaniflow_loss.py:25-79 with
+ * LOSS.J2D_LOSS_ON = 'point_est+samples' and APPLY_POINT_EST_LOSS off): pose NLL from the log-densities lp (B,P), shape NLL of Normal(shape_mode,
+ * exp(shape_log_std)) at shape_target (B,nb), the visible-2D-joint MSE of the orthographic projection s ((x, -y) + t) of the 17 COCO joints
+ * (coco17_host: their indices among the 90 output joints, HOST array) of the packed joints (B N + B, 90, 3) [rows b N + n = sample n of image b, rows
+ * B N + b = the point estimate] against joints2D_target (B,17,2) pixels normalised by img_wh, and the MSE of glob_R (B,9); weights and the
+ * reduction ('mean' = 1: the reference's denominators, 'sum' = 0) as LOSS.*.  Writes loss (1) and d loss / d {lp, shape_mode, shape_log_std, joints, cam,
+ * glob_R}.  ws: hmf_train_loss_workspace_bytes(B).  Deterministic. */
+long long hmf_train_loss_workspace_bytes(int B);
+int hmf_train_loss(const float* lp, int P, const float* shape_mode, const float* shape_log_std, const float* shape_target, int nb, const float* joints,
+                   const float* cam, const int* coco17_host, const float* joints2D_target, const unsigned char* joints2D_vis, const float* glob_R,
+                   const float* glob_target, int B, int N, float img_wh, float w_pose, float w_shape, float w_joints2D, float w_glob, int reduction_mean,
+                   float* loss, float* g_lp, float* g_shape_mode, float* g_shape_log_std, float* g_joints, float* g_cam, float* g_glob_R, void* ws,
+                   long long ws_bytes, void* stream);
+
 /* utils/sampling_utils.py:22-33 over N samples of one image.  verts: N x V x 3 ->
  * avg_l2: V, dir_std: V x 3.                                                                      */
 int hmf_vertex_variance(const float* verts, int N, int V, float* avg_l2, float* dir_std, void* stream);

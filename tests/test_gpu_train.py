@@ -450,3 +450,41 @@ def test_train_step_skips_non_finite_updates_on_the_device():
     assert steps_before == [float(opt.state[p]['step']) for p in params if p in opt.state]
     loss, sk = T.train_step(model, smpl, crit, opt, red, *batch, 2)
     assert float(sk) == 0.0 and not all(torch.equal(a, b.detach()) for a, b in zip(before, params))
+
+
+@pytest.mark.parametrize('reduction', ['mean', 'sum'])
+def test_fused_training_loss_equals_the_torch_operator_form(reduction):
+    """hmf_train_loss (csrc/train_loss.py: joint selection, flip, projection, the four loss terms and their gradients in two launches) against the same
+    step with HumaniflowLoss on torch operators (pinned to the reference's class by tests/golden/loss_golden.npz): loss and every parameter gradient."""
+    import copy
+    from humaniflow_amd import train as T
+    model, sd, cfg = _model(seed=4)
+    model.train()
+    dev = torch.device('cuda:0')
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to(dev)
+    for p in smpl.parameters():
+        p.requires_grad_(False)
+    B, N, S = 6, 3, cfg.DATA.PROXY_REP_SIZE
+    lcfg = copy.deepcopy(cfg.LOSS)
+    lcfg.REDUCTION = reduction
+    x, targets = T.synthetic_train_batch(smpl, B, S, dev, seed=5, data_cfg=cfg.DATA)
+    targets['joints2D_vis'][0, :5] = False                                   # some invisible joints
+    g = torch.Generator().manual_seed(6)
+    noise = {'shape': torch.randn(N, B, 10, generator=g).to(dev), 'pose': torch.randn(23, B, N, 3, generator=g).to(dev)}
+    feats = torch.randn(B, model.input_feats_dim, generator=g).to(dev)
+    res = {}
+    for fused in (True, False):
+        T.FUSED_LOSS = fused
+        try:
+            model.zero_grad()
+            f = feats.clone().requires_grad_(True)
+            loss, _ = T.train_forward_loss(model, smpl, H.HumaniflowLoss(lcfg, S), x, targets, N, noise=noise, input_feats=f)
+            loss.backward()
+        finally:
+            T.FUSED_LOSS = True
+        res[fused] = (loss.item(), f.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0]), (res[True][0], res[False][0])
+    assert (res[True][1] - res[False][1]).abs().max().item() <= 2e-5 * res[False][1].abs().max().item()
+    assert set(res[True][2]) == set(res[False][2])
+    for n, gr in res[False][2].items():
+        assert (res[True][2][n] - gr).abs().max().item() <= 2e-5 * max(gr.abs().max().item(), 1e-8), n
