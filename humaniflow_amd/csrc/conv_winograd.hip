@@ -47,13 +47,21 @@ constexpr int kWTH = 8, kWTW = 16, kWSC = 64;
 constexpr int kWPH = kWTH + 2;
 constexpr int kWCS = kWSC + 4;                       // LDS pixel stride (floats)
 constexpr int kWNG = kWSC / 8;                       // k-groups per slab
+typedef __attribute__((address_space(3))) void* wino_lds_ptr_t;
+// one LDS-DMA request: 64 lanes x 16 bytes, lane l's bytes from (rsrc base + voff + soff) land at dst + 16 l (non-template helper: see conv_gemm.hip dma16)
+static __device__ __forceinline__ void wino_dma16(__amdgpu_buffer_rsrc_t rsrc, wino_lds_ptr_t dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 0);
+}
+
 // NIMG = 1: the 8 x 16 tile lies in one image (patch 10 x 18).  NIMG = 2: maps at most 8 pixels wide (layer4 at 256x256 input) -- the tile
 // is 8 x 8 pixels of TWO consecutive images side by side (patch 10 x (10 + 10)), so the MFMA still sees 32 Winograd tiles.
 
 // MODE (tools/winograd_ablate.py, results wrong when != 0): & 1 = no patch fetch after the first slab, & 2 = no output transform / stores.
 // PIPE: 0 = transform of group g, then its MFMAs, fenced (round 1); 1 = the transform of group g + 1 is issued with the MFMAs of group g;
 // 2 = the same with an explicit 1 MFMA : 1 ds_read : 3 VALU interleave.
-template <int TN, int NIMG, int MODE = 0, int PIPE = 1, int OCC = 2>
+// DMA: the slab patch goes HBM -> LDS by LDS-DMA (the same LDS image, padding slots written as zeros from out-of-range lanes): no staging registers
+// (48 + 24 VGPRs), no ds_write, which is what lets the TN = 2 form (64 output channels per work-group: half the input transforms per MFMA) fit.
+template <int TN, int NIMG, int MODE = 0, int PIPE = 1, int OCC = 2, bool DMA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_winograd(const WinoArgs a) {
     // LDS image of the patch.  NIMG = 1: columns de-interleaved by parity (pixel (r, c) at slot (c & 1) * 9 + (c >> 1) of row r): the four patch
     // columns 2 tj + {0,1,2,3} of tile tj are then slots {tj, 9 + tj, tj + 1, 9 + tj + 1}, i.e. consecutive lanes read consecutive pixels (17 x 16 B
@@ -66,7 +74,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     static_assert(NIMG != 1 || (kWRP / 4) % 8 == 4, "row pitch must be 4 (mod 8) 16-byte slots");
     static_assert(NIMG != 2 || (kWRP / 4) % 16 == 10, "row pitch must be 10 (mod 16) 16-byte slots");
     constexpr int NV = kWPH * kWPW * (kWSC / 4), NIT = (NV + 255) / 256;
-    __shared__ float lds[kWPH * kWRP];               // patch (49 / 54 KB); reused for the accumulator exchange (2 x 32 KB halves)
+    constexpr int kSlotsRow = kWRP / 4, kSlots = kWPH * kSlotsRow, NQ = (kSlots + 63) / 64, NQW = (NQ + 3) / 4;      // DMA: 16-byte slots, requests, requests per wave
+    __shared__ __attribute__((aligned(16))) float lds[DMA ? NQ * 256 : kWPH * kWRP];     // patch (49 / 54 KB); reused for the accumulator exchange (2 x 32 KB halves)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lq = lane >> 5;
     HMF_WSTAMP(0, HMF_WCLK());
@@ -82,18 +91,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.H * a.W * a.Cin * 4, 0x00020000);
     constexpr int kOOB = (int)0x80000000;
-    int goff[NIT], loff[NIT];
+    int goff[DMA ? NQW : NIT], loff[DMA ? 1 : NIT];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    if (DMA) {
+        // request q = 4 k + wave fills LDS slots [64 q, 64 q + 64): slot -> (patch row, pixel slot, channel quad); padding slots, slots past the image and
+        // pixels outside the map read out of range (the DMA writes the 0 the buffer load returns)
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int e = tid + 256 * k;
-        const int p = e / (kWSC / 4), c4 = e - p * (kWSC / 4);
-        const int r = p / kWPW, col = p - r * kWPW;
-        const int img = NIMG == 1 ? 0 : col / 10;
-        const int ih = oh0 + r - 1, iw = NIMG == 1 ? ow0 + col - 1 : col - img * 10 - 1;
-        const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (b + img < a.B);
-        goff[k] = ok ? ((((b + img) * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
-        const int cl = col - img * 10;
-        loff[k] = r * kWRP + (NIMG == 1 ? (col & 1) * 9 + (col >> 1) : img * 10 + (cl & 1) * 5 + (cl >> 1)) * kWCS + 4 * c4;
+        for (int k = 0; k < NQW; ++k) {
+            const int sl = 64 * (4 * k + wv) + lane;
+            const int r = sl / kSlotsRow, rs = sl - r * kSlotsRow, ps = rs / (kWCS / 4), c4 = rs - ps * (kWCS / 4);
+            const int img = NIMG == 1 ? 0 : ps / 10, q10 = ps - img * 10;
+            const int col = NIMG == 1 ? (ps < 9 ? 2 * ps : 2 * (ps - 9) + 1) : (q10 < 5 ? 2 * q10 : 2 * (q10 - 5) + 1);
+            const int ih = oh0 + r - 1, iw = NIMG == 1 ? ow0 + col - 1 : col - 1;
+            const bool ok = (r < kWPH) & (ps < kWPW) & (c4 < kWSC / 4) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (b + img < a.B);
+            goff[k] = ok ? ((((b + img) * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
+        }
+        loff[0] = 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + 256 * k;
+            const int p = e / (kWSC / 4), c4 = e - p * (kWSC / 4);
+            const int r = p / kWPW, col = p - r * kWPW;
+            const int img = NIMG == 1 ? 0 : col / 10;
+            const int ih = oh0 + r - 1, iw = NIMG == 1 ? ow0 + col - 1 : col - img * 10 - 1;
+            const bool ok = (e < NV) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (b + img < a.B);
+            goff[k] = ok ? ((((b + img) * a.H + ih) * a.W + iw) * a.Cin + 4 * c4) * 4 : kOOB;
+            const int cl = col - img * 10;
+            loff[k] = r * kWRP + (NIMG == 1 ? (col & 1) * 9 + (col >> 1) : img * 10 + (cl & 1) * 5 + (cl >> 1)) * kWCS + 4 * c4;
+        }
     }
     const int nslab = a.Cin / kWSC;
     const int s_per = nslab / a.ksplit, s_begin = (int)blockIdx.y * s_per, s_end = s_begin + s_per;       // ksplit = 1: all slabs
@@ -134,6 +160,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #ifdef HMF_EXPERIMENTS
         const long long tA = HMF_WCLK();
 #endif
+        if (DMA) {
+            if (s != s_begin) __syncthreads();                           // every wave is past its reads of the previous slab
+#pragma unroll
+            for (int k = 0; k < NQW; ++k)
+                if (4 * k + wv < NQ)
+                    wino_dma16(rx, (wino_lds_ptr_t)((__attribute__((address_space(3))) float*)lds + (4 * k + wv) * 256), goff[k], s * kWSC * 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
         f32x4 pv[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -147,6 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         for (int k = 0; k < NIT; ++k)
             if (NV % 256 == 0 || k < NIT - 1 || tid + 256 * k < NV) *(f32x4*)&lds[loff[k]] = pv[k];
         __syncthreads();
+        }
 #ifdef HMF_EXPERIMENTS
         fetch_cyc += HMF_WCLK() - tA;
         if (s == s_begin) HMF_WSTAMP(1, HMF_WCLK());
@@ -705,6 +741,11 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
             // slab's / next pixel tile's patch requested under the current MFMA loop -- is no faster where it fits the register file (layer3 45.2 vs 45.5 us,
             // layer4 52.5 vs 51.1, layer1 at two waves per SIMD 49.6 vs 47.0) and spills at three waves per SIMD (+48 prefetch registers on 163): the
             // co-resident work-groups already hide the fetch; the kernel stays in the experiments build.
+            // Round 4, later (tools/winograd_ablate.py --dma; bitwise the same results): the slab patch by LDS-DMA into the same LDS image (template flag
+            // DMA: no staging registers, no ds_write) is no faster by itself (layer1-4: 48.5 / 45.5 / 44.2 / 51.0 vs 47.3 / 44.7 / 44.0 / 51.1 us) but frees
+            // the 72 VGPRs that made the 64-channel work-group spill; that form (TN = 2: half the input transforms per MFMA, 252 VGPRs, no spill) wins
+            // only on layer2 alone (42.4 vs 44.7 us) and leaves the three-stream step where it was (2.90-2.93 ms for every mix of layers against
+            // 2.91): the transform VALU is not what the step waits for.  Both stay in the experiments build (variants 500 / 540 / 541).
             if (!pair && Cin <= 128) hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 1, 3>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
             else if (pair) hipLaunchKernelGGL((k_conv_winograd<1, 2, 0, 0, 2>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 0, 2>), dim3((unsigned)blocks, a.ksplit), dim3(256), 0, st, a);
@@ -740,6 +781,19 @@ static int conv_winograd_impl(const float* x, const float* w_packed, const float
             a.xb = 1;
             if (variant == 40) hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 0, 2>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 1, 2>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
+            break;
+        case 500:           // LDS-DMA patch fetch, otherwise the product configuration
+            if (!pair && Cin <= 128) hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 1, 3, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else if (pair) hipLaunchKernelGGL((k_conv_winograd<1, 2, 0, 0, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_conv_winograd<1, 1, 0, 0, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            break;
+        case 540:           // LDS-DMA + two n-tiles per wave (64 output channels per work-group), fenced / pipelined transform
+        case 541:
+            if (pair || Cout % 64) return fail(HMF_ERR_INVALID, "hmf_conv_winograd_variant: variant 540/541 needs Cout %% 64 == 0 and maps wider than 8");
+            a.n_tiles = Cout / 64;
+            a.xb = 1;
+            if (variant == 540) hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 0, 2, true>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_conv_winograd<2, 1, 0, 1, 2, true>), dim3((unsigned)(blocks / 2)), dim3(256), 0, st, a);
             break;
         case 22: HMF_WINO_LAUNCH(0, 2, 2); break;
         case 4: HMF_WINO_LAUNCH(4, 0, 2); break;

@@ -28,6 +28,8 @@ VARIANTS = ((100, 'fenced transform, 2 waves/SIMD'), (30, 'pipelined + 3 waves/S
 if '--pf' in sys.argv:            # round 4: k_conv_winograd (300 = the round-3 defaults) vs the stage-pipelined k_conv_winograd_pf
     VARIANTS = ((300, 'product (round-3 kernel)'), (301, 'pf: 3 waves/SIMD + 2 tiles | 2 waves/SIMD'), (311, 'pf pipe occ3 1 tile'), (312, 'pf pipe occ3 2 tiles'), (314, 'pf pipe occ3 4 tiles'),
                 (321, 'pf fenced occ2 1 tile'), (322, 'pf fenced occ2 2 tiles'), (332, 'pf pipe occ2 2 tiles'))
+elif '--dma' in sys.argv:         # round 4: LDS-DMA patch fetch (500) and, with it, 64 output channels per work-group (540 fenced / 541 pipelined transform)
+    VARIANTS = ((300, 'product'), (500, 'DMA fetch'), (540, 'DMA + 64 ch, fenced'), (541, 'DMA + 64 ch, pipelined'))
 elif '--full' not in sys.argv:
     VARIANTS = VARIANTS[:4]
 ROUNDS = 7           # variants are timed round-robin and the median over rounds is reported: a single pass is dominated by clock ramp / order effects (+-15 %)
@@ -40,11 +42,13 @@ for name, hw, c in (('layer1', 64, 64), ('layer2', 32, 128), ('layer3', 16, 256)
     bias = torch.randn(c, device=dev)
     y = torch.empty(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     st = _lib.current_stream()
-    if '--pf' in sys.argv:        # the variants compute the same convolution: check them bit for bit against the round-3 kernel first
+    if '--pf' in sys.argv or '--dma' in sys.argv:        # the variants compute the same convolution: check them bit for bit against the round-3 kernel first
         res = torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
         ref = torch.empty_like(y)
         _lib.check(lib.hmf_conv_winograd_variant(x.data_ptr(), wk.data_ptr(), bias.data_ptr(), res.data_ptr(), ref.data_ptr(), B, hw, hw, c, c, 1, 300, st), 'wino')
         for var, lab in VARIANTS[1:]:
+            if hw <= 8 and var in (540, 541):
+                continue
             y.zero_()
             _lib.check(lib.hmf_conv_winograd_variant(x.data_ptr(), wk.data_ptr(), bias.data_ptr(), res.data_ptr(), y.data_ptr(), B, hw, hw, c, c, 1, var, st), 'wino')
             assert torch.equal(y, ref), (name, var, (y - ref).abs().max().item())
