@@ -287,3 +287,33 @@ def test_encoder_bn_fold_host_logic():
     enc._plan = plan
     enc.load_state_dict(enc.state_dict()); assert enc._plan is None
     assert len(enc.state_dict()) == 318 and 'layer1.0.downsample.0.weight' in enc.state_dict()     # torchvision names, no fc
+
+
+def test_round4_entry_points_size_their_workspaces_and_validate_arguments_without_a_gpu(lib):
+    """The workspace-size functions of the round-4 entries are pure host arithmetic: the small-launch split (fewer than 128 work-groups: the slab loop of a
+    3x3 layer is split over up to 8 work-groups per tile, at most 512 in all), the polyphase stem's halo records, the training loss's partial sums; and
+    the entries reject bad arguments before any launch."""
+    out = lambda B, H, W, C: 4 * B * H * W * C
+    # predict shape (one image): layer2 (2 slabs) / layer3 (4) / layer4 (8 slabs, two images per tile) are split; layer1 (one slab) and B = 32 are not
+    assert lib.hmf_conv_winograd_workspace_bytes(1, 32, 32, 128, 128) == 2 * out(1, 32, 32, 128)
+    assert lib.hmf_conv_winograd_workspace_bytes(1, 16, 16, 256, 256) == 4 * out(1, 16, 16, 256)
+    assert lib.hmf_conv_winograd_workspace_bytes(1, 8, 8, 512, 512) == 8 * out(1, 8, 8, 512)
+    assert lib.hmf_conv_winograd_workspace_bytes(1, 64, 64, 64, 64) == 0
+    for hw, c in ((64, 64), (32, 128), (16, 256), (8, 512)):
+        assert lib.hmf_conv_winograd_workspace_bytes(32, hw, hw, c, c) == 0
+    assert lib.hmf_conv_winograd_workspace_bytes(1, 16, 16, 100, 256) == 0            # not a shape the kernel takes
+    assert lib.hmf_conv_patch_workspace_bytes(1, 32, 32, 256, 256, 3, 2, 8210) == 4 * out(1, 16, 16, 256)
+    assert lib.hmf_conv_patch_workspace_bytes(1, 16, 16, 512, 512, 3, 2, 8210) == 8 * out(1, 8, 8, 512)
+    assert lib.hmf_conv_patch_workspace_bytes(32, 32, 32, 256, 256, 3, 2, 8210) == 0
+    # polyphase stem: 24 rim positions x 64 channels per 8 x 16 output tile
+    assert lib.hmf_stem_wino_pool_workspace_bytes(32, 256, 256) == 32 * 16 * 8 * 24 * 64 * 4
+    assert lib.hmf_stem_wino_pool_workspace_bytes(1, 18, 22) == 1 * 2 * 1 * 24 * 64 * 4
+    assert lib.hmf_stem_wino_packed_floats() == 4 * 9 * 13 * 64 * 4
+    assert lib.hmf_train_loss_workspace_bytes(72) == (4 * 72 + 4) * 4
+    buf = (C.c_float * 4096)()
+    p = C.c_void_p((C.cast(buf, C.c_void_p).value + 15) & ~15)
+    assert lib.hmf_stem_wino(p, p, None, p, 1, 17, 32, 32, 1, None) < 0 and b'18-channel' in lib.hmf_last_error()
+    assert lib.hmf_stem_wino_pool(p, p, None, p, 1, 18, 32, 32, None, 0, None) < 0 and b'workspace' in lib.hmf_last_error()
+    assert lib.hmf_stem_wino(p, C.c_void_p(p.value + 4), None, p, 1, 18, 32, 32, 1, None) < 0                       # unaligned packed filters
+    assert lib.hmf_conv_winograd_ws(p, p, None, None, p, 1, 8, 8, 512, 512, 1, p, 16, None) < 0 and b'workspace' in lib.hmf_last_error()
+    assert lib.hmf_train_loss(*([None] * 1), 23, *([None] * 3), 10, *([None] * 7), 2, 3, 256.0, 1.0, 1.0, 1.0, 1.0, 1, *([None] * 8), 0, None) < 0

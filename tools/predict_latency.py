@@ -64,7 +64,7 @@ ms, tag, rows = np.zeros(65536), np.zeros(65536, np.int32), np.zeros(65536, np.i
 n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), 65536)
 lib.hmf_profile_enable(0)
 names = {1: 'k_lbs_mfma', 2: 'k_rigid_chain', 3: 'k_joints_compact', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc', 8: '1x1 convolutions (30 launches)',
-         9: 'k_stem_conv + pool', 10: 'k_conv_patch (3 launches)', 11: 'k_conv_winograd (13 launches)', 15: 'k_heads_fc1 + k_heads_out'}
+         9: 'stem (k_stem_wino + k_stem_pool_rim)', 10: 'k_conv_patch (3 launches)', 11: 'k_conv_winograd (13 launches)', 15: 'k_heads_fc1 + k_heads_out'}
 tot = 0.0
 for tg in sorted(set(tag[:n].tolist())):
     us = ms[:n][tag[:n] == tg].sum() / reps * 1e3
