@@ -332,8 +332,10 @@ def main():
     model.image_encoder.gemm_terms = args.gemm_terms
     for kv in filter(None, os.environ.get('HMF_ENC_OPTS', '').split(',')):          # experiments only: e.g. HMF_ENC_OPTS=fuse_stem_pool=0,fuse_pairs=0
         k_, v_ = kv.split('=')
-        setattr(model.image_encoder, k_, bool(int(v_)))
-        log('encoder option %s = %s' % (k_, bool(int(v_))))
+        cur_ = getattr(model.image_encoder, k_)
+        val_ = int(v_) if (isinstance(cur_, int) and not isinstance(cur_, bool)) else bool(int(v_))
+        setattr(model.image_encoder, k_, val_)
+        log('encoder option %s = %s' % (k_, val_))
     smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=args.batch, create_transl=False, blend_dtype=args.blend_dtype).to(dev)
     B, N = args.batch, args.samples
     NB = max(1, args.batches)

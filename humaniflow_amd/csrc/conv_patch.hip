@@ -217,10 +217,11 @@ static long long patch_blocks(int B, int OH, int OW, int Cout, int TW, int TH, i
 
 using namespace hmf;
 
-// cfg = TW*1000 + PG*100 + TN*10: 16420 (8x16 pixels x 64 channels), 16410 (8x16 x 32), 8210 (8x8 x 64)
-static int patch_cfg_ok(int cfg) { return cfg == 16420 || cfg == 16410 || cfg == 8210; }
+// cfg = TW*1000 + PG*100 + TN*10 (+ 1: 32-channel slabs instead of 64): 16420 (8x16 pixels x 64 channels), 16410 (8x16 x 32), 8210 (8x8 x 64),
+// 8211 (8x8 x 64 with 32-channel slabs: half the LDS per work-group, stride-2 layers only)
+static int patch_cfg_ok(int cfg) { return cfg == 16420 || cfg == 16410 || cfg == 8210 || cfg == 8211; }
 static int patch_cfg_bn(int cfg) { const int pg = (cfg / 100) % 10, tn = (cfg / 10) % 10; return (4 / pg) * tn * 32; }
-static int patch_cfg_sc(int) { return 64; }
+static int patch_cfg_sc(int cfg) { return (cfg % 10) == 1 ? 32 : 64; }
 
 extern "C" long long hmf_conv_patch_packed_floats(int Cin, int Cout, int ks) { return (long long)Cout * ks * ks * Cin; }
 
@@ -246,7 +247,7 @@ extern "C" int hmf_conv_patch_pack_host(const float* w, float* packed, int Cin, 
 
 // tile geometry of a cfg: pixel tile TW x TH, channel tile BN (the 3x3 / stride 2 layers always run cfg 8210's 8 x 8 x 64)
 static void patch_cfg_tile(int cfg, int stride, int& TW, int& TH, int& BN) {
-    if (stride == 2) cfg = 8210;
+    if (stride == 2 && cfg != 8211) cfg = 8210;
     TW = cfg / 1000;
     const int pg = (cfg / 100) % 10;
     TH = pg * (32 / TW);
@@ -257,12 +258,12 @@ static int conv_patch_impl(const float* x, const float* w_packed, const float* b
                            int stride, int relu, int cfg, void* ws, long long ws_bytes, void* stream);
 
 extern "C" long long hmf_conv_patch_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ks, int stride, int cfg) {
-    if (B <= 0 || H <= 0 || W <= 0 || ks != 3 || (stride != 1 && stride != 2) || !patch_cfg_ok(cfg) || Cin % 64) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || ks != 3 || (stride != 1 && stride != 2) || !patch_cfg_ok(cfg) || Cin % 64 || (cfg == 8211 && stride != 2)) return 0;
     int TW, TH, BN;
     patch_cfg_tile(cfg, stride, TW, TH, BN);
     if (Cout % BN) return 0;
     const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
-    const int ks_ = small_launch_ksplit(patch_blocks(B, OH, OW, Cout, TW, TH, BN), Cin / 64);
+    const int ks_ = small_launch_ksplit(patch_blocks(B, OH, OW, Cout, TW, TH, BN), Cin / patch_cfg_sc(cfg));
     return ks_ > 1 ? ks_ * 4LL * B * OH * OW * Cout : 0;
 }
 
@@ -281,7 +282,8 @@ static int conv_patch_impl(const float* x, const float* w_packed, const float* b
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return fail(HMF_ERR_INVALID, "hmf_conv_patch: bad args");
     if (!patch_cfg_ok(cfg)) return fail(HMF_ERR_INVALID, "hmf_conv_patch: unknown cfg %d", cfg);
     if (ks != 3 || (stride != 1 && stride != 2)) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: ks=%d stride=%d (3x3, stride 1 or 2)", ks, stride);
-    if (ks == 3 && stride == 2 && cfg != 8210) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: 3x3 / stride 2 is built for cfg 8210 only");
+    if (ks == 3 && stride == 2 && cfg != 8210 && cfg != 8211) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: 3x3 / stride 2 is built for cfg 8210 / 8211 only");
+    if (cfg == 8211 && stride != 2) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: cfg 8211 (32-channel slabs) is built for the stride-2 layers only");
     const int SC = patch_cfg_sc(cfg), BN = patch_cfg_bn(cfg);
     if (Cin % SC || Cout % BN) return fail(HMF_ERR_UNSUPPORTED, "hmf_conv_patch: Cin=%d %% %d or Cout=%d %% %d", Cin, SC, Cout, BN);
     if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return fail(HMF_ERR_INVALID, "hmf_conv_patch: x and w_packed must be 16-byte aligned");
@@ -305,6 +307,7 @@ static int conv_patch_impl(const float* x, const float* w_packed, const float* b
     }
 #define PCASE(CFG, KS_, TW_, PG_, TN_, SC_) \
     if (cfg == CFG && ks == KS_) return launch_patch<KS_, TW_, PG_, TN_, SC_, 1>(a, st);
+    if (ks == 3 && stride == 2 && cfg == 8211) return launch_patch<3, 8, 2, 1, 32, 2>(a, st);
     if (ks == 3 && stride == 2) return launch_patch<3, 8, 2, 1, 64, 2>(a, st);
     PCASE(16420, 3, 16, 4, 2, 64) PCASE(16410, 3, 16, 4, 1, 64) PCASE(8210, 3, 8, 2, 1, 64)
     // 1x1 layers were measured on this kernel as well (64- and 128-channel slabs, single- and double-buffered patches): equal to or slower than

@@ -96,6 +96,7 @@ class ResNetEncoder(nn.Module):
     # eval-mode BatchNorm folded into the conv weight + a per-channel bias that the convolution kernel adds in its epilogue; a
     # downsample branch's bias is added to the block's last bias so that branch needs no pass of its own.
     fuse_stem_pool = True    # stem convolution + max-pool as one launch (hmf_stem_conv_pool / hmf_stem_wino_pool)
+    patch_s2_cfg = 8210      # tiling of the stride-2 3x3 layers (hmf_conv_patch): 8210 = 64-channel slabs, 8211 = 32-channel slabs (half the LDS)
     stem_polyphase = True    # the stem as a polyphase fast convolution (csrc/stem_wino.hip: 100 instead of 196 products per 2 x 2 outputs and channel,
                              # F(2,3)-class arithmetic); False: the direct form (csrc/stem_conv.hip)
     fuse_pairs = True        # a bottleneck's last 1x1 + the next bottleneck's first 1x1 as one launch where built (hmf_conv_pair: layer1 / layer2)
@@ -215,6 +216,8 @@ class ResNetEncoder(nn.Module):
             for stages, ds, dual in plan['blocks']:
                 for w, b, s, p in stages:
                     cfg = self._patch_cfg(w)
+                    if cfg and s[0] == 2:
+                        cfg = self.patch_s2_cfg
                     if cfg and s[0] == 1:
                         # stride-1 3x3 layers run as Winograd F(2x2,3x3) on maps >= 16 pixels wide (8x16-pixel tiles) and on 8-pixel maps (two
                         # images per tile); the patch kernel stays packed too for other widths (chosen per call from the activation width)
@@ -340,7 +343,7 @@ class ResNetEncoder(nn.Module):
             return y
         pk = self._plan['packed'].get(id(w)) if self._plan is not None else None
         if pk is not None:
-            cfg = 8210 if stride == 2 else pk[0]                            # the stride-2 3x3 variant is built for the 8x8 tile
+            cfg = pk[0]                                                     # stride 2: the 8x8 tile (8210 / 8211), chosen at plan time
             nbytes = int(lib.hmf_conv_patch_workspace_bytes(B, H, W, Cin, Cout, ks, stride, cfg))      # > 0: a small batch, the slab loop is split
             ws = self._small_launch_ws(x.device, nbytes) if nbytes else None
             _lib.check(lib.hmf_conv_patch_ws(x.data_ptr(), pk[1].data_ptr(), None if bias is None else bias.data_ptr(),

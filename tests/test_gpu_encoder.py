@@ -210,6 +210,10 @@ def test_patch_conv3x3_stride2():
     # the predict shape (one image): layer3.0 / layer4.0 sized reductions split over 4 / 8 slab ranges
     assert _patch_case(1, 32, 32, 256, 256, 3, 2, False, True, 8210, seed=4) > 0
     assert _patch_case(1, 16, 16, 512, 512, 3, 2, True, True, 8210, seed=5) > 0
+    # 32-channel slabs (cfg 8211: half the LDS per work-group)
+    _patch_case(2, 16, 16, 128, 64, 3, 2, False, True, 8211, seed=6)
+    _patch_case(1, 13, 9, 64, 128, 3, 2, True, False, 8211, seed=7)
+    assert _patch_case(1, 16, 16, 512, 512, 3, 2, True, True, 8211, seed=8) > 0
 
 
 def _wino_case(B, H, W, cin, cout, res, relu, seed=0):
