@@ -110,6 +110,10 @@ class PartFlow:
 
     # -- forward (sampling) direction: pyro_conditional_norm_flow.py:120-129 ------------
     def forward(self, z, context):
+        return radial_tanh_forward(self.forward_couplings(z, context), self.radius)
+
+    def forward_couplings(self, z, context):
+        """The [permutation, coupling] x T stack alone (the pyro part of the flow), before the reference's own radial tanh."""
         x = z
         for t, (perm, layers) in enumerate(zip(self.perms, self.couplings)):
             if self.plu is None:
@@ -120,16 +124,18 @@ class PartFlow:
                 x, _ = spline_coupling(layers, context, x, self.radius, count_bins=self.count_bins)
             else:
                 x = additive_coupling(layers, context, x)
-        return radial_tanh_forward(x, self.radius)
+        return x
 
     # -- density on the algebra: torch TransformedDistribution.log_prob ------------------
     def log_prob_so3(self, v, context):
         """log p(v | context), v (...,3) fp32 on the Lie algebra (|v| < radius)."""
+        x = radial_tanh_inverse(v, self.radius)
+        return self.log_prob_couplings(x, context) - radial_tanh_log_abs_det(x, v, self.radius)
+
+    def log_prob_couplings(self, u, context):
+        """log density of the base Normal pushed through the [permutation, coupling] x T stack alone, at the pre-tanh vector u."""
         lp = 0.0
-        y = v
-        x = radial_tanh_inverse(y, self.radius)
-        lp = lp - radial_tanh_log_abs_det(x, y, self.radius)
-        y = x
+        y = u
         for t in reversed(range(len(self.couplings))):
             perm, layers = self.perms[t], self.couplings[t]
             if self.transform_type == 'spline_coupling':

@@ -1,5 +1,5 @@
 """Pin the oracle's pyro-ppl 1.7.0 / smplx 0.1.26 restatements (oracle/spline.py, oracle/flow.py, oracle/smpl.py: "parity unpinned") against
-golden vectors generated FROM those packages by tests/golden/make_golden_thirdparty.py.  Neither package is installable in the build
+golden vectors generated FROM those packages by tests/golden/make_golden_thirdparty.py (or its reference-free twin make_golden_thirdparty_pip.py).  Neither package is installable in the build
 container, so tests/golden/thirdparty_golden.npz may be absent: every test here then skips, and turns into a real check the day the file is
 generated on a box that has the packages (one command, see the generator's docstring)."""
 import os
@@ -66,6 +66,12 @@ def test_whole_part_flow_forward_and_log_prob_match_the_reference_factory():
     k = int(z['flow_num_couplings'])
     pf = PartFlow([_layers(z, 'flow_t%d_' % t) for t in range(k)], BOUND, BASE_STD, 8)
     ctx, zz = _t(z['flow_ctx']), _t(z['flow_z'])
+    if 'flow_v' not in z.files:            # file written by the reference-free generator: the pyro stack alone, before the reference's radial tanh
+        u = pf.forward_couplings(zz, ctx)
+        assert np.abs(u.numpy() - z['flow_u']).max() < 5e-5
+        lp = pf.log_prob_couplings(_t(z['flow_u']), ctx)
+        assert np.abs(lp.numpy() - z['flow_log_prob_of_u']).max() < 1e-3
+        return
     v = pf.forward(zz, ctx)
     assert np.abs(v.numpy() - z['flow_v']).max() < 5e-5
     lp = pf.log_prob_so3(_t(z['flow_v']), ctx)
