@@ -43,7 +43,7 @@ class FlowGradRecords(C.Structure):
 
 class Rng(C.Structure):
     """hmf_rng_t: where hmf_flow_forward's in-kernel base noise sits in the device generator's Philox stream."""
-    _fields_ = [('seed', C.c_uint64), ('offset', C.c_uint64), ('state_dev', C.c_void_p), ('grid_cap_blocks', C.c_int)]
+    _fields_ = [('seed', C.c_uint64), ('offset', C.c_uint64), ('state_dev', C.c_void_p), ('mirror_dev', C.c_void_p), ('grid_cap_blocks', C.c_int)]
 
 
 _VP = C.c_void_p
@@ -171,7 +171,7 @@ def _bind(path, sigs, hint):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.hmf_abi_version() != 3:
+    if lib.hmf_abi_version() != 4:
         raise RuntimeError('humaniflow_amd: ABI version mismatch')
     return lib
 

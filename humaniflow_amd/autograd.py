@@ -387,7 +387,10 @@ class FusedTrainLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        grads = list(torch._foreach_mul(ctx.grads, g.to(torch.float32)))
-        ctx.grads = None
+        if ctx.grads is None:
+            raise RuntimeError('humaniflow_amd: FusedTrainLoss gradients were freed')
+        if g.requires_grad:
+            raise RuntimeError('humaniflow_amd: FusedTrainLoss has no double-backward (create_graph=True); use HumaniflowLoss on torch operators for that')
+        grads = list(torch._foreach_mul(ctx.grads, g.to(torch.float32)))          # the stored gradients stay: backward may run again (retain_graph=True)
         grads[5] = grads[5].reshape(ctx.glob_shape)
         return tuple(grads) + (None,) * 9

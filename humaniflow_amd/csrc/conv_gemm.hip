@@ -357,6 +357,8 @@ static int conv1x1_gemm_impl(const float* x, const float* x2, const float* w, co
     }
     hipStream_t st = (hipStream_t)stream;
     if ((tile % 1000) == 128 && N % 128) return fail(HMF_ERR_INVALID, "hmf_conv1x1_gemm: a 128-channel tile needs N %% 128 == 0");
+    if (pool && ((tile / 1000) % 1000 != 64 || tile / 10000000 != 0))      // launch_gemm has the pooled epilogue for 64-row, unsplit-K tiles only
+        return fail(HMF_ERR_UNSUPPORTED, "hmf_conv1x1_gemm_avgpool: tile %d has no pooled epilogue (64-row tiles without a K split only)", tile);
     switch (tile) {
         case 64064: launch_gemm<64, 64, 4, 2>(a, st); break;
         case 3064064: launch_gemm<64, 64, 3, 3>(a, st); break;

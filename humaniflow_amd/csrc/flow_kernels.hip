@@ -26,18 +26,14 @@ namespace hmf {
 __global__ __launch_bounds__(256) void k_isgc(FlowDev d, const float* __restrict__ feats, const float* __restrict__ shape,
                                               const float* __restrict__ glob_R, const float* __restrict__ cam, int B,
                                               int apply_elu, float* __restrict__ out, RngPass rng_imm, unsigned long long* __restrict__ rng_state,
-                                              unsigned long long rng_inc, RngPass* __restrict__ rng_pass) {
+                                              unsigned long long rng_inc, RngPass* __restrict__ rng_pass,
+                                              unsigned long long* __restrict__ rng_mirror) {
     // First kernel of a sampling pass: fix the pass' position in the generator's stream for the kernels that follow.  Eager calls carry
     // (seed, offset) as immediates (the host read them from the device generator and advances it); a pass captured into a HIP graph takes
     // them from a device-resident state that every replay advances atomically (concurrent replays on other streams get disjoint ranges).
-    if (rng_pass && blockIdx.x == 0 && threadIdx.x == 0) {
-        RngPass p = rng_imm;
-        if (rng_state) {
-            p.seed = rng_state[0];
-            p.offset = atomicAdd(rng_state + 1, rng_inc);
-        }
-        *rng_pass = p;
-    }
+    // An eager pass also leaves the generator's state AFTER itself in `rng_mirror` (that same device-resident state), so that a pass captured
+    // later continues the stream where the eager passes stopped instead of repeating what a warm-up pass already drew.
+    if (rng_pass && blockIdx.x == 0 && threadIdx.x == 0) *rng_pass = rng_begin_pass(rng_imm, rng_state, rng_inc, rng_mirror);
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nchunk = (B + 7) / 8;
@@ -68,13 +64,9 @@ __global__ __launch_bounds__(256) void k_isgc(FlowDev d, const float* __restrict
 
 // The pass' base noise as tensors (training keeps them for the reverse sweep; tests compare them with torch.randn): the same generator calls the
 // sampling kernels make in registers, materialised by one launch.
-__global__ void k_rng_snapshot(RngPass rng_imm, unsigned long long* __restrict__ rng_state, unsigned long long rng_inc, RngPass* __restrict__ rng_pass) {
-    RngPass p = rng_imm;
-    if (rng_state) {
-        p.seed = rng_state[0];
-        p.offset = atomicAdd(rng_state + 1, rng_inc);
-    }
-    *rng_pass = p;
+__global__ void k_rng_snapshot(RngPass rng_imm, unsigned long long* __restrict__ rng_state, unsigned long long rng_inc, RngPass* __restrict__ rng_pass,
+                               unsigned long long* __restrict__ rng_mirror) {
+    *rng_pass = rng_begin_pass(rng_imm, rng_state, rng_inc, rng_mirror);
 }
 __global__ __launch_bounds__(256) void k_draw_noise(NoiseSrc ns, unsigned int n_shape, unsigned int n_part, float* __restrict__ eps_shape,
                                                     float* __restrict__ eps_pose) {
@@ -1063,7 +1055,8 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
         const int nw = kIsgc * ((B + 7) / 8);
         ProfScope ps(7, B, st);
         hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, feats, (const float*)nullptr, glob_R, cam, B, 0, G, imm,
-                           draws ? (unsigned long long*)rng->state_dev : (unsigned long long*)nullptr, inc, draws ? pass : (RngPass*)nullptr);
+                           draws ? (unsigned long long*)rng->state_dev : (unsigned long long*)nullptr, inc, draws ? pass : (RngPass*)nullptr,
+                           draws ? (unsigned long long*)rng->mirror_dev : (unsigned long long*)nullptr);
         HMF_LAUNCH_CHECK();
     }
     if (h->g.enabled)
@@ -1116,7 +1109,8 @@ int hmf_flow_draw_noise(const hmf_rng_t* rng, int B, int N, int num_betas, float
     imm.seed = rng->seed; imm.offset = rng->offset; imm.cap_blocks = cap;
     const unsigned long long inc = (ns.draw_shape ? ns.inc_shape : 0ull) + (unsigned long long)kP * ns.inc_pose;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_rng_snapshot, dim3(1), dim3(1), 0, st, imm, (unsigned long long*)rng->state_dev, inc, (RngPass*)workspace);
+    hipLaunchKernelGGL(k_rng_snapshot, dim3(1), dim3(1), 0, st, imm, (unsigned long long*)rng->state_dev, inc, (RngPass*)workspace,
+                       (unsigned long long*)rng->mirror_dev);
     HMF_LAUNCH_CHECK();
     const unsigned int n_shape = ns.draw_shape ? (unsigned int)(N * B * num_betas) : 0u, n_part = (unsigned int)(B * N * 3);
     const unsigned long long total = (unsigned long long)n_shape + (unsigned long long)kP * n_part;
@@ -1130,7 +1124,7 @@ int hmf_flow_isgc(const hmf_flow_t* h, const float* feats, const float* shape, c
     if (!h || !feats || !shape || !glob_R || !cam || !isgc || B <= 0) return fail(HMF_ERR_INVALID, "hmf_flow_isgc: bad args");
     const int nw = kIsgc * ((B + 7) / 8);
     hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, feats, shape, glob_R, cam, B, 1, isgc, RngPass{},
-                       (unsigned long long*)nullptr, 0ull, (RngPass*)nullptr);
+                       (unsigned long long*)nullptr, 0ull, (RngPass*)nullptr, (unsigned long long*)nullptr);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -23,6 +23,21 @@ struct RngPass {
     unsigned int pad;
 };
 
+// Where a pass starts in the stream (one thread, first kernel of the pass).  `state` != NULL: a captured pass -- take (seed, offset) from the
+// device-resident state and advance it atomically.  Otherwise the immediates the host read from the generator; `mirror` != NULL then receives
+// the generator's state after this pass.
+__device__ inline RngPass rng_begin_pass(RngPass imm, unsigned long long* state, unsigned long long inc, unsigned long long* mirror) {
+    RngPass p = imm;
+    if (state) {
+        p.seed = state[0];
+        p.offset = atomicAdd(state + 1, inc);
+    } else if (mirror) {
+        mirror[0] = imm.seed;
+        mirror[1] = imm.offset + inc;
+    }
+    return p;
+}
+
 __host__ __device__ inline unsigned int rng_threads(unsigned long long numel, unsigned int cap_blocks) {
     unsigned long long g = (numel + 255) / 256;
     if (g > cap_blocks) g = cap_blocks;

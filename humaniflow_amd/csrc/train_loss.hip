@@ -146,6 +146,8 @@ extern "C" int hmf_train_loss(const float* lp, int P, const float* shape_mode, c
     a.vis = joints2D_vis; a.glob = glob_R; a.glob_t = glob_target;
     for (int j = 0; j < 17; ++j) {
         if (coco17_host[j] < 0 || coco17_host[j] >= 90) return fail(HMF_ERR_INVALID, "hmf_train_loss: joint index %d out of the 90 output joints", coco17_host[j]);
+        for (int i = 0; i < j; ++i)          // the kernel writes g_joints with plain stores, one per (sample, COCO joint, x/y): a repeated joint would overwrite
+            if (coco17_host[i] == coco17_host[j]) return fail(HMF_ERR_INVALID, "hmf_train_loss: output joint %d appears twice in the COCO map", coco17_host[j]);
         a.coco[j] = coco17_host[j];
     }
     a.B = B; a.N = N; a.P = P; a.nb = nb; a.mean = reduction_mean; a.img_wh = img_wh;

@@ -400,6 +400,22 @@ class HumaniflowModel(nn.Module):
     flow_chain32 = None      # None: by size (k_flow_chain16 up to 1,024 rows, the 32-row k_flow_chain beyond); True / False force one: cross-checks, tools
     heads_kernel = True      # inference: fc1 + ELU + fc_cam / fc_glob / fc_shape + init adds + 6D->R + exp(log_std) on hmf_heads; False: torch ops
 
+    def _heads_kernel_supports(self, input_feats):
+        """Shapes / alignment hmf_heads is built for (csrc/heads_kernels.hip: F and fc1.out_features multiples of 32, fc1.out_features <= 1024,
+        <= 16 shape parameters, 16-byte aligned float32 operands).  Anything else the reference accepts takes the torch operators of the
+        differentiable path (still on the device), announced once."""
+        F, N1 = input_feats.shape[1], self.fc1.out_features
+        ok = F % 32 == 0 and N1 % 32 == 0 and N1 <= 1024 and 1 <= self.num_shape_params <= 16 and input_feats.dim() == 2
+        if ok:
+            ts = [input_feats, self.fc1.weight, self.fc_cam.weight, self.fc_glob.weight, self.fc_shape.weight]
+            ok = all((not t.is_contiguous()) or t.dtype != torch.float32 or t.data_ptr() % 16 == 0 for t in ts)   # copies made by the wrapper are aligned
+        if not ok and not self.__dict__.get('_heads_fallback_warned'):
+            self.__dict__['_heads_fallback_warned'] = True
+            import warnings
+            warnings.warn('humaniflow_amd: hmf_heads is not built for F=%d, fc1.out_features=%d, num_shape_params=%d or unaligned operands; '
+                          'the heads run as torch operators on the device' % (F, N1, self.num_shape_params))
+        return ok
+
     def _heads_kernel(self, input_feats):
         """models/humaniflow_model.py:232-253 on hmf_heads (csrc/heads_kernels.hip): reads the live parameters, no packed copy."""
         lib = _lib.load()
@@ -425,8 +441,11 @@ class HumaniflowModel(nn.Module):
         """hmf_rng_t of one sampling pass: where the pass' 1 + 23 normal_() calls sit in the device generator's Philox stream.
         Eager: (seed, offset) read from torch.cuda.default_generators[device] and the generator advanced by what the reference's calls would
         consume -- torch.randn after the forward continues exactly where it would after the reference's forward.  Under HIP-graph capture the
-        host cannot touch the generator: the pass reads a device-resident (seed, offset) that every replay advances atomically; it is created by
-        the first eager pass on the device (capture without one raises) and re-based by reseed_captured_noise()."""
+        host cannot touch the generator: the pass reads a device-resident (seed, offset) that every replay advances atomically.  EVERY eager
+        pass leaves the generator's state after itself in that device-resident state (hmf_rng_t.mirror_dev, written by the pass' first kernel,
+        in stream order), so a pass captured after any number of eager warm-up passes continues the stream instead of repeating their noise.
+        Replays cannot advance the HOST generator: a caller who mixes replays with later eager passes or torch.randn calls on the same
+        generator calls sync_generator_with_captured_noise() after the replays (one 16-byte read-back), else those draws overlap the replays'."""
         lib = _lib.load()
         props = torch.cuda.get_device_properties(device)
         cap = props.multi_processor_count * (props.max_threads_per_multi_processor // 256)
@@ -445,9 +464,25 @@ class HumaniflowModel(nn.Module):
         inc = int(lib.hmf_flow_rng_increment(B, N, self.num_shape_params, int(draw_shape), cap))
         gen.set_offset(off + inc)
         r.seed, r.offset = seed & 0xFFFFFFFFFFFFFFFF, off
-        if idx not in st:           # the state captured passes will continue from: the generator right after this first eager pass
-            st[idx] = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off + inc], dtype=torch.int64).to(device)
+        if idx not in st:
+            st[idx] = torch.zeros(2, dtype=torch.int64, device=device)
+        r.mirror_dev = st[idx].data_ptr()           # the pass' first kernel stores {seed, off + inc} there
         return r
+
+    def sync_generator_with_captured_noise(self, device=None):
+        """Advance torch's device generator past the noise that replays of captured passes have consumed (they advance only the device-resident
+        state), so that the next eager pass / torch.randn continues after them.  One 16-byte device-to-host read (synchronises the
+        current stream).  No-op when no pass ran on the device or the generator carries another seed (the next eager pass re-bases the
+        device state).  Not called implicitly: a generator re-seeded to the SAME seed must restart at its own offset."""
+        device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = self.__dict__.get('_rng_dev', {})
+        if idx not in st:
+            return
+        seed_d, off_d = st[idx].tolist()
+        gen = torch.cuda.default_generators[idx]
+        if (seed_d & 0xFFFFFFFFFFFFFFFF) == (gen.initial_seed() & 0xFFFFFFFFFFFFFFFF) and off_d > gen.get_offset():
+            gen.set_offset(off_d)
 
     def draw_noise(self, device, B, N, draw_shape=True):
         """The base noise of one forward(num_samples = N) as tensors, consuming the device generator exactly as the reference's draws do (and as the
@@ -615,7 +650,7 @@ class HumaniflowModel(nn.Module):
         lib = _lib.load()
         nb, P, N = self.num_shape_params, self.num_bodyparts, int(num_samples)
 
-        if grad or not self.heads_kernel:
+        if grad or not self.heads_kernel or not self._heads_kernel_supports(input_feats):
             x = self.activation(self.fc1(input_feats))
             cam = self.fc_cam(x) + self.init_cam                                         # :237-238
             glob = self.fc_glob(x) + self.init_glob                                      # :243-244

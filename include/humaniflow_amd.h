@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMF_ABI_VERSION 3
+#define HMF_ABI_VERSION 4
 
 #define HMF_OK 0
 #define HMF_ERR_INVALID (-1)     /* bad argument / shape                                  */
@@ -118,7 +118,9 @@ int hmf_smpl_joints_backward(const hmf_smpl_t* h, const float* global_orient, co
  * (coco17_host: their indices among the 90 output joints, HOST array) of the packed joints (B N + B, 90, 3) [rows b N + n = sample n of image b, rows
  * B N + b = the point estimate] against joints2D_target (B,17,2) pixels normalised by img_wh, and the MSE of glob_R (B,9); weights and the
  * reduction ('mean' = 1: the reference's denominators, 'sum' = 0) as LOSS.*.  Writes loss (1) and d loss / d {lp, shape_mode, shape_log_std, joints, cam,
- * glob_R}.  ws: hmf_train_loss_workspace_bytes(B).  Deterministic. */
+ * glob_R}.  ws: hmf_train_loss_workspace_bytes(B).  Deterministic.  The 17 COCO indices must be distinct (HMF_ERR_INVALID otherwise: the joint gradients
+ * are written, not accumulated).  Deliberate difference: an image with NO visible joint contributes 0 to the 2D term (denominator max(1, #visible)),
+ * where the reference's MSELoss over an empty selection is NaN (losses/humaniflow_loss.py:48-60) and the step is then rolled back. */
 long long hmf_train_loss_workspace_bytes(int B);
 int hmf_train_loss(const float* lp, int P, const float* shape_mode, const float* shape_log_std, const float* shape_target, int nb, const float* joints,
                    const float* cam, const int* coco17_host, const float* joints2D_target, const unsigned char* joints2D_vis, const float* glob_R,
@@ -194,10 +196,14 @@ size_t hmf_flow_forward_workspace_bytes(const hmf_flow_t* h, int B, int N, int f
  *                   advances its generator by hmf_flow_rng_increment(...) afterwards;
  *   state_dev       NULL, or a DEVICE pointer to {uint64 seed, uint64 offset}: then seed / offset above are ignored, the pass takes them from
  *                   there and advances the offset itself with one atomic add (a pass captured into a HIP graph: every replay draws fresh noise);
+ *   mirror_dev      NULL, or a DEVICE pointer to {uint64 seed, uint64 offset} (normally the same 16 bytes a later captured pass names as
+ *                   state_dev): a pass that runs on the immediates above (state_dev == NULL) stores {seed, offset + increment} there, i.e. the
+ *                   generator's state after itself, so that captured passes continue the stream where the eager passes stopped (ABI 4);
  *   grid_cap_blocks #CU * (max threads per CU / 256): the grid cap of ATen's launch on this device (2048 on MI355X).                       */
 typedef struct {
     uint64_t seed, offset;
     void* state_dev;
+    void* mirror_dev;
     int grid_cap_blocks;
 } hmf_rng_t;
 /* generator offset one sampling pass consumes (draw_shape = 0 with use_shape_mode_for_samples or injected shape noise) */

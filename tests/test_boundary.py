@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), 'symbol %s declared in include/humaniflow_amd.h is not exported' % name
     assert sorted(declared) == sorted(_lib.EXPORTED_SYMBOLS)
-    assert lib.hmf_abi_version() == 3
+    assert lib.hmf_abi_version() == 4
 
 
 def test_product_library_has_no_timing_variants(lib):

@@ -197,6 +197,40 @@ def test_captured_step_draws_fresh_noise_on_every_replay():
     assert torch.equal(replayed, eager)
 
 
+def test_pass_captured_after_eager_warmups_continues_the_stream_instead_of_repeating_it():
+    """Advisor finding (round 4): the device-resident generator state captured passes draw from was written by the FIRST eager pass only, so
+    a capture after k warm-up passes replayed the noise of warm-up passes 2..k.  Every eager pass now leaves the generator's state after
+    itself on the device: 3 eager passes, capture, 2 replays = passes 4 and 5 of the reference's stream; and after
+    sync_generator_with_captured_noise() torch's own generator continues with pass 6."""
+    model, sd, cfg = _model(18)
+    B, N, nb = 3, 7, 10
+    torch.manual_seed(21)
+    want = [_reference_draws(B, N, nb) for _ in range(6)]                  # the reference's 1 + 23 normal_() calls, six passes in a row
+    torch.manual_seed(21)
+    for k in range(3):
+        es, ep = model.draw_noise('cuda:0', B, N)
+        assert torch.equal(es, want[k][0]) and torch.equal(ep, want[k][1])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+        es, ep = model.draw_noise('cuda:0', B, N)
+    for k in (3, 4):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(es, want[k][0]) and torch.equal(ep, want[k][1]), 'replay %d repeats or skips part of the stream' % (k - 2)
+    model.sync_generator_with_captured_noise('cuda:0')
+    es6, ep6 = _reference_draws(B, N, nb)                                  # torch.randn itself, continuing after the replays
+    assert torch.equal(es6, want[5][0]) and torch.equal(ep6, want[5][1])
+    # ... and an eager pass after further replays + sync continues too
+    g.replay()
+    torch.cuda.synchronize()
+    seen = ep.clone()
+    model.sync_generator_with_captured_noise('cuda:0')
+    _, ep8 = model.draw_noise('cuda:0', B, N)
+    assert not torch.equal(ep8, seen)
+
+
 def test_packed_smpl_launch_equals_the_two_reference_calls():
     model, sd, cfg = _model(18)
     smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
