@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOPs per image.sample of the SMPL stage: shape blend 0.413 + pose blend 8.557 +
 # 4-nnz skinning blend 0.66 + transform apply 0.145 MFLOP
 LBS_FLOP_PER_UNIT = 9.775e6
+FLOW_FLOP_PER_UNIT = 1.72e6              # 23 parts x (context layer 0.84 + two hyper-networks 0.87 MFLOP) per sampled row
 HBM_PEAK_GBS = 8000.0                  # guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3          # guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2516.6         # v_mfma_f32_32x32x16_bf16: 16x the k per instruction at half the issue time (the guide's ~2.5 PFLOP/s dense)
@@ -107,6 +108,7 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='BASELINE configs[3] flavour: + T-pose bodies, target bodies, device tracker update')
     ap.add_argument('--train', action='store_true', help='BASELINE configs[4] flavour: one training step (forward under grad, losses, backward, all-reduce, Adam)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[2]/[3]/[4] lines a default single-GPU run appends as `secondary`')
     ap.add_argument('--cpu-images', type=int, default=32, help='images of the bounded CPU-baseline sample')
     ap.add_argument('--blend-dtype', choices=['fp32', 'bf16'], default='fp32',
                     help="'bf16': BASELINE configs[2] (use with --batch 64): SMPL blend-shape GEMM operands in bf16, fp32 accumulate -- a parity-test "
@@ -164,13 +166,13 @@ def cpu_baseline(model_sd, cfg, smpl_model_dict, images, N, seed=0):
     x = xs_full
     run()                                           # warm-up
     ts = []
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         run()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
     return {'value': images * N / t, 'unit': 'images*samples/s', 'cores': best_nt, 'host_threads_available': avail, 'kind': 'port',
-            'sample': '%d images x %d samples (ResNet-50 + 23-part flow loop + smplx-style LBS), best of {8,16,32,64} host threads, median of 2 after 1 warm-up, %.2f s/iter'
+            'sample': '%d images x %d samples (ResNet-50 + 23-part flow loop + smplx-style LBS), best of {8,16,32,64} host threads, median of 3 timed iterations after 1 warm-up, %.2f s/iter'
                       % (images, N, t)}
 
 
@@ -303,21 +305,9 @@ def load_pmc_traffic(source_hash, workload):
     return best
 
 
-def main():
-    args = parse()
-    if args.dry_run_cpu:
-        return dry_run_cpu(args)
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device (the hot path has no CPU fallback)'
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    dist, world, rank = dist_setup(dev, 'nccl')
-    if args.gpus != world and rank == 0:
-        print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
-    if args.train:
-        from humaniflow_amd.train import bench_train
-        return bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist_gather_metrics)
-
+def run_inference(args, dev, dist, world, rank):
+    """One inference flavour (configs[1] by default; --eval = configs[3]; --batch 64 --blend-dtype bf16 = configs[2]): timed region, clock probe,
+    per-kernel measurement pass.  Returns (JSON dict on rank 0 else None, what cpu_baseline() needs)."""
     import humaniflow_amd as H
     from humaniflow_amd import _lib, evaluate as ev
     from humaniflow_amd.build import source_hash
@@ -570,14 +560,100 @@ def main():
                                    'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None}
         res['roofline_lbs'].update({'avg_launch_us': round(lbs_ms * 1e3, 2) if lbs_ms == lbs_ms else None, 'traffic': traffic_of('k_lbs_mfma', largest_grid=True),
                                     'algorithmic_flop_per_launch': LBS_FLOP_PER_UNIT * lbs_rows, 'algorithmic_bytes_per_launch': lbs_bytes})
+        # K3: the 23-part kinematic loop against the fp32 FMA peak -- expected low: the bound is the depth-8 dependency chain, so the
+        # time per dependency wave (round of <= 4 independent parts) is reported beside it
+        fl_us = {k.split('[')[0]: v['us'] for k, v in kern.items() if k.startswith(('k_flow_ctx0', 'k_flow_chain', 'k_isgc')) and '[M=' in k}
+        if 'k_flow_chain' in fl_us:
+            t_flow = sum(fl_us.values()) * 1e-6
+            ach = FLOW_FLOP_PER_UNIT * lbs_rows / t_flow / 1e12
+            res['roofline_flow'] = {'kernel': 'k_isgc + k_flow_ctx0 + k_flow_chain (23 ancestor-conditioned SO(3) flows in kinematic order, %d rows incl. the point estimate)' % lbs_rows,
+                                    'bound': 'fp32 FMA peak nominally; in fact the latency of 8 dependent rounds x ~10 dependent small GEMMs + 2 splines per part',
+                                    'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                                    'algorithmic_flop_per_launch_group': FLOW_FLOP_PER_UNIT * lbs_rows, 'us_per_step': round(t_flow * 1e6, 1), 'kernels_us': fl_us,
+                                    'us_per_dependency_wave': round(fl_us['k_flow_chain'] / 8.0, 2),
+                                    'how': 'SURVEY 8d K3: 1.72 MFLOP per sampled row (0.84 context + 0.87 hyper-networks) x rows / kernel execution time of the three flow kernels '
+                                           '(measurement pass, one stream); peak = the fp32 vector/matrix rate of the guide; us_per_dependency_wave = k_flow_chain / 8 rounds'}
         if res['roofline'] is None:
             res['roofline'] = res['roofline_lbs']
-        if world == 1 and not args.no_cpu_baseline:
-            log('measurement pass done; timing the CPU baseline (oracle, %d images x %d samples)' % (args.cpu_images, N))
-            res['cpu_baseline'] = cpu_baseline(model_sd, cfg, smpl.model_dict(), args.cpu_images, N)
-            res['speedup_vs_cpu_baseline'] = round(value / res['cpu_baseline']['value'], 1)
-        else:
-            res['cpu_baseline'] = None
+        res['cpu_baseline'] = None
+        return res, {'model_sd': model_sd, 'cfg': cfg, 'smpl_model': {k: v.detach().cpu() for k, v in smpl.model_dict().items()}}
+    return None, None
+
+
+SECONDARY = [   # the other BASELINE configurations, timed in-process after the headline so that the driver's one default run carries them
+    ('configs2', 'B=64, N=100, bf16 hi+lo blend-shape GEMM operands', {'batch': 64, 'blend_dtype': 'bf16'}),
+    ('configs3', 'per-GPU eval step B=32, N=100 (+ T-pose bodies, target bodies, device metric tracker)', {'eval': True}),
+    ('configs4', 'per-GPU train step B=72, N=8, ResNet-18 (forward, HumaniflowLoss, backward, Adam)', {'train': True, 'batch': 72, 'samples': 8, 'layers': 18}),
+]
+
+
+def run_secondary(args, dev, steps=20, warmup=6):
+    """configs[2] / [3] / [4] on this GPU, `steps` timed steps each with the same barrier + synchronise bracketing as the headline (world = 1).
+    Compact lines: value, ms_per_step, workload, dtype and the roofline fraction of the flavour's dominant kernel family."""
+    import copy
+    import gc
+    out = {}
+    for key, what, over in SECONDARY:
+        a = copy.copy(args)
+        a.eval = a.train = False
+        a.blend_dtype, a.batch, a.samples, a.layers, a.gemm_terms = 'fp32', 32, 100, 50, 0
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.steps, a.warmup, a.profile_steps, a.no_cpu_baseline = steps, warmup, 2, True
+        t0 = time.perf_counter()
+        try:
+            if a.train:
+                from humaniflow_amd.train import bench_train
+                r = bench_train(a, dev, None, 1, 0, log, dist_sync, dist_elapsed, dist_gather_metrics)
+            else:
+                r, _ = run_inference(a, dev, None, 1, 0)
+            roof = r.get('roofline') or {}
+            line = {'workload': r['config']['workload'], 'metric': r['metric'], 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'],
+                    'steps': steps, 'warmup': warmup, 'dtype': r['dtype'],
+                    'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac')}}
+            if r.get('roofline_lbs'):
+                line['roofline_lbs'] = {k: r['roofline_lbs'].get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us')}
+            if r.get('roofline_flow'):
+                line['roofline_flow'] = {k: r['roofline_flow'].get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac')}
+            if a.train:
+                line['train_images_per_s'] = r.get('train_images_per_s')
+        except Exception as e:                                          # a secondary flavour must not cost the headline line
+            line = {'workload': what, 'error': repr(e)}
+        line['wall_s'] = round(time.perf_counter() - t0, 1)
+        out[key] = line
+        log('secondary %s: %s' % (key, {k: line.get(k) for k in ('value', 'ms_per_step', 'wall_s', 'error') if k in line}))
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse()
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (the hot path has no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist, world, rank = dist_setup(dev, 'nccl')
+    if args.gpus != world and rank == 0:
+        print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    if args.train:
+        from humaniflow_amd.train import bench_train
+        res = bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist_gather_metrics)
+    else:
+        res, ctx = run_inference(args, dev, dist, world, rank)
+        headline = not (args.eval or args.gemm_terms or args.blend_dtype != 'fp32' or args.batch != 32 or args.samples != 100 or args.layers != 50)
+        if rank == 0 and world == 1 and headline and not args.no_secondary:
+            res['secondary'] = run_secondary(args, dev)
+            res['secondary_note'] = ('BASELINE configs[2] / [3] / [4] timed in this process after the headline region: %d steps each after %d warm-up steps; '
+                                     'their full lines (tools/profile_round.sh) are under profiles/' % (20, 6))
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            log('timing the CPU baseline (oracle, %d images x %d samples)' % (args.cpu_images, args.samples))
+            res['cpu_baseline'] = cpu_baseline(ctx['model_sd'], ctx['cfg'], ctx['smpl_model'], args.cpu_images, args.samples)
+            res['speedup_vs_cpu_baseline'] = round(res['value'] / res['cpu_baseline']['value'], 1)
+    if rank == 0:
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -424,9 +424,10 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
     except Exception as e:                                              # the measurement pass must not cost the bench line
         log('train roofline pass failed: %r' % (e,))
     optimiser.zero_grad(set_to_none=True)
+    res = None
     if rank == 0:
         value = world * B * N * args.steps / elapsed
-        print(json.dumps({
+        res = ({
             'metric': 'images*samples/sec, training step (B=%d, N=%d)' % (B, N), 'value': round(value, 1), 'unit': 'images*samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -440,6 +441,5 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
             'hand_written': 'encoder training graph (conv kernels incl. Winograd with device-side filter transform + hmf_bn_* + hmf_conv_wgrad + dgrad through the forward kernels), flow forward/backward '
                             '(hmf_flow_forward, hmf_flow_log_prob_SO3[_backward], hmf_flow_sample_backward), SMPL forward + joints backward, proxy front end; '
                             'library GEMMs (torch) for the heads and the dense weight-gradient reductions of the flow',
-            'roofline': roof, 'cpu_baseline': None}))
-    if dist is not None:
-        dist.destroy_process_group()
+            'roofline': roof, 'cpu_baseline': None})
+    return res

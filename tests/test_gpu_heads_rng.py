@@ -204,12 +204,13 @@ def test_pass_captured_after_eager_warmups_continues_the_stream_instead_of_repea
     sync_generator_with_captured_noise() torch's own generator continues with pass 6."""
     model, sd, cfg = _model(18)
     B, N, nb = 3, 7, 10
+    same = lambda got, ref: (got - ref).abs().max().item() < 1e-6           # bit-equal when the device math library matches torch's, else to the last ulp
     torch.manual_seed(21)
     want = [_reference_draws(B, N, nb) for _ in range(6)]                  # the reference's 1 + 23 normal_() calls, six passes in a row
     torch.manual_seed(21)
     for k in range(3):
         es, ep = model.draw_noise('cuda:0', B, N)
-        assert torch.equal(es, want[k][0]) and torch.equal(ep, want[k][1])
+        assert same(es, want[k][0]) and same(ep, want[k][1])
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     g = torch.cuda.CUDAGraph()
@@ -218,17 +219,17 @@ def test_pass_captured_after_eager_warmups_continues_the_stream_instead_of_repea
     for k in (3, 4):
         g.replay()
         torch.cuda.synchronize()
-        assert torch.equal(es, want[k][0]) and torch.equal(ep, want[k][1]), 'replay %d repeats or skips part of the stream' % (k - 2)
+        assert same(es, want[k][0]) and same(ep, want[k][1]), 'replay %d repeats or skips part of the stream' % (k - 2)
     model.sync_generator_with_captured_noise('cuda:0')
     es6, ep6 = _reference_draws(B, N, nb)                                  # torch.randn itself, continuing after the replays
-    assert torch.equal(es6, want[5][0]) and torch.equal(ep6, want[5][1])
+    assert torch.equal(es6, want[5][0]) and torch.equal(ep6, want[5][1])   # torch.randn vs torch.randn: exact
     # ... and an eager pass after further replays + sync continues too
     g.replay()
     torch.cuda.synchronize()
     seen = ep.clone()
     model.sync_generator_with_captured_noise('cuda:0')
     _, ep8 = model.draw_noise('cuda:0', B, N)
-    assert not torch.equal(ep8, seen)
+    assert not same(ep8, seen)
 
 
 def test_packed_smpl_launch_equals_the_two_reference_calls():
