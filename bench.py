@@ -334,7 +334,9 @@ def run_inference(args, dev, dist, world, rank):
     if args.eval:
         dset = ev.SyntheticEvalSet(world * NB * B, size=256, seed=7)
         batches = [dset.batch(ev.shard_indices(len(dset), rank, world)[i * B:(i + 1) * B], dev) for i in range(NB)]
-        trackers = [ev.EvalMetricsTracker(dev) for _ in range(NB)]
+        trackers = [ev.EvalMetricsTracker(dev, smpl=smpl) for _ in range(NB)]
+        side_streams = [torch.cuda.Stream(device=dev) for _ in range(NB)]
+        eval_side = os.environ.get('HMF_EVAL_SIDE', '0') == '1'        # experiments only
     else:
         batches = [{'input': synthetic_proxy_input(B, 256, seed=100 + rank * NB + i).to(dev)} for i in range(NB)]
     torch.manual_seed(1234 + rank)
@@ -343,8 +345,17 @@ def run_inference(args, dev, dist, world, rank):
         """One step on batch i; returns a small tuple of device tensors (kept alive as the graph's outputs)."""
         with torch.no_grad():
             if args.eval:
-                pred = ev.predict_batch(model, smpl, batches[i], N)
-                targ = ev.target_batch(smpl, batches[i])
+                # the target bodies depend on the labels only, so a side stream (a parallel branch of the captured graph) could build them under the
+                # encoder -- measured round 5, same box, 60 steps x 3: 3.397 ms with the side branch vs 3.233 ms without (more co-resident kernels evict
+                # each other's LDS allocations, as with the split encoder / tail graphs of round 4): off; HMF_EVAL_SIDE=1 turns it on
+                cur = torch.cuda.current_stream()
+                side_streams[i].wait_stream(cur)
+                with torch.cuda.stream(side_streams[i] if eval_side else cur):
+                    targ = ev.target_batch(smpl, batches[i], materialise_tpose=False)
+                pred = ev.predict_batch(model, smpl, batches[i], N, materialise_tpose=False)       # T-pose metrics from the shape vectors (hmf_smpl_tpose_errors)
+                cur.wait_stream(side_streams[i])
+                for t_ in targ.values():
+                    t_.record_stream(cur)
                 trackers[i].update_per_batch(pred, targ)
                 return pred['verts3D_samples'], pred['joints3D_samples'], pred['verts3D'], trackers[i].sums
             pred = model(batches[i]['input'], num_samples=N)

@@ -46,6 +46,14 @@ class Rng(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('offset', C.c_uint64), ('state_dev', C.c_void_p), ('mirror_dev', C.c_void_p), ('grid_cap_blocks', C.c_int)]
 
 
+class EvalBatch(C.Structure):
+    """hmf_eval_batch_t: one batch of the metric tracker after the point-set kernels (include/humaniflow_amd.h)."""
+    _fields_ = ([(k, C.c_int) for k in ('B', 'N', 'num_verts', 'num_joints', 'chunks_v', 'chunks_j')]
+                + [(k, C.c_void_p) for k in ('e_verts', 'e_tpose', 'e_joints', 'es_verts', 'es_tpose', 'es_joints', 'div_verts', 'div_joints',
+                                             'j2d_pred', 'j2d_samples', 'j2d_target', 'j2d_vis', 'scratch')]
+                + [('slot', C.c_int * 23)])
+
+
 _VP = C.c_void_p
 HMF_FLOW_POINT_EST, HMF_FLOW_PACKED_ROWS, HMF_FLOW_SHAPE_MODE, HMF_FLOW_CHAIN32, HMF_FLOW_CHAIN16 = 1, 2, 4, 8, 16          # flags of hmf_flow_forward (include/humaniflow_amd.h)
 _SIGS = {
@@ -119,6 +127,13 @@ _SIGS = {
     'hmf_conv_patch_ws': (C.c_int, [_VP] * 5 + [C.c_int] * 9 + [_VP, C.c_longlong, _VP]),
     'hmf_pointset_errors': (C.c_int, [_VP, _VP] + [C.c_int] * 4 + [_VP, _VP]),
     'hmf_sample_diversity': (C.c_int, [_VP] + [C.c_int] * 3 + [_VP, _VP]),
+    'hmf_sample_diversity_chunks': (C.c_int, [C.c_int]),
+    'hmf_eval_joints': (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float, _VP, _VP, _VP, _VP]),
+    'hmf_eval_tracker_scratch_bytes': (C.c_longlong, [C.c_int]),
+    'hmf_eval_tracker_update': (C.c_int, [C.POINTER(EvalBatch), _VP, _VP, _VP]),
+    'hmf_smpl_tpose_errors_workspace_bytes': (C.c_longlong, [C.c_int]),
+    'hmf_smpl_tpose_errors': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, C.c_longlong, _VP]),
+    'hmf_smpl_tpose_errors_packed': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, C.c_longlong, _VP]),
     'hmf_conv_pair_pack_host': (C.c_int, [_VP] * 4 + [C.c_int] * 3),
     'hmf_conv_pair': (C.c_int, [_VP] * 9 + [C.c_int] * 11 + [_VP]),
     'hmf_conv_winograd_packed_floats': (C.c_longlong, [C.c_int] * 2),

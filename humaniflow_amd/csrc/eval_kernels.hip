@@ -219,12 +219,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const float* t = T + (size_t)(pair / group) * npts * 3;
     // the prediction stays in registers; the target (shared by the `group` samples of an image: L2-resident) is read again in pass 2
     float pv[NPT][3];
+    struct P3 { float x, y, z; };                     // one 12-byte load per point (three dword loads per point made the kernel VMEM-issue bound)
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int i = threadIdx.x + 256 * k;
-        const bool ok = i < npts;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pv[k][c] = ok ? p[3 * i + c] : 0.f;
+        P3 v = {0.f, 0.f, 0.f};
+        if (i < npts) v = ((const P3*)p)[i];
+        pv[k][0] = v.x; pv[k][1] = v.y; pv[k][2] = v.z;
     }
     double s[17];
 #pragma unroll
@@ -290,12 +291,54 @@ __global__ __launch_bounds__(256) void k_pointset_errors_wave(const float* __res
     }
 }
 
-// S: (B, N, npts, 3); partial: (B, chunks) sums over n and the chunk's points of |S - mean_n S|
-__global__ __launch_bounds__(256) void k_sample_diversity(const float* __restrict__ S, int N, int npts, int chunks, float* __restrict__ partial) {
-    __shared__ double red[4];
+// S: (B, N, npts, 3); partial: (B, chunks) sums over n and the chunk's 64 points of |S - mean_n S|.
+// One pass (round 5): a work-group owns 64 points of one image, wave w the samples n = w, w + 4, ... -- every sample of the chunk sits in
+// registers (NPT x 3 per thread, all loads in flight at once), the four partial means meet in LDS, the distances come from the registers.
+// The round-1 kernel walked the N samples twice per thread with dependent scalar loads: 550 MB read for a 267 MB tensor, and 54 us of pure
+// latency for the 17-joint sets.
+template <int NPT>
+__global__ __launch_bounds__(256) void k_sample_diversity_reg(const float* __restrict__ S, int N, int npts, int chunks, float* __restrict__ partial) {
+    __shared__ float sm[4][3][64];
+    __shared__ float red[4];
     const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
-    const int i = ch * 256 + threadIdx.x;
-    double acc = 0.0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = ch * 64 + lane;
+    const bool ok = i < npts;
+    const float* s = S + ((size_t)b * N * npts + (ok ? i : 0)) * 3;
+    float q[NPT][3];
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int n = w + 4 * k;
+        const bool live = ok && n < N;
+        const float* r = s + (size_t)(live ? n : 0) * npts * 3;
+        q[k][0] = live ? r[0] : 0.f; q[k][1] = live ? r[1] : 0.f; q[k][2] = live ? r[2] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) { m0 += q[k][0]; m1 += q[k][1]; m2 += q[k][2]; }
+    sm[w][0][lane] = m0; sm[w][1][lane] = m1; sm[w][2][lane] = m2;
+    __syncthreads();
+    m0 = (sm[0][0][lane] + sm[1][0][lane] + sm[2][0][lane] + sm[3][0][lane]) / N;
+    m1 = (sm[0][1][lane] + sm[1][1][lane] + sm[2][1][lane] + sm[3][1][lane]) / N;
+    m2 = (sm[0][2][lane] + sm[1][2][lane] + sm[2][2][lane] + sm[3][2][lane]) / N;
+    float l2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const float dx = q[k][0] - m0, dy = q[k][1] - m1, dz = q[k][2] - m2;
+        l2 += (ok && w + 4 * k < N) ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l2 += __shfl_down(l2, o, 64);
+    if (lane == 0) red[w] = l2;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// any N: one wave per 64 points, two passes over the samples (the second one from L2)
+__global__ __launch_bounds__(64) void k_sample_diversity(const float* __restrict__ S, int N, int npts, int chunks, float* __restrict__ partial) {
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int i = ch * 64 + threadIdx.x;
+    float l2 = 0.f;
     if (i < npts) {
         const float* s = S + ((size_t)b * N * npts + i) * 3;
         float m0 = 0.f, m1 = 0.f, m2 = 0.f;
@@ -304,16 +347,174 @@ __global__ __launch_bounds__(256) void k_sample_diversity(const float* __restric
             m0 += q[0]; m1 += q[1]; m2 += q[2];
         }
         m0 /= N; m1 /= N; m2 /= N;
-        float l2 = 0.f;
         for (int n = 0; n < N; ++n) {
             const float* q = s + (size_t)n * npts * 3;
             const float dx = q[0] - m0, dy = q[1] - m1, dz = q[2] - m2;
             l2 += sqrtf(dx * dx + dy * dy + dz * dz);
         }
-        acc = l2;
     }
-    acc = block_sum(acc, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = (float)acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l2 += __shfl_down(l2, o, 64);
+    if (threadIdx.x == 0) partial[blockIdx.x] = l2;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_eval_joints: the joint-side glue of the evaluation step (evaluate/evaluate_humaniflow.py:138-143,176-183,197-206) in one launch --
+// from the packed (M, 90, 3) joints of the SMPL launch: the 14 H36M evaluation joints, the 17 COCO joints and their 2-D projection
+// undo_keypoint_normalisation(orthographic_project(flip about x, cam)).  Row r belongs to image r / N (sample rows) or r - B N (point estimates).
+// ---------------------------------------------------------------------------------------------------
+struct EvalJointsArgs {
+    const float* joints; const float* cam;
+    float *j14, *coco, *j2d;
+    int B, N, M;
+    float half_wh;
+    int idx14[14], idx17[17];
+};
+__global__ __launch_bounds__(256) void k_eval_joints(const EvalJointsArgs a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.M * 31) return;
+    const int row = g / 31, j = g - row * 31;
+    const float* src = a.joints + ((size_t)row * 90 + (j < 14 ? a.idx14[j] : a.idx17[j - 14])) * 3;
+    const float x = src[0], y = src[1], z = src[2];
+    if (j < 14) {
+        float* o = a.j14 + ((size_t)row * 14 + j) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    } else {
+        const int jj = j - 14, img = row < a.B * a.N ? row / a.N : row - a.B * a.N;
+        float* o = a.coco + ((size_t)row * 17 + jj) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+        const float s = a.cam[img * 3], tx = a.cam[img * 3 + 1], ty = a.cam[img * 3 + 2];
+        float* p = a.j2d + ((size_t)row * 17 + jj) * 2;
+        p[0] = (s * (x + tx) + 1.f) * a.half_wh;                       // flip about x: (x, -y, -z)
+        p[1] = (s * (-y + ty) + 1.f) * a.half_wh;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hmf_eval_tracker_update: everything metrics/eval_metrics_tracker.py:95-433 does with one batch AFTER the point-set kernels, in two launches:
+// k_eval_tracker_frames (one work-group per image: sample minima, diversity sums, 2-D joint errors -> the per-frame arrays) and
+// k_eval_tracker_sums (one thread per metric adds the B per-frame values to the fp64 running sums in image order: deterministic).
+// (As one work-group for the whole batch the first version took 135 us: one lane walking 108 diversity chunks per image.)
+// Metric order = humaniflow_amd/evaluate.py METRICS (20) followed by the three counts.
+// ---------------------------------------------------------------------------------------------------
+}  // namespace hmf
+#include "../../include/humaniflow_amd.h"
+namespace hmf {
+enum { M_PVE, M_PVE_SC, M_PVE_PA, M_PVET, M_PVET_SC, M_MPJPE, M_MPJPE_SC, M_MPJPE_PA, M_PVE_MIN, M_PVE_SC_MIN, M_PVE_PA_MIN, M_PVET_MIN, M_PVET_SC_MIN,
+       M_MPJPE_MIN, M_MPJPE_SC_MIN, M_MPJPE_PA_MIN, M_J2D, M_J2DS, M_DIV_V, M_DIV_J, C_TOTAL, C_VIS, C_VIS_S, kEvalSlots };
+static_assert(kEvalSlots == HMF_EVAL_NUM_SLOTS, "slot count of hmf_eval_batch_t");
+
+__device__ inline float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one work-group per image: wave 0 = point-estimate copies + vertex minima, wave 1 = T-pose and joint minima, wave 2 = diversity, wave 3 = 2-D joints
+__global__ __launch_bounds__(256) void k_eval_tracker_frames(const hmf_eval_batch_t a, float* __restrict__ frames) {
+    const int B = a.B, N = a.N, b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto F = [&](int m) -> float& { return frames[(size_t)m * B + b]; };
+    auto minima = [&](const float* es, int mbase, int ncol) {      // per metric: the sample with the smallest mean error (:230-280)
+        if (!es || N <= 0) return;
+        float v[3] = {INFINITY, INFINITY, INFINITY};
+        for (int n = lane; n < N; n += 64)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = fminf(v[c], es[((size_t)b * N + n) * 3 + c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = wave_min(v[c]);
+        if (lane == 0)
+            for (int c = 0; c < ncol; ++c) F(mbase + c) = v[c];
+    };
+    if (wave == 0) {
+        if (lane == 0) {
+            if (a.e_verts) { F(M_PVE) = a.e_verts[3 * b]; F(M_PVE_SC) = a.e_verts[3 * b + 1]; F(M_PVE_PA) = a.e_verts[3 * b + 2]; }
+            if (a.e_tpose) { F(M_PVET) = a.e_tpose[3 * b]; F(M_PVET_SC) = a.e_tpose[3 * b + 1]; }
+            if (a.e_joints) { F(M_MPJPE) = a.e_joints[3 * b]; F(M_MPJPE_SC) = a.e_joints[3 * b + 1]; F(M_MPJPE_PA) = a.e_joints[3 * b + 2]; }
+        }
+        minima(a.es_verts, M_PVE_MIN, 3);
+    } else if (wave == 1) {
+        minima(a.es_tpose, M_PVET_MIN, 2);
+        minima(a.es_joints, M_MPJPE_MIN, 3);
+    } else if (wave == 2) {
+        // diversity: the chunk partial sums of the image, in fp64
+        const float* dv[2] = {a.div_verts, a.div_joints};
+        const int dch[2] = {a.chunks_v, a.chunks_j}, dm[2] = {M_DIV_V, M_DIV_J}, dn[2] = {a.num_verts, 17};
+        for (int t = 0; t < 2; ++t)
+            if (dv[t]) {
+                double d = 0.0;
+                for (int c = lane; c < dch[t]; c += 64) d += (double)dv[t][(size_t)b * dch[t] + c];
+                d = wave_sum(d);
+                if (lane == 0) {
+                    F(dm[t]) = (float)(d / ((double)N * dn[t]));
+                    a.scratch[(size_t)t * B + b] = d;                     // the fp64 sum itself goes into the running sum
+                }
+            }
+    } else if (a.j2d_target) {
+        // 2-D joints (eval_metrics_tracker.py:284-359): |pred - target| over the visible joints; lane = joint (+ 17 x sample slot)
+        const int j = lane % 17, slot = lane / 17;                     // 3 sample slots of 17 lanes, lanes 51..63 idle
+        const bool vis_l = a.j2d_vis ? a.j2d_vis[b * 17 + j] != 0 : true;
+        const float visn = (float)__popcll(__ballot(vis_l && lane < 17));
+        const float tx = a.j2d_target[(b * 17 + j) * 2], ty = a.j2d_target[(b * 17 + j) * 2 + 1];
+        if (a.j2d_pred) {
+            float e = 0.f;
+            if (vis_l && lane < 17) {
+                const float dx = a.j2d_pred[(b * 17 + j) * 2] - tx, dy = a.j2d_pred[(b * 17 + j) * 2 + 1] - ty;
+                e = sqrtf(dx * dx + dy * dy);
+            }
+            const double sumd = wave_sum((double)e);
+            if (lane == 0) { F(M_J2D) = (float)sumd / visn; a.scratch[(size_t)2 * B + b] = sumd; }
+        }
+        if (a.j2d_samples && N > 0) {
+            double acc = 0.0;
+            if (vis_l && slot < 3)
+                for (int n = slot; n < N; n += 3) {
+                    const float* p = a.j2d_samples + (((size_t)b * N + n) * 17 + j) * 2;
+                    const float dx = p[0] - tx, dy = p[1] - ty;
+                    acc += (double)sqrtf(dx * dx + dy * dy);
+                }
+            acc = wave_sum(acc);
+            if (lane == 0) { F(M_J2DS) = (float)acc / (visn * N); a.scratch[(size_t)3 * B + b] = acc; }
+        }
+        if (lane == 0) a.scratch[(size_t)4 * B + b] = visn;
+    }
+}
+
+// running sums: one wave per slot (lanes stride the images, fixed butterfly order: deterministic)
+__global__ __launch_bounds__(1024) void k_eval_tracker_sums(const hmf_eval_batch_t a, double* __restrict__ sums, const float* __restrict__ frames) {
+    const int B = a.B, N = a.N, lane = threadIdx.x & 63;
+    for (int m = threadIdx.x >> 6; m < kEvalSlots; m += 16) {
+        if (a.slot[m] < 0) continue;
+        double s = 0.0;
+        bool have = true;
+        if (m == C_TOTAL) s = lane == 0 ? (double)B : 0.0;
+        else if (m == C_VIS || m == C_VIS_S) {
+            have = a.j2d_target && (m == C_VIS ? a.j2d_pred != nullptr : (a.j2d_samples != nullptr && N > 0));
+            if (have) for (int b = lane; b < B; b += 64) s += a.scratch[(size_t)4 * B + b] * (m == C_VIS ? 1.0 : (double)N);
+        } else if (m == M_DIV_V || m == M_DIV_J) {
+            have = (m == M_DIV_V ? a.div_verts : a.div_joints) != nullptr;
+            if (have) for (int b = lane; b < B; b += 64) s += a.scratch[(size_t)(m == M_DIV_V ? 0 : 1) * B + b];
+        } else if (m == M_J2D || m == M_J2DS) {
+            have = a.j2d_target && (m == M_J2D ? a.j2d_pred != nullptr : (a.j2d_samples != nullptr && N > 0));
+            if (have) for (int b = lane; b < B; b += 64) s += a.scratch[(size_t)(m == M_J2D ? 2 : 3) * B + b];
+        } else {
+            const bool vert = m <= M_PVET_SC || (m >= M_PVE_MIN && m <= M_PVET_SC_MIN);
+            const bool smp = m >= M_PVE_MIN;
+            const bool tp = m == M_PVET || m == M_PVET_SC || m == M_PVET_MIN || m == M_PVET_SC_MIN;
+            const float* src = smp ? (tp ? a.es_tpose : (vert ? a.es_verts : a.es_joints)) : (tp ? a.e_tpose : (vert ? a.e_verts : a.e_joints));
+            have = src != nullptr && (!smp || N > 0);
+            const double npts = vert ? a.num_verts : a.num_joints;
+            if (have) for (int b = lane; b < B; b += 64) s += (double)frames[(size_t)m * B + b];
+            s *= npts;
+        }
+        s = wave_sum(s);
+        if (have && lane == 0) sums[a.slot[m]] += s;
+    }
 }
 
 }  // namespace hmf
@@ -332,11 +533,49 @@ extern "C" int hmf_pointset_errors(const float* P, const float* T, int npairs, i
     return HMF_OK;
 }
 
+extern "C" int hmf_sample_diversity_chunks(int npts) { return (npts + 63) / 64; }
+
 extern "C" int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial, void* stream) {
     if (B == 0) return HMF_OK;
     if (!S || !partial || B < 0 || N < 1 || npts < 1) return fail(HMF_ERR_INVALID, "hmf_sample_diversity: bad args");
-    const int chunks = (npts + 255) / 256;
-    hipLaunchKernelGGL(k_sample_diversity, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, S, N, npts, chunks, partial);
+    const int chunks = (npts + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 32) hipLaunchKernelGGL(k_sample_diversity_reg<8>, dim3(B * chunks), dim3(256), 0, st, S, N, npts, chunks, partial);
+    else if (N <= 64) hipLaunchKernelGGL(k_sample_diversity_reg<16>, dim3(B * chunks), dim3(256), 0, st, S, N, npts, chunks, partial);
+    else if (N <= 100) hipLaunchKernelGGL(k_sample_diversity_reg<25>, dim3(B * chunks), dim3(256), 0, st, S, N, npts, chunks, partial);
+    else if (N <= 128) hipLaunchKernelGGL(k_sample_diversity_reg<32>, dim3(B * chunks), dim3(256), 0, st, S, N, npts, chunks, partial);
+    else hipLaunchKernelGGL(k_sample_diversity, dim3(B * chunks), dim3(64), 0, st, S, N, npts, chunks, partial);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+extern "C" int hmf_eval_joints(const float* joints, const float* cam, int B, int N, const int* idx14_host, const int* idx17_host, float img_wh, float* j14,
+                               float* coco3d, float* joints2d, void* stream) {
+    const long long M = (long long)B * N + B;
+    if (B == 0) return HMF_OK;
+    if (!joints || !cam || !idx14_host || !idx17_host || !j14 || !coco3d || !joints2d || B < 0 || N < 0 || M * 31 >= (1LL << 31))
+        return fail(HMF_ERR_INVALID, "hmf_eval_joints: bad args");
+    EvalJointsArgs a;
+    a.joints = joints; a.cam = cam; a.j14 = j14; a.coco = coco3d; a.j2d = joints2d; a.B = B; a.N = N; a.M = (int)M; a.half_wh = img_wh / 2.0f;
+    for (int i = 0; i < 14; ++i) { if (idx14_host[i] < 0 || idx14_host[i] >= 90) return fail(HMF_ERR_INVALID, "hmf_eval_joints: joint index out of the 90 output joints"); a.idx14[i] = idx14_host[i]; }
+    for (int i = 0; i < 17; ++i) { if (idx17_host[i] < 0 || idx17_host[i] >= 90) return fail(HMF_ERR_INVALID, "hmf_eval_joints: joint index out of the 90 output joints"); a.idx17[i] = idx17_host[i]; }
+    hipLaunchKernelGGL(k_eval_joints, dim3((unsigned)((M * 31 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+extern "C" long long hmf_eval_tracker_scratch_bytes(int B) { return (long long)5 * (B > 0 ? B : 1) * (long long)sizeof(double); }
+
+extern "C" int hmf_eval_tracker_update(const hmf_eval_batch_t* batch, double* sums, float* frames, void* stream) {
+    if (!batch || !sums || !frames) return fail(HMF_ERR_INVALID, "hmf_eval_tracker_update: null argument");
+    if (batch->B == 0) return HMF_OK;
+    if (batch->B < 0 || batch->N < 0 || !batch->scratch || batch->num_verts < 1 || batch->num_joints < 1)
+        return fail(HMF_ERR_INVALID, "hmf_eval_tracker_update: bad sizes or no scratch (hmf_eval_tracker_scratch_bytes)");
+    if ((batch->div_verts && batch->chunks_v < 1) || (batch->div_joints && batch->chunks_j < 1) || ((batch->div_verts || batch->div_joints) && batch->N < 1))
+        return fail(HMF_ERR_INVALID, "hmf_eval_tracker_update: diversity partials need their chunk counts and N >= 1");
+    hipLaunchKernelGGL(k_eval_tracker_frames, dim3(batch->B), dim3(256), 0, (hipStream_t)stream, *batch, frames);
+    HMF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_eval_tracker_sums, dim3(1), dim3(1024), 0, (hipStream_t)stream, *batch, sums, (const float*)frames);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

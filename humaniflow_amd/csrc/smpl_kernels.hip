@@ -54,6 +54,12 @@ struct SmplDev {
     // (M, n_ju, 3) buffer, and k_joints_compact finishes the 66 joints from it
     int* ju_slot;                    // [kVT * 32]: compact slot of vertex v, or -1
     int* jr_slot;                    // CSR column of jr_ptr in compact slots (= slot of jr_idx[e])
+    // T-pose bodies without materialising them (k_tpose_errors): per vertex the rows [template | shape basis] of its three coordinates,
+    // [V][3][tp_stride] (tp_stride = nb + 1 rounded up to 4), and the first / second moments of those rows over the vertices in fp64:
+    // tp_mom = mean[3][nb + 1] | gram[(nb + 1)^2]  (T(beta) = T0 + S beta is affine, so mean T and sum |T|^2 are closed forms of beta)
+    float* tp_pack;
+    double* tp_mom;
+    int tp_stride;
 };
 constexpr int kMaxJU = 320;          // >= 21 picks + 255 regressor non-zeros of the reference's tables
 
@@ -588,6 +594,119 @@ __global__ __launch_bounds__(256) void k_tpose(SmplDev d, const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_tpose_errors: the two T-pose metrics (PVE-T, PVE-T-SC: metrics/eval_metrics_tracker.py:200-222 via utils/eval_utils.py:107-125) of a
+// (prediction betas, target betas) pair WITHOUT the T-pose bodies ever existing in HBM.  T(beta) = T0 + S beta is affine in beta, so
+//   * the moments the scale + translation correction needs (mean, sum |.|^2 of both point sets) are closed forms of beta through the
+//     fp64 mean / Gram matrix of the rows [T0 | S] (hmf_smpl_create) -- no pass over the vertices;
+//   * the errors need one pass: D = S (beta_p - beta_t) (= P - T), e0 = |D|, e1 = |(a - 1) T + a D + (mu_t - a mu_p)|.
+// Lane = pair (the `group` predictions of one image share a target), a work-group walks a chunk of vertices: the chunk's 3 x (nb + 1) rows
+// and its target vertices sit in LDS and are read at wave-uniform addresses (broadcast reads: one row fetch per work-group instead of one per
+// pair), no cross-lane reduction anywhere; chunk partial sums are added in a fixed order by k_tpose_errors_finish.
+// Before: k_tpose wrote 267 MB of T-pose bodies per step and k_pointset_errors_reg read them back (round-4 review).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kTeChunk = 65;           // 6890 = 106 x 65
+constexpr int kTeChunks = (kV + kTeChunk - 1) / kTeChunk;
+// rows: [V][3][TS] (SmplDev::tp_pack) as a direct __restrict__ argument, so that the wave-uniform row reads of the main loop are SCALAR loads
+// (the rows of a vertex arrive in SGPRs and feed the FMAs as scalar operands: no LDS or vector-memory traffic per pair).
+// Pair pl of image b: pl < group -> row b * group + pl; pl == group (packed rows only, n_img_rows = 1) -> the point-estimate row B * group + b.
+template <int NB>
+__global__ __launch_bounds__(128) void k_tpose_errors(const float* __restrict__ rows_all, const double* __restrict__ mom, const float* __restrict__ betas_p,
+                                                      const float* __restrict__ betas_t, int group, int packed_extra, int npairs,
+                                                      float* __restrict__ partial /* [kTeChunks][npairs][2] */) {
+    constexpr int NQ = NB + 1, TS = (NB + 1 + 3) & ~3;
+    __shared__ float Tl[kTeChunk * 3];
+    const int img = blockIdx.x, chunk = blockIdx.y;
+    const int v0 = chunk * kTeChunk, nv = min(kTeChunk, kV - v0);
+    const float* bt = betas_t + (size_t)img * NB;                     // wave-uniform
+    const float* rows = rows_all + (size_t)v0 * 3 * TS;
+    for (int e = threadIdx.x; e < nv * 3; e += blockDim.x) {          // the chunk's target vertices, k_tpose's fma order
+        const float* row = rows + e * TS;
+        float t = row[0];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) t = fmaf(row[1 + k], bt[k], t);
+        Tl[e] = t;
+    }
+    const int pl = blockIdx.z * blockDim.x + threadIdx.x;             // pair within the image
+    const bool live = pl < group + packed_extra;
+    const size_t pair = !live ? 0 : (pl < group ? (size_t)img * group + pl : (size_t)gridDim.x * group + img);
+    const float* bp = betas_p + pair * NB;
+    float db[NB];
+    double qp[NQ], qt[NQ];
+    qp[0] = qt[0] = 1.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float p = bp[k], t = bt[k];
+        db[k] = p - t;
+        qp[1 + k] = p; qt[1 + k] = t;
+    }
+    // moments: mean_c = m[c] . q, sum |.|^2 = q^T G q
+    double mp[3], mt[3], sp = 0.0, st = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { a += mom[c * NQ + i] * qp[i]; b += mom[c * NQ + i] * qt[i]; }
+        mp[c] = a; mt[c] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) { const double g = mom[3 * NQ + i * NQ + j]; a += g * qp[j]; b += g * qt[j]; }
+        sp += a * qp[i]; st += b * qt[i];
+    }
+    const double n = kV;
+    const double varp = sp - n * (mp[0] * mp[0] + mp[1] * mp[1] + mp[2] * mp[2]);
+    const double vart = st - n * (mt[0] * mt[0] + mt[1] * mt[1] + mt[2] * mt[2]);
+    const float sa = (float)(sqrt(vart / n) / sqrt(varp / n));        // solve_alignment's sc_a (csrc/eval_kernels.hip)
+    const float sa1 = sa - 1.f;
+    float kc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) kc[c] = fmaf(-sa, (float)mp[c], (float)mt[c]);          // mu_t - a mu_p
+    __syncthreads();
+    float e0 = 0.f, e1 = 0.f;
+#pragma unroll 2
+    for (int v = 0; v < nv; ++v) {
+        float D[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* row = rows + (v * 3 + c) * TS;              // wave-uniform address: scalar loads
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) a = fmaf(row[1 + k], db[k], a);
+            D[c] = a;
+        }
+        e0 += __builtin_amdgcn_sqrtf(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);      // v_sqrt_f32 (1 ulp): mean distances of ~1e-2 m
+        const float x = fmaf(sa1, Tl[v * 3], fmaf(sa, D[0], kc[0]));
+        const float y = fmaf(sa1, Tl[v * 3 + 1], fmaf(sa, D[1], kc[1]));
+        const float z = fmaf(sa1, Tl[v * 3 + 2], fmaf(sa, D[2], kc[2]));
+        e1 += __builtin_amdgcn_sqrtf(x * x + y * y + z * z);
+    }
+    if (live) {
+        float* o = partial + ((size_t)chunk * npairs + pair) * 2;      // chunk-major: the finish pass reads a chunk's pairs as one run
+        o[0] = e0; o[1] = e1;
+    }
+}
+__global__ __launch_bounds__(64) void k_tpose_errors_finish(const float* __restrict__ partial, int npairs, float* __restrict__ out) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= npairs) return;
+    double a = 0.0, b = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < kTeChunks; ++c) {
+        const float2 v = ((const float2*)partial)[(size_t)c * npairs + p];
+        a += v.x; b += v.y;
+    }
+    out[3 * p] = (float)(a / kV); out[3 * p + 1] = (float)(b / kV); out[3 * p + 2] = 0.f;
+}
+
+template <int NB>
+static void launch_tpose_errors(const SmplDev& d, const float* bp, const float* bt, int nimg, int group, int extra, int npairs, float* partial, hipStream_t st) {
+    const int threads = group + extra > 64 ? 128 : 64;
+    hipLaunchKernelGGL((k_tpose_errors<NB>), dim3(nimg, kTeChunks, (group + extra + threads - 1) / threads), dim3(threads), 0, st, (const float*)d.tp_pack,
+                       (const double*)d.tp_mom, bp, bt, group, extra, npairs, partial);
+}
+
 __global__ void k_rest_joints(SmplDev d, const float* __restrict__ betas, int M, float* __restrict__ joints) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= M * kJ) return;
@@ -1051,6 +1170,19 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     for (int v = 0; v < kV; ++v)
         for (int c = 0; c < 3; ++c)
             for (int k = 0; k < nb; ++k) tpd[(size_t)k * kV * 3 + v * 3 + c] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
+    const int tps = (nb + 1 + 3) & ~3, nq = nb + 1;
+    std::vector<float> tpp((size_t)kV * 3 * tps, 0.f);
+    std::vector<double> tpm((size_t)3 * nq + (size_t)nq * nq, 0.0);
+    for (int v = 0; v < kV; ++v)
+        for (int c = 0; c < 3; ++c) {
+            float* row = &tpp[((size_t)v * 3 + c) * tps];
+            row[0] = m->v_template_host[v * 3 + c];
+            for (int k = 0; k < nb; ++k) row[1 + k] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
+            for (int i = 0; i < nq; ++i) {
+                tpm[(size_t)c * nq + i] += (double)row[i] / kV;
+                for (int j = 0; j < nq; ++j) tpm[(size_t)3 * nq + (size_t)i * nq + j] += (double)row[i] * (double)row[j];
+            }
+        }
     std::vector<float> blend((size_t)kVT * kKG * 3 * 64 * 4);
     pack_blend(m, blend.data());
     std::vector<unsigned short> blend16((size_t)kVT * kKG16 * 3 * 64 * 8), blend16l(blend16.size());
@@ -1066,6 +1198,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2), o_b16l = place(blend16l.size() * 2);
     const size_t o_jv = place(ju_vid.size() * 4 + 4), o_jp = place(ju_ptr.size() * 4), o_jo = place(ju_out.size() * 4 + 4), o_jw = place(ju_w.size() * 4 + 4);
     const size_t o_jsl = place(ju_slot.size() * 4), o_jrs = place(jr_slot.size() * 4 + 4);
+    const size_t o_tpp = place(tpp.size() * 4), o_tpm = place(tpm.size() * 8);
     void* arena = nullptr;
     HMF_HIP(hipMalloc(&arena, off));
     char* base = (char*)arena;
@@ -1088,6 +1221,8 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     if (e == hipSuccess && !ju_w.empty()) e = up(o_jw, ju_w.data(), ju_w.size() * 4);
     if (e == hipSuccess) e = up(o_jsl, ju_slot.data(), ju_slot.size() * 4);
     if (e == hipSuccess && !jr_slot.empty()) e = up(o_jrs, jr_slot.data(), jr_slot.size() * 4);
+    if (e == hipSuccess) e = up(o_tpp, tpp.data(), tpp.size() * 4);
+    if (e == hipSuccess) e = up(o_tpm, tpm.data(), tpm.size() * 8);
     if (e != hipSuccess) {
         (void)hipFree(arena);
         return fail(HMF_ERR_HIP, "hmf_smpl_create: upload failed: %s", hipGetErrorString(e));
@@ -1122,6 +1257,9 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     d.ju_w = (float*)(base + o_jw);
     d.ju_slot = (int*)(base + o_jsl);
     d.jr_slot = (int*)(base + o_jrs);
+    d.tp_pack = (float*)(base + o_tpp);
+    d.tp_mom = (double*)(base + o_tpm);
+    d.tp_stride = tps;
     *out = h;
     return HMF_OK;
 }
@@ -1271,6 +1409,41 @@ int hmf_smpl_joints_backward(const hmf_smpl_t* h, const float* global_orient, co
                        g_global_orient, g_body_pose, g_betas);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
+}
+
+long long hmf_smpl_tpose_errors_workspace_bytes(int npairs) { return (long long)align_up((size_t)std::max(npairs, 1) * kTeChunks * 2 * sizeof(float), 256); }
+
+static int tpose_errors_impl(const hmf_smpl_t* h, const float* betas_pred, const float* betas_target, int nimg, int group, int extra, float* out, void* ws,
+                             long long ws_bytes, void* stream, const char* who) {
+    const long long np = (long long)nimg * (group + extra);
+    if (np == 0) return HMF_OK;
+    if (!h || !betas_pred || !betas_target || !out || nimg < 0 || group < 0 || group + extra < 1 || np >= (1LL << 28)) return fail(HMF_ERR_INVALID, "%s: bad args", who);
+    if (!ws || ws_bytes < hmf_smpl_tpose_errors_workspace_bytes((int)np)) return fail(HMF_ERR_WORKSPACE, "%s: workspace too small", who);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    const int npairs = (int)np;
+    switch (h->d.num_betas) {
+#define HMF_TE(NB_) case NB_: launch_tpose_errors<NB_>(h->d, betas_pred, betas_target, nimg, group, extra, npairs, partial, st); break;
+        HMF_TE(1) HMF_TE(2) HMF_TE(3) HMF_TE(4) HMF_TE(5) HMF_TE(6) HMF_TE(7) HMF_TE(8) HMF_TE(9) HMF_TE(10) HMF_TE(11) HMF_TE(12) HMF_TE(13) HMF_TE(14)
+        HMF_TE(15) HMF_TE(16)
+#undef HMF_TE
+        default: return fail(HMF_ERR_UNSUPPORTED, "%s: num_betas=%d", who, h->d.num_betas);
+    }
+    HMF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tpose_errors_finish, dim3((npairs + 63) / 64), dim3(64), 0, st, partial, npairs, out);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_smpl_tpose_errors(const hmf_smpl_t* h, const float* betas_pred, const float* betas_target, int npairs, int group, float* out, void* ws,
+                          long long ws_bytes, void* stream) {
+    if (npairs < 0 || group < 1 || npairs % group) return fail(HMF_ERR_INVALID, "hmf_smpl_tpose_errors: npairs must be a multiple of group >= 1");
+    return tpose_errors_impl(h, betas_pred, betas_target, npairs / group, group, 0, out, ws, ws_bytes, stream, "hmf_smpl_tpose_errors");
+}
+
+int hmf_smpl_tpose_errors_packed(const hmf_smpl_t* h, const float* betas_packed, const float* betas_target, int B, int N, float* out, void* ws,
+                                 long long ws_bytes, void* stream) {
+    return tpose_errors_impl(h, betas_packed, betas_target, B, N, 1, out, ws, ws_bytes, stream, "hmf_smpl_tpose_errors_packed");
 }
 
 int hmf_vertex_variance(const float* verts, int N, int V, float* avg_l2, float* dir_std, void* stream) {

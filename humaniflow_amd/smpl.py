@@ -320,6 +320,39 @@ class SMPL(nn.Module):
                                           _lib.current_stream()), 'hmf_smpl_tpose')
         return verts
 
+    def tpose_errors(self, betas_pred, betas_target):
+        """PVE-T / PVE-T-SC of T-pose bodies WITHOUT building them (hmf_smpl_tpose_errors): betas_pred (Bt, nb) or (Bt, N, nb) against
+        betas_target (Bt, nb) -> (..., 3) = [mean |P - T|, mean |sc(P) - T|, 0], the layout of the point-set kernels' output.  The reference
+        (evaluate/evaluate_humaniflow.py:131-133,186-192 -> metrics/eval_metrics_tracker.py:200-222) materialises both vertex sets first."""
+        _lib.require_cuda(betas_pred, 'betas_pred')
+        lib = _lib.load()
+        bp, bt = self._f32c(betas_pred), self._f32c(betas_target)
+        lead = bp.shape[:-1]
+        npairs = 1
+        for d_ in lead:
+            npairs *= d_
+        out = torch.empty(npairs, 3, dtype=torch.float32, device=bp.device)
+        ws = torch.empty(int(lib.hmf_smpl_tpose_errors_workspace_bytes(npairs)), dtype=torch.uint8, device=bp.device)
+        with torch.cuda.device(bp.device):
+            _lib.check(lib.hmf_smpl_tpose_errors(self._handle(bp.device), _lib.dptr(bp), _lib.dptr(bt), npairs, npairs // max(bt.shape[0], 1), _lib.dptr(out),
+                                                 ws.data_ptr(), ws.numel(), _lib.current_stream()), 'hmf_smpl_tpose_errors')
+        return out.reshape(*lead, 3)
+
+    def tpose_errors_packed(self, betas_packed, betas_target, B, N):
+        """The same for the packed rows of an evaluation step (sample row b N + n, then point-estimate row B N + b) in ONE launch
+        (hmf_smpl_tpose_errors_packed): (B N + B, nb) against (B, nb) -> (B N + B, 3)."""
+        _lib.require_cuda(betas_packed, 'betas_packed')
+        lib = _lib.load()
+        bp, bt = self._f32c(betas_packed), self._f32c(betas_target)
+        M = B * N + B
+        assert bp.shape[0] == M and bt.shape[0] == B
+        out = torch.empty(M, 3, dtype=torch.float32, device=bp.device)
+        ws = torch.empty(int(lib.hmf_smpl_tpose_errors_workspace_bytes(M)), dtype=torch.uint8, device=bp.device)
+        with torch.cuda.device(bp.device):
+            _lib.check(lib.hmf_smpl_tpose_errors_packed(self._handle(bp.device), _lib.dptr(bp), _lib.dptr(bt), B, N, _lib.dptr(out), ws.data_ptr(), ws.numel(),
+                                                        _lib.current_stream()), 'hmf_smpl_tpose_errors_packed')
+        return out
+
     def model_dict(self):
         """CPU copies of the model arrays (for the oracle in tests)."""
         keys = ['v_template', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights', 'parents',

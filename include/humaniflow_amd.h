@@ -106,6 +106,20 @@ int hmf_smpl_lbs_packed(const hmf_smpl_t* h, const float* glob_R, int B, int N, 
  * v_template + shapedirs . beta.  joints nullable.                                                */
 int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts, float* joints,
                    void* stream);
+/* The T-pose metrics of the evaluation loop without the T-pose bodies (evaluate/evaluate_humaniflow.py:131-133,186-192 build
+ * `v_template + shapedirs . beta` for predictions and targets only to feed metrics/eval_metrics_tracker.py:200-222 -- PVE-T and, through
+ * utils/eval_utils.py:107-125, PVE-T-SC): pair p = (betas_pred[p], betas_target[p / group]), both npairs (resp. npairs / group) x nb;
+ * out npairs x 3 = [mean |P - T|, mean |sc(P) - T|, 0] in hmf_pointset_errors' layout.  The moments of the scale + translation correction
+ * are closed forms of beta (T is affine in beta), the errors take one pass over the model's 6890 x 3 x (nb + 1) rows: no vertex tensor is
+ * written or read.  ws: hmf_smpl_tpose_errors_workspace_bytes(npairs).  Deterministic.                                                */
+long long hmf_smpl_tpose_errors_workspace_bytes(int npairs);
+int hmf_smpl_tpose_errors(const hmf_smpl_t* h, const float* betas_pred, const float* betas_target, int npairs, int group, float* out, void* ws,
+                          long long ws_bytes, void* stream);
+/* The same for the packed rows of one evaluation step in ONE launch: betas_packed (B N + B) x nb = sample row b N + n, then the
+ * point-estimate row B N + b (the `betas` input of hmf_smpl_lbs_packed); both kinds of row of image b are scored against betas_target[b].
+ * out (B N + B) x 3 in the same row order.  ws: hmf_smpl_tpose_errors_workspace_bytes(B N + B).                                        */
+int hmf_smpl_tpose_errors_packed(const hmf_smpl_t* h, const float* betas_packed, const float* betas_target, int B, int N, float* out, void* ws,
+                                 long long ws_bytes, void* stream);
 /* Backward of the 90 joints of hmf_smpl_lbs w.r.t. its inputs (the 2D reprojection loss of the training step,
  * losses/humaniflow_loss.py:44-60): g_joints M x 90 x 3 -> g_global_orient M x 9, g_body_pose M x 23 x 9, g_betas M x nb.
  * All three inputs must be per-row (no broadcast).  Vertex gradients are not built (LOSS.APPLY_POINT_EST_LOSS = False).          */
@@ -457,9 +471,36 @@ int hmf_stem_wino_pool(const float* x, const float* w_packed, const float* bias,
  * out: (npairs, 3) = mean |P-T| (PVE / MPJPE), mean |sc(P)-T| with scale_and_translation_transform_batch (eval_utils.py:107-125),
  * mean |pa(P)-T| with procrustes_analysis_batch (:62-104; 0 when want_pa = 0).  All on the device, fp64 statistics. */
 int hmf_pointset_errors(const float* P, const float* T, int npairs, int group, int npts, int want_pa, float* out, void* stream);
-/* Sample diversity (eval_metrics_tracker.py:398-410): S (B, N, npts, 3) -> partial (B, ceil(npts/256)) partial sums over n and points
- * of |S - mean_n S|; the caller adds the chunks (deterministic) and divides by N * npts. */
+/* Sample diversity (eval_metrics_tracker.py:398-410): S (B, N, npts, 3) -> partial (B, hmf_sample_diversity_chunks(npts)) partial sums over n
+ * and 64 points each of |S - mean_n S|; the caller adds the chunks (deterministic) and divides by N * npts.  N <= 128: S is read ONCE (a
+ * chunk's samples stay in registers between the mean and the distances). */
+int hmf_sample_diversity_chunks(int npts);
 int hmf_sample_diversity(const float* S, int B, int N, int npts, float* partial, void* stream);
+/* The joint-side glue of one evaluation step (evaluate/evaluate_humaniflow.py:138-143,176-183,197-206) in one launch.  joints: the packed
+ * (B N + B, 90, 3) output of hmf_smpl_lbs_packed (sample row b N + n, then point-estimate row B N + b); cam (B, 3) weak-perspective
+ * [s, tx, ty].  Writes, per row: the 14 evaluation joints (idx14_host: ALL_JOINTS_TO_H36M_MAP o H36M_TO_J14), the 17 COCO joints
+ * (idx17_host) and their 2-D pixels undo_keypoint_normalisation(orthographic_project(rotate pi about x)) for an img_wh-pixel image. */
+int hmf_eval_joints(const float* joints, const float* cam, int B, int N, const int* idx14_host, const int* idx17_host, float img_wh, float* j14,
+                    float* coco3d, float* joints2d, void* stream);
+/* One batch of metrics/eval_metrics_tracker.py:95-433 after the point-set kernels, in two launches: minima over the N samples, the 2-D joint
+ * errors over the visible joints, the per-frame arrays and the fp64 running sums.  Any input pointer may be NULL (that group of metrics is
+ * skipped); slot[i] = position of metric / count i in `sums` or -1 (order: PVE, PVE-SC, PVE-PA, PVE-T, PVE-T-SC, MPJPE, MPJPE-SC, MPJPE-PA,
+ * the eight *_samples_min in the same order, joints2D-L2E, joints2Dsamples-L2E, verts3D_sample_diversity, joints3D_sample_diversity,
+ * num_total_test_data, num_vis_joints2D, num_vis_joints2Dsamples).  frames: (HMF_EVAL_NUM_SLOTS - 3, B) float32, row i = the batch's
+ * per-frame values of metric i.  sums is accumulated into (+=), images in order: deterministic. */
+#define HMF_EVAL_NUM_SLOTS 23
+typedef struct {
+    int B, N, num_verts, num_joints, chunks_v, chunks_j;
+    const float *e_verts, *e_tpose, *e_joints;          /* (B, 3) [plain, SC, PA] of the point estimates (hmf_pointset_errors / hmf_smpl_tpose_errors) */
+    const float *es_verts, *es_tpose, *es_joints;       /* (B, N, 3) of the samples                                                                  */
+    const float *div_verts, *div_joints;                /* (B, chunks_v) / (B, chunks_j) partials of hmf_sample_diversity (joints: the 17 COCO joints) */
+    const float *j2d_pred, *j2d_samples, *j2d_target;   /* (B, 17, 2), (B, N, 17, 2), (B, 17, 2) pixels                                                */
+    const unsigned char* j2d_vis;                       /* (B, 17) or NULL = all visible                                                               */
+    double* scratch;                                    /* hmf_eval_tracker_scratch_bytes(B)                                                           */
+    int slot[HMF_EVAL_NUM_SLOTS];
+} hmf_eval_batch_t;
+long long hmf_eval_tracker_scratch_bytes(int B);
+int hmf_eval_tracker_update(const hmf_eval_batch_t* batch, double* sums, float* frames, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Encoder, training mode (models/resnet.py under train(): nn.BatchNorm2d batch statistics) and its backward                 */

@@ -452,6 +452,16 @@ def test_configs3_eval_step_at_B32_N100():
     assert torch.allclose(frames['PVE-T-SC_samples_min'][sl].double().cpu(), e[..., 1].min(dim=1).values, rtol=2e-5, atol=1e-7)
     d = om.sample_diversity(P) / (100 * 6890)
     assert torch.allclose(frames['verts3D_sample_diversity'][sl].double().cpu(), d, rtol=2e-5)
+    # the bench's form of the same step: no T-pose bodies (shape vectors -> hmf_smpl_tpose_errors), same sums
+    noise = model.draw_noise(dev, 32, 100)
+    noise = {'shape': noise[0], 'pose': noise[1]}
+    predA = ev.predict_batch(model, smpl, batch, 100, noise=noise)
+    predB = ev.predict_batch(model, smpl, batch, 100, noise=noise, materialise_tpose=False)
+    assert 'tpose_verts3D' not in predB and predB['tpose_betas_samples'].shape == (32, 100, 10)
+    tA, tB = ev.EvalMetricsTracker(dev), ev.EvalMetricsTracker(dev, smpl=smpl)
+    tA.update_per_batch(predA, targ)
+    tB.update_per_batch(predB, ev.target_batch(smpl, batch, materialise_tpose=False))
+    assert torch.allclose(tA.sums, tB.sums, rtol=2e-6, atol=1e-9)
 
 
 def test_in_place_weight_updates_repack_on_the_device():
