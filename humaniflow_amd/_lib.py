@@ -164,6 +164,8 @@ EXPORTED_SYMBOLS = sorted(_SIGS)
 # include/humaniflow_amd_experiments.h: only in tools/libhumaniflow_amd_experiments.so (the same sources built with -DHMF_EXPERIMENTS)
 _EXPERIMENT_SIGS = {
     'hmf_conv_winograd_variant': (C.c_int, [_VP] * 5 + [C.c_int] * 7 + [_VP]),      # tools/winograd_ablate.py
+    'hmf_debug_set_wino_nw_mode': (C.c_int, [C.c_int]),                             # tools/wino_nw_probe.py
+    'hmf_conv_winograd_nw': (C.c_int, [_VP] * 5 + [C.c_int] * 6 + [_VP]),
     'hmf_debug_set_timeline': (C.c_int, [_VP]),                                     # tools/flow_timeline.py
     'hmf_debug_set_lbs_cycles': (C.c_int, [_VP]),                                   # tools/lbs_tune.py
     'hmf_debug_gemm_stamps': (C.c_int, [_VP, C.c_int]),

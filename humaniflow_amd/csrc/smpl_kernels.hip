@@ -752,7 +752,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // SPLIT (impl = 3): both operands as bf16 hi + bf16 lo (x = hi + lo to 2^-17 relative); every product is three bf16 MFMAs
 // (hi.hi + hi.lo + lo.hi, fp32 accumulate; lo.lo ~ 2^-18 dropped), which brings the vertices from 1.5e-3 m (plain bf16 operands) to within
 // 1e-4 m of the fp32 oracle -- the north-star tolerance -- at 3/16 of the fp32 MFMA time: still bound by the vertex write.
-template <int SLOTS, bool SPLIT>
+// ABL (experiments build only, tools/lbs16_tune.py; results wrong when != 0): & 1 no skinning epilogue, & 2 no B-operand stream (the first k-group's
+// fragments serve every k-group), & 4 no MFMAs, & 8 skinning without the vertex stores.
+template <int SLOTS, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
                                                      const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts,
                                                      float* __restrict__ cjv) {
@@ -829,23 +831,28 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
                 f32x4 n0 = b0, n1 = b1, n2 = b2, m0 = a0, m1 = a1;
                 f32x4 nl0 = bl0, nl1 = bl1, nl2 = bl2, ml0 = al0, ml1 = al1;
                 if (kg + 1 < kKG16) {
-                    n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128];
+                    if (!(ABL & 2)) { n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128]; }
                     m0 = *(const f32x4*)(ap + (kg + 1) * 16);
                     m1 = *(const f32x4*)(ap + 32 * kP16Stride + (kg + 1) * 16);
                     if (SPLIT) {
-                        nl0 = bpl[(kg + 1) * 192]; nl1 = bpl[(kg + 1) * 192 + 64]; nl2 = bpl[(kg + 1) * 192 + 128];
+                        if (!(ABL & 2)) { nl0 = bpl[(kg + 1) * 192]; nl1 = bpl[(kg + 1) * 192 + 64]; nl2 = bpl[(kg + 1) * 192 + 128]; }
                         ml0 = *(const f32x4*)(apl + (kg + 1) * 16);
                         ml1 = *(const f32x4*)(apl + 32 * kP16Stride + (kg + 1) * 16);
                     }
                 }
                 const bf16x8 A0 = __builtin_bit_cast(bf16x8, a0), A1 = __builtin_bit_cast(bf16x8, a1);
                 const bf16x8 B[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
+                if (ABL & 4) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { acc[0][c][kg] += a0[c] * b0[c] + al0[c] * bl1[c]; acc[1][c][kg] += a1[c] * b2[c] + al1[c] * bl2[c]; }
+                } else {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[c], acc[0][c], 0, 0, 0);
                     acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[c], acc[1][c], 0, 0, 0);
                 }
-                if (SPLIT) {
+                }
+                if (SPLIT && !(ABL & 4)) {
                     const bf16x8 L0 = __builtin_bit_cast(bf16x8, al0), L1 = __builtin_bit_cast(bf16x8, al1);
                     const bf16x8 BL[3] = {__builtin_bit_cast(bf16x8, bl0), __builtin_bit_cast(bf16x8, bl1), __builtin_bit_cast(bf16x8, bl2)};
 #pragma unroll
@@ -876,8 +883,22 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
             e.cj_row = d.n_ju * 3;
             e.cj = cjv + ((size_t)(row0 + 4 * half) * d.n_ju + (jslot >= 0 ? jslot : 0)) * 3;
             const char* lbase = (const char*)(sA + 4 * half * kAtr);
+            if (ABL & 1) {
+                if (e.ok_v && l31 == 0) {
+                    float sacc = 0.f;
 #pragma unroll
-            for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) sacc += acc[a][c][q];
+                    e.obase[0] = sacc;
+                }
+            } else {
+                if (ABL & 8) e.ok_v = e.ok_v && (row0 < 0);          // never true, not provable: the skinning is computed, nothing stored
+#pragma unroll
+                for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
+            }
         }
         __syncthreads();
         t = seg_end;
@@ -1319,6 +1340,25 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
         if (split) hipLaunchKernelGGL((k_lbs_mfma16<S, true>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv);     \
         else hipLaunchKernelGGL((k_lbs_mfma16<S, false>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv);          \
     } while (0)
+#ifdef HMF_EXPERIMENTS
+#define HMF_LBS16A(A) hipLaunchKernelGGL((k_lbs_mfma16<4, true, A>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv)
+        if (h->d.skin_slots == 4 && split && (impl >> 4)) {
+            switch (impl >> 4) {
+                case 1: HMF_LBS16A(1); break;
+                case 2: HMF_LBS16A(2); break;
+                case 3: HMF_LBS16A(3); break;
+                case 4: HMF_LBS16A(4); break;
+                case 5: HMF_LBS16A(5); break;
+                case 6: HMF_LBS16A(6); break;
+                case 7: HMF_LBS16A(7); break;
+                case 8: HMF_LBS16A(8); break;
+                case 10: HMF_LBS16A(10); break;
+                case 12: HMF_LBS16A(12); break;
+                default: HMF_LBS16A(0); break;
+            }
+        } else
+#undef HMF_LBS16A
+#endif
         if (h->d.skin_slots == 4) HMF_LBS16(4);
         else if (h->d.skin_slots == 8) HMF_LBS16(8);
         else HMF_LBS16(0);

@@ -413,6 +413,7 @@ long long hmf_conv_winograd_packed_floats(int Cin, int Cout);
 int hmf_conv_winograd_pack_host(const float* w, float* packed, int Cin, int Cout);
 int hmf_conv_winograd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                       int Cin, int Cout, int relu, void* stream);
+
 /* Small batches (predict: one image per call, predict/predict_humaniflow.py:112-115): a launch then has 16-64 work-groups, each walking all Cin / 64
  * slabs, on 256 CUs.  hmf_conv_winograd_ws splits the slab loop over up to 8 work-groups per tile when fewer than 128 work-groups would be launched;
  * the raw partial outputs go to `ws` (hmf_conv_winograd_workspace_bytes: 0 when the shape is not split, then ws may be NULL) and a second small launch

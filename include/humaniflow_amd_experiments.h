@@ -15,6 +15,14 @@ extern "C" {
 int hmf_conv_winograd_variant(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
                               int Cin, int Cout, int relu, int variant, void* stream);
 
+/* csrc/conv_winograd_nw.hip (round 5, measured slower than hmf_conv_winograd and not shipped): the same convolution, bitwise the same result, with a
+ * work-group of 8 x 16 pixels x 128 output channels and a wave that owns all sixteen transform positions of one 32-channel tile.
+ * HMF_ERR_UNSUPPORTED unless Cin % 64 == 0, Cout % 128 == 0 and W >= 16.  hmf_debug_set_wino_nw_mode: timing ablations (& 1 no next-slab patch DMA,
+ * & 2 no operand stream, & 4 no window reads; wrong results when != 0). */
+int hmf_conv_winograd_nw(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int B, int H, int W,
+                         int Cin, int Cout, int relu, void* stream);
+int hmf_debug_set_wino_nw_mode(int mode);
+
 /* Diagnostic: device buffer of 23 x 8 int64 that k_flow_chain's tile 0 fills with shader-clock stamps per part phase
  * (tools/flow_timeline.py); NULL (default) disables it. */
 int hmf_debug_set_timeline(void* dev_ptr);

@@ -63,11 +63,20 @@ torch.cuda.synchronize()
 ms, tag, rows = np.zeros(65536), np.zeros(65536, np.int32), np.zeros(65536, np.int32)
 n = lib.hmf_profile_collect(ms.ctypes.data_as(_lib.c_double_p), _lib.iptr(tag), _lib.iptr(rows), 65536)
 lib.hmf_profile_enable(0)
-names = {1: 'k_lbs_mfma', 2: 'k_rigid_chain', 3: 'k_joints_compact', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc', 8: '1x1 convolutions (30 launches)',
-         9: 'stem (k_stem_wino + k_stem_pool_rim)', 10: 'k_conv_patch (3 launches)', 11: 'k_conv_winograd (13 launches)', 15: 'k_heads_fc1 + k_heads_out'}
+names = {1: 'k_lbs_mfma', 2: 'k_rigid_chain', 3: 'k_joints_compact', 5: 'k_flow_ctx0', 6: 'k_flow_chain', 7: 'k_isgc', 8: '1x1 convolutions (k_conv_gemm / k_conv_igemm / k_conv_pair)',
+         9: 'stem (k_stem_wino + k_stem_pool_rim)', 10: 'k_conv_patch (+ split-K finish)', 11: 'k_conv_winograd (+ split-K finish)', 15: 'k_heads_fc1 + k_heads_out'}
+# A record is ONE ProfScope = one event pair around the launches of one library call (a split-K 3x3 layer: main kernel + finish pass); the pair's
+# time is start-of-first to end-of-last kernel of the call, i.e. it does not include the gap to the NEXT call.  (Round 4 printed "includes ~2 us
+# of launch gap each" on every row and a row label with a launch count the tag does not have: the 1x1 row is 30 records of ~0.9-3 us each.)
 tot = 0.0
+print('  per library call class: records per step, mean per record, total per step (HIP event pair around each call; gaps BETWEEN calls not included)')
 for tg in sorted(set(tag[:n].tolist())):
-    us = ms[:n][tag[:n] == tg].sum() / reps * 1e3
+    sel = tag[:n] == tg
+    us = ms[:n][sel].sum() / reps * 1e3
     tot += us
-    print('  %-34s %8.1f us per step (HIP events around every launch: includes ~2 us of launch gap each)' % (names.get(tg, 'tag %d' % tg), us))
-print('  %-34s %8.1f us' % ('sum', tot))
+    print('  %-62s %4.0f x %6.2f us = %8.1f us per step' % (names.get(tg, 'tag %d' % tg), sel.sum() / reps, us / (sel.sum() / reps), us))
+print('  %-62s %24.1f us (kernel spans; the graph replay above adds the gaps between the %d calls)' % ('sum', tot, int((tag[:n] >= 0).sum() / reps)))
+lay = ms[:n][tag[:n] == 11].reshape(reps, -1).mean(0) * 1e3
+print('  k_conv_winograd calls in plan order (us): ' + ' '.join('%.1f' % v for v in lay))
+lay = ms[:n][tag[:n] == 8].reshape(reps, -1).mean(0) * 1e3
+print('  1x1 calls in plan order (us): ' + ' '.join('%.1f' % v for v in lay))
