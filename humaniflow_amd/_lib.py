@@ -86,6 +86,8 @@ _SIGS = {
     'hmf_avgpool_nhwc': (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, _VP]),
     'hmf_heads_workspace_bytes': (C.c_size_t, [C.c_int] * 3),
     'hmf_heads': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_int] + [_VP] * 8 + [C.c_int] + [_VP] * 6 + [C.c_size_t, _VP]),
+    'hmf_heads_train': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_int] + [_VP] * 8 + [C.c_int] + [_VP] * 8 + [C.c_size_t, _VP]),
+    'hmf_heads_backward': (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int] + [_VP] * 16),
     'hmf_flow_isgc': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_context': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_SO3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),

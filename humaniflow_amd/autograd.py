@@ -355,6 +355,54 @@ class Rot6dToRotmat(torch.autograd.Function):
         return gx.reshape(x.shape).to(x.dtype)
 
 
+class HeadsTrain(torch.autograd.Function):
+    """models/humaniflow_model.py:232-253 under autograd on the library: forward = hmf_heads_train (fc1 + ELU, fc_cam / fc_glob / fc_shape, init adds,
+    6-D -> rotation: two launches), backward = hmf_heads_backward (everything below fc1's pre-activation, one launch) + two hmf_rows_atb_batched
+    calls (d fc1.weight / d fc1.bias, and the pull-back to the image features).  Replaces four nn.Linear (one vendor GEMM kernel per step in
+    profiles/r04_train_kernel_stats.md) and ~40 small ATen launches per training step."""
+
+    @staticmethod
+    def forward(ctx, feats, w1, b1, wc, bc, wg, bg, ws, bs, init_cam, init_glob):
+        lib = _lib.load()
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        feats_, w1_, b1_, wc_, bc_, wg_, bg_, ws_, bs_ = map(f, (feats, w1, b1, wc, bc, wg, bg, ws, bs))
+        B, Fd = feats_.shape
+        N1, nb = w1_.shape[0], ws_.shape[0] // 2
+        dev = feats_.device
+        new = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        cam, glob_R, mode, lstd, std, x1, glob6 = new(B, 3), new(B, 3, 3), new(B, nb), new(B, nb), new(B, nb), new(B, N1), new(B, 6)
+        ws_buf = torch.empty(int(lib.hmf_heads_workspace_bytes(B, Fd, N1)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.hmf_heads_train(_lib.dptr(feats_), B, Fd, _lib.dptr(w1_), _lib.dptr(b1_), N1, _lib.dptr(wc_), _lib.dptr(bc_), _lib.dptr(f(init_cam)),
+                                           _lib.dptr(wg_), _lib.dptr(bg_), _lib.dptr(f(init_glob)), _lib.dptr(ws_), _lib.dptr(bs_), nb, _lib.dptr(cam),
+                                           _lib.dptr(glob_R), _lib.dptr(mode), _lib.dptr(lstd), _lib.dptr(std), _lib.dptr(x1), _lib.dptr(glob6), ws_buf.data_ptr(),
+                                           ws_buf.numel(), _lib.current_stream()), 'hmf_heads_train')
+        ctx.save_for_backward(feats_, w1_, wc_, wg_, ws_, x1, glob6)
+        ctx.need_feats = feats.requires_grad
+        return cam, glob_R, mode, lstd
+
+    @staticmethod
+    def backward(ctx, g_cam, g_R, g_mode, g_lstd):
+        lib = _lib.load()
+        feats, w1, wc, wg, ws, x1, glob6 = ctx.saved_tensors
+        B, Fd = feats.shape
+        N1, nb = w1.shape[0], ws.shape[0] // 2
+        dev = feats.device
+        f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        g_cam, g_R, g_mode, g_lstd = f(g_cam), f(g_R), f(g_mode), f(g_lstd)
+        new = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        g_pre, g_pre_t = new(B, N1), new(N1, B)
+        gwc, gbc, gwg, gbg, gws, gbs = new(3, N1), new(3), new(6, N1), new(6), new(2 * nb, N1), new(2 * nb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.hmf_heads_backward(_lib.dptr(x1), _lib.dptr(glob6), B, N1, nb, _lib.dptr(wc), _lib.dptr(wg), _lib.dptr(ws), _lib.dptr(g_cam),
+                                              None if g_R is None else g_R.data_ptr(), _lib.dptr(g_mode), _lib.dptr(g_lstd), _lib.dptr(g_pre), _lib.dptr(g_pre_t),
+                                              _lib.dptr(gwc), _lib.dptr(gbc), _lib.dptr(gwg), _lib.dptr(gbg), _lib.dptr(gws), _lib.dptr(gbs), _lib.current_stream()),
+                       'hmf_heads_backward')
+        gw1, gb1 = _atb(g_pre, feats, 1, B, N1, Fd, N1, Fd, 0, 0, True)                   # d fc1.weight = g_pre^T feats, d fc1.bias = column sums of g_pre
+        g_feats = _atb(g_pre_t, w1, 1, N1, B, Fd, B, Fd, 0, 0, False)[0][0] if ctx.need_feats else None     # g_pre W1 as (g_pre^T)^T W1 over the N1 rows
+        return g_feats, gw1[0], gb1[0], gwc, gbc, gwg, gbg, gws, gbs, None, None
+
+
 class FusedTrainLoss(torch.autograd.Function):
     """HumaniflowLoss on the training step's own quantities (losses/humaniflow_loss.py:25-79, J2D_LOSS_ON = 'point_est+samples', no 3D point-estimate
     terms) with the joint selection / flip / projection of train/train_humaniflow.py:283-318 folded in: hmf_train_loss computes the scalar AND its

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_heads_fc1(const float* __restrict__ fea
 struct HeadsOut {
     const float *w_cam, *b_cam, *init_cam, *w_glob, *b_glob, *init_glob, *w_shape, *b_shape;
     float *cam, *glob_R, *shape_mode, *shape_log_std, *shape_std;
+    float *x1, *glob6;             // training forward only (else NULL): ELU(fc1) (B, N1) and the 6-D vector before Gram-Schmidt (B, 6), kept for hmf_heads_backward
 };
 
 // one work-group per image: x1 = ELU(sum of the K-split partials + b1) in LDS, then the 3 + 6 + 2 nb small outputs, one wave per output
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void k_heads_out(const float* __restrict__ par
         float v = partial[(size_t)b * N1 + n];
         for (int ks = 1; ks < KS; ++ks) v += partial[((size_t)ks * B + b) * N1 + n];
         sx[n] = elu1(v + b1[n]);
+        if (o.x1) o.x1[(size_t)b * N1 + n] = sx[n];
     }
     __syncthreads();
     // 3 + 6 + 2 nb outputs: eight lanes per output, each lane a contiguous eighth of the N1 axis with all its loads independent (round 4, first
@@ -105,6 +107,9 @@ __global__ __launch_bounds__(256) void k_heads_out(const float* __restrict__ par
         rot6d_to_rotmat_f32(g6, R);
 #pragma unroll
         for (int e = 0; e < 9; ++e) o.glob_R[(size_t)b * 9 + e] = R[e];
+        if (o.glob6)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) o.glob6[(size_t)b * 6 + e] = g6[e];
     }
     if (tid >= 128 && tid < 128 + 2 * nb) {                                                                  // :250-253
         const int e = tid - 128;
@@ -139,6 +144,68 @@ __global__ __launch_bounds__(256) void k_avgpool_nhwc(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the heads for the training step (the reference differentiates models/humaniflow_model.py:232-253 with autograd: ~40 small ATen
+// launches and a vendor GEMM per step).  k_heads_bwd: one thread per fc1 output channel n, the gradients of the 3 + 6 + 2 nb small outputs of
+// every image in LDS (the 6-D -> rotation pull-back applied on the way in):
+//   g_x1[b][n] = sum_o g_out[b][o] W_o[o][n];   g_pre[b][n] = g_x1 * ELU'(pre) (= x1 + 1 where x1 <= 0);   dW_o[o][n] = sum_b g_out[b][o] x1[b][n]
+// g_pre leaves in both layouts -- (B, N1) for dW1 = g_pre^T feats and (N1, B) for g_feats = g_pre W1 -- so that both dense products are calls of
+// hmf_rows_atb_batched without a transpose launch.  Images are summed in order: deterministic.
+// ---------------------------------------------------------------------------------------------------
+struct HeadsBwd {
+    const float *x1, *glob6, *w_cam, *w_glob, *w_shape;
+    const float *g_cam, *g_glob_R, *g_mode, *g_lstd;          // any may be NULL (= zero gradient)
+    float *g_pre, *g_pre_t, *g_w_cam, *g_b_cam, *g_w_glob, *g_b_glob, *g_w_shape, *g_b_shape;
+};
+constexpr int kHbMaxB = 128, kHbMaxO = 9 + 32;
+__global__ __launch_bounds__(64) void k_heads_bwd(int B, int N1, int nb, HeadsBwd a) {
+    __shared__ float go[kHbMaxB * kHbMaxO];
+    const int NO = 9 + 2 * nb, tid = threadIdx.x;
+    for (int b = tid; b < B; b += 64) {
+        float* g = go + b * NO;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) g[e] = a.g_cam ? a.g_cam[b * 3 + e] : 0.f;
+        float gx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.g_glob_R) rot6d_to_rotmat_bwd_f32(a.glob6 + b * 6, a.g_glob_R + b * 9, gx);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) g[3 + e] = gx[e];
+        for (int e = 0; e < nb; ++e) {
+            g[9 + e] = a.g_mode ? a.g_mode[b * nb + e] : 0.f;
+            g[9 + nb + e] = a.g_lstd ? a.g_lstd[b * nb + e] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 64 + tid;
+    if (blockIdx.x == 0)                                               // bias gradients of the small layers: column sums of g_out
+        for (int o = tid; o < NO; o += 64) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += go[b * NO + o];
+            (o < 3 ? a.g_b_cam + o : (o < 9 ? a.g_b_glob + (o - 3) : a.g_b_shape + (o - 9)))[0] = s;
+        }
+    if (n >= N1) return;
+    float w[kHbMaxO], dw[kHbMaxO];
+#pragma unroll
+    for (int o = 0; o < kHbMaxO; ++o) {
+        dw[o] = 0.f;
+        w[o] = o < NO ? (o < 3 ? a.w_cam[(size_t)o * N1 + n] : (o < 9 ? a.w_glob[(size_t)(o - 3) * N1 + n] : a.w_shape[(size_t)(o - 9) * N1 + n])) : 0.f;
+    }
+    for (int b = 0; b < B; ++b) {
+        const float x = a.x1[(size_t)b * N1 + n];
+        const float* g = go + b * NO;                                   // wave-uniform: LDS broadcast
+        float gx = 0.f;
+#pragma unroll
+        for (int o = 0; o < kHbMaxO; ++o)
+            if (o < NO) { gx = fmaf(g[o], w[o], gx); dw[o] = fmaf(g[o], x, dw[o]); }
+        const float gp = x > 0.f ? gx : gx * (x + 1.f);                 // ELU' = 1 (pre > 0) or exp(pre) = x1 + 1
+        a.g_pre[(size_t)b * N1 + n] = gp;
+        a.g_pre_t[(size_t)n * B + b] = gp;
+    }
+#pragma unroll
+    for (int o = 0; o < kHbMaxO; ++o)
+        if (o < NO) (o < 3 ? a.g_w_cam + (size_t)o * N1 : (o < 9 ? a.g_w_glob + (size_t)(o - 3) * N1 : a.g_w_shape + (size_t)(o - 9) * N1))[n] = dw[o];
+}
+
 static int heads_ksplit(int F) {
     for (int ks = 4; ks >= 1; ks >>= 1)
         if (F % (ks * 4 * 8) == 0) return ks;
@@ -156,9 +223,9 @@ size_t hmf_heads_workspace_bytes(int B, int F, int N1) {
     return (size_t)std::max(ks, 1) * std::max(B, 1) * N1 * sizeof(float);
 }
 
-int hmf_heads(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
+static int heads_impl(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
               const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
-              float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, void* workspace, size_t workspace_bytes, void* stream) {
+              float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, float* x1, float* glob6, void* workspace, size_t workspace_bytes, void* stream) {
     if (!feats || !w1 || !b1 || !w_cam || !b_cam || !init_cam || !w_glob || !b_glob || !init_glob || !w_shape || !b_shape || !cam || !glob_R || !shape_mode ||
         !shape_log_std || !shape_std)
         return fail(HMF_ERR_INVALID, "hmf_heads: null argument");
@@ -175,8 +242,36 @@ int hmf_heads(const float* feats, int B, int F, const float* w1, const float* b1
     ProfScope ps(15, B, st);
     hipLaunchKernelGGL(k_heads_fc1, dim3(N1 / 32, KS, (B + 31) / 32), dim3(256), 0, st, feats, w1, B, F, N1, F / (KS * 4), partial);
     HMF_LAUNCH_CHECK();
-    HeadsOut o{w_cam, b_cam, init_cam, w_glob, b_glob, init_glob, w_shape, b_shape, cam, glob_R, shape_mode, shape_log_std, shape_std};
+    HeadsOut o{w_cam, b_cam, init_cam, w_glob, b_glob, init_glob, w_shape, b_shape, cam, glob_R, shape_mode, shape_log_std, shape_std, x1, glob6};
     hipLaunchKernelGGL(k_heads_out, dim3(B), dim3(256), 0, st, partial, b1, B, N1, KS, nb, o);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_heads(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
+              const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
+              float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, void* workspace, size_t workspace_bytes, void* stream) {
+    return heads_impl(feats, B, F, w1, b1, N1, w_cam, b_cam, init_cam, w_glob, b_glob, init_glob, w_shape, b_shape, nb, cam, glob_R, shape_mode, shape_log_std,
+                      shape_std, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int hmf_heads_train(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
+                    const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
+                    float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, float* x1, float* glob6, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    if (!x1 || !glob6) return fail(HMF_ERR_INVALID, "hmf_heads_train: null x1 / glob6");
+    return heads_impl(feats, B, F, w1, b1, N1, w_cam, b_cam, init_cam, w_glob, b_glob, init_glob, w_shape, b_shape, nb, cam, glob_R, shape_mode, shape_log_std,
+                      shape_std, x1, glob6, workspace, workspace_bytes, stream);
+}
+
+int hmf_heads_backward(const float* x1, const float* glob6, int B, int N1, int nb, const float* w_cam, const float* w_glob, const float* w_shape,
+                       const float* g_cam, const float* g_glob_R, const float* g_shape_mode, const float* g_shape_log_std, float* g_pre, float* g_pre_t,
+                       float* g_w_cam, float* g_b_cam, float* g_w_glob, float* g_b_glob, float* g_w_shape, float* g_b_shape, void* stream) {
+    if (!x1 || !glob6 || !w_cam || !w_glob || !w_shape || !g_pre || !g_pre_t || !g_w_cam || !g_b_cam || !g_w_glob || !g_b_glob || !g_w_shape || !g_b_shape)
+        return fail(HMF_ERR_INVALID, "hmf_heads_backward: null argument");
+    if (B <= 0 || B > kHbMaxB || nb < 1 || nb > 16 || N1 <= 0) return fail(HMF_ERR_UNSUPPORTED, "hmf_heads_backward: B=%d (<= %d), nb=%d, N1=%d", B, kHbMaxB, nb, N1);
+    HeadsBwd a{x1, glob6, w_cam, w_glob, w_shape, g_cam, g_glob_R, g_shape_mode, g_shape_log_std, g_pre, g_pre_t, g_w_cam, g_b_cam, g_w_glob, g_b_glob, g_w_shape, g_b_shape};
+    hipLaunchKernelGGL(k_heads_bwd, dim3((N1 + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, N1, nb, a);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -650,7 +650,13 @@ class HumaniflowModel(nn.Module):
         lib = _lib.load()
         nb, P, N = self.num_shape_params, self.num_bodyparts, int(num_samples)
 
-        if grad or not self.heads_kernel or not self._heads_kernel_supports(input_feats):
+        if (grad and self.heads_kernel and batch_size <= 128 and isinstance(self.activation, torch.nn.ELU) and self._heads_kernel_supports(input_feats)):
+            from .autograd import HeadsTrain                                             # :232-253 under autograd: library kernels forward and backward
+            cam, glob_R, shape_mode, shape_log_std = HeadsTrain.apply(input_feats, self.fc1.weight, self.fc1.bias, self.fc_cam.weight, self.fc_cam.bias,
+                                                                      self.fc_glob.weight, self.fc_glob.bias, self.fc_shape.weight, self.fc_shape.bias,
+                                                                      self.init_cam, self.init_glob)
+            shape_std = torch.exp(shape_log_std)
+        elif grad or not self.heads_kernel or not self._heads_kernel_supports(input_feats):
             x = self.activation(self.fc1(input_feats))
             cam = self.fc_cam(x) + self.init_cam                                         # :237-238
             glob = self.fc_glob(x) + self.init_glob                                      # :243-244

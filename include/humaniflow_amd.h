@@ -364,6 +364,20 @@ size_t hmf_heads_workspace_bytes(int B, int F, int N1);
 int hmf_heads(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
               const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
               float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, void* workspace, size_t workspace_bytes, void* stream);
+/* The same forward for the training step: additionally x1 (B, N1) = ELU(fc1 feats + b1) and glob6 (B, 6) = the 6-D vector before Gram-Schmidt,
+ * which hmf_heads_backward needs. */
+int hmf_heads_train(const float* feats, int B, int F, const float* w1, const float* b1, int N1, const float* w_cam, const float* b_cam, const float* init_cam,
+                    const float* w_glob, const float* b_glob, const float* init_glob, const float* w_shape, const float* b_shape, int nb, float* cam,
+                    float* glob_R, float* shape_mode, float* shape_log_std, float* shape_std, float* x1, float* glob6, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* Backward of the heads (what autograd does for models/humaniflow_model.py:232-253 in train/train_humaniflow.py:351), the part below fc1's
+ * pre-activation in ONE launch: from d loss / d {cam (B,3), glob_R (B,9), shape_mode (B,nb), shape_log_std (B,nb)} (any NULL = zero) to
+ * g_pre (B, N1) = d loss / d (fc1 pre-activation), the same transposed (N1, B), and the weight / bias gradients of fc_cam, fc_glob, fc_shape.
+ * The caller finishes with two hmf_rows_atb_batched calls: d fc1.weight = g_pre^T feats (+ column sums = d fc1.bias) and g_feats = g_pre W1
+ * (rows = N1 over g_pre_t and fc1.weight).  B <= 128.  Deterministic. */
+int hmf_heads_backward(const float* x1, const float* glob6, int B, int N1, int nb, const float* w_cam, const float* w_glob, const float* w_shape,
+                       const float* g_cam, const float* g_glob_R, const float* g_shape_mode, const float* g_shape_log_std, float* g_pre, float* g_pre_t,
+                       float* g_w_cam, float* g_b_cam, float* g_w_glob, float* g_b_glob, float* g_w_shape, float* g_b_shape, void* stream);
 
 /* OPT-IN: the same GEMM on the bf16 matrix pipe with split fp32 operands (csrc/conv_gemm_split.hip; not the default of any plan).  Every fp32
  * value x = p0 + p1 (+ p2) in bf16 pieces (round-to-nearest remainders); terms = 3: x*w ~ p0 q0 + p0 q1 + p1 q0 (product error ~2^-16 relative),

@@ -207,27 +207,50 @@ def test_full_train_step_loss_and_gradients_at_batch_72():
     # (measured: modules.40.nn.layers.0 2.4e-3, fc_flow_context.20 5.3e-4 with these seeds -- in the float32 ORACLE as much as in the kernels).
     # The bar is therefore: within 5e-4 of the float64 gradient, plus twice the float32 oracle's own distance from it.
     _, gf32, g32 = oracle(torch.float32)
-    fg = feats.cuda().requires_grad_(True)
-    model.zero_grad()
-    loss, _ = train_forward_loss(model, smpl, H.HumaniflowLoss(cfg.LOSS, 256), None, {k: v.cuda() for k, v in targets.items()}, N,
-                                 noise={k: v.cuda() for k, v in noise.items()}, input_feats=fg)
-    assert abs(loss.item() - loss_ref) <= 2e-4 * abs(loss_ref), (loss.item(), loss_ref)
-    loss.backward()
+    def run(heads_kernel):
+        model.heads_kernel = heads_kernel
+        fg = feats.cuda().requires_grad_(True)
+        model.zero_grad()
+        loss, _ = train_forward_loss(model, smpl, H.HumaniflowLoss(cfg.LOSS, 256), None, {k: v.cuda() for k, v in targets.items()}, N,
+                                     noise={k: v.cuda() for k, v in noise.items()}, input_feats=fg)
+        assert abs(loss.item() - loss_ref) <= 2e-4 * abs(loss_ref), (loss.item(), loss_ref)
+        loss.backward()
+        miss = []
 
-    def close(name, got, ref, ref32):
-        got = got.detach().double().cpu()
-        scale = max(ref.abs().max().item(), 1e-12)
-        err, slack = (got - ref).abs().max().item(), (ref32 - ref).abs().max().item()
-        assert err <= 5e-4 * scale + 2.0 * slack, '%s: |hip - f64| %.3e, |f32 oracle - f64| %.3e, scale %.3e' % (name, err, slack, scale)
-    close('d input_feats', fg.grad, gf64, gf32)
-    n = 0
-    for name, p in model.named_parameters():
-        if name.startswith('image_encoder'):
-            continue
-        assert p.grad is not None, name
-        close(name, p.grad, g64[name], g32[name])
-        n += 1
-    assert n == 424                                                              # every non-encoder parameter of the checkpoint layout
+        def close(name, got, ref, ref32):
+            got = got.detach().double().cpu()
+            scale = max(ref.abs().max().item(), 1e-12)
+            err, slack = (got - ref).abs().max().item(), (ref32 - ref).abs().max().item()
+            if err > 5e-4 * scale + 2.0 * slack:
+                miss.append((name, '%s: |hip - f64| %.3e, |f32 oracle - f64| %.3e, scale %.3e' % (name, err, slack, scale)))
+                assert err <= 1e-2 * scale, miss[-1]
+        close('d input_feats', fg.grad, gf64, gf32)
+        n = 0
+        for name, p in model.named_parameters():
+            if name.startswith('image_encoder'):
+                continue
+            assert p.grad is not None, name
+            close(name, p.grad, g64[name], g32[name])
+            n += 1
+        assert n == 424                                                          # every non-encoder parameter of the checkpoint layout
+        return miss
+    # Heads on torch operators (round 4's graph): every tensor at the bar.  Heads on the library (HeadsTrain, round 5): the forward values of cam /
+    # glob_R / shape move in their last bit, which with these seeds puts ONE sample of ONE body part (15) on the other side of a spline break point
+    # -- the same C^0 effect as above, now on the kernels' side only.  Tensors that miss the bar must then all belong to that one part (its two
+    # coupling hyper-networks pose_so3flow_transform_modules.{2p, 2p+1} and its context layer fc_flow_context.p), by no more than 1e-2 of their
+    # scale (measured: modules.30.nn.layers.2.weight 3.2e-3, fc_flow_context.15.weight 1.3e-3); everything else stays at the bar.
+    assert run(False) == []
+    miss = run(True)
+    model.heads_kernel = True
+    def part_of(name):
+        bits = name.split('.')
+        if bits[0] == 'fc_flow_context':
+            return int(bits[1])
+        if bits[0] == 'pose_so3flow_transform_modules':
+            return int(bits[1]) // 2
+        return None
+    parts = {part_of(nm) for nm, _ in miss}
+    assert len(parts) <= 1 and None not in parts, miss
 
 
 def test_train_step_from_the_proxy_input_at_configs4_size():
@@ -488,3 +511,46 @@ def test_fused_training_loss_equals_the_torch_operator_form(reduction):
     assert set(res[True][2]) == set(res[False][2])
     for n, gr in res[False][2].items():
         assert (res[True][2][n] - gr).abs().max().item() <= 2e-5 * max(gr.abs().max().item(), 1e-8), n
+
+
+@pytest.mark.parametrize('layers,B', [(18, 72), (50, 5)])
+def test_heads_under_autograd_run_on_the_library_and_match_float64_autograd(layers, B):
+    """models/humaniflow_model.py:232-253 under autograd = HeadsTrain (hmf_heads_train forward, hmf_heads_backward + two hmf_rows_atb_batched
+    calls backward): outputs and every gradient (image features, fc1, fc_cam, fc_glob, fc_shape) vs torch autograd in float64 through the
+    same arithmetic (Linear, ELU, init adds, the reference's 6-D -> rotation map from oracle/so3.py)."""
+    from humaniflow_amd.autograd import HeadsTrain
+    from oracle import so3
+    model, sd, cfg = _model(layers=layers, seed=6)
+    g = torch.Generator().manual_seed(B)
+    F = model.fc1.in_features
+    feats = (torch.randn(B, F, generator=g) * 0.5).cuda().requires_grad_(True)
+    ps = [model.fc1.weight, model.fc1.bias, model.fc_cam.weight, model.fc_cam.bias, model.fc_glob.weight, model.fc_glob.bias, model.fc_shape.weight,
+          model.fc_shape.bias]
+    for p in ps:
+        p.grad = None
+    cam, R, mode, lstd = HeadsTrain.apply(feats, *ps, model.init_cam, model.init_glob)
+    wts = [torch.randn(t.shape, generator=g).cuda() for t in (cam, R, mode, lstd)]
+    (cam * wts[0]).sum().add((R * wts[1]).sum()).add((mode * wts[2]).sum()).add((lstd * wts[3]).sum()).backward()
+    # float64 reference
+    f64 = feats.detach().double().cpu().requires_grad_(True)
+    q = [p.detach().double().cpu().requires_grad_(True) for p in ps]
+    x = torch.nn.functional.elu(f64 @ q[0].t() + q[1])
+    cam_r = x @ q[2].t() + q[3] + model.init_cam.double().cpu()
+    glob = x @ q[4].t() + q[5] + model.init_glob.double().cpu()
+    R_r = so3.rot6d_to_rotmat(glob)
+    sp = x @ q[6].t() + q[7]
+    nb = sp.shape[1] // 2
+    outs_r = (cam_r, R_r, sp[:, :nb], sp[:, nb:])
+    sum((o * w.double().cpu()).sum() for o, w in zip(outs_r, wts)).backward()
+    for name, got, ref in zip(('cam', 'glob_R', 'shape_mode', 'shape_log_std'), (cam, R, mode, lstd), outs_r):
+        assert (got.detach().double().cpu() - ref.detach().reshape(got.shape)).abs().max() < 2e-5, name
+    _check('d feats', feats.grad, f64.grad)
+    for name, p, r in zip(('fc1.weight', 'fc1.bias', 'fc_cam.weight', 'fc_cam.bias', 'fc_glob.weight', 'fc_glob.bias', 'fc_shape.weight', 'fc_shape.bias'), ps, q):
+        _check(name, p.grad, r.grad)
+    # the model's own differentiable forward takes this path (no nn.Linear for the heads): same values as the inference kernels
+    model.train()
+    out = model(None, input_feats=feats.detach().requires_grad_(True), num_samples=0, compute_point_est=False)
+    assert out['cam_wp'].grad_fn is not None and 'HeadsTrain' in type(out['cam_wp'].grad_fn).__name__
+    with torch.no_grad():
+        ref = model.eval()(None, input_feats=feats.detach(), num_samples=0, compute_point_est=False)
+    assert torch.equal(out['cam_wp'].detach(), ref['cam_wp']) and torch.equal(out['glob_rotmat'].detach(), ref['glob_rotmat'])
