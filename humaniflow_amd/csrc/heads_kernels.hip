@@ -159,10 +159,12 @@ struct HeadsBwd {
     float *g_pre, *g_pre_t, *g_w_cam, *g_b_cam, *g_w_glob, *g_b_glob, *g_w_shape, *g_b_shape;
 };
 constexpr int kHbMaxB = 128, kHbMaxO = 9 + 32;
-__global__ __launch_bounds__(64) void k_heads_bwd(int B, int N1, int nb, HeadsBwd a) {
+// block = 64 channels x 4 image quarters (wave q takes images b = q, q + 4, ...); the four partial dW_o meet in LDS and are added in a fixed order
+__global__ __launch_bounds__(256) void k_heads_bwd(int B, int N1, int nb, HeadsBwd a) {
     __shared__ float go[kHbMaxB * kHbMaxO];
-    const int NO = 9 + 2 * nb, tid = threadIdx.x;
-    for (int b = tid; b < B; b += 64) {
+    __shared__ float pdw[3][kHbMaxO][64];
+    const int NO = 9 + 2 * nb, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    for (int b = tid; b < B; b += 256) {
         float* g = go + b * NO;
 #pragma unroll
         for (int e = 0; e < 3; ++e) g[e] = a.g_cam ? a.g_cam[b * 3 + e] : 0.f;
@@ -176,34 +178,48 @@ __global__ __launch_bounds__(64) void k_heads_bwd(int B, int N1, int nb, HeadsBw
         }
     }
     __syncthreads();
-    const int n = blockIdx.x * 64 + tid;
-    if (blockIdx.x == 0)                                               // bias gradients of the small layers: column sums of g_out
-        for (int o = tid; o < NO; o += 64) {
+    const int n = blockIdx.x * 64 + lane;
+    if (blockIdx.x == 0)                                               // bias gradients of the small layers: column sums of g_out, images in order
+        for (int o = tid; o < NO; o += 256) {
             float s = 0.f;
             for (int b = 0; b < B; ++b) s += go[b * NO + o];
             (o < 3 ? a.g_b_cam + o : (o < 9 ? a.g_b_glob + (o - 3) : a.g_b_shape + (o - 9)))[0] = s;
         }
-    if (n >= N1) return;
+    const bool live = n < N1;
     float w[kHbMaxO], dw[kHbMaxO];
 #pragma unroll
     for (int o = 0; o < kHbMaxO; ++o) {
         dw[o] = 0.f;
-        w[o] = o < NO ? (o < 3 ? a.w_cam[(size_t)o * N1 + n] : (o < 9 ? a.w_glob[(size_t)(o - 3) * N1 + n] : a.w_shape[(size_t)(o - 9) * N1 + n])) : 0.f;
+        w[o] = (live && o < NO) ? (o < 3 ? a.w_cam[(size_t)o * N1 + n] : (o < 9 ? a.w_glob[(size_t)(o - 3) * N1 + n] : a.w_shape[(size_t)(o - 9) * N1 + n])) : 0.f;
     }
-    for (int b = 0; b < B; ++b) {
-        const float x = a.x1[(size_t)b * N1 + n];
-        const float* g = go + b * NO;                                   // wave-uniform: LDS broadcast
-        float gx = 0.f;
+    if (live)
+        for (int b = q; b < B; b += 4) {
+            const float x = a.x1[(size_t)b * N1 + n];
+            const float* g = go + b * NO;                               // wave-uniform: LDS broadcast
+            float gx0 = 0.f, gx1 = 0.f;
+#pragma unroll
+            for (int o = 0; o < kHbMaxO; ++o)
+                if (o < NO) {
+                    const float gv = g[o];
+                    if (o & 1) gx1 = fmaf(gv, w[o], gx1); else gx0 = fmaf(gv, w[o], gx0);
+                    dw[o] = fmaf(gv, x, dw[o]);
+                }
+            const float gx = gx0 + gx1;
+            const float gp = x > 0.f ? gx : gx * (x + 1.f);             // ELU' = 1 (pre > 0) or exp(pre) = x1 + 1
+            a.g_pre[(size_t)b * N1 + n] = gp;
+            a.g_pre_t[(size_t)n * B + b] = gp;
+        }
+    if (q > 0)
 #pragma unroll
         for (int o = 0; o < kHbMaxO; ++o)
-            if (o < NO) { gx = fmaf(g[o], w[o], gx); dw[o] = fmaf(g[o], x, dw[o]); }
-        const float gp = x > 0.f ? gx : gx * (x + 1.f);                 // ELU' = 1 (pre > 0) or exp(pre) = x1 + 1
-        a.g_pre[(size_t)b * N1 + n] = gp;
-        a.g_pre_t[(size_t)n * B + b] = gp;
-    }
+            if (o < NO) pdw[q - 1][o][lane] = dw[o];
+    __syncthreads();
+    if (q == 0 && live)
 #pragma unroll
-    for (int o = 0; o < kHbMaxO; ++o)
-        if (o < NO) (o < 3 ? a.g_w_cam + (size_t)o * N1 : (o < 9 ? a.g_w_glob + (size_t)(o - 3) * N1 : a.g_w_shape + (size_t)(o - 9) * N1))[n] = dw[o];
+        for (int o = 0; o < kHbMaxO; ++o)
+            if (o < NO)
+                (o < 3 ? a.g_w_cam + (size_t)o * N1 : (o < 9 ? a.g_w_glob + (size_t)(o - 3) * N1 : a.g_w_shape + (size_t)(o - 9) * N1))[n] =
+                    ((dw[o] + pdw[0][o][lane]) + pdw[1][o][lane]) + pdw[2][o][lane];
 }
 
 static int heads_ksplit(int F) {
@@ -271,7 +287,7 @@ int hmf_heads_backward(const float* x1, const float* glob6, int B, int N1, int n
         return fail(HMF_ERR_INVALID, "hmf_heads_backward: null argument");
     if (B <= 0 || B > kHbMaxB || nb < 1 || nb > 16 || N1 <= 0) return fail(HMF_ERR_UNSUPPORTED, "hmf_heads_backward: B=%d (<= %d), nb=%d, N1=%d", B, kHbMaxB, nb, N1);
     HeadsBwd a{x1, glob6, w_cam, w_glob, w_shape, g_cam, g_glob_R, g_shape_mode, g_shape_log_std, g_pre, g_pre_t, g_w_cam, g_b_cam, g_w_glob, g_b_glob, g_w_shape, g_b_shape};
-    hipLaunchKernelGGL(k_heads_bwd, dim3((N1 + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, N1, nb, a);
+    hipLaunchKernelGGL(k_heads_bwd, dim3((N1 + 63) / 64), dim3(256), 0, (hipStream_t)stream, B, N1, nb, a);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -60,6 +60,10 @@ struct SmplDev {
     float* tp_pack;
     double* tp_mom;
     int tp_stride;
+    // k_smpl_joints_bwd: the pose / shape / template rows of the <= kMaxJU joint vertices as a dense matrix [kPoseFeat + nb + 1][ju_bstride] (entry
+    // u * 3 + c of row k = blend[k][ju_vid[u]][c]): both of its passes stream it instead of gathering from the packed MFMA operand
+    float* ju_blend;
+    int ju_bstride;
 };
 constexpr int kMaxJU = 320;          // >= 21 picks + 255 regressor non-zeros of the reference's tables
 
@@ -967,10 +971,13 @@ __global__ __launch_bounds__(256) void k_smpl_joints_bwd(SmplDev d, const float*
         }
         const int v = d.ju_vid[u], vt = v >> 5, l31 = v & 31;
         float vp[4] = {0.f, 0.f, 0.f, 1.f};
+        const float* jb = d.ju_blend + u * 3;                         // row k of the dense joint-vertex matrix: the same values as blend_index(k, v, c)
+#pragma unroll 8
         for (int k = 0; k < kdata; ++k) {
             const float a = s_feat[k];
+            const float* r = jb + (size_t)k * d.ju_bstride;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) vp[c] = fmaf(a, d.blend[blend_index(k, v, c)], vp[c]);
+            for (int c = 0; c < 3; ++c) vp[c] = fmaf(a, r[c], vp[c]);
         }
         float T[12];
 #pragma unroll
@@ -992,11 +999,15 @@ __global__ __launch_bounds__(256) void k_smpl_joints_bwd(SmplDev d, const float*
     __syncthreads();
     for (int k = tid; k < kPoseFeat + nb; k += 256) {     // blend-shape rows of the touched vertices: d L / d pose feature, d L / d beta
         float acc = 0.f;
-        for (int u = 0; u < d.n_ju; ++u) {
-            const int v = d.ju_vid[u];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc = fmaf(d.blend[blend_index(k, v, c)], s_gvp[u][c], acc);
+        const float* r = d.ju_blend + (size_t)k * d.ju_bstride;       // contiguous row: (vertex, component) in the order of s_gvp
+        const float* gq = &s_gvp[0][0];
+        const int n3 = d.n_ju * 3;
+        int i = 0;
+        for (; i + 4 <= n3; i += 4) {
+            const f32x4 q = *(const f32x4*)(r + i);
+            acc = fmaf(q[0], gq[i], acc); acc = fmaf(q[1], gq[i + 1], acc); acc = fmaf(q[2], gq[i + 2], acc); acc = fmaf(q[3], gq[i + 3], acc);
         }
+        for (; i < n3; ++i) acc = fmaf(r[i], gq[i], acc);
         s_gfeat[k] = acc;
     }
     __syncthreads();
@@ -1204,6 +1215,15 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
                 for (int j = 0; j < nq; ++j) tpm[(size_t)3 * nq + (size_t)i * nq + j] += (double)row[i] * (double)row[j];
             }
         }
+    const int jbs = (((int)ju_vid.size() * 3 + 3) & ~3), jbk = kPoseFeat + nb + 1;
+    std::vector<float> jub((size_t)jbk * std::max(jbs, 4), 0.f);
+    for (size_t u = 0; u < ju_vid.size(); ++u)
+        for (int c = 0; c < 3; ++c) {
+            const int v = ju_vid[u];
+            for (int k = 0; k < kPoseFeat; ++k) jub[(size_t)k * jbs + u * 3 + c] = m->posedirs_host[(size_t)k * kV * 3 + v * 3 + c];
+            for (int k = 0; k < nb; ++k) jub[(size_t)(kPoseFeat + k) * jbs + u * 3 + c] = m->shapedirs_host[((size_t)v * 3 + c) * nb + k];
+            jub[(size_t)(kPoseFeat + nb) * jbs + u * 3 + c] = m->v_template_host[v * 3 + c];
+        }
     std::vector<float> blend((size_t)kVT * kKG * 3 * 64 * 4);
     pack_blend(m, blend.data());
     std::vector<unsigned short> blend16((size_t)kVT * kKG16 * 3 * 64 * 8), blend16l(blend16.size());
@@ -1219,7 +1239,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2), o_b16l = place(blend16l.size() * 2);
     const size_t o_jv = place(ju_vid.size() * 4 + 4), o_jp = place(ju_ptr.size() * 4), o_jo = place(ju_out.size() * 4 + 4), o_jw = place(ju_w.size() * 4 + 4);
     const size_t o_jsl = place(ju_slot.size() * 4), o_jrs = place(jr_slot.size() * 4 + 4);
-    const size_t o_tpp = place(tpp.size() * 4), o_tpm = place(tpm.size() * 8);
+    const size_t o_tpp = place(tpp.size() * 4), o_tpm = place(tpm.size() * 8), o_jub = place(jub.size() * 4);
     void* arena = nullptr;
     HMF_HIP(hipMalloc(&arena, off));
     char* base = (char*)arena;
@@ -1244,6 +1264,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     if (e == hipSuccess && !jr_slot.empty()) e = up(o_jrs, jr_slot.data(), jr_slot.size() * 4);
     if (e == hipSuccess) e = up(o_tpp, tpp.data(), tpp.size() * 4);
     if (e == hipSuccess) e = up(o_tpm, tpm.data(), tpm.size() * 8);
+    if (e == hipSuccess) e = up(o_jub, jub.data(), jub.size() * 4);
     if (e != hipSuccess) {
         (void)hipFree(arena);
         return fail(HMF_ERR_HIP, "hmf_smpl_create: upload failed: %s", hipGetErrorString(e));
@@ -1281,6 +1302,8 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     d.tp_pack = (float*)(base + o_tpp);
     d.tp_mom = (double*)(base + o_tpm);
     d.tp_stride = tps;
+    d.ju_blend = (float*)(base + o_jub);
+    d.ju_bstride = jbs;
     *out = h;
     return HMF_OK;
 }
