@@ -14,6 +14,8 @@ augmentation, :113-246) is data generation outside the path: `synthetic_train_ba
 import math
 import time
 
+import os
+
 import torch
 
 from . import _lib
@@ -34,6 +36,20 @@ def _xy_sign(t):
     return v
 
 
+# Measured round 5 (bench.py --train, same box, x2): 13.64-13.81 ms with the density branch on a side stream vs 13.26-13.30 ms on one stream -- the
+# forks and joins the captured graph gains (autograd adds an event pair per cross-stream edge) cost more than the 0.6 ms of latency-class
+# kernels they overlap.  Off; HMF_TRAIN_SIDE=1 turns it on for experiments.
+OVERLAP_NLL_BRANCH = os.environ.get('HMF_TRAIN_SIDE', '0') == '1'
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=None, input_feats=None):
     """targets: pose_rotmats (B,23,3,3), glob_rotmats (B,3,3), shape (B,nb), joints2D (B,17,2) pixels, joints2D_vis (B,17) bool.
     Returns (loss, pred).  J2D_LOSS_ON = 'point_est+samples' | 'samples' | 'point_est' as LOSS.J2D_LOSS_ON."""
@@ -48,8 +64,21 @@ def train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples
         # :283-343 in two launches (csrc/train_loss.hip): joint selection, flip, projection and the four loss terms with their gradients; as torch
         # operators the same arithmetic is ~150 launches of a few hundred elements each (and the reference's own loop)
         from .autograd import FusedTrainLoss
-        pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True)
-        lp = criterion.pose_log_probs(dists, targets['pose_rotmats'].double())
+        # The pose NLL (teacher-forced densities) and the reprojection term (samples -> SMPL joints) are independent branches between the heads and the
+        # loss, and both are latency-class launches: the density branch CAN run on a side stream, forward and -- autograd replays a node on the stream
+        # of its forward -- backward (k_flow_logprob / _bwd: 0.6 ms of a step).  Measured slower (see OVERLAP_NLL_BRANCH): off by default.
+        if OVERLAP_NLL_BRANCH:
+            cur = torch.cuda.current_stream(joints_dev := pred['glob_rotmat'].device)
+            side = _side_stream(joints_dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                lp = criterion.pose_log_probs(dists, targets['pose_rotmats'].double())
+            pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True)
+            cur.wait_stream(side)
+            lp.record_stream(cur)
+        else:
+            pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True)
+            lp = criterion.pose_log_probs(dists, targets['pose_rotmats'].double())
         W = cfg_l.WEIGHTS
         loss = FusedTrainLoss.apply(lp, pred['shape_mode'], pred['shape_log_std'], joints, pred['cam_wp'], pred['glob_rotmat'], targets['shape'],
                                     targets['joints2D'], targets['joints2D_vis'], targets['glob_rotmats'], N, ALL_JOINTS_TO_COCO_MAP, criterion.img_wh,

@@ -52,6 +52,9 @@ pmc_pair() {   # $1 = tag, $2 = workload label, rest = bench flags
 if [ "${HMF_PROFILE_FLAVOURS:-1}" = "1" ] && [ "$PART" != "main" ]; then
     pmc_pair eval "B=32,N=100,fp32,eval" --eval
     python bench.py --eval --no-cpu-baseline > "$OUT/${R}_bench_eval_configs3.json" 2> "$OUT/${R}_bench_eval.log"
+    # the eval step on ONE stream, eagerly: which kernels the evaluation epilogue adds to the predict step (no at::native row should be left inside a step)
+    rocprofv3 --kernel-trace --stats -d /tmp/prof_e1 -o e1 -- python bench.py --eval --steps 20 --warmup 4 --no-cpu-baseline --profile-steps 0 --streams 1 --no-graph > /dev/null 2>/tmp/e1.log
+    python tools/rocpd_stats.py "$(find /tmp/prof_e1 -name '*.db' | head -1)" 70 --steps 20 > "$OUT/${R}_eval_kernel_stats_1stream.md"
     pmc_pair bf16 "B=64,N=100,bf16" --batch 64 --blend-dtype bf16
     python bench.py --batch 64 --blend-dtype bf16 --no-cpu-baseline > "$OUT/${R}_bench_configs2_bf16_B64.json" 2> "$OUT/${R}_bench_bf16.log"
     pmc_pair train "train,B=72,N=8" --train
