@@ -5,7 +5,7 @@ set -u
 T=${1:-r04}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/profiles
-B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-steps 0 --streams 1 --no-graph"
+B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 --streams 1 --no-graph"
 rm -rf /tmp/pp_a /tmp/pp_b
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d /tmp/pp_a -o a -- $B >/dev/null 2>/tmp/pp_a.log
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d /tmp/pp_b -o b -- $B >/dev/null 2>/tmp/pp_b.log

@@ -9,9 +9,9 @@ OUT=$PWD/gpurun_out/profiles
 mkdir -p "$OUT"
 STEPS=30; WARM=6
 # the profiled command = the default bench without its trailing measurement pass / CPU baseline, so that the timed region ends the process
-BENCH="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --profile-steps 0"
+BENCH="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-secondary --profile-steps 0"
 # counter passes serialise every dispatch: a few steps carry every kernel of the step often enough
-PMCBENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-steps 0"
+PMCBENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0"
 stamp() { echo "[$(date +%H:%M:%S)] $*"; }
 PART=${HMF_PROFILE_PART:-all}          # all | main | flavours (two gpurun calls when one would exceed its time limit)
 if [ "$PART" != "flavours" ]; then
