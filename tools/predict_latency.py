@@ -1,7 +1,7 @@
 """Latency of the `predict` shape (predict/predict_humaniflow.py:112-131: one image, N = 10 hierarchical samples, point estimate + samples through
 SMPL): nothing hides a kernel behind another batch here, so this is where the latency-class flow kernels (k_flow_ctx0 / k_flow_chain: eight
 dependent rounds of the kinematic tree) show.  Reports the step eagerly on one stream, as a replayed HIP graph, and per library kernel.
-    python tools/predict_latency.py [B] [N]"""
+    python tools/predict_latency.py [B] [N] [resnet layers: 18 (the reference's default) | 50]"""
 import os
 import sys
 
@@ -17,6 +17,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 lib = _lib.load()
 dev = torch.device('cuda:0')
 cfg = H.get_humaniflow_cfg_defaults()
+if len(sys.argv) > 3:
+    cfg.MODEL.NUM_RESNET_LAYERS = int(sys.argv[3])            # default: the reference's configuration default (configs/humaniflow_config.py: 18)
 torch.manual_seed(0)
 model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).eval().to(dev)
 smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=B, create_transl=False).to(dev)
@@ -43,7 +45,7 @@ def timed(fn, reps=50):
     return a.elapsed_time(b) / reps * 1e3
 
 
-print('predict shape: B = %d image(s), N = %d samples, ResNet-50 + heads + flow + SMPL (M = %d bodies), fp32' % (B, N, B * N + B))
+print('predict shape: B = %d image(s), N = %d samples, ResNet-%d + heads + flow + SMPL (M = %d bodies), fp32' % (B, N, cfg.MODEL.NUM_RESNET_LAYERS, B * N + B))
 print('eager, one stream            : %8.1f us per step (host-issue bound: ~60 launches)' % timed(step))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
