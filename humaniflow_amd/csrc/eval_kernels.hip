@@ -191,18 +191,22 @@ __device__ inline void accumulate17(double* s, float px, float py, float pz, flo
     s[14] += (double)pz * tx; s[15] += (double)pz * ty; s[16] += (double)pz * tz;
 }
 
+// Distances of the error and diversity sums: v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf expansion (~20 instructions, three per point in
+// the error pass: it was most of that pass' VALU time).  Mean distances of ~1e-2 m against a 2e-5 relative bar; sqrt(0) stays an exact 0.
+__device__ __forceinline__ float dist_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 __device__ inline void errors3(const Align& al, int want_pa, float px, float py, float pz, float tx, float ty, float tz, double& e0, double& e1, double& e2) {
     float dx = px - tx, dy = py - ty, dz = pz - tz;
-    e0 += sqrtf(dx * dx + dy * dy + dz * dz);
+    e0 += dist_sqrt(dx * dx + dy * dy + dz * dz);
     dx = (px - al.mu_p[0]) * al.sc_a + al.mu_t[0] - tx;
     dy = (py - al.mu_p[1]) * al.sc_a + al.mu_t[1] - ty;
     dz = (pz - al.mu_p[2]) * al.sc_a + al.mu_t[2] - tz;
-    e1 += sqrtf(dx * dx + dy * dy + dz * dz);
+    e1 += dist_sqrt(dx * dx + dy * dy + dz * dz);
     if (want_pa) {
         dx = al.pa_s * (al.R[0] * px + al.R[1] * py + al.R[2] * pz) + al.pa_t[0] - tx;
         dy = al.pa_s * (al.R[3] * px + al.R[4] * py + al.R[5] * pz) + al.pa_t[1] - ty;
         dz = al.pa_s * (al.R[6] * px + al.R[7] * py + al.R[8] * pz) + al.pa_t[2] - tz;
-        e2 += sqrtf(dx * dx + dy * dy + dz * dz);
+        e2 += dist_sqrt(dx * dx + dy * dy + dz * dz);
     }
 }
 
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256) void k_sample_diversity_reg(const float* __res
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const float dx = q[k][0] - m0, dy = q[k][1] - m1, dz = q[k][2] - m2;
-        l2 += (ok && w + 4 * k < N) ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f;
+        l2 += (ok && w + 4 * k < N) ? dist_sqrt(dx * dx + dy * dy + dz * dz) : 0.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) l2 += __shfl_down(l2, o, 64);
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(64) void k_sample_diversity(const float* __restrict
         for (int n = 0; n < N; ++n) {
             const float* q = s + (size_t)n * npts * 3;
             const float dx = q[0] - m0, dy = q[1] - m1, dz = q[2] - m2;
-            l2 += sqrtf(dx * dx + dy * dy + dz * dz);
+            l2 += dist_sqrt(dx * dx + dy * dy + dz * dz);
         }
     }
 #pragma unroll

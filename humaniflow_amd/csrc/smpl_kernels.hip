@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void k_smpl_joints_bwd(SmplDev d, const float*
                                                          const float* __restrict__ betas, int M, const float* __restrict__ g_joints,
                                                          float* __restrict__ g_glob, float* __restrict__ g_body, float* __restrict__ g_betas) {
     __shared__ float sR[kJ][9], sJ[kJ][3], sG[kJ][12], sA[kJ][12], s_gA[kJ][12], s_gG[kJ][12], s_gJ[kJ][3], s_gR[kJ][9];
-    __shared__ float s_gj[kOutJ][3], s_feat[kKpad], s_gfeat[kKpad], s_gvp[kMaxJU][3];
+    __shared__ float s_gj[kOutJ][3], s_feat[kKpad], s_gfeat[kKpad], s_gvp[kMaxJU][3], s_gJrel[kJ][3];
     const int tid = threadIdx.x, row = blockIdx.x, nb = d.num_betas;
     const float* beta = betas + (size_t)row * nb;
     for (int i = tid; i < kJ * 9; i += 256) {
@@ -938,26 +938,28 @@ __global__ __launch_bounds__(256) void k_smpl_joints_bwd(SmplDev d, const float*
     }
     __syncthreads();
     for (int k = tid; k < kKpad; k += 256) { s_feat[k] = pose_feature(k, nb, &sR[1][0], beta); s_gfeat[k] = 0.f; }
-    if (tid == 0) {                                     // smplx batch_rigid_transform, sequential over the 24 joints
-        for (int j = 0; j < kJ; ++j) {
+    __syncthreads();
+    // smplx batch_rigid_transform, level by level of the kinematic tree (depth <= 8 for SMPL): thread = (joint, element of its 3 x 4 transform), the same
+    // expressions as the one-thread loop this replaces (two serial 24-joint chains through LDS were ~100 us of the kernel's 170)
+    for (int L = 0; L <= d.depth_max; ++L) {
+        for (int idx = tid; idx < kJ * 12; idx += 256) {
+            const int j = idx / 12, e = idx - j * 12, i = e >> 2, c = e & 3;
+            if (d.depth[j] != L) continue;
             const int par = d.parents[j];
-            float rel[3] = {sJ[j][0], sJ[j][1], sJ[j][2]};
-            if (j > 0) { rel[0] -= sJ[par][0]; rel[1] -= sJ[par][1]; rel[2] -= sJ[par][2]; }
-            for (int i = 0; i < 3; ++i) {
-                if (j == 0) {
-                    for (int c = 0; c < 3; ++c) sG[0][i * 4 + c] = sR[0][i * 3 + c];
-                    sG[0][i * 4 + 3] = rel[i];
-                } else {
-                    for (int c = 0; c < 3; ++c)
-                        sG[j][i * 4 + c] = sG[par][i * 4 + 0] * sR[j][0 * 3 + c] + sG[par][i * 4 + 1] * sR[j][1 * 3 + c] + sG[par][i * 4 + 2] * sR[j][2 * 3 + c];
-                    sG[j][i * 4 + 3] = sG[par][i * 4 + 0] * rel[0] + sG[par][i * 4 + 1] * rel[1] + sG[par][i * 4 + 2] * rel[2] + sG[par][i * 4 + 3];
-                }
-            }
-            for (int i = 0; i < 3; ++i) {
-                for (int c = 0; c < 3; ++c) sA[j][i * 4 + c] = sG[j][i * 4 + c];
-                sA[j][i * 4 + 3] = sG[j][i * 4 + 3] - (sG[j][i * 4 + 0] * sJ[j][0] + sG[j][i * 4 + 1] * sJ[j][1] + sG[j][i * 4 + 2] * sJ[j][2]);
+            if (j == 0) {
+                sG[0][e] = c < 3 ? sR[0][i * 3 + c] : sJ[0][i];
+            } else if (c < 3) {
+                sG[j][e] = sG[par][i * 4 + 0] * sR[j][0 * 3 + c] + sG[par][i * 4 + 1] * sR[j][1 * 3 + c] + sG[par][i * 4 + 2] * sR[j][2 * 3 + c];
+            } else {
+                const float rel[3] = {sJ[j][0] - sJ[par][0], sJ[j][1] - sJ[par][1], sJ[j][2] - sJ[par][2]};
+                sG[j][e] = sG[par][i * 4 + 0] * rel[0] + sG[par][i * 4 + 1] * rel[1] + sG[par][i * 4 + 2] * rel[2] + sG[par][i * 4 + 3];
             }
         }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < kJ * 12; idx += 256) {
+        const int j = idx / 12, e = idx - j * 12, i = e >> 2, c = e & 3;
+        sA[j][e] = c < 3 ? sG[j][e] : sG[j][i * 4 + 3] - (sG[j][i * 4 + 0] * sJ[j][0] + sG[j][i * 4 + 1] * sJ[j][1] + sG[j][i * 4 + 2] * sJ[j][2]);
     }
     __syncthreads();
     // ---- the vertices the gathered joints read: joint gradient -> vertex gradient -> skinning blend / posed-vertex gradients ----
@@ -1011,41 +1013,66 @@ __global__ __launch_bounds__(256) void k_smpl_joints_bwd(SmplDev d, const float*
         s_gfeat[k] = acc;
     }
     __syncthreads();
-    if (tid == 0) {                                     // reverse of the chain
-        for (int j = 0; j < kJ; ++j) {
-            // A_R = G_R, A_t = G_t - G_R J;  posed joint j = G_t
-            for (int i = 0; i < 3; ++i) {
-                const float gat = s_gA[j][i * 4 + 3];
-                for (int c = 0; c < 3; ++c) {
-                    s_gG[j][i * 4 + c] = s_gA[j][i * 4 + c] - gat * sJ[j][c];
-                    s_gJ[j][c] -= sG[j][i * 4 + c] * gat;
-                }
-                s_gG[j][i * 4 + 3] = gat + s_gj[j][i];
-            }
-        }
-        for (int j = kJ - 1; j >= 1; --j) {
-            const int par = d.parents[j];
-            const float rel[3] = {sJ[j][0] - sJ[par][0], sJ[j][1] - sJ[par][1], sJ[j][2] - sJ[par][2]};
-            for (int a = 0; a < 3; ++a)                 // g_R_j = G_R_par^T g_G_R_j
-                for (int c = 0; c < 3; ++c)
-                    s_gR[j][a * 3 + c] = sG[par][0 * 4 + a] * s_gG[j][0 * 4 + c] + sG[par][1 * 4 + a] * s_gG[j][1 * 4 + c] + sG[par][2 * 4 + a] * s_gG[j][2 * 4 + c];
-            for (int a = 0; a < 3; ++a) {               // g_rel = G_R_par^T g_G_t_j
-                const float gr = sG[par][0 * 4 + a] * s_gG[j][0 * 4 + 3] + sG[par][1 * 4 + a] * s_gG[j][1 * 4 + 3] + sG[par][2 * 4 + a] * s_gG[j][2 * 4 + 3];
-                s_gJ[j][a] += gr;
-                s_gJ[par][a] -= gr;
-            }
-            for (int i = 0; i < 3; ++i) {               // g_G_R_par += g_G_R_j R_j^T + g_G_t_j (x) rel;  g_G_t_par += g_G_t_j
-                for (int a = 0; a < 3; ++a)
-                    s_gG[par][i * 4 + a] += s_gG[j][i * 4 + 0] * sR[j][a * 3 + 0] + s_gG[j][i * 4 + 1] * sR[j][a * 3 + 1] + s_gG[j][i * 4 + 2] * sR[j][a * 3 + 2]
-                                            + s_gG[j][i * 4 + 3] * rel[a];
-                s_gG[par][i * 4 + 3] += s_gG[j][i * 4 + 3];
-            }
-        }
-        for (int i = 0; i < 3; ++i) {
-            for (int c = 0; c < 3; ++c) s_gR[0][i * 3 + c] = s_gG[0][i * 4 + c];
-            s_gJ[0][i] += s_gG[0][i * 4 + 3];
-        }
+    // ---- reverse of the chain, level by level from the leaves.  Same expressions and the same per-accumulator order as the one-thread loop it
+    // replaces (j = 23 .. 1: a parent receives its children in DESCENDING index order, after its own descendants are complete).
+    for (int idx = tid; idx < kJ * 3; idx += 256) {                   // A_R = G_R, A_t = G_t - G_R J;  posed joint j = G_t
+        const int j = idx / 3, i = idx - j * 3;
+        const float gat = s_gA[j][i * 4 + 3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_gG[j][i * 4 + c] = s_gA[j][i * 4 + c] - gat * sJ[j][c];
+        s_gG[j][i * 4 + 3] = gat + s_gj[j][i];
     }
+    __syncthreads();
+    for (int idx = tid; idx < kJ * 3; idx += 256) {                   // s_gJ[j][c] -= G_R[i][c] * g_A_t[i], i = 0, 1, 2 in order
+        const int j = idx / 3, c = idx - j * 3;
+        float acc = s_gJ[j][c];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc -= sG[j][i * 4 + c] * s_gA[j][i * 4 + 3];
+        s_gJ[j][c] = acc;
+    }
+    __syncthreads();
+    float (*s_gr)[3] = s_gJrel;                                        // g_rel of every joint (LDS)
+    for (int L = d.depth_max; L >= 1; --L) {
+        // step A: joints of level L (their s_gG is final): g_R_j = G_R_par^T g_G_R_j, g_rel = G_R_par^T g_G_t_j, s_gJ[j] += g_rel
+        for (int idx = tid; idx < kJ * 12; idx += 256) {
+            const int j = idx / 12, e = idx - j * 12;
+            if (j == 0 || d.depth[j] != L) continue;
+            const int par = d.parents[j];
+            if (e < 9) {
+                const int a = e / 3, c = e - a * 3;
+                s_gR[j][a * 3 + c] = sG[par][0 * 4 + a] * s_gG[j][0 * 4 + c] + sG[par][1 * 4 + a] * s_gG[j][1 * 4 + c] + sG[par][2 * 4 + a] * s_gG[j][2 * 4 + c];
+            } else {
+                const int a = e - 9;
+                const float gr = sG[par][0 * 4 + a] * s_gG[j][0 * 4 + 3] + sG[par][1 * 4 + a] * s_gG[j][1 * 4 + 3] + sG[par][2 * 4 + a] * s_gG[j][2 * 4 + 3];
+                s_gr[j][a] = gr;
+                s_gJ[j][a] += gr;
+            }
+        }
+        __syncthreads();
+        // step B: parents at level L - 1 gather their level-L children in descending index order
+        for (int idx = tid; idx < kJ * 15; idx += 256) {
+            const int p = idx / 15, e = idx - p * 15;
+            if (d.depth[p] != L - 1) continue;
+            for (int j = kJ - 1; j > p; --j) {
+                if (d.parents[j] != p) continue;
+                if (e < 12) {
+                    const int i = e >> 2, a = e & 3;
+                    if (a < 3) {
+                        const float rel_a = sJ[j][a] - sJ[p][a];
+                        s_gG[p][i * 4 + a] += s_gG[j][i * 4 + 0] * sR[j][a * 3 + 0] + s_gG[j][i * 4 + 1] * sR[j][a * 3 + 1] + s_gG[j][i * 4 + 2] * sR[j][a * 3 + 2]
+                                              + s_gG[j][i * 4 + 3] * rel_a;
+                    } else {
+                        s_gG[p][i * 4 + 3] += s_gG[j][i * 4 + 3];
+                    }
+                } else {
+                    s_gJ[p][e - 12] -= s_gr[j][e - 12];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 9) s_gR[0][tid] = s_gG[0][(tid / 3) * 4 + (tid % 3)];
+    if (tid >= 64 && tid < 67) s_gJ[0][tid - 64] += s_gG[0][(tid - 64) * 4 + 3];
     __syncthreads();
     for (int i = tid; i < 9; i += 256) g_glob[(size_t)row * 9 + i] = s_gR[0][i];
     for (int i = tid; i < kPoseFeat; i += 256) g_body[(size_t)row * kPoseFeat + i] = s_gR[1 + i / 9][i % 9] + s_gfeat[i];
