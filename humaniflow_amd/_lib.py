@@ -89,6 +89,8 @@ _SIGS = {
     'hmf_heads_train': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_int] + [_VP] * 8 + [C.c_int] + [_VP] * 8 + [C.c_size_t, _VP]),
     'hmf_heads_backward': (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int] + [_VP] * 16),
     'hmf_flow_isgc': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP, _VP]),
+    'hmf_flow_isgc_train': (C.c_int, [_VP] * 7 + [C.c_int, C.c_int, _VP, _VP, _VP]),
+    'hmf_flow_isgc_train_backward': (C.c_int, [_VP] * 4 + [C.c_int, C.c_int] + [_VP] * 6),
     'hmf_flow_context': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_SO3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_so3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),

@@ -355,6 +355,65 @@ class Rot6dToRotmat(torch.autograd.Function):
         return gx.reshape(x.shape).to(x.dtype)
 
 
+class IsgcTrain(torch.autograd.Function):
+    """compute_input_shape_glob_cam_feats (models/humaniflow_model.py:116-150) under autograd for BOTH uses of a training pass -- the per-sample rows of the
+    reparameterised samples (:302-311, predicted global rotation) and the teacher-forced rows (:279-283, target global rotation, target shape) -- on the
+    library: forward hmf_flow_isgc_train (three launches), backward hmf_flow_isgc_train_backward (two) + hmf_rows_atb_batched for every dense product.
+    Round 4 ran it as F.linear x 5 + cat + ELU on torch operators: the one vendor GEMM kernel left in a training step and ~45 small launches.
+    Reads the layer's weights from the flow handle's arena (kept in step with the parameters by HumaniflowModel._flow_handle), returns the gradient
+    w.r.t. the parameter tensors."""
+
+    @staticmethod
+    def forward(ctx, model, feats, W, bias, glob_R, cam, shape_samples, glob_R_ll, shape_ll):
+        lib = _lib.load()
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        feats_, R_, cam_, ss_, Rl_, sl_ = f(feats), f(glob_R).reshape(-1, 9), f(cam), f(shape_samples), f(glob_R_ll).reshape(-1, 9), f(shape_ll)
+        B, N, nb = ss_.shape
+        dev = feats_.device
+        pre = torch.empty(2, B, 256, dtype=torch.float32, device=dev)
+        H = torch.empty(B * N + B, 256, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.hmf_flow_isgc_train(model._flow_handle(dev), _lib.dptr(feats_), _lib.dptr(R_), _lib.dptr(Rl_), _lib.dptr(cam_), _lib.dptr(ss_),
+                                               _lib.dptr(sl_), B, N, _lib.dptr(pre), _lib.dptr(H), _lib.current_stream()), 'hmf_flow_isgc_train')
+        rc = torch.cat([torch.cat([Rl_, cam_], dim=1), torch.cat([R_, cam_], dim=1)], dim=0)          # (2B, 12): teacher-forced rows, then sample-path rows
+        shapes = torch.cat([ss_.reshape(B * N, nb), sl_], dim=0)
+        ctx.save_for_backward(feats_, W.detach(), H, rc, shapes)
+        ctx.model, ctx.dims = model, (B, N, nb)
+        ctx.needs = (feats.requires_grad, glob_R.requires_grad, cam.requires_grad, shape_samples.requires_grad)
+        return H[:B * N].view(B, N, 256), H[B * N:]
+
+    @staticmethod
+    def backward(ctx, g_rows, g_ll):
+        lib = _lib.load()
+        feats, W, H, rc, shapes = ctx.saved_tensors
+        B, N, nb = ctx.dims
+        Fd, in_dim = feats.shape[1], W.shape[1]
+        dev = feats.device
+        f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        g_rows, g_ll = f(g_rows), f(g_ll)
+        new = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        delta, g_pre_f, g_pre_f_t, g_pre_s_t, g_shape = new(B * N + 2 * B, 256), new(B, 256), new(256, B), new(256, B), new(B * N + B, nb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.hmf_flow_isgc_train_backward(ctx.model._flow_handle(dev), _lib.dptr(H), _lib.dptr(g_rows), _lib.dptr(g_ll), B, N, _lib.dptr(delta),
+                                                        _lib.dptr(g_pre_f), _lib.dptr(g_pre_f_t), _lib.dptr(g_pre_s_t), _lib.dptr(g_shape),
+                                                        _lib.current_stream()), 'hmf_flow_isgc_train_backward')
+        Wc = W.to(torch.float32)
+        assert Wc.is_contiguous()
+        gW = new(256, in_dim)
+        gWf, gb = _atb(g_pre_f, feats, 1, B, 256, Fd, 256, Fd, 0, 0, True)                       # d W[:, :F], d bias
+        gWs = _atb(delta, shapes, 1, B * N + B, 256, nb, 256, nb, 0, 0, False)[0]                # d W[:, F:F+nb]
+        gWrc = _atb(delta[B * N:], rc, 1, 2 * B, 256, 12, 256, 12, 0, 0, False)[0]               # d W[:, F+nb:]: teacher-forced rows + g_pre_s rows
+        gW[:, :Fd] = gWf[0]
+        gW[:, Fd:Fd + nb] = gWs[0]
+        gW[:, Fd + nb:] = gWrc[0]
+        need_f, need_R, need_c, need_s = ctx.needs
+        g_feats = _atb(g_pre_f_t, Wc, 1, 256, B, Fd, B, in_dim, 0, 0, False)[0][0] if need_f else None
+        g_R = _atb(g_pre_s_t, Wc[:, Fd + nb:], 1, 256, B, 9, B, in_dim, 0, 0, False)[0][0].view(B, 3, 3) if need_R else None
+        g_cam = _atb(g_pre_f_t, Wc[:, Fd + nb + 9:], 1, 256, B, 3, B, in_dim, 0, 0, False)[0][0] if need_c else None
+        g_ss = g_shape[:B * N].view(B, N, nb) if need_s else None
+        return None, g_feats, gW, gb[0], g_R, g_cam, g_ss, None, None
+
+
 class HeadsTrain(torch.autograd.Function):
     """models/humaniflow_model.py:232-253 under autograd on the library: forward = hmf_heads_train (fc1 + ELU, fc_cam / fc_glob / fc_shape, init adds,
     6-D -> rotation: two launches), backward = hmf_heads_backward (everything below fc1's pre-activation, one launch) + two hmf_rows_atb_batched

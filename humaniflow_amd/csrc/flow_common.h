@@ -56,7 +56,7 @@ struct FlowDev {
     const float* arena;
     const PartTab* tab;              // [23] device copy
     const int* anc_off;              // [23][64] float offset of flattened ancestor entry k (kAncZero = pad)
-    int o_wisgc, o_bisgc, o_wbeta;   // natural [256][in_dim], [256], [256][nb]
+    int o_wisgc, o_bisgc, o_wbeta;   // natural [256][in_dim], [256]; o_wbeta: W[:, F:F+nb] in MFMA A-operand order (k_flow_ctx0)
     Levels lev;
 };
 

@@ -62,6 +62,71 @@ __global__ __launch_bounds__(256) void k_isgc(FlowDev d, const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The isgc layer under autograd (training step; models/humaniflow_model.py:116-150 differentiated by the reference's autograd).
+// Forward: pre[u][b] = W.[f_b, 0, vec(R^u_b), cam_b] + bias (k_isgc without shape / ELU) for the two uses of a training pass -- u = 0 the sample path with
+// the PREDICTED global rotation, u = 1 the teacher-forced path with the TARGET one (:279-283) -- then one row kernel for both:
+//   H[row] = ELU(pre[use of row][image of row] + W_beta . shape[row]),  rows = the B N per-sample shapes, then the B teacher-forced shapes.
+// Backward: delta = g_H * ELU'(H) per row (stored for the dense weight-gradient reductions), g_pre_s[b] = sum of an image's sample rows of delta (fixed
+// order), g_pre_f = g_pre_s + delta_ll (what reaches the shared image-feature product), g_shape[row] = W_beta^T delta[row].  The dense products with the
+// image features and W stay calls of hmf_rows_atb_batched.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_isgc_rows(FlowDev d, const float* __restrict__ pre, const float* __restrict__ shape_rows, const float* __restrict__ shape_ll,
+                                                   int B, int N, float* __restrict__ H) {
+    const int row = blockIdx.x, o = threadIdx.x, BN = B * N, nb = d.nb;
+    const int b = row < BN ? row / N : row - BN;
+    const float* sh = row < BN ? shape_rows + (size_t)row * nb : shape_ll + (size_t)(row - BN) * nb;      // wave-uniform
+    const float* wb = d.arena + d.o_wisgc + (size_t)o * d.in_dim + d.feat_dim;       // W[o][F : F + nb] of the natural copy (o_wbeta is in MFMA operand order)
+    float acc = pre[((size_t)(row < BN ? 0 : B) + b) * kIsgc + o];
+    for (int k = 0; k < nb; ++k) acc = fmaf(wb[k], sh[k], acc);
+    H[(size_t)row * kIsgc + o] = elu1(acc);
+}
+// thread (image b, channel o): deltas of the image's N sample rows and of its teacher-forced row.  `delta` has (B N + 2 B) rows: sample rows, teacher-forced
+// rows, then g_pre_s -- so that rows [B N, B N + 2 B) are one contiguous operand for the [vec(R), cam] weight gradient.
+__global__ __launch_bounds__(256) void k_isgc_bwd_delta(const float* __restrict__ H, const float* __restrict__ gH_rows, const float* __restrict__ gH_ll, int B, int N,
+                                                        float* __restrict__ delta, float* __restrict__ g_pre_f, float* __restrict__ g_pre_f_t,
+                                                        float* __restrict__ g_pre_s_t) {
+    const int b = blockIdx.x, o = threadIdx.x, BN = B * N;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const size_t row = (size_t)b * N + n;
+        float dl = 0.f;
+        if (gH_rows) {
+            const float g = gH_rows[row * kIsgc + o], h = H[row * kIsgc + o];
+            dl = h > 0.f ? g : g * (h + 1.f);                          // ELU' = 1 (pre > 0) or exp(pre) = H + 1
+        }
+        delta[row * kIsgc + o] = dl;
+        acc += dl;
+    }
+    float dll = 0.f;
+    if (gH_ll) {
+        const float g = gH_ll[(size_t)b * kIsgc + o], h = H[((size_t)BN + b) * kIsgc + o];
+        dll = h > 0.f ? g : g * (h + 1.f);
+    }
+    delta[((size_t)BN + b) * kIsgc + o] = dll;
+    delta[((size_t)BN + B + b) * kIsgc + o] = acc;                       // g_pre_s
+    g_pre_s_t[(size_t)o * B + b] = acc;
+    g_pre_f[(size_t)b * kIsgc + o] = acc + dll;
+    g_pre_f_t[(size_t)o * B + b] = acc + dll;
+}
+// thread (row, k): g_shape[row][k] = sum_o delta[row][o] W_beta[o][k]
+__global__ __launch_bounds__(256) void k_isgc_bwd_shape(FlowDev d, const float* __restrict__ delta, int rows, float* __restrict__ g_shape) {
+    const int gid = blockIdx.x * 256 + threadIdx.x, nb = d.nb;
+    if (gid >= rows * nb) return;
+    const int row = gid / nb, k = gid - row * nb;
+    const float* dl = delta + (size_t)row * kIsgc;
+    const float* wb = d.arena + d.o_wisgc + d.feat_dim + k;          // W[o][F + k] of the natural copy
+    const size_t ld = d.in_dim;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int o = 0; o < kIsgc; o += 4) {
+        a0 = fmaf(dl[o], wb[(size_t)o * ld], a0);
+        a1 = fmaf(dl[o + 1], wb[(size_t)(o + 1) * ld], a1);
+        a2 = fmaf(dl[o + 2], wb[(size_t)(o + 2) * ld], a2);
+        a3 = fmaf(dl[o + 3], wb[(size_t)(o + 3) * ld], a3);
+    }
+    g_shape[gid] = (a0 + a1) + (a2 + a3);
+}
+
 // The pass' base noise as tensors (training keeps them for the reverse sweep; tests compare them with torch.randn): the same generator calls the
 // sampling kernels make in registers, materialised by one launch.
 __global__ void k_rng_snapshot(RngPass rng_imm, unsigned long long* __restrict__ rng_state, unsigned long long rng_inc, RngPass* __restrict__ rng_pass,
@@ -1125,6 +1190,35 @@ int hmf_flow_isgc(const hmf_flow_t* h, const float* feats, const float* shape, c
     const int nw = kIsgc * ((B + 7) / 8);
     hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, feats, shape, glob_R, cam, B, 1, isgc, RngPass{},
                        (unsigned long long*)nullptr, 0ull, (RngPass*)nullptr, (unsigned long long*)nullptr);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_isgc_train(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* glob_R_ll, const float* cam, const float* shape_rows,
+                        const float* shape_ll, int B, int N, float* pre, float* H, void* stream) {
+    if (!h || !feats || !glob_R || !glob_R_ll || !cam || !pre || !H || B <= 0 || N < 1 || !shape_rows || !shape_ll)
+        return fail(HMF_ERR_INVALID, "hmf_flow_isgc_train: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = kIsgc * ((B + 7) / 8);
+    for (int u = 0; u < 2; ++u) {
+        hipLaunchKernelGGL(k_isgc, dim3((nw + 3) / 4), dim3(256), 0, st, h->d, feats, (const float*)nullptr, u ? glob_R_ll : glob_R, cam, B, 0,
+                           pre + (size_t)u * B * kIsgc, RngPass{}, (unsigned long long*)nullptr, 0ull, (RngPass*)nullptr, (unsigned long long*)nullptr);
+        HMF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_isgc_rows, dim3(B * N + B), dim3(256), 0, st, h->d, pre, shape_rows, shape_ll, B, N, H);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_isgc_train_backward(const hmf_flow_t* h, const float* H, const float* g_H_rows, const float* g_H_ll, int B, int N, float* delta, float* g_pre_f,
+                                 float* g_pre_f_t, float* g_pre_s_t, float* g_shape, void* stream) {
+    if (!h || !H || !delta || !g_pre_f || !g_pre_f_t || !g_pre_s_t || !g_shape || B <= 0 || N < 1)
+        return fail(HMF_ERR_INVALID, "hmf_flow_isgc_train_backward: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_isgc_bwd_delta, dim3(B), dim3(256), 0, st, H, g_H_rows, g_H_ll, B, N, delta, g_pre_f, g_pre_f_t, g_pre_s_t);
+    HMF_LAUNCH_CHECK();
+    const int rows = B * N + B, n = rows * h->d.nb;
+    hipLaunchKernelGGL(k_isgc_bwd_shape, dim3((n + 255) / 256), dim3(256), 0, st, h->d, delta, rows, g_shape);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -21,6 +21,7 @@ Training (BASELINE configs[4]): forward under autograd returns differentiable sa
 passes of the flow live in csrc/flow_grad.hip and are wired up in autograd.py.
 """
 import ctypes as C
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -398,6 +399,7 @@ class HumaniflowModel(nn.Module):
 
     # ---- heads + base noise ------------------------------------------------------------------------------------------
     flow_chain32 = None      # None: by size (k_flow_chain16 up to 1,024 rows, the 32-row k_flow_chain beyond); True / False force one: cross-checks, tools
+    isgc_kernel = os.environ.get('HMF_ISGC_TRAIN', '1') != '0'      # training: both uses of the isgc layer on autograd.IsgcTrain (False: torch operators)
     heads_kernel = True      # inference: fc1 + ELU + fc_cam / fc_glob / fc_shape + init adds + 6D->R + exp(log_std) on hmf_heads; False: torch ops
 
     def _heads_kernel_supports(self, input_feats):
@@ -643,6 +645,7 @@ class HumaniflowModel(nn.Module):
             raise NotImplementedError('humaniflow_amd: grad_for_pose_point_est=True (gradients through the z = 0 point-estimate chain) is not built')
         grad = torch.is_grad_enabled() and (input_feats.requires_grad or any(p.requires_grad for p in self.parameters()))
         isgc_feat_part = None                   # W[:, :F] . feats of the isgc layer, once per differentiable pass
+        isgc_ll = None                          # the teacher-forced isgc rows when autograd.IsgcTrain produced both uses at once
         flow_anchor = None                      # autograd.new_flow_anchor of this pass (made by the first differentiable flow consumer)
         if grad and not self.default_flow:
             raise NotImplementedError('humaniflow_amd: gradients are built for the default flow configuration (spline_coupling + permute); call the '
@@ -724,8 +727,16 @@ class HumaniflowModel(nn.Module):
                     shape_samples = shape_mode[:, None, :].expand(-1, N, -1)
                 else:
                     shape_samples = (shape_mode + eps_shape * torch.exp(shape_log_std)).transpose(0, 1)        # (B,N,nb), = the kernel's values
-                isgc_feat_part = self._isgc_feat_part(input_feats)          # shared with the teacher-forced path below
-                H = self._isgc_autograd(input_feats, shape_samples, glob_R, cam, isgc_feat_part).reshape(BN, -1)
+                if (compute_for_loglik and self.heads_kernel and self.isgc_kernel and input_feats.shape[1] % 256 == 0 and shape_for_loglik.shape == shape_mode.shape
+                        and self.fc_input_shape_glob_cam_feats.out_features == 256 and self.fc_input_shape_glob_cam_feats.weight.is_contiguous()):
+                    # both uses of the isgc layer in this pass (per-sample rows here, teacher-forced rows below) on the library: autograd.IsgcTrain
+                    from .autograd import IsgcTrain
+                    lin = self.fc_input_shape_glob_cam_feats
+                    H, isgc_ll = IsgcTrain.apply(self, input_feats, lin.weight, lin.bias, glob_R, cam, shape_samples, glob_R_for_loglik, shape_for_loglik)
+                    H = H.reshape(BN, -1)
+                else:
+                    isgc_feat_part = self._isgc_feat_part(input_feats)          # shared with the teacher-forced path below
+                    H = self._isgc_autograd(input_feats, shape_samples, glob_R, cam, isgc_feat_part).reshape(BN, -1)
                 rot_s = FlowSampleChain.apply(self, H, rot_s, eps_pose, *flow_anchor)
                 if packed:
                     rot_all = torch.cat([rot_s.reshape(BN, P, 3, 3), rot_p], dim=0)
@@ -741,7 +752,8 @@ class HumaniflowModel(nn.Module):
                                                 else shape_samples)
 
         if compute_for_loglik:
-            isgc = self.compute_input_shape_glob_cam_feats(input_feats, shape_for_loglik, glob_R_for_loglik, cam, isgc_feat_part)    # :279-283
+            isgc = isgc_ll if isgc_ll is not None else \
+                self.compute_input_shape_glob_cam_feats(input_feats, shape_for_loglik, glob_R_for_loglik, cam, isgc_feat_part)    # :279-283
             ctx = self.compute_flow_context_all(isgc, pose_R_for_loglik, anchor=flow_anchor)                          # :315-318
             return_dict['conditioned_pose_so3flow_dists_for_loglik'] = [
                 self.pose_so3flow_dists[j].condition(ctx[:, j], parent=(ctx, j)) for j in range(P)]

@@ -248,6 +248,20 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
  * feats B x feat_dim, shape B x nb, glob_R B x 9, cam B x 3 -> isgc B x isgc_dim.               */
 int hmf_flow_isgc(const hmf_flow_t* h, const float* feats, const float* shape, const float* glob_R,
                   const float* cam, int B, float* isgc, void* stream);
+/* The same layer for the training step, where autograd differentiates it (train/train_humaniflow.py:351 through :116-150), for BOTH of its uses in one
+ * call: pre (2 x B x 256) = W [f, 0, vec(R), cam] + b without shape and ELU -- [0] with glob_R (the predicted rotation: sample path), [1] with glob_R_ll (the
+ * target rotation: teacher-forced path, :279-283); H ((B N + B) x 256) = ELU(pre[use][image] + W_beta shape[row]) for the B N per-sample shapes
+ * (shape_rows, row b N + n) followed by the B teacher-forced shapes (shape_ll).  Three launches.  N >= 1. */
+int hmf_flow_isgc_train(const hmf_flow_t* h, const float* feats, const float* glob_R, const float* glob_R_ll, const float* cam, const float* shape_rows,
+                        const float* shape_ll, int B, int N, float* pre, float* H, void* stream);
+/* Its backward below the dense products: from d loss / d H (g_H_rows (B N) x 256 and g_H_ll B x 256, either may be NULL = zero) to
+ *   delta ((B N + 2 B) x 256): g_H * ELU'(H) of the sample rows, of the teacher-forced rows, then g_pre_s[b] = the sum of image b's sample rows (fixed order);
+ *   g_pre_f (B x 256) = g_pre_s + delta_ll (what reaches the shared image-feature product and the bias), g_pre_f_t / g_pre_s_t (256 x B): transposes;
+ *   g_shape ((B N + B) x nb) = delta W_beta.
+ * The caller finishes with hmf_rows_atb_batched: d W[:, F:F+nb] = delta[:B N + B]^T shapes, d W[:, :F] = g_pre_f^T feats (+ column sums = d bias),
+ * d W[:, F+nb:] = delta[B N:]^T [vec(R_ll), cam | vec(R), cam], g_feats = g_pre_f W[:, :F], g_vec(R) = g_pre_s W[:, F+nb:F+nb+9], g_cam = g_pre_f W[:, F+nb+9:]. */
+int hmf_flow_isgc_train_backward(const hmf_flow_t* h, const float* H, const float* g_H_rows, const float* g_H_ll, int B, int N, float* delta, float* g_pre_f,
+                                 float* g_pre_f_t, float* g_pre_s_t, float* g_shape, void* stream);
 /* compute_flow_context :152-186 for all 23 parts with GIVEN (teacher-forced) rotations.
  * isgc B x isgc_dim, pose_R B x 23 x 9 fp32 -> ctx B x 23 x ctx_dim.                            */
 int hmf_flow_context(const hmf_flow_t* h, const float* isgc, const float* pose_R, int B, float* ctx,

@@ -554,3 +554,36 @@ def test_heads_under_autograd_run_on_the_library_and_match_float64_autograd(laye
     with torch.no_grad():
         ref = model.eval()(None, input_feats=feats.detach(), num_samples=0, compute_point_est=False)
     assert torch.equal(out['cam_wp'].detach(), ref['cam_wp']) and torch.equal(out['glob_rotmat'].detach(), ref['glob_rotmat'])
+
+
+def test_isgc_layer_under_autograd_runs_on_the_library_and_matches_float64_autograd():
+    """compute_input_shape_glob_cam_feats (models/humaniflow_model.py:116-150) for both uses of a training pass = autograd.IsgcTrain: outputs and every
+    gradient (image features, the layer's weight and bias, predicted global rotation, camera, per-sample shapes) vs torch autograd in float64."""
+    from humaniflow_amd.autograd import IsgcTrain
+    model, sd, cfg = _model(seed=8)
+    B, N, nb, F = 9, 5, 10, 512
+    g = torch.Generator().manual_seed(4)
+    mk = lambda *sh: torch.randn(*sh, generator=g)
+    feats, cam, ss, sl = mk(B, F) * 0.5, mk(B, 3) * 0.3, mk(B, N, nb), mk(B, nb)
+    R, Rl = random_rotmats(B, 0.8, seed=5), random_rotmats(B, 0.8, seed=6)
+    lin = model.fc_input_shape_glob_cam_feats
+    lin.weight.grad = lin.bias.grad = None
+    dv = lambda t: t.cuda().requires_grad_(True)
+    f_, R_, cam_, ss_ = dv(feats), dv(R), dv(cam), dv(ss)
+    Hs, Hl = IsgcTrain.apply(model, f_, lin.weight, lin.bias, R_, cam_, ss_, Rl.cuda(), sl.cuda())
+    w1, w2 = mk(B, N, 256), mk(B, 256)
+    ((Hs * w1.cuda()).sum() + (Hl * w2.cuda()).sum()).backward()
+    # float64 reference: the reference's cat + Linear + ELU
+    d64 = lambda t: t.double().requires_grad_(True)
+    f6, R6, c6, s6, W6, b6 = d64(feats), d64(R), d64(cam), d64(ss), d64(lin.weight.detach().cpu()), d64(lin.bias.detach().cpu())
+    def layer(shape, rot):
+        lead = shape.shape[:-1]
+        ex = lambda t: t if len(lead) == 1 else t[:, None].expand(-1, N, -1)
+        x = torch.cat([ex(f6), shape, ex(rot.reshape(B, 9)), ex(c6)], dim=-1)
+        return torch.nn.functional.elu(x @ W6.t() + b6)
+    Hs6, Hl6 = layer(s6, R6), layer(sl.double(), Rl.double())
+    ((Hs6 * w1.double()).sum() + (Hl6 * w2.double()).sum()).backward()
+    assert (Hs.detach().double().cpu() - Hs6.detach()).abs().max() < 2e-5 and (Hl.detach().double().cpu() - Hl6.detach()).abs().max() < 2e-5
+    for name, got, ref in (('d feats', f_.grad, f6.grad), ('d glob_R', R_.grad, R6.grad), ('d cam', cam_.grad, c6.grad), ('d shape_samples', ss_.grad, s6.grad),
+                           ('d weight', lin.weight.grad, W6.grad), ('d bias', lin.bias.grad, b6.grad)):
+        _check(name, got, ref)
