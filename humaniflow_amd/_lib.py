@@ -66,6 +66,7 @@ _SIGS = {
     'hmf_so3_log': (C.c_int, [_VP, C.c_int, _VP, _VP]),
     'hmf_so3_log_abs_det_jacobian': (C.c_int, [_VP, C.c_int, _VP, _VP]),
     'hmf_batch_rodrigues': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'hmf_batch_rodrigues_pose': (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     'hmf_smpl_create': (C.c_int, [C.POINTER(_VP), C.POINTER(SmplHost)]),
     'hmf_smpl_destroy': (None, [_VP]),
     'hmf_smpl_lbs_workspace_bytes': (C.c_size_t, [C.c_int]),

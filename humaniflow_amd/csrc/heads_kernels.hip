@@ -65,14 +65,17 @@ struct HeadsOut {
 
 // one work-group per image: x1 = ELU(sum of the K-split partials + b1) in LDS, then the 3 + 6 + 2 nb small outputs, one wave per output
 __global__ __launch_bounds__(256) void k_heads_out(const float* __restrict__ partial, const float* __restrict__ b1, int B, int N1, int KS, int nb, HeadsOut o) {
-    __shared__ __attribute__((aligned(16))) float sx[1024];
+    // the eight lanes of an output read eight contiguous eighths of x1: each eighth starts 4 floats later than its length, so that the eight 16-byte reads of
+    // a step hit eight different bank groups (unpadded: 84 % of the kernel's LDS cycles were bank conflicts, round-4 PMC)
+    __shared__ __attribute__((aligned(16))) float sx[1024 + 32];
     __shared__ float so[48];
     const int tid = threadIdx.x, b = blockIdx.x;
     for (int n = tid; n < N1; n += 256) {
         float v = partial[(size_t)b * N1 + n];
         for (int ks = 1; ks < KS; ++ks) v += partial[((size_t)ks * B + b) * N1 + n];
-        sx[n] = elu1(v + b1[n]);
-        if (o.x1) o.x1[(size_t)b * N1 + n] = sx[n];
+        const float xv = elu1(v + b1[n]);
+        sx[n + 4 * (n / (N1 / 8))] = xv;
+        if (o.x1) o.x1[(size_t)b * N1 + n] = xv;
     }
     __syncthreads();
     // 3 + 6 + 2 nb outputs: eight lanes per output, each lane a contiguous eighth of the N1 axis with all its loads independent (round 4, first
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void k_heads_out(const float* __restrict__ par
             const float* wrow = oi < 3 ? o.w_cam + (size_t)oi * N1 : (oi < 9 ? o.w_glob + (size_t)(oi - 3) * N1 : o.w_shape + (size_t)(oi - 9) * N1);
             const int n8 = N1 / 8;                                 // N1 % 32 == 0: a multiple of 4 floats per lane
             const f32x4* wp = (const f32x4*)(wrow + part * n8);
-            const f32x4* xp = (const f32x4*)(sx + part * n8);
+            const f32x4* xp = (const f32x4*)(sx + part * (n8 + 4));
             float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
             for (int k4 = 0; k4 < n8 / 4; ++k4) {

@@ -132,6 +132,19 @@ __global__ void k_rodrigues(const float* __restrict__ v, int n, float* __restric
     for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = out[k];
 }
 
+// the same for whole SMPL poses: row r of `aa` = 24 axis-angle vectors (global orientation first); the rotations leave in the two tensors the SMPL
+// launch takes (smplx's global_orient / body_pose split), so that no slice has to be copied
+__global__ void k_rodrigues_pose(const float* __restrict__ aa, int M, float* __restrict__ glob, float* __restrict__ body) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * 24) return;
+    const int row = i / 24, j = i - row * 24;
+    float in[3] = {aa[(size_t)i * 3], aa[(size_t)i * 3 + 1], aa[(size_t)i * 3 + 2]}, out[9];
+    batch_rodrigues_f32(in, out);
+    float* o = j == 0 ? glob + (size_t)row * 9 : body + ((size_t)row * 23 + (j - 1)) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = out[k];
+}
+
 }  // namespace hmf
 
 namespace hmf {
@@ -217,5 +230,13 @@ HMF_ELEMENTWISE(hmf_so3_exp, k_so3_exp, double, double)
 HMF_ELEMENTWISE(hmf_so3_log, k_so3_log, double, double)
 HMF_ELEMENTWISE(hmf_so3_log_abs_det_jacobian, k_so3_logdet, double, double)
 HMF_ELEMENTWISE(hmf_batch_rodrigues, k_rodrigues, float, float)
+
+int hmf_batch_rodrigues_pose(const float* aa, int M, float* global_orient, float* body_pose, void* stream) {
+    if (M < 0 || (M > 0 && (!aa || !global_orient || !body_pose))) return fail(HMF_ERR_INVALID, "hmf_batch_rodrigues_pose: bad args");
+    if (M == 0) return HMF_OK;
+    hipLaunchKernelGGL(k_rodrigues_pose, dim3((M * 24 + 255) / 256), dim3(256), 0, (hipStream_t)stream, aa, M, global_orient, body_pose);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
 
 }  // extern "C"

@@ -201,7 +201,8 @@ class EvalMetricsTracker:
                 put('j2d_samples', f32(pred['joints2Dsamples']))
                 N = N or pred['joints2Dsamples'].shape[1]
             if 'joints2D_vis' in target:
-                put('j2d_vis', target['joints2D_vis'].to(torch.uint8).contiguous())
+                vis = target['joints2D_vis'].contiguous()
+                put('j2d_vis', vis.view(torch.uint8) if vis.dtype == torch.bool else vis.to(torch.uint8))      # bool is one byte: no conversion launch
         eb.N = N
         names = METRICS + self.COUNTS
         for i, nm in enumerate(names):
@@ -482,8 +483,13 @@ def eval_joints(joints_packed, cam, B, N, img_wh):
 @torch.no_grad()
 def target_batch(smpl, batch, materialise_tpose=True):
     """evaluate/evaluate_humaniflow.py:83-110 (single body model: the synthetic set has no gender split)."""
-    t = smpl(body_pose=batch['pose'][:, 3:], global_orient=batch['pose'][:, :3], betas=batch['shape'])
-    out = {'verts3D': t.vertices, 'joints3D': select_joints(t.joints, 'h36m_j14')}
+    verts, joints = smpl.forward_axis_angle(batch['pose'], batch['shape'])           # = smpl(body_pose=pose[:, 3:], global_orient=pose[:, :3], betas=shape)
+    B = verts.shape[0]
+    key = ('zero_cam', str(joints.device), B)
+    if key not in _INDEX_CACHE:
+        _INDEX_CACHE[key] = joints.new_zeros(B, 3)
+    j14, _, _ = eval_joints(joints, _INDEX_CACHE[key], B, 0, 2.0)                    # the 14 evaluation joints (the camera outputs are not used)
+    out = {'verts3D': verts, 'joints3D': j14}
     if materialise_tpose:
         out['tpose_verts3D'] = smpl.tpose(batch['shape'])
     else:

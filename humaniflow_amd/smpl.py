@@ -265,6 +265,20 @@ class SMPL(nn.Module):
         return SMPLOutput(vertices=verts, joints=joints, full_pose=full_pose, betas=betas, global_orient=global_orient,
                           body_pose=body_pose)
 
+    def forward_axis_angle(self, pose, betas, impl=None):
+        """Bodies from whole axis-angle poses (M, 72) -- the evaluation targets of evaluate/evaluate_humaniflow.py:83-87 -- without slicing the pose
+        tensor first: hmf_batch_rodrigues_pose writes the global-orientation and body-pose rotations as the two tensors the LBS launch takes (the two
+        slices, their contiguous copies and smplx's `full_pose` cat were five small ATen launches per evaluation step).  Returns (vertices, joints)."""
+        _lib.require_cuda(pose, 'pose')
+        lib = _lib.load()
+        p, be = self._f32c(pose).reshape(-1, 72), self._f32c(betas)
+        M = p.shape[0]
+        g = torch.empty(M, 9, dtype=torch.float32, device=p.device)
+        b = torch.empty(M, 23 * 9, dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(lib.hmf_batch_rodrigues_pose(_lib.dptr(p), M, _lib.dptr(g), _lib.dptr(b), _lib.current_stream()), 'hmf_batch_rodrigues_pose')
+            return self._lbs_kernel(g, b, be, impl)
+
     def forward_samples_and_point_est(self, pred, return_packed=False):
         """One launch for what the reference does with two SMPL calls (evaluate/evaluate_humaniflow.py:124-127,168-172,
         predict/predict_humaniflow.py:128-131,160-163): the B point-estimate bodies and the B*N sampled bodies of a

@@ -63,6 +63,9 @@ int hmf_so3_log_abs_det_jacobian(const double* v, int n, double* out, void* stre
 /* smplx.lbs.batch_rodrigues (fp32, angle = |v + 1e-8|), call sites models/humaniflow_model.py:299,
  * evaluate/evaluate_humaniflow.py:83.  v: n x 3 -> R: n x 9.                                   */
 int hmf_batch_rodrigues(const float* v, int n, float* R, void* stream);
+/* The same for M whole SMPL poses (M x 72 axis-angle, global orientation first: data/pw3d_eval_dataset.py `pose`; evaluate/evaluate_humaniflow.py:83-87),
+ * written as the two tensors hmf_smpl_lbs takes: global_orient M x 9, body_pose M x 23 x 9. */
+int hmf_batch_rodrigues_pose(const float* aa, int M, float* global_orient, float* body_pose, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* SMPL: shape/pose blend-shapes + LBS + 90 joints  (models/smpl.py:27-41 -> smplx lbs)         */

@@ -260,3 +260,15 @@ def test_configs2_bf16_kernel_at_full_size_M6400():
     # same inputs again: deterministic
     a2 = s16(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
     assert torch.equal(a.vertices, a2.vertices)
+
+
+def test_forward_axis_angle_equals_the_sliced_reference_call():
+    """SMPL.forward_axis_angle(pose72, betas) (hmf_batch_rodrigues_pose + the LBS launch) == smpl(body_pose=pose[:, 3:], global_orient=pose[:, :3], betas)."""
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    g = torch.Generator().manual_seed(2)
+    pose = (torch.randn(7, 72, generator=g) * 0.4).cuda()
+    pose[0] = 0.0
+    betas = (torch.randn(7, 10, generator=g) * 1.25).cuda()
+    ref = smpl(body_pose=pose[:, 3:], global_orient=pose[:, :3], betas=betas)
+    v, j = smpl.forward_axis_angle(pose, betas)
+    assert torch.equal(v, ref.vertices) and torch.equal(j, ref.joints)
