@@ -305,6 +305,113 @@ __device__ __forceinline__ void skin_element(const SmplDev& d, const char* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 2a. The same kernel on 32-row groups (round 5, the round-4 review's "<= 64 KB LDS" variant): pose-feature panel [224][32] (28 KB) + 32 x 24 skinning
+//     transforms (36 KB) = 64 KB per work-group, so TWO work-groups (four waves per SIMD) share a CU -- or one leaves room for another batch's convolution
+//     work-groups.  A wave tile is 32 rows x 32 vertices x 3 components (one accumulator set): every operand fragment streamed from L2 now serves 32 rows
+//     instead of 64.  Reads the same 64-row panels (half of one) and the same packed operand as k_lbs_mfma; same arithmetic per (row, vertex): bitwise the
+//     same vertices.  SMPL(lbs_rows=32) / hmf_smpl_lbs impl = 4.
+// ---------------------------------------------------------------------------------------------------
+template <int SLOTS>
+__global__ __launch_bounds__(512, 4) void k_lbs_mfma32(SmplDev d, int M, int nrg32, int wpx, const float* __restrict__ panel,
+                                                     const float* __restrict__ atr, float* __restrict__ verts, float* __restrict__ cjv) {
+    constexpr int kR = 32;
+    __shared__ __attribute__((aligned(16))) float smem[kKpad * kR + kR * kAtr];      // 28 + 36 KB
+    float* sPF = smem;
+    float* sA = smem + kKpad * kR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int xr = blockIdx.x & 7;
+    const int chunk = blockIdx.x >> 3;
+    const int T = nrg32 * kVTperX;
+    int t = (int)((long long)chunk * T / wpx);
+    const int t1 = (int)((long long)(chunk + 1) * T / wpx);
+    const int nslots = d.skin_slots;
+    const int ks_valid = (kPoseFeat + d.num_betas + 2) / 2;
+    while (t < t1) {
+        const int rg = t / kVTperX;                       // 32-row group
+        const int seg_end = min(t1, (rg + 1) * kVTperX);
+        const int row0 = rg * kR;
+        {
+            // rows [32 (rg & 1), +32) of the 64-row panel rg >> 1: element (k, r) at k * 64 + r
+            const f32x4* src = (const f32x4*)(panel + (size_t)(rg >> 1) * (kKpad * 64)) + (rg & 1) * 8;
+            f32x4* dst = (f32x4*)sPF;
+            for (int i = tid; i < kKpad * kR / 4; i += 512) dst[i] = src[(i >> 3) * 16 + (i & 7)];
+            const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
+            f32x4* dst2 = (f32x4*)sA;
+            const int n4 = min(kR, M - row0) * (kAtr / 4);
+            for (int ii = tid; ii < kR * (kAtr / 4); ii += 512) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                dst2[ii] = (ii < n4) ? src2[ii] : z;
+            }
+        }
+        __syncthreads();
+        for (int tt = t + wave; tt < seg_end; tt += 8) {
+            const int vt = xr * kVTperX + (tt - rg * kVTperX);
+            int off[SLOTS > 0 ? SLOTS : 1];
+            float w[SLOTS > 0 ? SLOTS : 1];
+            if (SLOTS > 0) {
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    off[sl] = d.skin_off[((size_t)vt * nslots + sl) * 32 + l31];
+                    w[sl] = d.skin_w[((size_t)vt * nslots + sl) * 32 + l31];
+                }
+            }
+            const int jslot = cjv ? d.ju_slot[vt * 32 + l31] : -1;
+            f32x16 acc[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[0][c][e] = 0.f; acc[1][c][e] = 0.f; }
+            const f32x4* bp = (const f32x4*)(d.blend + (size_t)vt * kKG * 3 * 64 * 4) + lane;
+            const float* ap = sPF + half * kR + l31;
+            f32x4 b0 = bp[0], b1 = bp[64], b2 = bp[128];
+            float a0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a0[u] = ap[u * 2 * kR];
+#pragma unroll 2
+            for (int kg = 0; kg < kKG; ++kg) {
+                f32x4 n0 = b0, n1 = b1, n2 = b2;
+                float m0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m0[u] = a0[u];
+                if (kg + 1 < kKG) {
+                    n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) m0[u] = ap[((kg + 1) * 4 + u) * 2 * kR];
+                }
+                const float bv[12] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = kg * 4 + u;
+                    if (ks >= ks_valid) continue;                                   // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], bv[u * 3 + c], acc[0][c], 0, 0, 0);
+                }
+                b0 = n0; b1 = n1; b2 = n2;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a0[u] = m0[u];
+            }
+            EpiCtx e;
+            const int v = vt * 32 + l31;
+            e.ok_v = v < kV;
+            e.full_rows = row0 + kR <= M;
+            e.row_lim = M - row0 - 4 * half;
+            e.obase = verts + ((size_t)(row0 + 4 * half) * kV + v) * 3;
+            e.lane_has_ju = jslot >= 0;
+            e.tile_has_ju = __builtin_amdgcn_ballot_w64(e.lane_has_ju) != 0;
+            e.cj_row = d.n_ju * 3;
+            e.cj = cjv + ((size_t)(row0 + 4 * half) * d.n_ju + (jslot >= 0 ? jslot : 0)) * 3;
+            const char* lbase = (const char*)(sA + 4 * half * kAtr);
+#pragma unroll
+            for (int el = 0; el < 16; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, 0, 0, el, e);
+        }
+        __syncthreads();
+        t = seg_end;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 2. fused pose-blend GEMM + skinning.  One workgroup (8 waves, 2 per SIMD) per CU; it owns a contiguous chunk of
 //    (row-group of 64 rows, vertex tile) pairs inside ONE of the 8 vertex ranges (27 tiles = 2.3 MB of packed operand,
@@ -1357,7 +1464,7 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
     if (!workspace || workspace_bytes < hmf_smpl_lbs_workspace_bytes(M))
         return fail(HMF_ERR_WORKSPACE, "hmf_smpl_lbs: workspace %zu < %zu bytes", workspace_bytes, hmf_smpl_lbs_workspace_bytes(M));
 #ifndef HMF_EXPERIMENTS
-    if (impl < 0 || impl > 3) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: impl=%d (0 = fp32 MFMA, 1 = scalar cross-check, 2 = bf16 operands, 3 = bf16 hi+lo split operands)", impl);
+    if (impl < 0 || impl > 4) return fail(HMF_ERR_INVALID, "hmf_smpl_lbs: impl=%d (0 = fp32 MFMA, 1 = scalar cross-check, 2 = bf16 operands, 3 = bf16 hi+lo split operands, 4 = fp32 MFMA on 32-row groups)", impl);
 #endif
     hipStream_t st = (hipStream_t)stream;
     float* atr = (float*)workspace;
@@ -1413,6 +1520,15 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
         else if (h->d.skin_slots == 8) HMF_LBS16(8);
         else HMF_LBS16(0);
 #undef HMF_LBS16
+    } else if ((impl & 15) == 4) {
+        ProfScope ps(1, M, st);
+        const int nrg32 = (M + 31) / 32;
+        const int T = nrg32 * kVTperX;
+        const int wpx = std::max(1, std::min(64, (T + 7) / 8));          // two work-groups per CU: up to 64 per XCD
+        const dim3 grid(8 * wpx), block(512);
+        if (h->d.skin_slots == 4) hipLaunchKernelGGL((k_lbs_mfma32<4>), grid, block, 0, st, h->d, M, nrg32, wpx, panel, atr, verts, cjv);
+        else if (h->d.skin_slots == 8) hipLaunchKernelGGL((k_lbs_mfma32<8>), grid, block, 0, st, h->d, M, nrg32, wpx, panel, atr, verts, cjv);
+        else hipLaunchKernelGGL((k_lbs_mfma32<0>), grid, block, 0, st, h->d, M, nrg32, wpx, panel, atr, verts, cjv);
     } else {
         ProfScope ps(1, M, st);
         const int nrg = (M + kRowsPerWG - 1) / kRowsPerWG;

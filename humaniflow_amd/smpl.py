@@ -100,6 +100,7 @@ class SMPL(nn.Module):
             raise ValueError("blend_dtype must be 'fp32', 'bf16' (BASELINE configs[2]: bf16 MFMA blend-shape GEMMs, fp32 accumulate; operands as bf16 hi + lo "
                              "pairs, three MFMAs per product: vertices within 1e-4 m of fp32) or 'bf16_plain' (single bf16 operands: 1.5e-3 m)")
         self.blend_dtype = blend_dtype
+        self.lbs_rows = int(os.environ.get('HMF_LBS_ROWS', '64'))     # 64: k_lbs_mfma (128 KB of LDS, one work-group per CU); 32: k_lbs_mfma32 (64 KB, two per CU)
         if model_data is None:
             model_data = load_smpl_pkl(model_path, gender, num_betas)
         self.gender = gender
@@ -180,6 +181,12 @@ class SMPL(nn.Module):
         except Exception:
             pass
 
+    def _impl(self):
+        """hmf_smpl_lbs `impl` of this module's configuration."""
+        if self.blend_dtype == 'fp32':
+            return 4 if self.lbs_rows == 32 else 0
+        return {'bf16': 3, 'bf16_plain': 2}[self.blend_dtype]
+
     def _workspace(self, device, M):
         # one scratch buffer per (device, stream): calls issued on different streams may be in flight together
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -215,7 +222,7 @@ class SMPL(nn.Module):
             ws = self._workspace(dev, M)
             _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
                                         _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(),
-                                        int({'fp32': 0, 'bf16': 3, 'bf16_plain': 2}[self.blend_dtype] if impl is None else impl),
+                                        int(self._impl() if impl is None else impl),
                                         _lib.current_stream()), 'hmf_smpl_lbs')
         return verts, joints
 
@@ -310,7 +317,7 @@ class SMPL(nn.Module):
                 ws = self._workspace(dev, M)
                 _lib.check(lib.hmf_smpl_lbs_packed(self._handle(dev), _lib.dptr(gc), B, N, _lib.dptr(bc), _lib.dptr(bec), _lib.dptr(verts), _lib.dptr(joints),
                                                    _lib.dptr(full_pose), _lib.dptr(ws), ws.numel(),
-                                                   int({'fp32': 0, 'bf16': 3, 'bf16_plain': 2}[self.blend_dtype]), _lib.current_stream()),
+                                                   int(self._impl()), _lib.current_stream()),
                            'hmf_smpl_lbs_packed')
             if hasattr(self, 'transl') and self.transl is not None:
                 joints = joints + self.transl.unsqueeze(1)

@@ -91,6 +91,8 @@ size_t hmf_smpl_lbs_workspace_bytes(int M);
 /* Posed bodies.  global_orient: Mg x 9, body_pose: M x 23 x 9 (rotation matrices, pose2rot=False
  * layout; use hmf_batch_rodrigues first for axis-angle input); betas: Mb x num_betas with Mb in
  * {1, M} (smplx broadcast rule); Mg in {1, M}.  verts: M x 6890 x 3; joints: M x 90 x 3 (nullable).
+ * impl 4 (round 5) = the fp32 MFMA kernel on 32-row groups (64 KB of LDS, two work-groups per CU; bitwise the same result; measured 7 % slower alone and
+ * 0.2-0.6 % slower in the three-stream step: opt-in, SMPL.lbs_rows = 32).
  * impl: 0 = fp32 MFMA kernel (product path), 1 = scalar cross-check kernel (tests only), 2 / 3 = BASELINE configs[2] variants:
  * blend-shape GEMM operands in bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fp32 template add and fp32 skinning (profiler
  * tag 12).  2: single bf16 operands (vertices within ~1.5e-3 m of the fp32 path for SMPL-sized bases).  3: both operands as bf16 hi + lo

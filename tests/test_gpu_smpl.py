@@ -272,3 +272,17 @@ def test_forward_axis_angle_equals_the_sliced_reference_call():
     ref = smpl(body_pose=pose[:, 3:], global_orient=pose[:, :3], betas=betas)
     v, j = smpl.forward_axis_angle(pose, betas)
     assert torch.equal(v, ref.vertices) and torch.equal(j, ref.joints)
+
+
+@pytest.mark.parametrize('M', [1, 31, 33, 100, 257])
+def test_32_row_group_lbs_kernel_is_bitwise_the_64_row_one(M):
+    """k_lbs_mfma32 (impl = 4: 64 KB of LDS, two work-groups per CU; SMPL.lbs_rows = 32) reads the same panels and operand as k_lbs_mfma and does the same
+    arithmetic per (row, vertex): identical vertices and joints, ragged row counts included."""
+    from oracle.so3 import so3_exp
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    g = torch.Generator().manual_seed(M)
+    R = so3_exp(torch.randn(M * 24, 3, generator=g, dtype=torch.float64) * 0.5).float().view(M, 24, 3, 3).cuda()
+    betas = (torch.randn(M, 10, generator=g) * 1.25).cuda()
+    a = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False, impl=0)
+    b = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False, impl=4)
+    assert torch.equal(a.vertices, b.vertices) and torch.equal(a.joints, b.joints)
