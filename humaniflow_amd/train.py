@@ -5,7 +5,9 @@
   loss       HumaniflowLoss: pose NLL + shape NLL + visible-2D-joint MSE + global-rotation MSE                                        :323-343
   backward   HIP reverse sweeps of the flow / SMPL (autograd.py) and of the encoder (encoder_train.py), torch autograd for the four head GEMMs
   exchange   gradients bucketed (25 MB) and all-reduced over RCCL while the rest of the backward still runs (xGMI rings are per-link bound)
-  update     Adam; a non-finite loss or gradient skips the update instead of the reference's deep-copy / reload roll-back (:264-278, :345-347)
+  update     Adam.  nan_policy = 'skip' (default): a non-finite loss or gradient skips the update on the device, no host read;
+             nan_policy = 'rollback': the reference's own semantics (:261-278, :348-349) -- NaNs in the forward's outputs undo the LAST update
+             (parameters, buffers, optimiser state as they were before it: LastBatchState) and the batch is run again
 
 What the reference's loop does around this (pytorch3d rendering of the synthetic person, texture / background / occlusion
 augmentation, :113-246) is data generation outside the path: `synthetic_train_batch` stands in with SMPL-consistent targets
@@ -246,7 +248,77 @@ def grads_finite(params):
     return bool(torch.isfinite(torch.stack(norms)).all())
 
 
-def train_step(model, smpl, criterion, optimiser, reducer, proxy_input, targets, num_samples, noise=None):
+class LastBatchState:
+    """The reference's `last_batch_model_state_dict` / `last_batch_opt_state_dict` (train/train_humaniflow.py:348-349: deep copies of both state
+    dicts taken before every backward + step; :264-268 loads them back when the NEXT forward's outputs hold NaNs), as in-place device copies:
+    save() mirrors every tensor of model.state_dict() and of the optimiser's per-parameter state into buffers allocated once (two multi-tensor
+    copies per step instead of a few hundred tensor allocations), restore() copies them back INTO the live tensors -- parameter, moment and
+    step-count storage keeps its address, so gradient buckets, a captured step and a fused optimiser stay valid, which load_state_dict (new
+    state tensors for the optimiser) would not give.  Non-tensor optimiser state (python step counts of a non-fused / non-capturable optimiser)
+    is kept by value.  Restoring to the state before the update that poisoned the weights and stepping again from the current batch is exactly
+    the reference's trajectory."""
+
+    def __init__(self, model, optimiser):
+        self.model, self.optimiser = model, optimiser
+        self._live, self._kept, self._plain, self._keys = None, None, None, None
+
+    def _tensors(self):
+        live = [t for t in self.model.state_dict(keep_vars=True).values() if isinstance(t, torch.Tensor)]
+        plain = {}
+        for gi, g in enumerate(self.optimiser.param_groups):
+            for pi, p in enumerate(g['params']):
+                for k, v in sorted(self.optimiser.state.get(p, {}).items()):
+                    if isinstance(v, torch.Tensor):
+                        live.append(v)
+                    else:
+                        plain[(gi, pi, k)] = v
+        return live, plain
+
+    def valid(self):
+        return self._kept is not None
+
+    @torch.no_grad()
+    def save(self):
+        live, plain = self._tensors()
+        keys = [(t.data_ptr(), tuple(t.shape), t.dtype) for t in live]
+        if self._keys != keys:                       # first call, or the optimiser created its state since (Adam does on its first step)
+            self._kept = [torch.empty_like(t) for t in live]
+            self._keys = keys
+        self._live = live
+        if live:
+            torch._foreach_copy_(self._kept, [t.detach() for t in live])
+        self._plain = dict(plain)
+
+    @torch.no_grad()
+    def restore(self):
+        if self._kept is None:
+            raise RuntimeError('LastBatchState.restore() before any save(): there is no earlier state to go back to')
+        torch._foreach_copy_([t.detach() for t in self._live], self._kept)
+        # state the optimiser created AFTER the snapshot (first update) has no earlier value: the reference's load_state_dict drops it
+        kept_ptrs = {k[0] for k in self._keys}
+        for gi, g in enumerate(self.optimiser.param_groups):
+            for pi, p in enumerate(g['params']):
+                st = self.optimiser.state.get(p)
+                if not st:
+                    continue
+                for k in list(st.keys()):
+                    v = st[k]
+                    if isinstance(v, torch.Tensor):
+                        if v.data_ptr() not in kept_ptrs:
+                            del st[k]
+                    elif (gi, pi, k) in self._plain:
+                        st[k] = self._plain[(gi, pi, k)]
+                    else:
+                        del st[k]
+
+
+def nans_in_output(pred):
+    """utils/train_utils.py:4-12 (check_for_nans_in_output) with one host read: any NaN in any tensor value of the forward's return dict."""
+    flags = [v.isnan().any() for v in pred.values() if isinstance(v, torch.Tensor) and v.is_floating_point()]
+    return torch.stack(flags).any() if flags else torch.zeros((), dtype=torch.bool)
+
+
+def train_step(model, smpl, criterion, optimiser, reducer, proxy_input, targets, num_samples, noise=None, nan_policy='skip', last_state=None):
     """One optimisation step.  Returns (loss tensor, skipped): a non-finite loss or gradient skips the update (the reference reloads the previous
     state dicts, train/train_humaniflow.py:264-278).  With a fused Adam on the device the decision never leaves the device: the finite flag is
     handed to the optimiser as `found_inf` (the fused kernel then leaves parameters, moments and step counts untouched), `skipped` is a 0-dim
@@ -254,10 +326,32 @@ def train_step(model, smpl, criterion, optimiser, reducer, proxy_input, targets,
     The flag is AND-reduced over the ranks (reducer.all_finite): the local loss differs per rank, the decision must not.
     Difference from the reference's roll-back: the BatchNorm running statistics (and num_batches_tracked) of a skipped step's forward stay
     updated -- the reference restores the whole state dict including buffers; the trained parameters, Adam moments and step counts are
-    untouched in both.  Skips in a row are counted on the device (reducer.consecutive_skips); reducer.check_progress() raises on a stall."""
+    untouched in both.  Skips in a row are counted on the device (reducer.consecutive_skips); reducer.check_progress() raises on a stall.
+
+    nan_policy='rollback' (with last_state = LastBatchState(model, optimiser), kept across steps) is the reference's loop instead (:261-278,
+    :348-349): NaNs in the forward's outputs -> print, restore the state from before the last update, forward again; the state is saved before
+    every backward + step.  It costs one host read per step (the reference's check is a host read per output tensor) and one copy of the
+    weights + moments (ResNet-18: ~140 MB, ~0.06 ms), and it cannot run inside a captured graph (the redo is host control flow).  The
+    non-finite-gradient skip below stays armed in both modes (the reference has no such check; with finite gradients it never fires)."""
+    if nan_policy not in ('skip', 'rollback'):
+        raise ValueError("nan_policy must be 'skip' or 'rollback', got %r" % (nan_policy,))
+    if nan_policy == 'rollback' and last_state is None:
+        raise ValueError("nan_policy='rollback' needs last_state=LastBatchState(model, optimiser), kept across steps")
     optimiser.zero_grad(set_to_none=True)
     reducer.begin()
-    loss, _ = train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=noise)
+    loss, pred = train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=noise)
+    if nan_policy == 'rollback':
+        nan = nans_in_output(pred)
+        if reducer.world > 1:                                           # every rank must take the same branch
+            nan = ~reducer.all_finite(~nan)
+        if bool(nan) and last_state.valid():
+            print('Reloading model and optimiser state from before last SGD step.')
+            last_state.restore()
+            print('Re-doing current batch forward pass.')
+            del loss, pred
+            reducer.begin()
+            loss, pred = train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples, noise=noise)
+        last_state.save()
     loss.backward()
     reducer.finish()
     params = [p for g in optimiser.param_groups for p in g['params']]

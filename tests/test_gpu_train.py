@@ -475,6 +475,52 @@ def test_train_step_skips_non_finite_updates_on_the_device():
     assert float(sk) == 0.0 and not all(torch.equal(a, b.detach()) for a, b in zip(before, params))
 
 
+def test_train_step_rollback_policy_undoes_the_last_update_and_redoes_the_batch():
+    """train/train_humaniflow.py:261-278 + :348-349 as nan_policy='rollback': an update that leaves NaN weights behind is found by the next
+    forward's outputs, undone (parameters, BatchNorm buffers, Adam moments and step counts as before that update) and the batch is run again:
+    after it exactly ONE update from the initial weights has been applied."""
+    import humaniflow_amd as H
+    from humaniflow_amd import train as T
+    from humaniflow_amd.losses import HumaniflowLoss
+    from humaniflow_amd.synthetic import init_benchmark_weights
+    dev = torch.device('cuda')
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_RESNET_LAYERS = 18
+    model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).to(dev).train()
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), batch_size=4, create_transl=False).to(dev)
+    crit = HumaniflowLoss(cfg.LOSS, cfg.DATA.PROXY_REP_SIZE)
+    params = [p for p in model.parameters() if p.requires_grad]
+    lr = 1e-4
+    opt = torch.optim.Adam(params, lr=lr, fused=True)
+    red = T.GradBucketReducer(params, None)
+    keep = T.LastBatchState(model, opt)
+    b0 = T.synthetic_train_batch(smpl, 4, cfg.DATA.PROXY_REP_SIZE, dev, seed=5, data_cfg=cfg.DATA)
+    b1 = T.synthetic_train_batch(smpl, 4, cfg.DATA.PROXY_REP_SIZE, dev, seed=6, data_cfg=cfg.DATA)
+    init = [p.detach().clone() for p in params]
+    ptrs = [p.data_ptr() for p in params]
+    loss, sk = T.train_step(model, smpl, crit, opt, red, *b0, 2, nan_policy='rollback', last_state=keep)
+    assert float(sk) == 0.0 and torch.isfinite(loss) and keep.valid()
+    with torch.no_grad():
+        model.fc1.weight[0, 0] = float('nan')                                  # "some numerical instability" of the update, :262
+    loss, sk = T.train_step(model, smpl, crit, opt, red, *b1, 2, nan_policy='rollback', last_state=keep)
+    assert float(sk) == 0.0 and torch.isfinite(loss)
+    assert ptrs == [p.data_ptr() for p in params]
+    assert all(float(opt.state[p]['step']) == 1.0 for p in params if p in opt.state)       # update 0 undone, update on b1 applied
+    moved = 0
+    for a, p in zip(init, params):
+        d = (p.detach() - a).abs()
+        assert torch.isfinite(p).all() and float(d.max()) <= lr * 1.001            # Adam's first step moves a weight by <= lr
+        moved += int((d > 0).sum())
+    assert moved > 0
+    # the kept state is now "before the update on b1": the initial weights again
+    live, _ = keep._tensors()
+    by_ptr = {t.data_ptr(): k for t, k in zip(live, keep._kept)}
+    assert all(torch.equal(by_ptr[p.data_ptr()], a) for a, p in zip(init, params))
+    # without a NaN the policy is the plain step
+    loss, sk = T.train_step(model, smpl, crit, opt, red, *b0, 2, nan_policy='rollback', last_state=keep)
+    assert float(sk) == 0.0 and all(float(opt.state[p]['step']) == 2.0 for p in params if p in opt.state)
+
+
 @pytest.mark.parametrize('reduction', ['mean', 'sum'])
 def test_fused_training_loss_equals_the_torch_operator_form(reduction):
     """hmf_train_loss (csrc/train_loss.py: joint selection, flip, projection, the four loss terms and their gradients in two launches) against the same
