@@ -41,6 +41,11 @@ class FlowGradRecords(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('D1', 'D2', 'D3', 'D4', 'A1', 'A2', 'A3', 'XIN', 'ACTX', 'DCTX')] + [('rows', C.c_int)]
 
 
+class FlowVariantGradRecords(C.Structure):
+    """hmf_flow_generic_grad_records_t: records of the variants' reverse sweeps (per part, transform, row); zero-filled by the caller."""
+    _fields_ = [(k, C.c_void_p) for k in ('D', 'A', 'XIN', 'DP', 'AP', 'GLU', 'ACTX', 'DCTX')] + [('rows', C.c_int), ('L', C.c_int), ('LP', C.c_int)]
+
+
 class Rng(C.Structure):
     """hmf_rng_t: where hmf_flow_forward's in-kernel base noise sits in the device generator's Philox stream."""
     _fields_ = [('seed', C.c_uint64), ('offset', C.c_uint64), ('state_dev', C.c_void_p), ('mirror_dev', C.c_void_p), ('grid_cap_blocks', C.c_int)]
@@ -97,6 +102,8 @@ _SIGS = {
     'hmf_flow_log_prob_so3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_SO3_backward': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP, C.POINTER(FlowGradRecords), _VP]),
     'hmf_flow_sample_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.POINTER(FlowGradRecords), _VP]),
+    'hmf_flow_generic_log_prob_SO3_backward': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP, C.POINTER(FlowVariantGradRecords), _VP]),
+    'hmf_flow_generic_sample_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.POINTER(FlowVariantGradRecords), _VP]),
     'hmf_rows_atb_batched': (C.c_int, [_VP] * 4 + [C.c_int] * 6 + [C.c_longlong] * 2 + [_VP]),
     'hmf_smpl_joints_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
     'hmf_bn_stats': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP]),

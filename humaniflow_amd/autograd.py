@@ -78,6 +78,134 @@ def _hypernet_params(model, part0, P):
     return out
 
 
+def _is_variant(model):
+    """The handle runs the generic kernels of csrc/flow_generic.hip (any non-default configuration, or the default one forced through them)."""
+    return (not model.default_flow) or bool(model.force_generic_flow)
+
+
+def _variant_dims(model):
+    """(T, L, LP, K, N, KP, NP): transforms per part, layers of a transform / PLU hyper-network and their (in, out) widths."""
+    nf = model.model_cfg.NORM_FLOW
+    hd = list(nf.TRANSFORM_NN_HIDDEN_DIMS)
+    odim = 62 if nf.TRANSFORM_TYPE == 'spline_coupling' else 2
+    K, N = [nf.CONTEXT_DIM + 1] + hd, hd + [odim]
+    KP = NP = []
+    if nf.PERMUTE_TYPE == 'conditional_linear_plu':
+        ph = list(nf.PERMUTE_NN_HIDDEN_DIMS)
+        KP, NP = [nf.CONTEXT_DIM] + ph, ph + [9]
+    return nf.NUM_TRANSFORMS, len(N), len(NP), K, N, KP, NP
+
+
+def _variant_modules(model, j, t):
+    """(permute module or None, coupling module) of transform t of part j in pose_so3flow_transform_modules' order."""
+    per = 1 if model.model_cfg.NORM_FLOW.PERMUTE_TYPE == 'permute' else 2
+    base = (j * model.model_cfg.NORM_FLOW.NUM_TRANSFORMS + t) * per
+    mods = model.pose_so3flow_transform_modules
+    return (mods[base] if per == 2 else None), mods[base + per - 1]
+
+
+def _variant_params(model, part0, P):
+    """Flat list [part][transform]([LU] | [PLU layers (weight, bias)]) + [coupling layers (weight, bias)] -- the order VariantRecords.grads() is unpacked in."""
+    T = model.model_cfg.NORM_FLOW.NUM_TRANSFORMS
+    out = []
+    for j in range(part0, part0 + P):
+        for t in range(T):
+            perm, cpl = _variant_modules(model, j, t)
+            if perm is not None:
+                if hasattr(perm, 'LU'):
+                    out.append(perm.LU)
+                else:
+                    for lin in perm.cond_plu_nn.layers:
+                        out += [lin.weight, lin.bias]
+            for lin in cpl.nn.layers:
+                out += [lin.weight, lin.bias]
+    return out
+
+
+class _VariantRecords:
+    """Device buffers for hmf_flow_generic_grad_records_t, zero-filled (the kernels skip masked rows and channels beyond a layer's width)."""
+
+    def __init__(self, model, P, rows, device, with_dctx):
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        self.T, self.L, self.LP, self.K, self.N, self.KP, self.NP = _variant_dims(model)
+        self.P, self.rows = P, rows
+        T, L, LP = self.T, self.L, self.LP
+        self.D, self.A, self.XIN = z(P, T, L, rows, 64), z(P, T, L, rows, 64), z(P, T, rows)
+        self.DP = z(P, T, LP, rows, 64) if LP else None
+        self.AP = z(P, T, LP, rows, 64) if LP else None
+        self.GLU = z(P, T, rows, 9) if model.model_cfg.NORM_FLOW.PERMUTE_TYPE == 'linear_plu' else None
+        self.ACTX = z(P, rows, 64)
+        self.DCTX = z(P, rows, 64) if with_dctx else None
+
+    def struct(self):
+        s = _lib.FlowVariantGradRecords()
+        for k in ('D', 'A', 'XIN', 'DP', 'AP', 'GLU', 'ACTX', 'DCTX'):
+            t = getattr(self, k)
+            setattr(s, k, None if t is None else t.data_ptr())
+        s.rows, s.L, s.LP = self.rows, self.L, self.LP
+        return s
+
+    def grads(self):
+        """{'tr': [(dW (P,T,N_l,K_l), db (P,T,N_l)) per layer], 'plu': [...] | None, 'lu': (P,T,3,3) | None}: dW_l = D_l^T . input_l over the row axis."""
+        P, T, R = self.P, self.T, self.rows
+
+        def net(D, A, L, K, N, a0):
+            out = []
+            for l in range(L):
+                if l == 0:
+                    Cm, sm = _atb(D[:, :, 0], a0, P * T, R, N[0], K[0], 64, a0.shape[-1], L * R * 64, R * a0.shape[-1], True)
+                else:
+                    Cm, sm = _atb(D[:, :, l], A[:, :, l], P * T, R, N[l], K[l], 64, 64, L * R * 64, L * R * 64, True)
+                out.append((Cm.view(P, T, N[l], K[l]), sm.view(P, T, N[l])))
+            return out
+        ctx_t = self.ACTX[:, None].expand(-1, T, -1, -1)
+        res = {'tr': net(self.D, self.A, self.L, self.K, self.N, torch.cat([ctx_t, self.XIN[..., None]], dim=-1).contiguous()), 'plu': None, 'lu': None}
+        if self.LP:
+            res['plu'] = net(self.DP, self.AP, self.LP, self.KP, self.NP, ctx_t.contiguous())
+        if self.GLU is not None:
+            res['lu'] = self.GLU.sum(dim=2).view(P, T, 3, 3)
+        return res
+
+
+def _variant_sum(a, b):
+    if a is None:
+        return b
+    out = {'tr': [(x[0] + y[0], x[1] + y[1]) for x, y in zip(a['tr'], b['tr'])], 'plu': None, 'lu': None}
+    if a['plu'] is not None:
+        out['plu'] = [(x[0] + y[0], x[1] + y[1]) for x, y in zip(a['plu'], b['plu'])]
+    if a['lu'] is not None:
+        out['lu'] = a['lu'] + b['lu']
+    return out
+
+
+def _variant_embed(model, g, part0, n):
+    """Gradients of parts part0 .. part0+n-1 embedded into the full stack of P parts."""
+    P = model.num_bodyparts
+
+    def emb(t):
+        full = t.new_zeros((P,) + t.shape[1:])
+        full[part0:part0 + n] = t
+        return full
+    return {'tr': [(emb(w), emb(b)) for w, b in g['tr']], 'plu': None if g['plu'] is None else [(emb(w), emb(b)) for w, b in g['plu']],
+            'lu': None if g['lu'] is None else emb(g['lu'])}
+
+
+def _variant_unpack(model, g):
+    """Per-parameter gradients in _variant_params(model, 0, P) order."""
+    P, T = model.num_bodyparts, model.model_cfg.NORM_FLOW.NUM_TRANSFORMS
+    out = []
+    for j in range(P):
+        for t in range(T):
+            if g['lu'] is not None:
+                out.append(g['lu'][j, t])
+            if g['plu'] is not None:
+                for dW, db in g['plu']:
+                    out += [dW[j, t], db[j, t]]
+            for dW, db in g['tr']:
+                out += [dW[j, t], db[j, t]]
+    return out
+
+
 # ---- context layers: shared dense pull-back ---------------------------------------------------------------------------------
 def _anc_index(model, device):
     """Per part: column indices of its ancestors' flattened rotations inside a (rows, 23*9) rotation matrix block."""
@@ -166,11 +294,14 @@ class FlowParamAnchor(torch.autograd.Function):
         ctx.stash.clear()
         P = model.num_bodyparts
         needs = ctx.needs_input_grad[2:]
-        g_full, g_db, hyper = None, None, None
+        g_full, g_db, hyper, hyperv = None, None, None, None
         for e in entries:
             if e[0] == 'ctx':
                 g_full = e[1] if g_full is None else g_full + e[1]
                 g_db = e[2] if g_db is None else g_db + e[2]
+            elif e[0] == 'hyperv':                               # variants: stacked dictionaries (_VariantRecords.grads)
+                _, part0, n, grads = e
+                hyperv = _variant_sum(hyperv, grads if n == P else _variant_embed(model, grads, part0, n))
             else:
                 _, part0, n, grads = e
                 if n != P:                                       # a sub-range of parts (per-part log_prob calls): embed into the full stack
@@ -188,20 +319,23 @@ class FlowParamAnchor(torch.autograd.Function):
                 out += [dW[j], g_db[j]]
         else:
             out += [None] * (2 * P)
-        if hyper is not None:
+        if hyperv is not None:
+            out += _variant_unpack(model, hyperv)
+        elif hyper is not None:
             for p in range(P):
                 for c in range(2):
                     for l in range(4):
                         out += [hyper[l][0][p, c], hyper[l][1][p, c]]
         else:
-            out += [None] * (16 * P)
+            out += [None] * (len(needs) - len(out))
         return (None, None) + tuple(gr if n else None for gr, n in zip(out, needs))
 
 
 def new_flow_anchor(model):
     """(token, stash) for one forward pass: pass both to every consumer of that pass."""
     stash = {}
-    token = FlowParamAnchor.apply(model, stash, *(_ctx_params(model) + _hypernet_params(model, 0, model.num_bodyparts)))
+    hyper = _variant_params(model, 0, model.num_bodyparts) if _is_variant(model) else _hypernet_params(model, 0, model.num_bodyparts)
+    token = FlowParamAnchor.apply(model, stash, *(_ctx_params(model) + hyper))
     return token, stash
 
 
@@ -244,17 +378,19 @@ class FlowLogProbSO3(torch.autograd.Function):
         model, P, part0 = ctx.model, ctx.P, ctx.part0
         B = cvec.shape[0]
         lib = _lib.load()
-        rec = _Records(P, 3 * B, cvec.device, with_dctx=False)
+        variant = _is_variant(model)
+        rec = _VariantRecords(model, P, 3 * B, cvec.device, with_dctx=False) if variant else _Records(P, 3 * B, cvec.device, with_dctx=False)
         g_ctx = torch.empty_like(cvec)
         gc = g.detach().to(torch.float32).contiguous()
         ids = (C.c_int32 * P)(*range(part0, part0 + P)) if P != model.num_bodyparts else None
         st = rec.struct()
+        fn, name = ((lib.hmf_flow_generic_log_prob_SO3_backward, 'hmf_flow_generic_log_prob_SO3_backward') if variant else
+                    (lib.hmf_flow_log_prob_SO3_backward, 'hmf_flow_log_prob_SO3_backward'))
         with torch.cuda.device(cvec.device):
-            _lib.check(lib.hmf_flow_log_prob_SO3_backward(model._flow_handle(cvec.device), _lib.dptr(cvec), ids, P, _lib.dptr(R64), B,
-                                                          _lib.dptr(gc), _lib.dptr(g_ctx), C.byref(st), _lib.current_stream()),
-                       'hmf_flow_log_prob_SO3_backward')
+            _lib.check(fn(model._flow_handle(cvec.device), _lib.dptr(cvec), ids, P, _lib.dptr(R64), B, _lib.dptr(gc), _lib.dptr(g_ctx), C.byref(st),
+                          _lib.current_stream()), name)
         if ctx.needs_input_grad[5]:                                   # the token
-            ctx.stash[(id(ctx), 'hyper')] = ('hyper', part0, P, rec.hypernet_grads())
+            ctx.stash[(id(ctx), 'hyper')] = ('hyperv', part0, P, rec.grads()) if variant else ('hyper', part0, P, rec.hypernet_grads())
         return None, None, None, g_ctx if ctx.needs_input_grad[3] else None, None, g.new_zeros(()), None
 
 
@@ -276,16 +412,19 @@ class FlowSampleChain(torch.autograd.Function):
         model, B, N = ctx.model, ctx.B, ctx.N
         P = model.num_bodyparts
         lib = _lib.load()
-        rec = _Records(P, B * N, H.device, with_dctx=True)
+        variant = _is_variant(model)
+        rec = _VariantRecords(model, P, B * N, H.device, with_dctx=True) if variant else _Records(P, B * N, H.device, with_dctx=True)
         g_rot = g.detach().to(torch.float32).contiguous().clone()                                       # in/out: descendants add to ancestors
         st = rec.struct()
+        fn, name = ((lib.hmf_flow_generic_sample_backward, 'hmf_flow_generic_sample_backward') if variant else
+                    (lib.hmf_flow_sample_backward, 'hmf_flow_sample_backward'))
         with torch.cuda.device(H.device):
-            _lib.check(lib.hmf_flow_sample_backward(model._flow_handle(H.device), _lib.dptr(H), _lib.dptr(rot), _lib.dptr(eps), B, N,
-                                                    _lib.dptr(g_rot), C.byref(st), _lib.current_stream()), 'hmf_flow_sample_backward')
+            _lib.check(fn(model._flow_handle(H.device), _lib.dptr(H), _lib.dptr(rot), _lib.dptr(eps), B, N, _lib.dptr(g_rot), C.byref(st),
+                          _lib.current_stream()), name)
         g_full, db, g_H = _context_pullback(model, rec.DCTX, H, rot.reshape(B * N, P, 9), want_weight_grads=ctx.needs_input_grad[4])
         if ctx.needs_input_grad[4]:                                   # the token
             ctx.stash[(id(ctx), 'ctx')] = ('ctx', g_full, db)
-            ctx.stash[(id(ctx), 'hyper')] = ('hyper', 0, P, rec.hypernet_grads())
+            ctx.stash[(id(ctx), 'hyper')] = ('hyperv', 0, P, rec.grads()) if variant else ('hyper', 0, P, rec.hypernet_grads())
         return None, g_H, None, None, g_rot.new_zeros(()), None
 
 

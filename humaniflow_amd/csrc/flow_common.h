@@ -66,7 +66,7 @@ constexpr int kMaxLayers = 5;     // up to 4 hidden layers + output
 struct GenNet {
     int nl;                       // number of layers (0 = absent)
     int K[kMaxLayers], N[kMaxLayers];
-    int o_w[kMaxLayers], o_b[kMaxLayers];     // arena offsets: W^T [K][64] (columns >= N zero), bias [64]
+    int o_w[kMaxLayers], o_b[kMaxLayers];     // arena offsets: W^T [K][64] (columns >= N zero) followed by the natural copy [64 outputs][64 inputs], bias [64]
 };
 struct GenPartTab {
     GenNet tr[kMaxT];             // transform hyper-network ConditionalDenseNN([context, x1]) -> 62 (spline) | 2 (additive)

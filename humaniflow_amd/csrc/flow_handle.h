@@ -29,5 +29,6 @@ struct hmf_flow {
     const int* d_ids;   // device table 0..22
     const int* d_map = nullptr;   // arena slot -> flat parameter position + 1 (0 = padding); hmf_flow_create_updatable only
     size_t arena_floats = 0, flat_count = 0;
+    int gen_layers_tr = 0, gen_layers_plu = 0;   // variants: layers (hidden + 1) of a transform / PLU hyper-network (records of the reverse sweeps)
     void* mem;
 };

@@ -251,9 +251,12 @@ int build_flow_pack(const hmf_flow_host_t* w, FlowPack& fp) {
             for (int l = 0; l <= nhid; ++l) {
                 const int n = l < nhid ? hidden[l] : odim;
                 g.K[l] = k; g.N[l] = n;
-                g.o_w[l] = (int)P.place((size_t)k * 64);
+                // W^T [K][64] (lane = output), then the NATURAL copy [64 rows = output][64: lane = input k < min(K, 64)] at + K * 64 for the reverse sweeps
+                g.o_w[l] = (int)P.place((size_t)k * 64 + 64 * 64);
                 for (int kk = 0; kk < k; ++kk)
                     for (int nn = 0; nn < n; ++nn) P.buf[g.o_w[l] + (size_t)kk * 64 + nn] = W[l][(size_t)nn * k + kk];
+                for (int nn = 0; nn < n; ++nn)
+                    for (int kk = 0; kk < std::min(k, 64); ++kk) P.buf[g.o_w[l] + (size_t)k * 64 + (size_t)nn * 64 + kk] = W[l][(size_t)nn * k + kk];
                 g.o_b[l] = (int)P.place(64);
                 std::copy(Bv[l], Bv[l] + n, P.buf.begin() + g.o_b[l]);
                 k = n;
@@ -441,6 +444,12 @@ static int create_impl(hmf_flow_t** out, const hmf_flow_host_t* w, const float* 
     d.o_wisgc = fp.o_wisgc; d.o_bisgc = fp.o_bisgc; d.o_wbeta = fp.o_wbeta;
     d.lev = fp.lev;
     h->g.enabled = fp.generic ? 1 : 0;
+    if (fp.generic) {
+        int nh_;
+        gen_hidden(w, nh_);
+        h->gen_layers_tr = nh_ + 1;
+        h->gen_layers_plu = w->permute_type == 2 ? w->plu_num_hidden + 1 : 0;
+    }
     h->g.T = fp.T; h->g.transform_type = fp.transform_type; h->g.permute_type = fp.permute_type;
     h->g.tab = fp.generic ? (const GenPartTab*)(base + b_arena + b_tab + b_anc + b_ids) : nullptr;
     *out = h;

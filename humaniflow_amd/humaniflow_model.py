@@ -519,9 +519,6 @@ class HumaniflowModel(nn.Module):
     def _needs_grad(self, *tensors):
         need = torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
                                             or any(p.requires_grad for p in self._flow_params()))
-        if need and not self.default_flow:
-            raise NotImplementedError('humaniflow_amd: gradients are built for the default flow configuration (spline_coupling + permute); call the '
-                                      'variants under torch.no_grad()')
         return need
 
     def _isgc_kernel(self, input_feats, shape, glob_R, cam):
@@ -647,9 +644,6 @@ class HumaniflowModel(nn.Module):
         isgc_feat_part = None                   # W[:, :F] . feats of the isgc layer, once per differentiable pass
         isgc_ll = None                          # the teacher-forced isgc rows when autograd.IsgcTrain produced both uses at once
         flow_anchor = None                      # autograd.new_flow_anchor of this pass (made by the first differentiable flow consumer)
-        if grad and not self.default_flow:
-            raise NotImplementedError('humaniflow_amd: gradients are built for the default flow configuration (spline_coupling + permute); call the '
-                                      'variants under torch.no_grad()')
         lib = _lib.load()
         nb, P, N = self.num_shape_params, self.num_bodyparts, int(num_samples)
 

@@ -323,6 +323,31 @@ int hmf_rows_atb_batched(const float* A, const float* B, float* C, float* a_cols
 int hmf_flow_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const float* rotmats_samples, const float* eps_pose, int B, int N,
                              float* g_rotmats, const hmf_flow_grad_records_t* rec, void* stream);
 
+/* The same two reverse sweeps for the flow VARIANTS (PERMUTE_TYPE linear_plu / conditional_linear_plu, TRANSFORM_TYPE
+ * additive_coupling, other NUM_TRANSFORMS / hidden sizes -- every handle that runs the generic kernels, models/norm_flows/
+ * pyro_conditional_norm_flow.py:60-106; the reference trains them through the same loss.backward()).  Records per (part, transform, row);
+ * T = NUM_TRANSFORMS, L = len(TRANSFORM_NN_HIDDEN_DIMS) + 1, LP = len(PERMUTE_NN_HIDDEN_DIMS) + 1.  Weight gradients, as above:
+ *   dW_l[part, t] = D[part, t, l]^T . (l == 0 ? [ACTX[part] | XIN[part, t]] : A[part, t, l]),  db_l = column sums of D[part, t, l]
+ *   conditional_linear_plu: the same with DP / AP (layer 0 reads ACTX[part]);  linear_plu: d LU[part, t] = sum over rows of GLU[part, t].
+ * The CALLER ZERO-FILLS every array (rows of masked pre-images and channels beyond a layer's width are not written). */
+typedef struct {
+    float* D;    /* [P][T][L][rows][64]   deltas of the transform hyper-network's layers                                      */
+    float* A;    /* [P][T][L][rows][64]   inputs of layers 1 .. L-1 (slot 0 unused)                                          */
+    float* XIN;  /* [P][T][rows]          the scalar x1 fed to the hyper-network next to the context                         */
+    float* DP;   /* [P][T][LP][rows][64]  conditional_linear_plu: deltas of the PLU network (linearPLU_transform.py:123-150); else NULL */
+    float* AP;   /* [P][T][LP][rows][64]  inputs of its layers 1 .. LP-1; else NULL                                          */
+    float* GLU;  /* [P][T][rows][9]       linear_plu: d L / d LU (row-major 3 x 3) of the row; else NULL                     */
+    float* ACTX; /* [P][rows][64]         context vector                                                                      */
+    float* DCTX; /* [P][rows][64]         delta of the context layer (hmf_flow_generic_sample_backward only; else NULL)       */
+    int rows, L, LP;
+} hmf_flow_generic_grad_records_t;
+/* Arguments as hmf_flow_log_prob_SO3_backward / hmf_flow_sample_backward; HMF_ERR_UNSUPPORTED on a handle of the default configuration
+ * (and the two entry points above return it on a variant handle). */
+int hmf_flow_generic_log_prob_SO3_backward(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const double* R, int B,
+                                           const float* g_logp, float* g_ctx, const hmf_flow_generic_grad_records_t* rec, void* stream);
+int hmf_flow_generic_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const float* rotmats_samples, const float* eps_pose, int B, int N,
+                                     float* g_rotmats, const hmf_flow_generic_grad_records_t* rec, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------ */
 /* Proxy-representation front end: models/canny_edge_detector.py:104-166 +          */
