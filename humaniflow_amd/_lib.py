@@ -113,6 +113,9 @@ _SIGS = {
     'hmf_bn_bwd_finalize': (C.c_int, [_VP, C.c_int, C.c_int] + [_VP] * 9),
     'hmf_bn_bwd_apply': (C.c_int, [_VP] * 8 + [C.c_int] * 3 + [_VP]),
     'hmf_maxpool3x3s2_nhwc_backward': (C.c_int, [_VP] * 3 + [C.c_int] * 4 + [_VP]),
+    'hmf_bn_relu_maxpool3x3s2_nhwc': (C.c_int, [_VP] * 5 + [C.c_int] * 4 + [_VP]),
+    'hmf_bn_relu_maxpool3x3s2_nhwc_bwd_reduce': (C.c_int, [_VP] * 6 + [C.c_int] * 4 + [_VP, _VP]),
+    'hmf_bn_relu_maxpool3x3s2_nhwc_bwd_apply': (C.c_int, [_VP] * 8 + [C.c_int] * 4 + [_VP]),
     'hmf_conv_wgrad': (C.c_int, [_VP] * 3 + [C.c_int] * 8 + [_VP]),
     'hmf_conv_wgrad_winograd_workspace_floats': (C.c_size_t, [C.c_int, C.c_int]),
     'hmf_conv_wgrad_winograd_supported': (C.c_int, [C.c_int] * 4),

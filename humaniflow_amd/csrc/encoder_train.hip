@@ -254,6 +254,123 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const f32x4* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Stem tail, training: BatchNorm affine + ReLU + max-pool 3x3 / stride 2 / pad 1 in ONE pass over the convolution's output (round 5).
+// models/resnet.py:148-151 (bn1, relu, maxpool) on the 302 MB stem map of the training batch: as three kernels the map is written once more
+// (bn_apply), read back by the pool, and in the backward re-read by the pool's backward, the BatchNorm reduction and the BatchNorm input
+// gradient with a 302 MB pool gradient written in between.  Here the activated map never exists: the forward reads y and writes the pooled
+// map + one byte per pooled element (which of the 9 taps was the FIRST maximum, torch's strict `>` scan), the backward reduction walks the
+// pooled elements (each routes its gradient to exactly one input element: sum_m gz = sum over pooled elements with a positive maximum) and the
+// input-gradient pass is per input element (<= 4 covering windows, matched against the recorded tap).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_relu_pool(const f32x4* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     f32x4* __restrict__ out, unsigned int* __restrict__ idx, int B, int H, int W, int C4, int OH, int OW) {
+    const long long n = (long long)B * OH * OW * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        long long p = e / C4;
+        const int ow = (int)(p % OW);
+        p /= OW;
+        const int oh = (int)(p % OH), b = (int)(p / OH);
+        const f32x4 sc = *(const f32x4*)(scale + 4 * c), sh = *(const f32x4*)(shift + 4 * c);
+        f32x4 v[9];
+        bool in[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = 2 * oh - 1 + t / 3, iw = 2 * ow - 1 + t % 3;
+            in[t] = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            v[t] = in[t] ? y[(((long long)b * H + ih) * W + iw) * C4 + c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned int bi[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = in[t] ? fmaxf(fmaf(v[t][k], sc[k], sh[k]), 0.f) : -INFINITY;
+                if (a > best[k]) { best[k] = a; bi[k] = (unsigned)t; }
+            }
+        }
+        out[e] = best;
+        idx[e] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+
+// acc[0][C] += sum gz, acc[1][C] += sum gz xhat over the INPUT elements of the fused tail = over the pooled elements whose maximum is positive
+// (gz of the arg-max element = the pooled gradient, every other element of the window gets nothing from it).  Block = 16 row lanes x 16 float4 lanes.
+__global__ __launch_bounds__(256) void k_bn_relu_pool_bwd_reduce(const float* __restrict__ g, const unsigned int* __restrict__ idx, const float* __restrict__ pooled,
+                                                                const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                int B, int H, int W, int C, int OH, int OW, double* __restrict__ acc) {
+    __shared__ float red[2][16][64 + 1];
+    const int c16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 64 + c16 * 4;
+    const int M = B * OH * OW;
+    const int m0 = blockIdx.y * kBnRows, m1 = min(m0 + kBnRows, M);
+    const f32x4 mu = *(const f32x4*)(mean + c0), rs = *(const f32x4*)(rstd + c0);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = m0 + r16; m < m1; m += 16) {
+        const size_t o = (size_t)m * C + c0;
+        const f32x4 gv = *(const f32x4*)(g + o), pv = *(const f32x4*)(pooled + o);
+        const unsigned int iv = idx[o >> 2];
+        const int ow = m % OW, oh = (m / OW) % OH, b = m / (OW * OH);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = (iv >> (8 * k)) & 0xff;
+            const int ih = 2 * oh - 1 + t / 3, iw = 2 * ow - 1 + t % 3;
+            const float yv = y[(((size_t)b * H + ih) * W + iw) * C + c0 + k];
+            const float gg = pv[k] > 0.f ? gv[k] : 0.f;
+            s[k] += gg;
+            sx[k] = fmaf(gg, (yv - mu[k]) * rs[k], sx[k]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][r16][c16 * 4 + e] = s[e]; red[1][r16][c16 * 4 + e] = sx[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += (double)red[which][r][c];
+        atomicAdd(acc + (size_t)which * C + blockIdx.x * 64 + c, t);
+    }
+}
+
+// gy = a gz + b y + c per input element; gz = sum over the <= 4 pooled windows that cover it of [it is the window's recorded arg-max and the maximum
+// is positive] * pooled gradient.  Window (oh, ow) covers input row h with tap row dh = h - 2 oh + 1: h even -> oh = h / 2 (dh = 1); h odd ->
+// oh = (h - 1) / 2 (dh = 2) and oh = (h + 1) / 2 (dh = 0).
+__global__ __launch_bounds__(256) void k_bn_relu_pool_bwd_apply(const f32x4* __restrict__ g, const unsigned int* __restrict__ idx, const f32x4* __restrict__ pooled,
+                                                               const f32x4* __restrict__ y, const float* __restrict__ ca, const float* __restrict__ cb,
+                                                               const float* __restrict__ cc, f32x4* __restrict__ gy, int B, int H, int W, int C4, int OH, int OW) {
+    const long long n = (long long)B * H * W * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        long long p = e / C4;
+        const int w = (int)(p % W);
+        p /= W;
+        const int h = (int)(p % H), b = (int)(p / H);
+        const int oh0 = h >> 1, ow0 = w >> 1;                          // first covering window; odd coordinates have a second one at + 1
+        const int nh = 1 + (h & 1), nw = 1 + (w & 1);
+        f32x4 gz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oh = oh0 + i, ow = ow0 + j;
+                if (i < nh && j < nw && oh < OH && ow < OW) {
+                    const unsigned int me = (unsigned)((h - 2 * oh + 1) * 3 + (w - 2 * ow + 1));
+                    const long long o = (((long long)b * OH + oh) * OW + ow) * C4 + c;
+                    const unsigned int iv = idx[o];
+                    const f32x4 gv = g[o], pv = pooled[o];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (((iv >> (8 * k)) & 0xff) == me && pv[k] > 0.f) gz[k] += gv[k];
+                }
+            }
+        const f32x4 a = *(const f32x4*)(ca + 4 * c), bb = *(const f32x4*)(cb + 4 * c), k0 = *(const f32x4*)(cc + 4 * c);
+        gy[e] = a * gz + bb * y[e] + k0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight gradient.  gy [M][Cout] (M = B OH OW), x NHWC [B][H][W][Cin] (STEM: the NCHW proxy input [B][Cin][H][W]),
 // dw [Cout][K]: K = KS*KS*Cin in (kh, kw, ci) order = channels_last filter layout (STEM: (ci, kh, kw) order = torch's native layout).
 // One work-group of 4 waves per (64 x 64 tile of dw, slice of the pixel axis): each wave multiplies a quarter of the slice into its own
@@ -703,6 +820,45 @@ int hmf_bn_bwd_apply(const float* g, const float* out, const float* y, const flo
     long long blocks = std::min<long long>((n4 + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)g, (const f32x4*)out, (const f32x4*)y, ca, cb,
                        cc, (f32x4*)gy, (f32x4*)gz_out, n4, C / 4, relu);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_bn_relu_maxpool3x3s2_nhwc(const float* y, const float* scale, const float* shift, float* out, unsigned char* argmax, int B, int H, int W, int C,
+                                  void* stream) {
+    if (!y || !scale || !shift || !out || !argmax || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || ((uintptr_t)argmax & 3))
+        return fail(HMF_ERR_INVALID, "hmf_bn_relu_maxpool3x3s2_nhwc: bad args (C %% 4 == 0, argmax 4-byte aligned)");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long n = (long long)B * OH * OW * (C / 4);
+    long long blocks = std::min<long long>((n + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_bn_relu_pool, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)y, scale, shift, (f32x4*)out,
+                       (unsigned int*)argmax, B, H, W, C / 4, OH, OW);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_bn_relu_maxpool3x3s2_nhwc_bwd_reduce(const float* g_out, const unsigned char* argmax, const float* out, const float* y, const float* mean,
+                                             const float* rstd, int B, int H, int W, int C, double* acc, void* stream) {
+    if (!g_out || !argmax || !out || !y || !mean || !rstd || !acc || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 64)
+        return fail(HMF_ERR_INVALID, "hmf_bn_relu_maxpool3x3s2_nhwc_bwd_reduce: bad args (C %% 64 == 0 required)");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long M = (long long)B * OH * OW;
+    if (M * C >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_bn_relu_maxpool3x3s2_nhwc_bwd_reduce: pooled map exceeds 2^31 elements");
+    hipLaunchKernelGGL(k_bn_relu_pool_bwd_reduce, dim3(C / 64, (unsigned)((M + kBnRows - 1) / kBnRows)), dim3(256), 0, (hipStream_t)stream, g_out,
+                       (const unsigned int*)argmax, out, y, mean, rstd, B, H, W, C, OH, OW, acc);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_bn_relu_maxpool3x3s2_nhwc_bwd_apply(const float* g_out, const unsigned char* argmax, const float* out, const float* y, const float* ca,
+                                            const float* cb, const float* cc, float* gy, int B, int H, int W, int C, void* stream) {
+    if (!g_out || !argmax || !out || !y || !ca || !cb || !cc || !gy || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4)
+        return fail(HMF_ERR_INVALID, "hmf_bn_relu_maxpool3x3s2_nhwc_bwd_apply: bad args");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long n = (long long)B * H * W * (C / 4);
+    long long blocks = std::min<long long>((n + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_bn_relu_pool_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)g_out, (const unsigned int*)argmax,
+                       (const f32x4*)out, (const f32x4*)y, ca, cb, cc, (f32x4*)gy, B, H, W, C / 4, OH, OW);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

@@ -20,6 +20,8 @@ models/resnet.py).  One `torch.autograd.Function` spans the whole encoder, so no
   max-pool: hmf_maxpool3x3s2_nhwc / hmf_maxpool3x3s2_nhwc_backward; global average pool: torch mean / broadcast (B x C values).
 Filter re-layouts (flip, transpose, channels_last) are small torch copies per step (the filters total 45-94 MB).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -198,12 +200,18 @@ class _ZeroPool:
 
 
 class _Saved:
-    __slots__ = ('conv', 'bn', 'x', 'y', 'out', 'mean', 'rstd', 'relu', 'stride', 'stem')
+    __slots__ = ('conv', 'bn', 'x', 'y', 'out', 'mean', 'rstd', 'relu', 'stride', 'stem', 'pooled', 'argmax')
 
 
-def _bn_forward(y, bn, residual, relu, pool=None, tracked=None):
+# The stem's bn1 -> relu -> maxpool as one pass over the convolution's output (hmf_bn_relu_maxpool3x3s2_nhwc) with a two-pass backward: the activated
+# 302 MB map of the training batch is never written or re-read.  HMF_STEM_TAIL=0: the three separate passes (A/B runs, tests).
+STEM_TAIL_FUSED = os.environ.get('HMF_STEM_TAIL', '1') != '0'
+
+
+def _bn_forward(y, bn, residual, relu, pool=None, tracked=None, fuse_maxpool=False):
     """Training-mode BatchNorm on the NHWC rows of y, running statistics updated in place.  Returns (out, mean, rstd).
-    pool: _ZeroPool for the fp64 sums; tracked: list collecting num_batches_tracked tensors for ONE batched increment by the caller."""
+    pool: _ZeroPool for the fp64 sums; tracked: list collecting num_batches_tracked tensors for ONE batched increment by the caller.
+    fuse_maxpool: returns ((pooled, argmax), mean, rstd) instead -- relu(bn(y)) max-pooled 3x3 / 2 / pad 1 without materialising it."""
     lib = _lib.load()
     B, C, H, W = y.shape
     M = B * H * W
@@ -227,10 +235,36 @@ def _bn_forward(y, bn, residual, relu, pool=None, tracked=None):
             tracked.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked += 1
+    if fuse_maxpool:
+        assert relu and residual is None
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        pooled = _cl_empty(B, C, OH, OW, dev)
+        argmax = torch.empty(B, OH, OW, C, dtype=torch.uint8, device=dev)
+        _lib.check(lib.hmf_bn_relu_maxpool3x3s2_nhwc(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), pooled.data_ptr(), argmax.data_ptr(), B, H, W, C, st),
+                   'hmf_bn_relu_maxpool3x3s2_nhwc')
+        return (pooled, argmax), mean, rstd
     out = _cl_empty(B, C, H, W, dev)
     _lib.check(lib.hmf_bn_apply(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if residual is None else residual.data_ptr(), out.data_ptr(),
                                 M, C, int(relu), st), 'hmf_bn_apply')
     return out, mean, rstd
+
+
+def _bn_pool_backward(g, s, pool=None):
+    """Backward of the fused stem tail: g = dL/d pooled map -> (gy = dL/d conv output, d gamma, d beta)."""
+    lib = _lib.load()
+    B, C, H, W = s.y.shape
+    dev = g.device
+    st = _lib.current_stream()
+    acc = pool.take(C) if pool is not None else torch.zeros(2, C, dtype=torch.float64, device=dev)
+    _lib.check(lib.hmf_bn_relu_maxpool3x3s2_nhwc_bwd_reduce(g.data_ptr(), s.argmax.data_ptr(), s.pooled.data_ptr(), s.y.data_ptr(), s.mean.data_ptr(),
+                                                            s.rstd.data_ptr(), B, H, W, C, acc.data_ptr(), st), 'hmf_bn_relu_maxpool3x3s2_nhwc_bwd_reduce')
+    gg, gb, ca, cb, cc = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(5))
+    _lib.check(lib.hmf_bn_bwd_finalize(acc.data_ptr(), B * H * W, C, s.bn.weight.data_ptr(), s.mean.data_ptr(), s.rstd.data_ptr(), gg.data_ptr(), gb.data_ptr(),
+                                       ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), st), 'hmf_bn_bwd_finalize')
+    gy = _cl_empty(B, C, H, W, dev)
+    _lib.check(lib.hmf_bn_relu_maxpool3x3s2_nhwc_bwd_apply(g.data_ptr(), s.argmax.data_ptr(), s.pooled.data_ptr(), s.y.data_ptr(), ca.data_ptr(), cb.data_ptr(),
+                                                           cc.data_ptr(), gy.data_ptr(), B, H, W, C, st), 'hmf_bn_relu_maxpool3x3s2_nhwc_bwd_apply')
+    return gy, gg, gb
 
 
 def _bn_backward(g, s, want_gz, pool=None):
@@ -388,6 +422,12 @@ class EncoderTrainFn(torch.autograd.Function):
                     _lib.check(lib.hmf_stem_conv(xin.data_ptr(), packed.data_ptr(), None, s.y.data_ptr(), B, C, H, W, 0, _lib.current_stream()), 'hmf_stem_conv')
             else:
                 s.y = _conv_any(xin, conv.weight.detach(), s.stride, native=(conv.weight, False))
+            s.pooled = s.argmax = None
+            if stem and STEM_TAIL_FUSED and s.y.shape[1] % 64 == 0:
+                (s.pooled, s.argmax), s.mean, s.rstd = _bn_forward(s.y, bn, None, True, pool, tracked, fuse_maxpool=True)
+                s.out = None
+                saved.append(s)
+                return s.pooled
             s.out, s.mean, s.rstd = _bn_forward(s.y, bn, residual, relu, pool, tracked)
             saved.append(s)
             return s.out
@@ -396,9 +436,12 @@ class EncoderTrainFn(torch.autograd.Function):
             _pack_all_winograd(enc, dev)
             xin = x.detach().float().contiguous()
             a0 = unit(enc.conv1, enc.bn1, xin, True, stem=True)
-            B, C, H, W = a0.shape
-            p0 = _cl_empty(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dev)
-            _lib.check(lib.hmf_maxpool3x3s2_nhwc(a0.data_ptr(), p0.data_ptr(), B, H, W, C, _lib.current_stream()), 'hmf_maxpool3x3s2_nhwc')
+            if saved[0].pooled is not None:                           # bn1 + relu + maxpool in one pass: `a0` is already the pooled map
+                p0, a0 = a0, None
+            else:
+                B, C, H, W = a0.shape
+                p0 = _cl_empty(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dev)
+                _lib.check(lib.hmf_maxpool3x3s2_nhwc(a0.data_ptr(), p0.data_ptr(), B, H, W, C, _lib.current_stream()), 'hmf_maxpool3x3s2_nhwc')
             cur = p0
             plan = []
             for li in range(1, 5):
@@ -480,13 +523,16 @@ class EncoderTrainFn(torch.autograd.Function):
                     g_h = _dgrad(gy, ds, residual=g_h)
                 g = g_h
             # max-pool and stem
-            a0 = ctx.a0
-            B, C, H, W = a0.shape
-            g_a0 = _cl_empty(B, C, H, W, dev)
-            _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(a0.data_ptr(), g.data_ptr(), g_a0.data_ptr(), B, H, W, C, _lib.current_stream()),
-                       'hmf_maxpool3x3s2_nhwc_backward')
             s = saved[0]
-            gy, _, gg, gb = _bn_backward(g_a0, s, want_gz=False, pool=pool)
+            if s.pooled is not None:
+                gy, gg, gb = _bn_pool_backward(g, s, pool=pool)
+            else:
+                a0 = ctx.a0
+                B, C, H, W = a0.shape
+                g_a0 = _cl_empty(B, C, H, W, dev)
+                _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(a0.data_ptr(), g.data_ptr(), g_a0.data_ptr(), B, H, W, C, _lib.current_stream()),
+                           'hmf_maxpool3x3s2_nhwc_backward')
+                gy, _, gg, gb = _bn_backward(g_a0, s, want_gz=False, pool=pool)
             grads[id(s.bn.weight)], grads[id(s.bn.bias)] = gg, gb
             grads[id(s.conv.weight)] = wgrad(gy, s)
             wgrad.join()

@@ -589,6 +589,19 @@ int hmf_bn_bwd_apply(const float* g, const float* out, const float* y, const flo
 /* Backward of hmf_maxpool3x3s2_nhwc: x (B,H,W,C) the pooled tensor's input, g_out (B,OH,OW,C) -> g_x; ties go to the first maximum in
  * (kh, kw) scan order, as torch's forward records them.                                                                               */
 int hmf_maxpool3x3s2_nhwc_backward(const float* x, const float* g_out, float* g_x, int B, int H, int W, int C, void* stream);
+/* The stem's tail in training mode (models/resnet.py:148-151: bn1 -> relu -> maxpool 3x3 / 2 / pad 1) as ONE pass over the convolution's output and
+ * its two-pass backward, round 5: the activated (B,H,W,C) map is never written.
+ *   forward     out (B,OH,OW,C) = maxpool(relu(scale[c] y + shift[c])),  argmax (B,OH,OW,C) bytes = tap 3 dh + dw of the FIRST maximum (torch's scan)
+ *   bwd_reduce  acc[0][C] += sum gz, acc[1][C] += sum gz xhat over the INPUT elements (gz = pooled gradient at a window's recorded arg-max when the
+ *               maximum is positive, else 0) -- feeds hmf_bn_bwd_finalize exactly as hmf_bn_bwd_reduce does (M = B H W there)
+ *   bwd_apply   gy (B,H,W,C) = ca gz + cb y + cc: the convolution's output gradient (what hmf_maxpool3x3s2_nhwc_backward + hmf_bn_bwd_apply produce)
+ * `out` is the forward's pooled map (its sign is the ReLU mask).  C % 64 == 0 for the reduction, C % 4 elsewhere; argmax 4-byte aligned.            */
+int hmf_bn_relu_maxpool3x3s2_nhwc(const float* y, const float* scale, const float* shift, float* out, unsigned char* argmax, int B, int H, int W, int C,
+                                  void* stream);
+int hmf_bn_relu_maxpool3x3s2_nhwc_bwd_reduce(const float* g_out, const unsigned char* argmax, const float* out, const float* y, const float* mean,
+                                             const float* rstd, int B, int H, int W, int C, double* acc, void* stream);
+int hmf_bn_relu_maxpool3x3s2_nhwc_bwd_apply(const float* g_out, const unsigned char* argmax, const float* out, const float* y, const float* ca,
+                                            const float* cb, const float* cc, float* gy, int B, int H, int W, int C, void* stream);
 /* Weight gradient of a convolution: gy (B,OH,OW,Cout), x (B,H,W,Cin) NHWC -> dw [Cout][ks][ks][Cin] (channels_last filter layout), padding ks/2.
  * stem_nchw = 1: x is the NCHW proxy input (B,Cin,H,W) and dw comes out as [Cout][Cin][ks][ks] (torch's native layout).
  * dw is zeroed, then accumulated with float atomics over slices of the pixel axis (run-to-run differences at rounding level).            */

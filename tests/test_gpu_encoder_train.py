@@ -184,6 +184,47 @@ def test_stem_weight_gradient_and_maxpool_backward_match_torch():
         assert _rel(ga, ar.grad) < 1e-6, (hh, ww)
 
 
+@pytest.mark.parametrize('B,H,W', [(3, 32, 32), (2, 31, 29), (2, 7, 10), (1, 128, 128)])
+def test_fused_stem_tail_bn_relu_maxpool_matches_torch(B, H, W):
+    """models/resnet.py:148-151 in training mode as one pass (hmf_bn_relu_maxpool3x3s2_nhwc) and its two-pass backward vs float64 autograd through
+    BatchNorm2d -> relu -> max_pool2d: pooled map, running statistics, d conv-output, d gamma, d beta; and vs the three separate passes."""
+    torch.manual_seed(B * 100 + H)
+    C = 64
+    y = (torch.randn(B, C, H, W, device='cuda') * 1.5 + 0.2).contiguous(memory_format=CL)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    ref_bn = copy.deepcopy(bn).double()
+    bn2 = copy.deepcopy(bn)
+    yr = y.double().requires_grad_(True)
+    pr = F.max_pool2d(F.relu(ref_bn(yr)), 3, 2, 1)
+    g = torch.randn_like(pr).float().contiguous(memory_format=CL)
+    pr.backward(g.double())
+    with torch.no_grad():
+        (pooled, argmax), mean, rstd = et._bn_forward(y, bn, None, True, fuse_maxpool=True)
+        s = et._Saved()
+        s.bn, s.y, s.mean, s.rstd, s.relu, s.pooled, s.argmax = bn, y, mean, rstd, True, pooled, argmax
+        gy, gg, gb = et._bn_pool_backward(g, s)
+    assert pooled.shape == pr.shape and _rel(pooled, pr.detach()) < 1e-5
+    assert int(argmax.max()) <= 8
+    assert _rel(bn.running_mean, ref_bn.running_mean) < 1e-5 and _rel(bn.running_var, ref_bn.running_var) < 1e-5 and int(bn.num_batches_tracked) == 1
+    assert _rel(gy, yr.grad) < 2e-5
+    assert _rel(gg, ref_bn.weight.grad) < 2e-5 and _rel(gb, ref_bn.bias.grad) < 2e-5
+    # the three separate passes on the same tensors
+    lib = _lib.load()
+    with torch.no_grad():
+        out, mean2, rstd2 = et._bn_forward(y, bn2, None, True)
+        p2 = torch.empty_like(pooled)
+        _lib.check(lib.hmf_maxpool3x3s2_nhwc(out.data_ptr(), p2.data_ptr(), B, H, W, C, _lib.current_stream()), 'maxpool')
+        g_a0 = torch.empty_like(out)
+        _lib.check(lib.hmf_maxpool3x3s2_nhwc_backward(out.data_ptr(), g.data_ptr(), g_a0.data_ptr(), B, H, W, C, _lib.current_stream()), 'maxpool bwd')
+        s2 = et._Saved()
+        s2.bn, s2.y, s2.out, s2.mean, s2.rstd, s2.relu = bn2, y, out, mean2, rstd2, True
+        gy2, _, gg2, gb2 = et._bn_backward(g_a0, s2, want_gz=False)
+    assert torch.equal(pooled, p2)
+    assert _rel(gy, gy2) < 1e-6 and _rel(gg, gg2) < 1e-6 and _rel(gb, gb2) < 1e-6
+
+
 @pytest.mark.parametrize('layers,B,size', [(18, 4, 64), (50, 3, 64), (18, 6, 128)])
 def test_whole_encoder_training_graph_matches_module_autograd(layers, B, size):
     torch.manual_seed(layers)
