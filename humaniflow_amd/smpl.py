@@ -100,7 +100,9 @@ class SMPL(nn.Module):
             raise ValueError("blend_dtype must be 'fp32', 'bf16' (BASELINE configs[2]: bf16 MFMA blend-shape GEMMs, fp32 accumulate; operands as bf16 hi + lo "
                              "pairs, three MFMAs per product: vertices within 1e-4 m of fp32) or 'bf16_plain' (single bf16 operands: 1.5e-3 m)")
         self.blend_dtype = blend_dtype
-        self.lbs_rows = int(os.environ.get('HMF_LBS_ROWS', '64'))     # 64: k_lbs_mfma (128 KB of LDS, one work-group per CU); 32: k_lbs_mfma32 (64 KB, two per CU)
+        # 64: k_lbs_mfma (128 KB of LDS, one work-group per CU); 32: k_lbs_mfma32 (64 KB, two per CU); 0 (default): 32-row groups for calls of
+        # <= 32 bodies (the predict shape, M = 11: a 64-row tile would spend half its MFMAs on dead rows), 64 beyond.  Bitwise the same results.
+        self.lbs_rows = int(os.environ.get('HMF_LBS_ROWS', '0'))
         if model_data is None:
             model_data = load_smpl_pkl(model_path, gender, num_betas)
         self.gender = gender
@@ -181,10 +183,10 @@ class SMPL(nn.Module):
         except Exception:
             pass
 
-    def _impl(self):
-        """hmf_smpl_lbs `impl` of this module's configuration."""
+    def _impl(self, M=None):
+        """hmf_smpl_lbs `impl` of this module's configuration for a call of M bodies."""
         if self.blend_dtype == 'fp32':
-            return 4 if self.lbs_rows == 32 else 0
+            return 4 if (self.lbs_rows == 32 or (self.lbs_rows == 0 and M is not None and M <= 32)) else 0
         return {'bf16': 3, 'bf16_plain': 2}[self.blend_dtype]
 
     def _workspace(self, device, M):
@@ -222,7 +224,7 @@ class SMPL(nn.Module):
             ws = self._workspace(dev, M)
             _lib.check(lib.hmf_smpl_lbs(self._handle(dev), _lib.dptr(g), g.shape[0], _lib.dptr(b), _lib.dptr(be), be.shape[0], M,
                                         _lib.dptr(verts), _lib.dptr(joints), _lib.dptr(ws), ws.numel(),
-                                        int(self._impl() if impl is None else impl),
+                                        int(self._impl(M) if impl is None else impl),
                                         _lib.current_stream()), 'hmf_smpl_lbs')
         return verts, joints
 
@@ -317,7 +319,7 @@ class SMPL(nn.Module):
                 ws = self._workspace(dev, M)
                 _lib.check(lib.hmf_smpl_lbs_packed(self._handle(dev), _lib.dptr(gc), B, N, _lib.dptr(bc), _lib.dptr(bec), _lib.dptr(verts), _lib.dptr(joints),
                                                    _lib.dptr(full_pose), _lib.dptr(ws), ws.numel(),
-                                                   int(self._impl()), _lib.current_stream()),
+                                                   int(self._impl(M)), _lib.current_stream()),
                            'hmf_smpl_lbs_packed')
             if hasattr(self, 'transl') and self.transl is not None:
                 joints = joints + self.transl.unsqueeze(1)
