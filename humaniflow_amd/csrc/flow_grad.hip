@@ -122,11 +122,16 @@ __device__ __forceinline__ void store_net(const GradRec& G, int p, int c, int r,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// log p(v | ctx) on the algebra with its reverse sweep (mirrors log_prob_so3 of flow_kernels.hip).
-// g: upstream gradient of this term (wave-uniform).  do_bwd = false: value only.
+// log p(v | ctx) on the algebra (mirrors log_prob_so3 of flow_kernels.hip) in two halves: the forward keeps what the reverse sweep needs in
+// registers (AlgState), so that a wave evaluates its pre-image ONCE and the three pre-images of a (row, part) run on three waves side by side.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float algebra_logprob(const FlowDev& d, const PartTab& pt, int lane, float ctx_lane, const float (&v)[3], bool do_bwd,
-                                                 float g, float& g_ctx_acc, const GradRec& G, int p, int row) {
+struct AlgState {
+    NetAct A0, A1;
+    float raw0, raw1;             // hyper-network outputs (lane = spline parameter)
+    float x0, u0, in0, in1, z1, z2;
+};
+
+__device__ __forceinline__ float algebra_fwd(const FlowDev& d, const PartTab& pt, int lane, float ctx_lane, const float (&v)[3], AlgState& S) {
     const float r = d.radius;
     float x[3] = {v[0], v[1], v[2]};
     {
@@ -143,57 +148,69 @@ __device__ __forceinline__ float algebra_logprob(const FlowDev& d, const PartTab
     if (yn > 1e-7f) lp = -(2.f * (logf(yn) - logf(xn)) + log1pf(-((yn / r) * (yn / r))));
     const int dim = lane & 1;
     // coupling 1 inverse: hyper-net on (ctx, x0); dims (x1, x2) -> (a, b)
-    NetAct A1;
-    const float raw1 = hypernet_fwd(d, pt, 1, lane, ctx_lane, x[0], A1);
+    S.x0 = x[0];
+    S.raw1 = hypernet_fwd(d, pt, 1, lane, ctx_lane, x[0], S.A1);
     float w1[8], h1[8], d1[7], l1[8];
-    gather_raw(raw1, dim, w1, h1, d1, l1);
-    const float in1 = dim ? x[2] : x[1];
+    gather_raw(S.raw1, dim, w1, h1, d1, l1);
+    S.in1 = dim ? x[2] : x[1];
     float ld1;
-    const float o1 = rational_linear_spline<true>(in1, w1, h1, d1, l1, r, &ld1);
+    const float o1 = rational_linear_spline<true>(S.in1, w1, h1, d1, l1, r, &ld1);
     const float a = __shfl(o1, 0), b = __shfl(o1, 1);
     lp += __shfl(ld1, 0) + __shfl(ld1, 1);
     // Permute([1,2,0]) inverse: u = (b, x0, a); coupling 0 inverse: hyper-net on (ctx, u0); dims (u1, u2) -> (z1, z2)
     const float u0 = b, u1 = x[0], u2 = a;
-    NetAct A0;
-    const float raw0 = hypernet_fwd(d, pt, 0, lane, ctx_lane, u0, A0);
+    S.u0 = u0;
+    S.raw0 = hypernet_fwd(d, pt, 0, lane, ctx_lane, u0, S.A0);
     float w0[8], h0[8], d0[7], l0[8];
-    gather_raw(raw0, dim, w0, h0, d0, l0);
-    const float in0 = dim ? u2 : u1;
+    gather_raw(S.raw0, dim, w0, h0, d0, l0);
+    S.in0 = dim ? u2 : u1;
     float ld0;
-    const float o0 = rational_linear_spline<true>(in0, w0, h0, d0, l0, r, &ld0);
-    const float z1 = __shfl(o0, 0), z2 = __shfl(o0, 1);
+    const float o0 = rational_linear_spline<true>(S.in0, w0, h0, d0, l0, r, &ld0);
+    S.z1 = __shfl(o0, 0); S.z2 = __shfl(o0, 1);
     lp += __shfl(ld0, 0) + __shfl(ld0, 1);
     const float var = d.base_std * d.base_std, lsc = logf(d.base_std), hl2pi = 0.91893853320467274178f;
-    lp += -(u0 * u0 + z1 * z1 + z2 * z2) / (2.f * var) - 3.f * (lsc + hl2pi);
-    if (!do_bwd) return lp;
-    // ---- reverse sweep ----
-    const float g_z0 = -g * u0 / var, g_z1 = -g * z1 / var, g_z2 = -g * z2 / var;
-    SplineGrad S0;
-    float t0, t1;
-    spline_vjp<true>(in0, w0, h0, d0, l0, r, dim ? g_z2 : g_z1, g, t0, t1, S0);
-    NetDelta D0;
-    float g_ctx0, g_x1_0;
-    hypernet_bwd(d, pt, 0, lane, A0, scatter_raw_grad(S0, lane), D0, g_ctx0, g_x1_0);
-    const float g_u0 = g_z0 + g_x1_0;
-    const float g_u2 = __shfl(S0.g_x, 1);                       // u2 is the input of dimension 1 of spline 0
-    SplineGrad S1;
-    spline_vjp<true>(in1, w1, h1, d1, l1, r, dim ? g_u0 : g_u2, g, t0, t1, S1);     // a = out of dim 0 -> u2; b = out of dim 1 -> u0
-    NetDelta D1;
-    float g_ctx1, g_x1_1;
-    hypernet_bwd(d, pt, 1, lane, A1, scatter_raw_grad(S1, lane), D1, g_ctx1, g_x1_1);
-    g_ctx_acc += g_ctx0 + g_ctx1;
-    store_net(G, p, 0, row, lane, D0, A0, u0);
-    store_net(G, p, 1, row, lane, D1, A1, x[0]);
+    lp += -(u0 * u0 + S.z1 * S.z1 + S.z2 * S.z2) / (2.f * var) - 3.f * (lsc + hl2pi);
     return lp;
 }
 
+// g: upstream gradient of this term (wave-uniform).  Returns d L / d ctx of this lane's channel; writes the records of row `row`.
+__device__ __forceinline__ float algebra_bwd(const FlowDev& d, const PartTab& pt, int lane, float g, const AlgState& S, const GradRec& G, int p, int row) {
+    const float r = d.radius;
+    const int dim = lane & 1;
+    const float var = d.base_std * d.base_std;
+    const float g_z0 = -g * S.u0 / var, g_z1 = -g * S.z1 / var, g_z2 = -g * S.z2 / var;
+    float w0[8], h0[8], d0[7], l0[8];
+    gather_raw(S.raw0, dim, w0, h0, d0, l0);
+    SplineGrad S0;
+    float t0, t1;
+    spline_vjp<true>(S.in0, w0, h0, d0, l0, r, dim ? g_z2 : g_z1, g, t0, t1, S0);
+    NetDelta D0;
+    float g_ctx0, g_x1_0;
+    hypernet_bwd(d, pt, 0, lane, S.A0, scatter_raw_grad(S0, lane), D0, g_ctx0, g_x1_0);
+    const float g_u0 = g_z0 + g_x1_0;
+    const float g_u2 = __shfl(S0.g_x, 1);                       // u2 is the input of dimension 1 of spline 0
+    float w1[8], h1[8], d1[7], l1[8];
+    gather_raw(S.raw1, dim, w1, h1, d1, l1);
+    SplineGrad S1;
+    spline_vjp<true>(S.in1, w1, h1, d1, l1, r, dim ? g_u0 : g_u2, g, t0, t1, S1);     // a = out of dim 0 -> u2; b = out of dim 1 -> u0
+    NetDelta D1;
+    float g_ctx1, g_x1_1;
+    hypernet_bwd(d, pt, 1, lane, S.A1, scatter_raw_grad(S1, lane), D1, g_ctx1, g_x1_1);
+    store_net(G, p, 0, row, lane, D0, S.A0, S.u0);
+    store_net(G, p, 1, row, lane, D1, S.A1, S.x0);
+    return g_ctx0 + g_ctx1;
+}
+
 // Teacher-forced NLL, reverse sweep.  Records: R = 3 * B rows per part, row = term * B + b (terms of out-of-support pre-images: zeros).
-__global__ __launch_bounds__(256) void k_flow_logprob_bwd(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids, int P,
+// One work-group of three waves per (row, part), wave c = pre-image c (round 5; the single-wave form walked the three forwards, then forward + reverse
+// again per live pre-image: 5-6 dependent passes of the hyper-networks per wave, 395 us at B = 72; here one forward and one reverse per wave).
+__global__ __launch_bounds__(192) void k_flow_logprob_bwd(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids, int P,
                                                           const double* __restrict__ Rin, int B, const float* __restrict__ g_logp,
                                                           float* __restrict__ g_ctx, GradRec G) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gw >= B * P) return;
+    __shared__ float s_term[3];
+    __shared__ float s_gctx[3][64];
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int gw = blockIdx.x;
     const int b = gw / P, p = gw % P;
     const int j = part_ids ? part_ids[p] : p;
     const PartTab& pt = d.tab[j];
@@ -204,55 +221,40 @@ __global__ __launch_bounds__(256) void k_flow_logprob_bwd(FlowDev d, const float
     so3_log_f64(R, x);
     const double kTwoPi = 6.28318530717958647692;
     const double n = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    // The three pre-images are walked by ROLLED loops (the body inlines the whole density + reverse sweep: unrolled three times it does not fit the
-    // unroller's budget, and a partly unrolled loop indexes its per-candidate arrays dynamically, which puts them in scratch memory).  Per-candidate
-    // values therefore live in named registers, selected by compare chains.
-    float c0[3] = {0.f, 0.f, 0.f}, c1[3] = {0.f, 0.f, 0.f}, c2[3] = {0.f, 0.f, 0.f};
-    float t0 = -INFINITY, t1 = -INFINITY, t2 = -INFINITY;
-    bool ok0 = true, ok1 = false, ok2 = false;
-    float dummy = 0.f;
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-        double cd[3] = {x[0], x[1], x[2]};
-        bool okc = true;
-        if (c > 0) {
-            const double k = c == 1 ? -1.0 : 1.0;
-            const double sc = (n + kTwoPi * k);
-            cd[0] = x[0] / n * sc; cd[1] = x[1] / n * sc; cd[2] = x[2] / n * sc;
-            const double cn = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
-            okc = cn < (double)d.radius;
-            if (!okc) { cd[0] = 0.0; cd[1] = 0.0; cd[2] = 0.0; }
-        }
+    double cd[3] = {x[0], x[1], x[2]};
+    bool okc = true;
+    if (c > 0) {
+        const double sc = n + kTwoPi * (c == 1 ? -1.0 : 1.0);
+        cd[0] = x[0] / n * sc; cd[1] = x[1] / n * sc; cd[2] = x[2] / n * sc;
+        okc = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]) < (double)d.radius;
+    }
+    const int row = c * B + b;
+    G.ACTX[((size_t)p * G.R + row) * 64 + lane] = ctx_lane;
+    AlgState S;
+    float term = -INFINITY;
+    if (okc) {                                                        // wave-uniform
         const float ldc = -(float)so3_logdet_f64(cd);
         const float cc[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
-        const float lp = okc ? algebra_logprob(d, pt, lane, ctx_lane, cc, false, 0.f, dummy, G, p, 0) : 0.f;
-        const float tc = okc ? (ldc + lp) : -INFINITY;
-        if (c == 0) { c0[0] = cc[0]; c0[1] = cc[1]; c0[2] = cc[2]; t0 = tc; ok0 = okc; }
-        else if (c == 1) { c1[0] = cc[0]; c1[1] = cc[1]; c1[2] = cc[2]; t1 = tc; ok1 = okc; }
-        else { c2[0] = cc[0]; c2[1] = cc[1]; c2[2] = cc[2]; t2 = tc; ok2 = okc; }
+        term = ldc + algebra_fwd(d, pt, lane, ctx_lane, cc, S);
     }
-    const float m = fmaxf(t0, fmaxf(t1, t2));
-    const float s = expf(t0 - m) + expf(t1 - m) + expf(t2 - m);
-    const float gup = g_logp[gw];
+    if (lane == 0) s_term[c] = term;
+    __syncthreads();
     float g_acc = 0.f;
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-        const int row = c * B + b;
-        const bool okc = c == 0 ? ok0 : (c == 1 ? ok1 : ok2);
-        const float tc = c == 0 ? t0 : (c == 1 ? t1 : t2);
-        const float cc[3] = {c == 0 ? c0[0] : (c == 1 ? c1[0] : c2[0]), c == 0 ? c0[1] : (c == 1 ? c1[1] : c2[1]), c == 0 ? c0[2] : (c == 1 ? c1[2] : c2[2])};
-        if (okc) {
-            const float wgt = expf(tc - m) / s;                       // d logsumexp / d term_c
-            algebra_logprob(d, pt, lane, ctx_lane, cc, true, gup * wgt, g_acc, G, p, row);
-        } else {                                                      // masked pre-image: no contribution
-            NetDelta Z = {0.f, 0.f, 0.f, 0.f};
-            NetAct ZA = {0.f, 0.f, 0.f};
-            store_net(G, p, 0, row, lane, Z, ZA, 0.f);
-            store_net(G, p, 1, row, lane, Z, ZA, 0.f);
-        }
-        G.ACTX[((size_t)p * G.R + row) * 64 + lane] = ctx_lane;
+    if (okc) {
+        const float t0 = s_term[0], t1 = s_term[1], t2 = s_term[2];
+        const float m = fmaxf(t0, fmaxf(t1, t2));
+        const float ssum = expf(t0 - m) + expf(t1 - m) + expf(t2 - m);
+        const float wgt = expf(term - m) / ssum;                      // d logsumexp / d term_c
+        g_acc = algebra_bwd(d, pt, lane, g_logp[gw] * wgt, S, G, p, row);
+    } else {                                                          // masked pre-image: no contribution
+        NetDelta Z = {0.f, 0.f, 0.f, 0.f};
+        NetAct ZA = {0.f, 0.f, 0.f};
+        store_net(G, p, 0, row, lane, Z, ZA, 0.f);
+        store_net(G, p, 1, row, lane, Z, ZA, 0.f);
     }
-    g_ctx[(size_t)gw * kCtx + lane] = g_acc;
+    s_gctx[c][lane] = g_acc;
+    __syncthreads();
+    if (c == 0) g_ctx[(size_t)gw * kCtx + lane] = (s_gctx[0][lane] + s_gctx[1][lane]) + s_gctx[2][lane];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -426,7 +428,7 @@ int hmf_flow_log_prob_SO3_backward(const hmf_flow_t* h, const float* ctx, const 
     if (rc) return rc;
     if (G.R != 3 * B) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_SO3_backward: records need rows == 3 * B");
     const int nw = B * P;
-    hipLaunchKernelGGL(k_flow_logprob_bwd, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, B, g_logp, g_ctx, G);
+    hipLaunchKernelGGL(k_flow_logprob_bwd, dim3(nw), dim3(192), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, B, g_logp, g_ctx, G);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

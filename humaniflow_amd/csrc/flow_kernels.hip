@@ -986,10 +986,9 @@ __device__ __forceinline__ float log_prob_so3(const FlowDev& d, const PartTab& p
     return lp + base;
 }
 
-// mode 0: SO(3) density of R (fp64, B x P x 9); mode 1: algebra density of v (fp32, B x P x 3)
+// algebra density of v (fp32, B x P x 3): one wave per (row, part)
 __global__ __launch_bounds__(256) void k_flow_logprob(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids,
-                                                      int P, const double* __restrict__ Rin, const float* __restrict__ vin, int B,
-                                                      int mode, float* __restrict__ logp) {
+                                                      int P, const float* __restrict__ vin, int B, float* __restrict__ logp) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gw >= B * P) return;
@@ -997,41 +996,51 @@ __global__ __launch_bounds__(256) void k_flow_logprob(FlowDev d, const float* __
     const int j = part_ids ? part_ids[p] : p;
     const PartTab& pt = d.tab[j];
     const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
-    if (mode == 1) {
-        const float v[3] = {vin[(size_t)gw * 3], vin[(size_t)gw * 3 + 1], vin[(size_t)gw * 3 + 2]};
-        const float lp = log_prob_so3(d, pt, lane, ctx_lane, v);
-        if (lane == 0) logp[gw] = lp;
-        return;
-    }
+    const float v[3] = {vin[(size_t)gw * 3], vin[(size_t)gw * 3 + 1], vin[(size_t)gw * 3 + 2]};
+    const float lp = log_prob_so3(d, pt, lane, ctx_lane, v);
+    if (lane == 0) logp[gw] = lp;
+}
+
+// SO(3) density of R (fp64, B x P x 9), candidate-parallel form (round 5): one work-group of THREE waves per (row, part), wave c = pre-image c of
+// so3_xset (utils/rigid_transform_utils.py:282-295) with k = 0, -1, +1 and the support mask (so3_exp_transform.py:36-41; NaN at x = 0 fails the
+// comparison, as in the reference, quirk 2).  The single-wave form of rounds 1-4 walked the three pre-images one after the other (three dependent passes of the two hyper-networks: ~200 us at B = 72 whatever the grid,
+// since every wave is resident at once and the launch lasts one wave's lifetime); here a wave evaluates one, masked pre-images (outside the support:
+// usually two of the three) end at once, and the log-sum-exp meets in LDS.  Same arithmetic per term, same sum order.
+__global__ __launch_bounds__(192) void k_flow_logprob_SO3_par(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids, int P,
+                                                              const double* __restrict__ Rin, float* __restrict__ logp) {
+    __shared__ float s_term[3];
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int gw = blockIdx.x;
+    const int p = gw % P;
+    const int j = part_ids ? part_ids[p] : p;
+    const PartTab& pt = d.tab[j];
     double R[9], x[3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) R[e] = Rin[(size_t)gw * 9 + e];
     so3_log_f64(R, x);
-    // so3_xset (utils/rigid_transform_utils.py:282-295) with k = -1, +1 and the support mask
-    // (so3_exp_transform.py:36-41); NaN at x = 0 fails the comparison, as in the reference (quirk 2)
     const double kTwoPi = 6.28318530717958647692;
     const double n = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    float terms[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double cand[3] = {x[0], x[1], x[2]};
-        bool ok = true;
-        if (c > 0) {
-            const double k = c == 1 ? -1.0 : 1.0;
-            const double sc = (n + kTwoPi * k);
-            cand[0] = x[0] / n * sc; cand[1] = x[1] / n * sc; cand[2] = x[2] / n * sc;
-            const double cn = sqrt(cand[0] * cand[0] + cand[1] * cand[1] + cand[2] * cand[2]);
-            ok = cn < (double)d.radius;
-            if (!ok) { cand[0] = 0.0; cand[1] = 0.0; cand[2] = 0.0; }
-        }
+    double cand[3] = {x[0], x[1], x[2]};
+    bool ok = true;
+    if (c > 0) {
+        const double sc = n + kTwoPi * (c == 1 ? -1.0 : 1.0);
+        cand[0] = x[0] / n * sc; cand[1] = x[1] / n * sc; cand[2] = x[2] / n * sc;
+        ok = sqrt(cand[0] * cand[0] + cand[1] * cand[1] + cand[2] * cand[2]) < (double)d.radius;
+    }
+    float term = -INFINITY;
+    if (ok) {                                                          // wave-uniform
+        const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
         const float ld = -(float)so3_logdet_f64(cand);
         const float v[3] = {(float)cand[0], (float)cand[1], (float)cand[2]};
-        const float lp = log_prob_so3(d, pt, lane, ctx_lane, v);
-        terms[c] = ok ? (ld + lp) : -INFINITY;
+        term = ld + log_prob_so3(d, pt, lane, ctx_lane, v);
     }
-    const float m = fmaxf(terms[0], fmaxf(terms[1], terms[2]));
-    const float s = expf(terms[0] - m) + expf(terms[1] - m) + expf(terms[2] - m);
-    if (lane == 0) logp[gw] = m + logf(s);
+    if (lane == 0) s_term[c] = term;
+    __syncthreads();
+    if (c == 0 && lane == 0) {
+        const float t0 = s_term[0], t1 = s_term[1], t2 = s_term[2];
+        const float m = fmaxf(t0, fmaxf(t1, t2));
+        logp[gw] = m + logf(expf(t0 - m) + expf(t1 - m) + expf(t2 - m));
+    }
 }
 
 }  // namespace hmf
@@ -1246,7 +1255,12 @@ static int logprob_common(const hmf_flow_t* h, const float* ctx, const int32_t* 
     }
     if (h->g.enabled) return generic_logprob(h, ctx, dev_ids, P, R, v, B, mode, logp, (hipStream_t)stream);
     const int nw = B * P;
-    hipLaunchKernelGGL(k_flow_logprob, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, v, B, mode, logp);
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_flow_logprob_SO3_par, dim3(nw), dim3(192), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, logp);
+        HMF_LAUNCH_CHECK();
+        return HMF_OK;
+    }
+    hipLaunchKernelGGL(k_flow_logprob, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, v, B, logp);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }
