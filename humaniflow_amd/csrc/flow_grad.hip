@@ -354,9 +354,13 @@ __global__ __launch_bounds__(256) void k_flow_chain_bwd(FlowDev d, int lev, cons
 // lane = column -- 128-byte coalesced loads, no transpose, no LDS.  rows <= a few hundred: a launch is latency-sized (tens of us), it replaces
 // the library GEMMs (torch.matmul / einsum) the round-2 backward called here.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_atb_batched(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm, float* __restrict__ asum,
-                                                    int rows, int m, int n, int lda, int ldb, long long sA, long long sB, int mt, int nt) {
-    const int lane = threadIdx.x, li = lane & 31, lq = lane >> 5;
+// Round 5: FOUR waves per tile, each a quarter of the row axis (the launch is latency-sized: one wave walking 576 rows is a chain of 288 dependent MFMAs
+// behind their loads, 15-35 us x ~18 launches per training step); the four partial tiles meet in LDS and are summed in a fixed order.
+__global__ __launch_bounds__(256) void k_atb_batched(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm, float* __restrict__ asum,
+                                                     int rows, int m, int n, int lda, int ldb, long long sA, long long sB, int mt, int nt) {
+    __shared__ float part[3][16][64];
+    __shared__ float psum[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lq = lane >> 5;
     int t = blockIdx.x;
     const int jn = t % nt; t /= nt;
     const int im = t % mt;
@@ -370,13 +374,15 @@ __global__ __launch_bounds__(64) void k_atb_batched(const float* __restrict__ A,
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float s = 0.f;
     constexpr int U = 8;                                         // k-steps (row pairs) in flight
-    for (int r0 = 0; r0 < rows; r0 += 2 * U) {
+    const int per = ((rows + 3) / 4 + 1) & ~1;                   // rows per wave, even: a k-step is a row pair
+    const int r_begin = wave * per, r_end = min(rows, r_begin + per);
+    for (int r0 = r_begin; r0 < r_end; r0 += 2 * U) {
         float fa[U], fb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int r = r0 + 2 * u + lq;
-            fa[u] = (va && r < rows) ? a[(long long)r * lda + ca] : 0.f;
-            fb[u] = (vb && r < rows) ? bb[(long long)r * ldb + cb] : 0.f;
+            fa[u] = (va && r < r_end) ? a[(long long)r * lda + ca] : 0.f;
+            fb[u] = (vb && r < r_end) ? bb[(long long)r * ldb + cb] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -384,6 +390,16 @@ __global__ __launch_bounds__(64) void k_atb_batched(const float* __restrict__ A,
             s += fa[u];
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
+        psum[wave - 1][lane] = s;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];
+    s = ((s + psum[0][lane]) + psum[1][lane]) + psum[2][lane];
     // accumulator register r of lane (j = li, q): C row (r & 3) + 8 (r >> 2) + 4 q of the tile, column j
     float* c = Cm + (long long)b * m * n;
 #pragma unroll
@@ -457,7 +473,7 @@ int hmf_rows_atb_batched(const float* A, const float* B, float* C, float* a_cols
     const int mt = (m + 31) / 32, nt = (n + 31) / 32;
     const long long blocks = (long long)batch * mt * nt;
     if (blocks >= (1LL << 31)) return fail(HMF_ERR_UNSUPPORTED, "hmf_rows_atb_batched: too many tiles");
-    hipLaunchKernelGGL(k_atb_batched, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, A, B, C, a_colsum, rows, m, n, lda, ldb, batch_stride_a,
+    hipLaunchKernelGGL(k_atb_batched, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, B, C, a_colsum, rows, m, n, lda, ldb, batch_stride_a,
                        batch_stride_b, mt, nt);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
