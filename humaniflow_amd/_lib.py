@@ -106,6 +106,7 @@ _SIGS = {
     'hmf_flow_generic_sample_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.POINTER(FlowVariantGradRecords), _VP]),
     'hmf_rows_atb_batched': (C.c_int, [_VP] * 4 + [C.c_int] * 6 + [C.c_longlong] * 2 + [_VP]),
     'hmf_smpl_joints_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    'hmf_smpl_joints': (C.c_int, [_VP] * 4 + [C.c_int, _VP, _VP]),
     'hmf_bn_stats': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP]),
     'hmf_bn_finalize': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_float, C.c_float] + [_VP] * 7),
     'hmf_bn_apply': (C.c_int, [_VP] * 5 + [C.c_int] * 3 + [_VP]),

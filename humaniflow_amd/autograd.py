@@ -436,7 +436,11 @@ class SmplJoints(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, smpl, glob9, body207, betas, impl):
-        verts, joints = smpl._lbs_kernel(glob9.detach(), body207.detach(), betas.detach(), impl)
+        if impl == -1:                                                # joints only (hmf_smpl_joints): the training loss never reads the vertices
+            joints = smpl._joints_kernel(glob9.detach(), body207.detach(), betas.detach())
+            verts = joints.new_empty(0)
+        else:
+            verts, joints = smpl._lbs_kernel(glob9.detach(), body207.detach(), betas.detach(), impl)
         ctx.smpl = smpl
         ctx.save_for_backward(glob9.detach(), body207.detach(), betas.detach())
         ctx.set_materialize_grads(False)

@@ -1017,6 +1017,93 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The 90 output joints WITHOUT the body (round 5): what the training loss consumes (2D reprojection of joints[:, ALL_JOINTS_TO_COCO_MAP],
+// train/train_humaniflow.py:283-318; the vertices of the same SMPL call feed only the reference's metric tracker).  One work-group per row: rest
+// joints, the 24-joint chain level by level, then only the <= kMaxJU vertices the gathered joints touch go through the blend shapes (the dense
+// joint-vertex matrix of k_smpl_joints_bwd) and the skinning; joints 0..23 are the chain's translations, 24..89 the regressor rows of
+// k_joints_compact.  218 x 3 x n_ju FMAs per row instead of 218 x 3 x 6890 + an 82.7 KB vertex row: ~20 us for the training batch against
+// k_rigid_chain + k_lbs_mfma + k_joints_compact (~140 us).  The same function as hmf_smpl_lbs's joints up to fp32 summation order.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_smpl_joints_fwd(SmplDev d, const float* __restrict__ glob, const float* __restrict__ body,
+                                                         const float* __restrict__ betas, int M, float* __restrict__ joints) {
+    __shared__ float sR[kJ][9], sJ[kJ][3], sG[kJ][12], sA[kJ][12];
+    __shared__ float s_feat[kKpad], s_v[kMaxJU][3];
+    const int tid = threadIdx.x, row = blockIdx.x, nb = d.num_betas;
+    const float* beta = betas + (size_t)row * nb;
+    for (int i = tid; i < kJ * 9; i += 256) {
+        const int j = i / 9, e = i % 9;
+        sR[j][e] = j == 0 ? glob[(size_t)row * 9 + e] : body[((size_t)row * 23 + (j - 1)) * 9 + e];
+    }
+    for (int i = tid; i < kJ * 3; i += 256) {
+        const int j = i / 3, c = i % 3;
+        float acc = d.j_template[j * 3 + c];
+        for (int k = 0; k < nb; ++k) acc = fmaf(d.j_dirs[(j * 3 + c) * nb + k], beta[k], acc);
+        sJ[j][c] = acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < kKpad; k += 256) s_feat[k] = pose_feature(k, nb, &sR[1][0], beta);
+    for (int L = 0; L <= d.depth_max; ++L) {                          // smplx batch_rigid_transform, level by level (the expressions of k_smpl_joints_bwd)
+        for (int idx = tid; idx < kJ * 12; idx += 256) {
+            const int j = idx / 12, e = idx - j * 12, i = e >> 2, c = e & 3;
+            if (d.depth[j] != L) continue;
+            const int par = d.parents[j];
+            if (j == 0) {
+                sG[0][e] = c < 3 ? sR[0][i * 3 + c] : sJ[0][i];
+            } else if (c < 3) {
+                sG[j][e] = sG[par][i * 4 + 0] * sR[j][0 * 3 + c] + sG[par][i * 4 + 1] * sR[j][1 * 3 + c] + sG[par][i * 4 + 2] * sR[j][2 * 3 + c];
+            } else {
+                const float rel[3] = {sJ[j][0] - sJ[par][0], sJ[j][1] - sJ[par][1], sJ[j][2] - sJ[par][2]};
+                sG[j][e] = sG[par][i * 4 + 0] * rel[0] + sG[par][i * 4 + 1] * rel[1] + sG[par][i * 4 + 2] * rel[2] + sG[par][i * 4 + 3];
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < kJ * 12; idx += 256) {
+        const int j = idx / 12, e = idx - j * 12, i = e >> 2, c = e & 3;
+        sA[j][e] = c < 3 ? sG[j][e] : sG[j][i * 4 + 3] - (sG[j][i * 4 + 0] * sJ[j][0] + sG[j][i * 4 + 1] * sJ[j][1] + sG[j][i * 4 + 2] * sJ[j][2]);
+    }
+    __syncthreads();
+    const int kdata = kPoseFeat + nb + 1;
+    for (int u = tid; u < d.n_ju; u += 256) {
+        const int v = d.ju_vid[u], vt = v >> 5, l31 = v & 31;
+        float vp[3] = {0.f, 0.f, 0.f};
+        const float* jb = d.ju_blend + u * 3;
+#pragma unroll 8
+        for (int k = 0; k < kdata; ++k) {
+            const float a = s_feat[k];
+            const float* r = jb + (size_t)k * d.ju_bstride;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vp[c] = fmaf(a, r[c], vp[c]);
+        }
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = 0.f;
+        for (int s = 0; s < d.skin_slots; ++s) {
+            const int jn = d.skin_off[((size_t)vt * d.skin_slots + s) * 32 + l31] / 48;
+            const float w = d.skin_w[((size_t)vt * d.skin_slots + s) * 32 + l31];
+            if (w != 0.f) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = fmaf(w, sA[jn][i], T[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s_v[u][i] = T[i * 4 + 0] * vp[0] + T[i * 4 + 1] * vp[1] + T[i * 4 + 2] * vp[2] + T[i * 4 + 3];
+    }
+    __syncthreads();
+    float* o = joints + (size_t)row * kOutJ * 3;
+    for (int i = tid; i < kJ * 3; i += 256) o[i] = sG[i / 3][(i % 3) * 4 + 3];
+    for (int i = tid; i < kOutJ - kJ; i += 256) {
+        float x = 0.f, y = 0.f, z = 0.f;
+        for (int e = d.jr_ptr[i]; e < d.jr_ptr[i + 1]; ++e) {
+            const float w = d.jr_w[e];
+            const float* p = s_v[d.jr_slot[e]];
+            x = fmaf(w, p[0], x); y = fmaf(w, p[1], y); z = fmaf(w, p[2], z);
+        }
+        o[(kJ + i) * 3 + 0] = x; o[(kJ + i) * 3 + 1] = y; o[(kJ + i) * 3 + 2] = z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Backward of the 90 output joints w.r.t. (global_orient, body_pose, betas) -- what the 2D reprojection loss of the training step needs
 // (losses/humaniflow_loss.py:44-60 on joints[:, ALL_JOINTS_TO_COCO_MAP]; train/train_humaniflow.py:283-318).  One work-group per row:
 // rest joints and the 24-joint chain are recomputed, the <= 276 vertices that the gathered joints touch are pushed back through the
@@ -1603,6 +1690,14 @@ int hmf_smpl_tpose(const hmf_smpl_t* h, const float* betas, int M, float* verts,
         hipLaunchKernelGGL(k_joints, dim3((n + 255) / 256), dim3(256), 0, st, h->d, verts, M, joints);
         HMF_LAUNCH_CHECK();
     }
+    return HMF_OK;
+}
+
+int hmf_smpl_joints(const hmf_smpl_t* h, const float* global_orient, const float* body_pose, const float* betas, int M, float* joints, void* stream) {
+    if (M == 0) return HMF_OK;
+    if (!h || !global_orient || !body_pose || !betas || !joints || M < 0) return fail(HMF_ERR_INVALID, "hmf_smpl_joints: bad args");
+    hipLaunchKernelGGL(k_smpl_joints_fwd, dim3(M), dim3(256), 0, (hipStream_t)stream, h->d, global_orient, body_pose, betas, M, joints);
+    HMF_LAUNCH_CHECK();
     return HMF_OK;
 }
 

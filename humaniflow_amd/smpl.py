@@ -211,6 +211,16 @@ class SMPL(nn.Module):
         _lib.check(lib.hmf_batch_rodrigues(_lib.dptr(v), n, _lib.dptr(R), _lib.current_stream()), 'hmf_batch_rodrigues')
         return R
 
+    def _joints_kernel(self, g, b, be):
+        """The 90 joints without the body (hmf_smpl_joints): g (M, 9), b (M, 207), be (M, nb) contiguous fp32 device tensors -> (M, 90, 3)."""
+        lib = _lib.load()
+        M = b.shape[0]
+        joints = torch.empty(M, 90, 3, dtype=torch.float32, device=b.device)
+        with torch.cuda.device(b.device):
+            _lib.check(lib.hmf_smpl_joints(self._handle(b.device), _lib.dptr(g), _lib.dptr(b), _lib.dptr(be), M, _lib.dptr(joints), _lib.current_stream()),
+                       'hmf_smpl_joints')
+        return joints
+
     def _lbs_kernel(self, g, b, be, impl=None):
         """g (Mg, 9), b (M, 207), be (Mb, nb) contiguous fp32 device tensors (Mg, Mb in {1, M}) -> vertices (M,6890,3), joints (M,90,3)."""
         lib = _lib.load()
@@ -228,9 +238,10 @@ class SMPL(nn.Module):
                                         _lib.current_stream()), 'hmf_smpl_lbs')
         return verts, joints
 
-    def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, impl=None, **kwargs):
+    def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, impl=None, joints_only=False, **kwargs):
         """models/smpl.py:27-41 over smplx SMPL.forward.  `get_skin`/`return_verts` kwargs are accepted and ignored
-        (vertices are always produced, as the reference forces).  With rotation-matrix inputs (pose2rot=False) under autograd the JOINTS
+        (vertices are always produced, as the reference forces) -- except with the extension keyword joints_only=True under autograd (the training
+        loss reads joints only: hmf_smpl_joints poses just the <= 320 vertices the joint tables touch; `.vertices` is then None).  With rotation-matrix inputs (pose2rot=False) under autograd the JOINTS
         are differentiable w.r.t. global_orient / body_pose / betas (the training step's 2D reprojection loss); vertices are not."""
         global_orient = self.global_orient if global_orient is None else global_orient
         body_pose = self.body_pose if body_pose is None else body_pose
@@ -253,7 +264,9 @@ class SMPL(nn.Module):
                 from .autograd import SmplJoints
                 verts, joints = SmplJoints.apply(self, global_orient.to(torch.float32).reshape(M, 9).contiguous(),
                                                  body_pose.to(torch.float32).reshape(M, 23 * 9).contiguous(),
-                                                 betas.to(torch.float32).contiguous(), impl)
+                                                 betas.to(torch.float32).contiguous(), -1 if joints_only else impl)
+                if joints_only:
+                    verts = None
             else:
                 if pose2rot:
                     g = self._rodrigues(global_orient, global_orient.shape[0])
@@ -267,7 +280,7 @@ class SMPL(nn.Module):
                 verts, joints = self._lbs_kernel(g, b, self._f32c(betas), impl)
         if transl is not None:
             joints = joints + transl.unsqueeze(1)
-            verts = verts + transl.unsqueeze(1)
+            verts = None if verts is None else verts + transl.unsqueeze(1)
         full_pose = None
         if global_orient.dim() == body_pose.dim():
             full_pose = torch.cat([global_orient, body_pose], dim=1)
@@ -288,7 +301,7 @@ class SMPL(nn.Module):
             _lib.check(lib.hmf_batch_rodrigues_pose(_lib.dptr(p), M, _lib.dptr(g), _lib.dptr(b), _lib.current_stream()), 'hmf_batch_rodrigues_pose')
             return self._lbs_kernel(g, b, be, impl)
 
-    def forward_samples_and_point_est(self, pred, return_packed=False):
+    def forward_samples_and_point_est(self, pred, return_packed=False, joints_only=False):
         """One launch for what the reference does with two SMPL calls (evaluate/evaluate_humaniflow.py:124-127,168-172,
         predict/predict_humaniflow.py:128-131,160-163): the B point-estimate bodies and the B*N sampled bodies of a
         HumaniflowModel.forward(num_samples=N) result, M = B*N + B rows -- the M = B launch alone fills 1/8 of the GPU for 1 % of the work.
@@ -301,7 +314,7 @@ class SMPL(nn.Module):
         wants_grad = torch.is_grad_enabled() and (body.requires_grad or betas.requires_grad or g.requires_grad)
         if wants_grad or N == 0:
             glob_all = torch.cat([g[:, None].expand(B, N, 3, 3).reshape(BN, 1, 3, 3), g[:, None]], dim=0)
-            out = self(body_pose=body, global_orient=glob_all, betas=betas, pose2rot=False)
+            out = self(body_pose=body, global_orient=glob_all, betas=betas, pose2rot=False, joints_only=joints_only and wants_grad)
             verts, joints, full_pose = out.vertices, out.joints, out.full_pose
         else:
             # hmf_smpl_lbs_packed indexes image b's rotation for its N sample rows and its point-estimate row inside the kernel (the reference
@@ -324,7 +337,7 @@ class SMPL(nn.Module):
             if hasattr(self, 'transl') and self.transl is not None:
                 joints = joints + self.transl.unsqueeze(1)
                 verts = verts + self.transl.unsqueeze(1)
-        cut = lambda sl: SMPLOutput(vertices=verts[sl], joints=joints[sl], full_pose=None if full_pose is None else full_pose[sl], betas=betas[sl],
+        cut = lambda sl: SMPLOutput(vertices=None if verts is None else verts[sl], joints=joints[sl], full_pose=None if full_pose is None else full_pose[sl], betas=betas[sl],
                                     global_orient=full_pose[sl, :1] if full_pose is not None else None, body_pose=body[sl])
         if return_packed:
             return cut(slice(BN, BN + B)), cut(slice(0, BN)), joints

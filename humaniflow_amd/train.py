@@ -27,6 +27,7 @@ from .losses import HumaniflowLoss
 
 _XY_SIGN = {}
 FUSED_LOSS = True               # the step's loss and its gradients on hmf_train_loss (two launches); False: HumaniflowLoss on torch operators
+JOINTS_ONLY = os.environ.get('HMF_TRAIN_JOINTS_ONLY', '1') != '0'    # fused-loss path: SMPL joints without the vertices (hmf_smpl_joints); the loss reads joints only
 
 
 def _xy_sign(t):
@@ -75,11 +76,11 @@ def train_forward_loss(model, smpl, criterion, proxy_input, targets, num_samples
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 lp = criterion.pose_log_probs(dists, targets['pose_rotmats'].double())
-            pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True)
+            pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True, joints_only=JOINTS_ONLY)
             cur.wait_stream(side)
             lp.record_stream(cur)
         else:
-            pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True)
+            pe, sa, joints = smpl.forward_samples_and_point_est(pred, return_packed=True, joints_only=JOINTS_ONLY)
             lp = criterion.pose_log_probs(dists, targets['pose_rotmats'].double())
         W = cfg_l.WEIGHTS
         loss = FusedTrainLoss.apply(lp, pred['shape_mode'], pred['shape_log_std'], joints, pred['cam_wp'], pred['glob_rotmat'], targets['shape'],

@@ -130,6 +130,11 @@ int hmf_smpl_tpose_errors_packed(const hmf_smpl_t* h, const float* betas_packed,
  * All three inputs must be per-row (no broadcast).  Vertex gradients are not built (LOSS.APPLY_POINT_EST_LOSS = False).          */
 int hmf_smpl_joints_backward(const hmf_smpl_t* h, const float* global_orient, const float* body_pose, const float* betas, int M,
                              const float* g_joints, float* g_global_orient, float* g_body_pose, float* g_betas, void* stream);
+/* The 90 joints of hmf_smpl_lbs WITHOUT its vertices (round 5): the training loss reads joints only (train/train_humaniflow.py:283-318), and only the
+ * <= 320 vertices the joint tables touch are posed.  global_orient M x 9, body_pose M x 23 x 9, betas M x nb, all per row (the layout of
+ * hmf_smpl_joints_backward) -> joints M x 90 x 3; equal to hmf_smpl_lbs's joints up to fp32 summation order (the blend sum runs in k order on one
+ * thread here, through the MFMA accumulators there).                                                                                              */
+int hmf_smpl_joints(const hmf_smpl_t* h, const float* global_orient, const float* body_pose, const float* betas, int M, float* joints, void* stream);
 
 /* The training loss of one step and its gradients in two launches (train/train_humaniflow.py:283-343 through losses/humaniflow_loss.py:25-79 with
  * LOSS.J2D_LOSS_ON = 'point_est+samples' and APPLY_POINT_EST_LOSS off): pose NLL from the log-densities lp (B,P), shape NLL of Normal(shape_mode,

@@ -286,3 +286,27 @@ def test_32_row_group_lbs_kernel_is_bitwise_the_64_row_one(M):
     a = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False, impl=0)
     b = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False, impl=4)
     assert torch.equal(a.vertices, b.vertices) and torch.equal(a.joints, b.joints)
+
+
+@pytest.mark.parametrize('M', [1, 7, 130])
+def test_joints_only_forward_equals_the_joints_of_the_full_lbs(M):
+    """hmf_smpl_joints (the training loss path: only the vertices the joint tables touch are posed) vs the joints of hmf_smpl_lbs on the same inputs, and
+    its autograd form: same joints, no vertices, the same backward."""
+    from oracle.so3 import so3_exp
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    g = torch.Generator().manual_seed(100 + M)
+    R = so3_exp(torch.randn(M * 24, 3, generator=g, dtype=torch.float64) * 0.6).float().view(M, 24, 3, 3).cuda()
+    betas = (torch.randn(M, 10, generator=g) * 1.25).cuda()
+    full = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+    j = smpl._joints_kernel(R[:, 0].reshape(M, 9).contiguous(), R[:, 1:].reshape(M, 207).contiguous(), betas.contiguous())
+    assert (j - full.joints).abs().max().item() < 2e-6
+    w = torch.randn(M, 90, 3, generator=g).cuda()
+    grads = []
+    for jo in (False, True):
+        body, glob, be = R[:, 1:].clone().requires_grad_(True), R[:, :1].clone().requires_grad_(True), betas.clone().requires_grad_(True)
+        out = smpl(body_pose=body, global_orient=glob, betas=be, pose2rot=False, joints_only=jo)
+        assert (out.vertices is None) == jo
+        (out.joints * w).sum().backward()
+        grads.append((body.grad, glob.grad, be.grad))
+    for a, b in zip(*grads):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
