@@ -99,3 +99,44 @@ def test_train_step_rejects_unknown_policy_and_missing_state():
         T.train_step(None, None, None, None, None, None, None, 2, nan_policy='reload')
     with pytest.raises(ValueError):
         T.train_step(None, None, None, None, None, None, None, 2, nan_policy='rollback')
+
+
+@pytest.mark.parametrize('permute,transform,T,hidden,plu_hidden', [('linear_plu', 'spline_coupling', 2, (64, 32, 32), None),
+                                                                    ('conditional_linear_plu', 'additive_coupling', 3, (40, 20), (16,)),
+                                                                    ('permute', 'spline_coupling', 3, (48, 48, 24, 24), None)])
+def test_variant_gradient_bookkeeping_matches_the_module_parameter_order(permute, transform, T, hidden, plu_hidden):
+    """Host logic of the variants' training path (autograd._variant_params / _variant_unpack / _variant_embed / _variant_sum): the stacked per-layer
+    gradient tensors the reverse sweeps produce are unpacked into exactly the parameters FlowParamAnchor registered, in the same order and shapes."""
+    import humaniflow_amd as H
+    from humaniflow_amd import autograd as AG
+    cfg = H.get_humaniflow_cfg_defaults()
+    nf = cfg.MODEL.NORM_FLOW
+    nf.PERMUTE_TYPE, nf.TRANSFORM_TYPE, nf.NUM_TRANSFORMS = permute, transform, T
+    nf.TRANSFORM_NN_HIDDEN_DIMS = list(hidden)
+    nf.PERMUTE_NN_HIDDEN_DIMS = None if plu_hidden is None else list(plu_hidden)
+    cfg.MODEL.NUM_RESNET_LAYERS = 18
+    model = H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS)
+    assert AG._is_variant(model)
+    P = model.num_bodyparts
+    params = AG._variant_params(model, 0, P)
+    # every parameter of the transform modules exactly once, in module order
+    want = [p for m in model.pose_so3flow_transform_modules for p in m.parameters()]
+    assert len(params) == len(want) and all(a is b for a, b in zip(params, want))
+    Tn, L, LP, K, N, KP, NP = AG._variant_dims(model)
+    assert (Tn, L) == (T, len(hidden) + 1) and K[0] == 65 and N[-1] == (62 if transform == 'spline_coupling' else 2)
+    g = torch.Generator().manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    grads = {'tr': [(mk(P, T, N[l], K[l]), mk(P, T, N[l])) for l in range(L)],
+             'plu': [(mk(P, T, NP[l], KP[l]), mk(P, T, NP[l])) for l in range(LP)] if LP else None,
+             'lu': mk(P, T, 3, 3) if permute == 'linear_plu' else None}
+    flat = AG._variant_unpack(model, grads)
+    assert len(flat) == len(params) and all(tuple(a.shape) == tuple(b.shape) for a, b in zip(flat, params))
+    # a sub-range of parts embeds into the full stack with zeros elsewhere, and sums add tensor by tensor
+    sub = {'tr': [(w[3:5], b[3:5]) for w, b in grads['tr']], 'plu': None if grads['plu'] is None else [(w[3:5], b[3:5]) for w, b in grads['plu']],
+           'lu': None if grads['lu'] is None else grads['lu'][3:5]}
+    emb = AG._variant_embed(model, sub, 3, 2)
+    assert torch.equal(emb['tr'][0][0][3:5], grads['tr'][0][0][3:5]) and float(emb['tr'][0][0][:3].abs().sum()) == 0.0 and float(emb['tr'][0][0][5:].abs().sum()) == 0.0
+    tot = AG._variant_sum(AG._variant_sum(None, grads), emb)
+    assert torch.equal(tot['tr'][-1][1][4], grads['tr'][-1][1][4] * 2) and torch.equal(tot['tr'][-1][1][0], grads['tr'][-1][1][0])
+    if grads['lu'] is not None:
+        assert torch.equal(tot['lu'][3], grads['lu'][3] * 2)
