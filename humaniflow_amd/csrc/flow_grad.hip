@@ -230,29 +230,30 @@ __global__ __launch_bounds__(192) void k_flow_logprob_bwd(FlowDev d, const float
     }
     const int row = c * B + b;
     G.ACTX[((size_t)p * G.R + row) * 64 + lane] = ctx_lane;
-    AlgState S;
-    float term = -INFINITY;
-    if (okc) {                                                        // wave-uniform
-        const float ldc = -(float)so3_logdet_f64(cd);
-        const float cc[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
-        term = ldc + algebra_fwd(d, pt, lane, ctx_lane, cc, S);
-    }
-    if (lane == 0) s_term[c] = term;
-    __syncthreads();
-    float g_acc = 0.f;
-    if (okc) {
-        const float t0 = s_term[0], t1 = s_term[1], t2 = s_term[2];
-        const float m = fmaxf(t0, fmaxf(t1, t2));
-        const float ssum = expf(t0 - m) + expf(t1 - m) + expf(t2 - m);
-        const float wgt = expf(term - m) / ssum;                      // d logsumexp / d term_c
-        g_acc = algebra_bwd(d, pt, lane, g_logp[gw] * wgt, S, G, p, row);
-    } else {                                                          // masked pre-image: no contribution
+    if (!okc) {
+        // masked pre-image (wave-uniform; usually two of the three waves): -inf into the log-sum-exp, zero records, no context gradient -- and the wave
+        // ENDS here instead of idling at the two barriers below with its registers held (the hardware barrier counts live waves only; the fence makes
+        // its LDS writes land first).  Wave 0 (the principal pre-image) is never masked.
+        if (lane == 0) s_term[c] = -INFINITY;
+        s_gctx[c][lane] = 0.f;
         NetDelta Z = {0.f, 0.f, 0.f, 0.f};
         NetAct ZA = {0.f, 0.f, 0.f};
         store_net(G, p, 0, row, lane, Z, ZA, 0.f);
         store_net(G, p, 1, row, lane, Z, ZA, 0.f);
+        __threadfence_block();
+        return;
     }
-    s_gctx[c][lane] = g_acc;
+    AlgState S;
+    const float ldc = -(float)so3_logdet_f64(cd);
+    const float cc[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
+    const float term = ldc + algebra_fwd(d, pt, lane, ctx_lane, cc, S);
+    if (lane == 0) s_term[c] = term;
+    __syncthreads();
+    const float t0 = s_term[0], t1 = s_term[1], t2 = s_term[2];
+    const float m = fmaxf(t0, fmaxf(t1, t2));
+    const float ssum = expf(t0 - m) + expf(t1 - m) + expf(t2 - m);
+    const float wgt = expf(term - m) / ssum;                          // d logsumexp / d term_c
+    s_gctx[c][lane] = algebra_bwd(d, pt, lane, g_logp[gw] * wgt, S, G, p, row);
     __syncthreads();
     if (c == 0) g_ctx[(size_t)gw * kCtx + lane] = (s_gctx[0][lane] + s_gctx[1][lane]) + s_gctx[2][lane];
 }

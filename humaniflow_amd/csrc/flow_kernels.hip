@@ -1027,13 +1027,15 @@ __global__ __launch_bounds__(192) void k_flow_logprob_SO3_par(FlowDev d, const f
         cand[0] = x[0] / n * sc; cand[1] = x[1] / n * sc; cand[2] = x[2] / n * sc;
         ok = sqrt(cand[0] * cand[0] + cand[1] * cand[1] + cand[2] * cand[2]) < (double)d.radius;
     }
-    float term = -INFINITY;
-    if (ok) {                                                          // wave-uniform
-        const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
-        const float ld = -(float)so3_logdet_f64(cand);
-        const float v[3] = {(float)cand[0], (float)cand[1], (float)cand[2]};
-        term = ld + log_prob_so3(d, pt, lane, ctx_lane, v);
+    if (!ok) {                                                         // wave-uniform: a masked pre-image ends here (see k_flow_logprob_bwd); wave 0 never is
+        if (lane == 0) s_term[c] = -INFINITY;
+        __threadfence_block();
+        return;
     }
+    const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
+    const float ld = -(float)so3_logdet_f64(cand);
+    const float v[3] = {(float)cand[0], (float)cand[1], (float)cand[2]};
+    const float term = ld + log_prob_so3(d, pt, lane, ctx_lane, v);
     if (lane == 0) s_term[c] = term;
     __syncthreads();
     if (c == 0 && lane == 0) {
