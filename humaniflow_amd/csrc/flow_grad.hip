@@ -266,7 +266,7 @@ __global__ __launch_bounds__(192) void k_flow_logprob_bwd(FlowDev d, const float
 __global__ __launch_bounds__(256) void k_flow_chain_bwd(FlowDev d, int lev, const float* __restrict__ H, const float* __restrict__ rot,
                                                         const float* __restrict__ eps, int B, int N, float* __restrict__ g_rot, GradRec G) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // launched with ONE wave per work-group: 1,700 waves of a round spread evenly over the CUs
     const int rows = B * N;
     const int nparts = d.lev.start[lev + 1] - d.lev.start[lev];
     if (gw >= rows * nparts) return;
@@ -461,7 +461,7 @@ int hmf_flow_sample_backward(const hmf_flow_t* h, const float* isgc_rows, const 
     if (G.R != B * N) return fail(HMF_ERR_INVALID, "hmf_flow_sample_backward: records need rows == B * N");
     for (int lev = h->d.lev.nlev - 1; lev >= 0; --lev) {
         const int nw = B * N * (h->d.lev.start[lev + 1] - h->d.lev.start[lev]);
-        hipLaunchKernelGGL(k_flow_chain_bwd, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, lev, isgc_rows, rotmats_samples, eps_pose, B, N,
+        hipLaunchKernelGGL(k_flow_chain_bwd, dim3(nw), dim3(64), 0, (hipStream_t)stream, h->d, lev, isgc_rows, rotmats_samples, eps_pose, B, N,
                            g_rotmats, G);
         HMF_LAUNCH_CHECK();
     }
