@@ -130,32 +130,64 @@ def parse():
     return a
 
 
+def parity_noise(B, N, seed=0):
+    """The base noise both legs of the parity block consume: the reference's draw shapes (models/humaniflow_model.py:258,309), one (N,B,10)
+    standard normal for the shape samples and one (B,N,3) per body part."""
+    g = torch.Generator().manual_seed(seed)
+    return {'shape': torch.randn(N, B, 10, generator=g), 'pose': torch.randn(23, B, N, 3, generator=g)}
+
+
+def parity_targets(B, seed=11):
+    """Teacher-forced targets for the log-prob leg: random rotations (angles up to ~2.5 rad, so some rows have a second pre-image in the
+    flow's support) with the reference's edge cases planted: R = I (utils/rigid_transform_utils.py:246-262 zero-angle branch) and theta = pi - 1e-4
+    (the near-pi branch of so3_log)."""
+    import math
+    from oracle import so3 as oso3
+    g = torch.Generator().manual_seed(seed)
+    ax = torch.randn(B * 23, 3, generator=g, dtype=torch.float64)
+    ax = ax / ax.norm(dim=-1, keepdim=True)
+    ang = torch.rand(B * 23, 1, generator=g, dtype=torch.float64) * 2.5
+    R = oso3.so3_exp(ax * ang).float().view(B, 23, 3, 3)
+    R[0, 0] = torch.eye(3)
+    R[1 % B, 1] = oso3.so3_exp(torch.tensor([[0.6, 0.0, 0.8]], dtype=torch.float64) * (math.pi - 1e-4))[0].float()
+    R[2 % B, 2] = oso3.so3_exp(torch.tensor([[0.0, 1.0, 0.0]], dtype=torch.float64) * 2.0)[0].float()
+    ax_g = torch.randn(B, 3, generator=g, dtype=torch.float64)
+    glob = oso3.so3_exp(ax_g / ax_g.norm(dim=-1, keepdim=True) * torch.rand(B, 1, generator=g, dtype=torch.float64) * 3.0).float()
+    return {'pose_R': R, 'shape': torch.randn(B, 10, generator=g), 'glob_R': glob}
+
+
 def cpu_baseline(model_sd, cfg, smpl_model_dict, images, N, seed=0):
     """The oracle in reference mode (Python loop over 23 parts, per-call hyper-nets, fp64 exp, smplx-style dense LBS with
-    the (M,6890,4,4) temporary) on `images` synthetic inputs x N samples, all host cores."""
+    the (M,6890,4,4) temporary) on `images` synthetic inputs x N samples, all host cores.  Returns (cpu_baseline dict, reference outputs of the
+    last timed iteration + the teacher-forced log-probs): the second half is what the `parity` block of the JSON line checks the HIP path against."""
     from oracle import model as omodel
     from oracle import smpl as osmpl
     from humaniflow_amd.synthetic import synthetic_proxy_input
     ocfg = omodel.OracleCfg(num_resnet_layers=cfg.MODEL.NUM_RESNET_LAYERS, num_betas=cfg.MODEL.NUM_SMPL_BETAS)
     x = synthetic_proxy_input(images, 256, seed=seed)
     sm = {k: (v.long() if k == 'parents' else v.float()) for k, v in smpl_model_dict.items()}
+    noise_full = parity_noise(images, N)
+    noise = noise_full
+    keep = {}
 
     def run():
-        nonlocal x
-        out = omodel.forward(model_sd, ocfg, input=x, num_samples=N)
+        out = omodel.forward(model_sd, ocfg, input=x, num_samples=N, noise=noise)
         g = out['glob_rotmat']
-        osmpl.smpl_forward(sm, out['shape_mode'], out['pose_rotmats_point_est'], g[:, None], pose2rot=False)
-        osmpl.smpl_forward(sm, out['shape_samples'].reshape(-1, 10), out['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
-                           g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3), pose2rot=False)
+        vp, jp = osmpl.smpl_forward(sm, out['shape_mode'], out['pose_rotmats_point_est'], g[:, None], pose2rot=False)
+        vs, js = osmpl.smpl_forward(sm, out['shape_samples'].reshape(-1, 10), out['pose_rotmats_samples'].reshape(-1, 23, 3, 3),
+                                    g[:, None].expand(-1, N, -1, -1).reshape(-1, 1, 3, 3), pose2rot=False)
+        keep.update(out=out, verts_point_est=vp, joints_point_est=jp, verts_samples=vs, joints_samples=js)
     # Host-thread choice: the path is thousands of small ops, so "all cores" is NOT the fastest setting on a many-core
     # host (measured on the 256-thread bench box: 16 threads beat 128 by 8x).  Give the baseline its best shot: probe a
     # few thread counts on a 4-image slice, then time the full sample with the winner.
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     xs_full = x
     best_nt, best_t = None, None
+    ns = min(4, images)
     for nt in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
-        x = xs_full[:min(4, images)]
+        x = xs_full[:ns]
+        noise = {'shape': noise_full['shape'][:, :ns].contiguous(), 'pose': noise_full['pose'][:, :ns].contiguous()}
         run()
         t0 = time.perf_counter()
         run()
@@ -163,7 +195,7 @@ def cpu_baseline(model_sd, cfg, smpl_model_dict, images, N, seed=0):
         if best_t is None or dt < best_t:
             best_nt, best_t = nt, dt
     torch.set_num_threads(best_nt)
-    x = xs_full
+    x, noise = xs_full, noise_full
     run()                                           # warm-up
     ts = []
     for _ in range(3):
@@ -171,9 +203,51 @@ def cpu_baseline(model_sd, cfg, smpl_model_dict, images, N, seed=0):
         run()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
+    # teacher-forced log-probabilities (losses/humaniflow_loss.py:30-31 call pattern) on the reference features of the same images: not timed
+    tg = parity_targets(images)
+    ll = omodel.forward(model_sd, ocfg, input_feats=keep['out']['input_feats'], compute_point_est=False, compute_for_loglik=True,
+                        shape_for_loglik=tg['shape'], pose_R_for_loglik=tg['pose_R'], glob_R_for_loglik=tg['glob_R'])
+    keep.update(x=xs_full, noise=noise_full, targets=tg, flow_context_for_loglik=ll['flow_context_for_loglik'],
+                log_prob=omodel.log_prob_SO3(model_sd, ocfg, ll['flow_context_for_loglik'], tg['pose_R'].double()))
     return {'value': images * N / t, 'unit': 'images*samples/s', 'cores': best_nt, 'host_threads_available': avail, 'kind': 'port',
             'sample': '%d images x %d samples (ResNet-50 + 23-part flow loop + smplx-style LBS), best of {8,16,32,64} host threads, median of 3 timed iterations after 1 warm-up, %.2f s/iter'
-                      % (images, N, t)}
+                      % (images, N, t)}, keep
+
+
+PARITY_TOL = {'vertex': 1e-4, 'joint': 1e-4, 'logprob': 1e-3}         # BASELINE.json north_star: vertices/joints within 1e-4, log-probs within 1e-3
+
+
+def parity_block(model, smpl, ref, N, dev):
+    """The second half of BASELINE.json's metric ("vertex L-inf vs ref") at the bench's own size: the product path END TO END (hand-written
+    encoder -> heads -> flow -> one fused SMPL launch) on the same weights, inputs and base noise as the CPU oracle iteration `ref` that
+    cpu_baseline() kept, outside every timed region.  Reference op chain: models/humaniflow_model.py:188-340, models/smpl.py:27-41."""
+    o = ref['out']
+    B = ref['x'].shape[0]
+    cu = lambda d: {k: v.to(dev) for k, v in d.items()}
+    with torch.no_grad():
+        out = model(ref['x'].to(dev), num_samples=N, noise=cu(ref['noise']), return_input_feats=True)
+        pe, sa = smpl.forward_samples_and_point_est(out)
+        tg = ref['targets']
+        ll = model(None, input_feats=out['input_feats'], compute_point_est=False, compute_for_loglik=True, shape_for_loglik=tg['shape'].to(dev),
+                   pose_R_for_loglik=tg['pose_R'].to(dev), glob_R_for_loglik=tg['glob_R'].to(dev))
+        lp = model.log_prob_all_parts(ll['flow_context_for_loglik'], tg['pose_R'].to(dev)).cpu()
+    linf = lambda a, b: float((a.detach().cpu().double() - b.double()).abs().max())
+    fscale = max(1.0, float(o['input_feats'].abs().max()))
+    p = {'what': 'product path end to end vs the CPU oracle (reference mode) on the same weights, %d synthetic inputs and base noise; '
+                 'log-probs teacher-forced on %d x 23 random target rotations incl. R = I, theta = pi - 1e-4 and theta > pi/2' % (B, B),
+         'rows': B * N + B, 'images': B, 'samples_per_image': N,
+         'vertex_linf': max(linf(sa.vertices, ref['verts_samples']), linf(pe.vertices, ref['verts_point_est'])),
+         'joint_linf': max(linf(sa.joints, ref['joints_samples']), linf(pe.joints, ref['joints_point_est'])),
+         'rotmat_linf': max(linf(out['pose_rotmats_samples'], o['pose_rotmats_samples']), linf(out['pose_rotmats_point_est'], o['pose_rotmats_point_est'])),
+         'shape_samples_linf': linf(out['shape_samples'], o['shape_samples']),
+         'glob_rotmat_linf': linf(out['glob_rotmat'], o['glob_rotmat']), 'cam_wp_linf': linf(out['cam_wp'], o['cam_wp']),
+         'encoder_feats_rel_linf': linf(out['input_feats'], o['input_feats']) / fscale,
+         'flow_context_linf': linf(ll['flow_context_for_loglik'], ref['flow_context_for_loglik']),
+         'logprob_max_abs': linf(lp, ref['log_prob']), 'logprob_rows': int(lp.numel()), 'logprob_finite': bool(torch.isfinite(lp).all()),
+         'vertex_abs_max': float(ref['verts_samples'].abs().max()), 'tolerances': dict(PARITY_TOL)}
+    p['ok'] = bool(p['vertex_linf'] <= PARITY_TOL['vertex'] and p['joint_linf'] <= PARITY_TOL['joint'] and p['logprob_max_abs'] <= PARITY_TOL['logprob']
+                   and p['logprob_finite'])
+    return p
 
 
 _T0 = time.time()
@@ -232,6 +306,7 @@ def dry_run_cpu(args):
     """The rank plumbing of main() with a stand-in CPU step (no model, no HIP): what tests/test_distributed.py launches with gloo ranks."""
     dev = torch.device('cpu')
     dist, world, rank = dist_setup(dev, 'gloo')
+    check_ranks(args, world, rank)
     B, N = args.batch, args.samples
     step = lambda: torch.full((4,), float(rank + 1), dtype=torch.float64) * torch.randn(1000).square().mean().clamp(1, 1)
     for _ in range(args.warmup):
@@ -243,6 +318,7 @@ def dry_run_cpu(args):
     gathered = dist_gather_metrics(vec, dist, world)
     elapsed = dist_elapsed(t0, dist, dev)
     if rank == 0:
+        check_ranks(args, world, rank, int(gathered.shape[0]))
         print(json.dumps({'metric': 'images*samples/sec (B=%d, N=%d)' % (B, N), 'value': world * B * N * args.steps / elapsed, 'unit': 'images*samples/s',
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dry_run': True,
@@ -599,7 +675,7 @@ def run_inference(args, dev, dist, world, rank):
         if res['roofline'] is None:
             res['roofline'] = res['roofline_lbs']
         res['cpu_baseline'] = None
-        return res, {'model_sd': model_sd, 'cfg': cfg, 'smpl_model': {k: v.detach().cpu() for k, v in smpl.model_dict().items()}}
+        return res, {'model_sd': model_sd, 'cfg': cfg, 'smpl_model': {k: v.detach().cpu() for k, v in smpl.model_dict().items()}, 'model': model, 'smpl': smpl}
     return None, None
 
 
@@ -651,17 +727,52 @@ def run_secondary(args, dev, steps=20, warmup=6):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment) and N > 1: start the N ranks ourselves, exactly as the
+    driver's documented form does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>),
+    and return the launcher's exit code.  The alternative -- one rank printing an n_gpus = 1 line under a --gpus N command -- would let a scaling
+    run read N = 1 throughput N times."""
+    import socket
+    import subprocess
+    if not args.dry_run_cpu:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.exit('bench.py: --gpus %d but only %d HIP device(s) visible; refusing to fall back to fewer ranks' % (args.gpus, have))
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('no launcher in the environment: starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def check_ranks(args, world, rank, seen=None):
+    """--gpus N must be what runs: N ranks from the launcher, and (after the exchange step) N rows in the gathered metric tensor."""
+    if args.gpus != world:
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE = %d rank(s)' % (args.gpus, world))
+    if seen is not None and rank == 0 and seen != world:
+        sys.exit('bench.py: the metric all-gather returned %d rank rows, expected %d' % (seen, world))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     if args.dry_run_cpu:
         return dry_run_cpu(args)
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (the hot path has no CPU fallback)'
+    if local >= torch.cuda.device_count():
+        sys.exit('bench.py: LOCAL_RANK %d but only %d HIP device(s) visible' % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist, world, rank = dist_setup(dev, 'nccl')
-    if args.gpus != world and rank == 0:
-        print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    parity_failed = False
+    check_ranks(args, world, rank)
     if args.train:
         from humaniflow_amd.train import bench_train
         res = bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist_gather_metrics)
@@ -674,12 +785,22 @@ def main():
                                      'their full lines (tools/profile_round.sh) are under profiles/' % (20, 6))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             log('timing the CPU baseline (oracle, %d images x %d samples)' % (args.cpu_images, args.samples))
-            res['cpu_baseline'] = cpu_baseline(ctx['model_sd'], ctx['cfg'], ctx['smpl_model'], args.cpu_images, args.samples)
+            res['cpu_baseline'], ref = cpu_baseline(ctx['model_sd'], ctx['cfg'], ctx['smpl_model'], args.cpu_images, args.samples)
             res['speedup_vs_cpu_baseline'] = round(res['value'] / res['cpu_baseline']['value'], 1)
+            # the second half of BASELINE.json's metric: full-size end-to-end parity against the oracle iteration the baseline leg just ran
+            res['parity'] = parity_block(ctx['model'], ctx['smpl'], ref, args.samples, dev)
+            parity_failed = not res['parity']['ok']
+            log('parity (%d rows): vertex Linf %.3g, joint Linf %.3g, rotmat Linf %.3g, log-prob max abs %.3g -> %s'
+                % (res['parity']['rows'], res['parity']['vertex_linf'], res['parity']['joint_linf'], res['parity']['rotmat_linf'],
+                   res['parity']['logprob_max_abs'], 'ok' if res['parity']['ok'] else 'OUT OF TOLERANCE'))
     if rank == 0:
+        check_ranks(args, world, rank, res.get('rccl_ranks_seen'))
+        assert res['n_gpus'] == args.gpus
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit('bench.py: parity out of tolerance (see the "parity" object of the JSON line)')
 
 
 if __name__ == '__main__':

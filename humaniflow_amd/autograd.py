@@ -503,12 +503,18 @@ class IsgcTrain(torch.autograd.Function):
     reparameterised samples (:302-311, predicted global rotation) and the teacher-forced rows (:279-283, target global rotation, target shape) -- on the
     library: forward hmf_flow_isgc_train (three launches), backward hmf_flow_isgc_train_backward (two) + hmf_rows_atb_batched for every dense product.
     Round 4 ran it as F.linear x 5 + cat + ELU on torch operators: the one vendor GEMM kernel left in a training step and ~45 small launches.
-    Reads the layer's weights from the flow handle's arena (kept in step with the parameters by HumaniflowModel._flow_handle), returns the gradient
-    w.r.t. the parameter tensors."""
+    Reads the layer's weights from the flow handle's arena (kept in step with the parameters by HumaniflowModel._flow_handle: re-packed whenever a
+    parameter's version counter or storage address changes), returns the gradient w.r.t. the parameter tensors.  The forward therefore runs on the
+    MODULE's weights: a `W` that is another tensor than the module's parameter (torch.func.functional_call with substituted parameters) would give a
+    forward and a backward on different weights, so it is refused."""
 
     @staticmethod
     def forward(ctx, model, feats, W, bias, glob_R, cam, shape_samples, glob_R_ll, shape_ll):
         lib = _lib.load()
+        own_W, own_b = model._flow_params()[0], model._flow_params()[1]
+        if (W is not own_W and W.data_ptr() != own_W.data_ptr()) or (bias is not own_b and bias.data_ptr() != own_b.data_ptr()):
+            raise RuntimeError('IsgcTrain: the weight/bias passed in are not fc_input_shape_glob_cam_feats\' own parameters; the kernel reads the packed '
+                               'arena of the module parameters (substituted parameters are not supported: set HMF_ISGC_TRAIN=0 for the torch-operator form)')
         f = lambda t: t.detach().to(torch.float32).contiguous()
         feats_, R_, cam_, ss_, Rl_, sl_ = f(feats), f(glob_R).reshape(-1, 9), f(cam), f(shape_samples), f(glob_R_ll).reshape(-1, 9), f(shape_ll)
         B, N, nb = ss_.shape

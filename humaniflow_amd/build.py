@@ -13,7 +13,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['so3_kernels.hip', 'smpl_kernels.hip', 'flow_pack.hip', 'flow_kernels.hip', 'flow_grad.hip', 'flow_generic.hip', 'proxy_kernels.hip', 'encoder_train.hip', 'conv_wgrad_wino.hip', 'conv_dgrad_s2.hip', 'conv_igemm.hip', 'conv_gemm.hip', 'conv_gemm_split.hip', 'conv_pair.hip', 'conv_patch.hip', 'conv_winograd.hip', 'conv_winograd_nw.hip', 'stem_conv.hip', 'stem_wino.hip', 'train_loss.hip', 'eval_kernels.hip', 'heads_kernels.hip']
+SOURCES = ['so3_kernels.hip', 'smpl_kernels.hip', 'flow_pack.hip', 'flow_kernels.hip', 'flow_grad.hip', 'flow_generic.hip', 'proxy_kernels.hip', 'encoder_train.hip', 'conv_wgrad_wino.hip', 'conv_dgrad_s2.hip', 'conv_igemm.hip', 'conv_gemm.hip', 'conv_gemm_split.hip', 'conv_pair.hip', 'conv_patch.hip', 'conv_winograd.hip', 'stem_conv.hip', 'stem_wino.hip', 'train_loss.hip', 'eval_kernels.hip', 'heads_kernels.hip']
+# compiled only into tools/libhumaniflow_amd_experiments.so (--experiments): measured negative results kept for their probes, not product code
+EXPERIMENT_SOURCES = ['conv_winograd_nw.hip']
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + ['../../include/humaniflow_amd.h', '../../include/humaniflow_amd_experiments.h']
 LIB = os.path.join(HERE, 'libhumaniflow_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -36,7 +38,7 @@ def source_hash(experiments=False):
     by mtimes -- the snapshot that carries the tree to the GPU box does not preserve them."""
     import hashlib
     h = hashlib.sha256(' '.join(FLAGS + (['-DHMF_EXPERIMENTS'] if experiments else [])).encode())
-    for d in sorted(SOURCES) + sorted(HEADERS):
+    for d in sorted(SOURCES + (EXPERIMENT_SOURCES if experiments else [])) + sorted(HEADERS):
         with open(os.path.join(CSRC, d), 'rb') as f:
             h.update(d.encode() + b'\0' + f.read())
     return h.hexdigest()
@@ -80,7 +82,7 @@ def _build_locked(verbose, experiments=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
-    for s in SOURCES:
+    for s in SOURCES + (EXPERIMENT_SOURCES if experiments else []):
         o = os.path.join(objdir, s.replace('.hip', '.o'))
         objs.append(o)
         cmd = [HIPCC] + flags + ['-c', os.path.join(CSRC, s), '-o', o]

@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void k_bn_apply(const f32x4* __restrict__ y, c
         const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
         f32x4 v = y[i] * sc + sh;
         if (res) v += res[i];
-        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (relu) {                                    // NaN-propagating, like torch.relu (fmaxf alone would turn a NaN into 0 and hide it from nan_policy='rollback')
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (v[k] != v[k]) ? v[k] : fmaxf(v[k], 0.f);
+        }
         out[i] = v;
     }
 }
@@ -286,8 +289,9 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool(const f32x4* __restrict__ 
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float a = in[t] ? fmaxf(fmaf(v[t][k], sc[k], sh[k]), 0.f) : -INFINITY;
-                if (a > best[k]) { best[k] = a; bi[k] = (unsigned)t; }
+                const float z = fmaf(v[t][k], sc[k], sh[k]);
+                const float a = in[t] ? ((z != z) ? z : fmaxf(z, 0.f)) : -INFINITY;          // relu and max both propagate NaN, as torch.relu / max_pool2d do
+                if (a > best[k] || ((a != a) && !(best[k] != best[k]))) { best[k] = a; bi[k] = (unsigned)t; }
             }
         }
         out[e] = best;

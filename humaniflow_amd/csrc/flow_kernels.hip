@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_flow_logprob(FlowDev d, const float* __
 // so3_xset (utils/rigid_transform_utils.py:282-295) with k = 0, -1, +1 and the support mask (so3_exp_transform.py:36-41; NaN at x = 0 fails the
 // comparison, as in the reference, quirk 2).  The single-wave form of rounds 1-4 walked the three pre-images one after the other (three dependent passes of the two hyper-networks: ~200 us at B = 72 whatever the grid,
 // since every wave is resident at once and the launch lasts one wave's lifetime); here a wave evaluates one, masked pre-images (outside the support:
-// usually two of the three) end at once, and the log-sum-exp meets in LDS.  Same arithmetic per term, same sum order.
+// usually two of the three) skip the evaluation and wait at the barrier, and the log-sum-exp meets in LDS.  Same arithmetic per term, same sum order.
 __global__ __launch_bounds__(192) void k_flow_logprob_SO3_par(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids, int P,
                                                               const double* __restrict__ Rin, float* __restrict__ logp) {
     __shared__ float s_term[3];
@@ -1027,15 +1027,15 @@ __global__ __launch_bounds__(192) void k_flow_logprob_SO3_par(FlowDev d, const f
         cand[0] = x[0] / n * sc; cand[1] = x[1] / n * sc; cand[2] = x[2] / n * sc;
         ok = sqrt(cand[0] * cand[0] + cand[1] * cand[1] + cand[2] * cand[2]) < (double)d.radius;
     }
-    if (!ok) {                                                         // wave-uniform: a masked pre-image ends here (see k_flow_logprob_bwd); wave 0 never is
-        if (lane == 0) s_term[c] = -INFINITY;
-        __threadfence_block();
-        return;
+    // `ok` is wave-uniform.  A masked pre-image (outside the support: usually two of the three) skips both hyper-network passes but stays alive
+    // to the barrier: returning before it relied on ended waves dropping out of s_barrier, which the HIP model does not promise.
+    float term = -INFINITY;
+    if (ok) {
+        const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
+        const float ld = -(float)so3_logdet_f64(cand);
+        const float v[3] = {(float)cand[0], (float)cand[1], (float)cand[2]};
+        term = ld + log_prob_so3(d, pt, lane, ctx_lane, v);
     }
-    const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
-    const float ld = -(float)so3_logdet_f64(cand);
-    const float v[3] = {(float)cand[0], (float)cand[1], (float)cand[2]};
-    const float term = ld + log_prob_so3(d, pt, lane, ctx_lane, v);
     if (lane == 0) s_term[c] = term;
     __syncthreads();
     if (c == 0 && lane == 0) {

@@ -74,7 +74,22 @@ class EvalMetricsTracker:
         self.slots = self.metrics + self.COUNTS
         self.sums = torch.zeros(len(self.slots), dtype=torch.float64, device=device)
         self.per_frame = {m: [] for m in self.metrics}
+        self.frame_index, self.frame_outputs = [], []             # record_frames(): dataset indices and the reference's per-frame model outputs
         self._pending, self._consts = None, {}
+
+    def record_frames(self, index, pred=None):
+        """Dataset indices of the frames of the batch just scored and, with `pred` carrying glob_rotmat / pose_rotmats_point_est / shape_mode /
+        cam_wp, the per-frame outputs evaluate/evaluate_humaniflow.py:260-268 saves: pose (24,3,3) = [global | 23 body rotations], shape (nb),
+        camera (3) -- one fixed-width float32 row per frame, kept on the device.  reduce() returns every per-frame array in DATASET order through
+        these indices, whatever the sharding."""
+        dev = self.sums.device
+        idx = torch.as_tensor(index, dtype=torch.float32).to(dev)     # exact below 2**24 frames; rides in the float32 all-gather
+        assert idx.numel() == 0 or float(idx.max()) < 2 ** 24
+        self.frame_index.append(idx)
+        if pred is not None and all(k in pred for k in ('glob_rotmat', 'pose_rotmats_point_est', 'shape_mode', 'cam_wp')):
+            B = idx.numel()
+            self.frame_outputs.append(torch.cat([pred['glob_rotmat'].reshape(B, 9), pred['pose_rotmats_point_est'].reshape(B, -1),
+                                                 pred['shape_mode'].reshape(B, -1), pred['cam_wp'].reshape(B, 3)], dim=1).float())
 
     def _acc(self, name, value):
         if torch.is_tensor(value) and self._pending is not None:          # inside update_per_batch: one index_add_ for the whole batch (_flush)
@@ -119,6 +134,14 @@ class EvalMetricsTracker:
         HIP epilogue (hmf_pointset_errors / hmf_sample_diversity); there is no host path."""
         from . import _lib
         _lib.require_cuda(pred['verts3D'], "pred['verts3D']")
+        if 'tpose_verts3D' not in pred or 'tpose_verts3D' not in target:
+            # batches built with materialise_tpose=False carry shape vectors instead of T-pose meshes: both sides must, and the tracker needs the body model
+            if ('tpose_verts3D' in pred) != ('tpose_verts3D' in target) or 'tpose_betas' not in pred or 'tpose_betas' not in target:
+                raise ValueError("EvalMetricsTracker.update_per_batch: pred and target must BOTH carry 'tpose_verts3D', or BOTH carry 'tpose_betas' "
+                                 '(predict_batch / target_batch with the same materialise_tpose)')
+            if self.smpl is None:
+                raise ValueError("EvalMetricsTracker.update_per_batch: the batch carries 'tpose_betas' instead of T-pose vertices; construct the tracker "
+                                 'with smpl=<the humaniflow_amd.SMPL of the predictions> so that hmf_smpl_tpose_errors can score them')
         if self.fused and self._fused_ok(pred, target):
             return self._update_fused(pred, target)
         self._pending = ([], [])
@@ -326,51 +349,93 @@ class EvalMetricsTracker:
         """The ONE exchange step of the path, as exactly two collectives whatever the number of metrics:
           1. all_reduce(SUM) of one float64 vector = the packed metric sums | one frame-count slot per rank (only the own slot is non-zero),
              so every rank learns every rank's frame count in the same message that sums the metrics;
-          2. all_gather of ONE (n_metrics, nmax) float32 tensor holding every per-frame array, padded to the largest rank's count.
-        Messages are bytes to KB: latency-bound, so the count of collectives is what matters on the xGMI ring."""
+          2. all_gather of ONE (rows, nmax) float32 tensor holding every per-frame array -- the metric frames and, when record_frames() was fed,
+             the frames' dataset indices and the reference's per-frame outputs (pose 216 | shape nb | cam 3) -- padded to the largest rank's count.
+        Messages are bytes to KB: latency-bound, so the count of collectives is what matters on the xGMI ring.
+        With recorded indices every returned array is in DATASET order (the reference's single-process order, evaluate_humaniflow.py:260-286);
+        without them it is rank-major (rank 0's frames, then rank 1's, ...)."""
         sums = self.sums.clone()
-        frames = {m: (torch.cat(v) if v else torch.zeros(0, device=self.sums.device)) for m, v in self.per_frame.items()}
+        dev = sums.device
+        frames = {m: (torch.cat(v) if v else torch.zeros(0, device=dev)) for m, v in self.per_frame.items()}
+        index = torch.cat(self.frame_index) if self.frame_index else None
+        outs = torch.cat(self.frame_outputs) if self.frame_outputs else None
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-            W, rank, dev = dist.get_world_size(), dist.get_rank(), sums.device
+            W, rank = dist.get_world_size(), dist.get_rank()
             names = [m for m in frames]                                       # same order on every rank (dict order of the constructor)
-            n_local = max(len(v) for v in frames.values())
+            n_local = max([len(v) for v in frames.values()] + [len(index) if index is not None else 0])
             present = torch.tensor([float(len(frames[m]) > 0) for m in names], dtype=sums.dtype, device=dev)
             # per-frame arrays of one rank must have one length.  A rank that breaks this must not raise BEFORE the collective (the others would
             # block in all_reduce for ever): it reports the fault in the packed vector and every rank raises together after collective 1.
             bad = [m for m in names if len(frames[m]) not in (0, n_local)]
-            packed = torch.zeros(sums.numel() + len(names) + W + 3, dtype=sums.dtype, device=dev)
-            packed[-3] = float(len(bad) > 0)
+            if index is not None and len(index) != n_local:
+                bad.append('frame index')
+            if outs is not None and (index is None or len(outs) != n_local):
+                bad.append('per-frame outputs')
+            TAIL = 5                                                            # [fault, num_verts, num_samples, ranks with indices, output row width]
+            packed = torch.zeros(sums.numel() + len(names) + W + TAIL, dtype=sums.dtype, device=dev)
+            packed[-5] = float(len(bad) > 0)
             packed[:sums.numel()] = sums
             packed[sums.numel():sums.numel() + len(names)] = present           # a metric present on ANY rank is gathered (a rank may own zero frames)
             packed[sums.numel() + len(names) + rank] = n_local
             if n_local > 0:                                                     # mesh size / sample count of the ranks that saw data (a rank that owns
-                packed[-2] = getattr(self, 'num_verts', 0)                      # no item learns them here: the final ratios divide by them)
-                packed[-1] = getattr(self, 'num_samples', 0)
+                packed[-4] = getattr(self, 'num_verts', 0)                      # no item learns them here: the final ratios divide by them)
+                packed[-3] = getattr(self, 'num_samples', 0)
+                packed[-2] = float(index is not None)
+                packed[-1] = float(outs.shape[1]) if outs is not None else 0.0
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)                       # collective 1
             sums = packed[:sums.numel()].clone()
-            host = packed[sums.numel():].tolist()                               # one D2H of n_metrics + W + 2 numbers
-            if host[-3] > 0:
+            host = packed[sums.numel():].tolist()                               # one D2H of n_metrics + W + TAIL numbers
+            if host[-5] > 0:
                 raise RuntimeError('EvalMetricsTracker.reduce: per-frame arrays of one rank must have one length (%d rank(s) report a mismatch%s)'
-                                   % (int(host[-3]), '; here: ' + ', '.join('%s=%d' % (m, len(frames[m])) for m in bad) + ' vs %d' % n_local if bad else ''))
-            have, counts = [h > 0 for h in host[:len(names)]], [int(c) for c in host[len(names):-3]]
+                                   % (int(host[-5]), '; here: ' + ', '.join('%s=%d' % (m, len(frames[m])) if m in frames else m for m in bad)
+                                      + ' vs %d' % n_local if bad else ''))
+            have, counts = [h > 0 for h in host[:len(names)]], [int(c) for c in host[len(names):-TAIL]]
             nmax = max(counts)
             with_data = sum(c > 0 for c in counts)
+            all_idx, ow = False, 0
             if with_data:
-                nv, ns = int(round(host[-2] / with_data)), int(round(host[-1] / with_data))
+                nv, ns = int(round(host[-4] / with_data)), int(round(host[-3] / with_data))
                 if nv > 0:
                     self.num_verts = nv
                 if ns > 0:
                     self.num_samples = ns
+                all_idx = int(round(host[-2])) == with_data                     # every rank that saw data recorded its frames' indices
+                ow = int(round(host[-1] / with_data)) if all_idx else 0
+                if ow and abs(host[-1] - ow * with_data) > 0.5:
+                    raise RuntimeError('EvalMetricsTracker.reduce: per-frame outputs recorded on some ranks only')
             sel = [m for m, h in zip(names, have) if h]
-            if sel and nmax > 0:
-                mine = torch.zeros((len(sel), nmax), dtype=torch.float32, device=dev)
+            rows = len(sel) + (1 if all_idx else 0) + ow
+            if rows and nmax > 0:
+                mine = torch.zeros((rows, nmax), dtype=torch.float32, device=dev)
                 for i, m in enumerate(sel):
                     if len(frames[m]):
                         mine[i, :n_local] = frames[m].float()
-                got = torch.empty((W, len(sel), nmax), dtype=torch.float32, device=dev)
+                if all_idx and n_local:
+                    mine[len(sel), :n_local] = index
+                    if ow:
+                        mine[len(sel) + 1:, :n_local] = outs.t()
+                got = torch.empty((W, rows, nmax), dtype=torch.float32, device=dev)
                 dist.all_gather_into_tensor(got.view(-1), mine.view(-1))       # collective 2
                 for i, m in enumerate(sel):
                     frames[m] = torch.cat([got[r, i, :counts[r]] for r in range(W)])
+                if all_idx:
+                    index = torch.cat([got[r, len(sel), :counts[r]] for r in range(W)])
+                    outs = torch.cat([got[r, len(sel) + 1:, :counts[r]].t() for r in range(W)]) if ow else None
+                else:
+                    index = outs = None
+            else:
+                index = outs = None
+        if index is not None and index.numel():
+            order = torch.argsort(index, stable=True)                          # the inverse of the sharding permutation
+            n = index.numel()
+            frames = {m: (v[order] if v.numel() == n else v) for m, v in frames.items()}
+            frames['index'] = index[order].long()
+            if outs is not None and outs.shape[0] == n:
+                outs = outs[order]
+                nb = outs.shape[1] - 219
+                frames['pose_per_frame'] = outs[:, :216].reshape(n, 24, 3, 3)
+                frames['shape_per_frame'] = outs[:, 216:216 + nb]
+                frames['cam_per_frame'] = outs[:, 216 + nb:]
         return sums, frames
 
     def compute_final_metrics(self, dist=None, num_verts=None, num_joints=14, num_samples=None):
@@ -426,6 +491,9 @@ class SyntheticEvalSet:
                 'joints2D': torch.stack(j2d).to(device), 'joints2D_visib': torch.stack(vis).to(device), 'index': torch.tensor(indices)}
 
 
+PER_FRAME_MODEL_KEYS = ('glob_rotmat', 'pose_rotmats_point_est', 'shape_mode', 'cam_wp')     # what evaluate_humaniflow.py:260-268 saves per frame
+
+
 @torch.no_grad()
 def predict_batch(model, smpl, batch, num_samples, noise=None, materialise_tpose=True):
     """evaluate/evaluate_humaniflow.py:113-192 on the device: model -> SMPL point estimate + samples (ONE launch of B*N + B bodies) ->
@@ -446,6 +514,7 @@ def predict_batch(model, smpl, batch, num_samples, noise=None, materialise_tpose
                'verts3D_samples': sa.vertices.reshape(B, N, -1, 3), 'joints3D_samples': j14[:B * N].reshape(B, N, 14, 3),
                'joints3D_coco_samples': jc[:B * N].reshape(B, N, 17, 3),                       # :180-183
                'joints2Dsamples': j2d[:B * N].reshape(B, N, 17, 2)}                              # :197-206
+        out.update({k: pred[k] for k in PER_FRAME_MODEL_KEYS})
         if materialise_tpose:
             tp = smpl.tpose(betas)
             out['tpose_verts3D'], out['tpose_verts3D_samples'] = tp[B * N:], tp[:B * N].reshape(B, N, -1, 3)                     # :186-192
@@ -459,6 +528,7 @@ def predict_batch(model, smpl, batch, num_samples, noise=None, materialise_tpose
         out['tpose_verts3D'] = smpl.tpose(pred['shape_mode'])
     else:
         out['tpose_betas'] = pred['shape_mode']
+    out.update({k: pred[k] for k in PER_FRAME_MODEL_KEYS})
     return out
 
 
@@ -501,10 +571,13 @@ def target_batch(smpl, batch, materialise_tpose=True):
     return out
 
 
-def evaluate_humaniflow(dataset, batch_size, device, predict_fn, target_fn, dist=None, rank=0, world_size=1, tracker=None, overlap_targets=False):
+def evaluate_humaniflow(dataset, batch_size, device, predict_fn, target_fn, dist=None, rank=0, world_size=1, tracker=None, overlap_targets=False,
+                        save_per_frame=True):
     """Sharded evaluation loop.  predict_fn(batch) / target_fn(batch) return the dicts EvalMetricsTracker consumes.  overlap_targets: the
     target bodies depend on the labels only, so they CAN be built on a side stream while the model runs (their M = B launches are latency-bound);
-    off by default: at B = 32, N = 100 the side branch made the three-stream step slower (3.40 vs 3.23 ms, bench.py --eval, round 5)."""
+    off by default: at B = 32, N = 100 the side branch made the three-stream step slower (3.40 vs 3.23 ms, bench.py --eval, round 5).
+    save_per_frame: record every frame's dataset index and point-estimate outputs (record_frames), so the returned per-frame arrays are in
+    dataset order and carry the reference's pose / shape / cam per-frame outputs (evaluate_humaniflow.py:260-286)."""
     tracker = EvalMetricsTracker(device) if tracker is None else tracker
     mine = shard_indices(len(dataset), rank, world_size)
     dev = torch.device(device)
@@ -524,4 +597,20 @@ def evaluate_humaniflow(dataset, batch_size, device, predict_fn, target_fn, dist
                 if torch.is_tensor(t):
                     t.record_stream(cur)
         tracker.update_per_batch(pred, targ)
+        if save_per_frame:
+            tracker.record_frames(batch['index'] if 'index' in batch else mine[s:s + batch_size], pred)
     return tracker.compute_final_metrics(dist)
+
+
+def save_per_frame_outputs(frames, save_path, fnames=None):
+    """Writes what the reference writes with save_per_frame_metrics (evaluate/evaluate_humaniflow.py:271-286, metrics/eval_metrics_tracker.py:498-501):
+    fname / pose / shape / cam `_per_frame.npy` in dataset order plus one `<metric>_per_frame.npy` per tracked metric.  `fnames`: the dataset's
+    file names (indexed by frames['index']); without them the indices themselves are saved."""
+    import os
+    import numpy as np
+    os.makedirs(save_path, exist_ok=True)
+    idx = frames['index'].cpu().numpy()
+    np.save(os.path.join(save_path, 'fname_per_frame.npy'), np.asarray(fnames)[idx] if fnames is not None else idx)
+    for k, v in frames.items():
+        if k != 'index' and torch.is_tensor(v) and v.numel():
+            np.save(os.path.join(save_path, k + '.npy' if k.endswith('_per_frame') else k + '_per_frame.npy'), v.cpu().numpy())

@@ -362,7 +362,10 @@ class HumaniflowModel(nn.Module):
         step, in-place copy) re-packs ON THE DEVICE: one concatenation + one gather kernel through the slot->parameter index map the
         handle recorded at creation (hmf_flow_update_from_device) -- no host round trip, no reallocation."""
         lib = _lib.load()
-        vkey = tuple([t._version for t in self._flow_params()])
+        # staleness contract: the arena is re-packed when a flow parameter's (version counter, storage address) changes -- optimiser steps, in-place
+        # copies, load_state_dict and `p.data = other` are all seen.  Substituting parameter OBJECTS (torch.func.functional_call) is not: the kernels
+        # read this module's own parameters (autograd.IsgcTrain checks that the tensor autograd hands it is the one the arena was packed from).
+        vkey = tuple([(t._version, t.data_ptr()) for t in self._flow_params()])
         key = (device.type, device.index)
         h = self._handles.get(key)
         if h is not None and self.__dict__.get('_flow_key') != vkey:

@@ -471,6 +471,35 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
         w_ = torch.randn_like(feats)
         stages['of_backward: encoder_ms'], _ = tm(lambda: (feats * w_).sum().backward())
     optimiser.zero_grad(set_to_none=True)
+    # ---- like-for-like note: the default step builds SMPL JOINTS only (the loss reads nothing else); the reference's step always builds
+    # the vertices too (train/train_humaniflow.py:262-283, used by its metric tracking).  Same eager issue for both, a few steps each, untimed region.
+    global JOINTS_ONLY
+    like = None
+    try:
+        def eager_ms(k_steps=4):
+            with reducer.disabled():
+                train_step(model, smpl, criterion, optimiser, reducer, *batches[0], N)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for k in range(k_steps):
+                    train_step(model, smpl, criterion, optimiser, reducer, *batches[k % NB], N)
+                b.record()
+                torch.cuda.synchronize()
+            return a.elapsed_time(b) / k_steps
+        keep_jo = JOINTS_ONLY
+        t_jo = eager_ms()
+        JOINTS_ONLY = False
+        t_full = eager_ms()
+        JOINTS_ONLY = keep_jo
+        like = {'eager_ms_per_step_smpl_joints_only': round(t_jo, 3), 'eager_ms_per_step_full_smpl_vertices': round(t_full, 3),
+                'note': 'the timed step builds SMPL joints without the vertices (HMF_TRAIN_JOINTS_ONLY=1, default: the loss reads joints only); the reference step '
+                        'also builds the 6890-vertex meshes of the point estimate and the samples for its metric tracking.  Both forms issued eagerly on one '
+                        'stream here: the difference is what the like-for-like step would add to ms_per_step'}
+    except Exception as e:
+        JOINTS_ONLY = os.environ.get('HMF_TRAIN_JOINTS_ONLY', '1') != '0'
+        log('like-for-like pass failed: %r' % (e,))
+    optimiser.zero_grad(set_to_none=True)
     # ---- per-kernel-family measurement pass: HIP event pair around every convolution / weight-gradient launch of 2 more steps ----
     roof = None
     try:
@@ -561,7 +590,11 @@ def bench_train(args, dev, dist, world, rank, log, dist_sync, dist_elapsed, dist
                        'exchange': ('gradient all-reduce over RCCL, %d buckets of <= 25 MB, launched from gradient-ready hooks' % len(reducer.buckets))
                        if world > 1 else 'none'},
             'rccl_ranks_seen': int(gathered.shape[0]), 'mean_loss': float(gathered[:, 0].mean()), 'skipped_steps': int(gathered[:, 1].sum()),
-            'train_images_per_s': round(world * B * args.steps / elapsed, 1), 'stages_ms': {k: round(v, 3) for k, v in stages.items()},
+            'train_images_per_s': round(world * B * args.steps / elapsed, 1),
+            'smpl_work_vs_reference_step': like,
+            'stages_ms_eager_synchronised': {k: round(v, 3) for k, v in stages.items()},
+            'stages_note': 'one EAGER pass with a host synchronise around every stage (launch-bound: ~500 launches issued from Python); NOT a breakdown of '
+                           'ms_per_step, which is the graph-replayed step',
             'hand_written': 'encoder training graph (conv kernels incl. Winograd with device-side filter transform + hmf_bn_* + hmf_conv_wgrad + dgrad through the forward kernels), flow forward/backward '
                             '(hmf_flow_forward, hmf_flow_log_prob_SO3[_backward], hmf_flow_sample_backward), SMPL forward + joints backward, proxy front end; '
                             'library GEMMs (torch) for the heads and the dense weight-gradient reductions of the flow',

@@ -94,6 +94,9 @@ def _fake(batch, salt, samples):
             d['joints3D_samples'] = torch.randn(5, 14, 3, generator=g)
             d['joints3D_coco_samples'] = torch.randn(5, 17, 3, generator=g)
             d['joints2Dsamples'] = torch.rand(5, 17, 2, generator=g) * 256
+            # the model outputs the reference saves per frame (evaluate/evaluate_humaniflow.py:260-268)
+            d.update(glob_rotmat=torch.randn(3, 3, generator=g), pose_rotmats_point_est=torch.randn(23, 3, 3, generator=g),
+                     shape_mode=torch.randn(10, generator=g), cam_wp=torch.randn(3, generator=g))
         else:
             d['joints2D_vis'] = torch.rand(17, generator=g) > 0.3
         outs.append(d)
@@ -158,13 +161,28 @@ def test_two_rank_gloo_eval_equals_single_process(n):
         assert metrics['num_total_test_data'] == n
         for k, v in single.items():
             assert abs(metrics[k] - v) < 1e-9 * max(1.0, abs(v)), (k, metrics[k], v)       # sums are order-independent up to fp64
+        # every per-frame array -- metric frames AND the reference's pose / shape / cam per-frame outputs -- comes back in DATASET order
+        # (evaluate/evaluate_humaniflow.py:260-286), i.e. equal to the single-process run, on every rank
+        assert set(frames) == set(frames1) and {'index', 'pose_per_frame', 'shape_per_frame', 'cam_per_frame'} <= set(frames)
+        assert np.array_equal(frames['index'], np.arange(n))
+        assert frames['pose_per_frame'].shape == (n, 24, 3, 3) and frames['shape_per_frame'].shape == (n, 10) and frames['cam_per_frame'].shape == (n, 3)
         for k in frames1:
-            assert frames[k].shape == (n,)
-            # per-frame arrays come back rank-major (rank 0's items r, r+W, ... first)
-            order = ev.shard_indices(n, 0, 2) + ev.shard_indices(n, 1, 2)
-            ref = np.empty(n)
-            ref[:] = frames1[k].numpy()
-            assert np.allclose(frames[k], ref[order], atol=1e-6)
+            assert frames[k].shape == frames1[k].shape
+            assert np.allclose(frames[k], frames1[k].numpy(), atol=1e-6), k
+        for i in range(n):                                               # the outputs of frame i are the ones the model produced for item i
+            d = _fake({'index': torch.tensor([i])}, 1, True)
+            assert np.array_equal(frames['pose_per_frame'][i, 0], d['glob_rotmat'][0].numpy())
+            assert np.array_equal(frames['pose_per_frame'][i, 1:], d['pose_rotmats_point_est'][0].numpy())
+            assert np.array_equal(frames['shape_per_frame'][i], d['shape_mode'][0].numpy()) and np.array_equal(frames['cam_per_frame'][i], d['cam_wp'][0].numpy())
+
+
+def test_save_per_frame_outputs_writes_the_reference_files(tmp_path):
+    _, frames = _run_eval(0, 1, 5, None)
+    ev.save_per_frame_outputs(frames, str(tmp_path), fnames=['img_%02d.png' % i for i in range(5)])
+    assert np.load(str(tmp_path / 'pose_per_frame.npy')).shape == (5, 24, 3, 3)
+    assert np.load(str(tmp_path / 'shape_per_frame.npy')).shape == (5, 10) and np.load(str(tmp_path / 'cam_per_frame.npy')).shape == (5, 3)
+    assert list(np.load(str(tmp_path / 'fname_per_frame.npy'))) == ['img_%02d.png' % i for i in range(5)]
+    assert np.load(str(tmp_path / 'PVE_per_frame.npy')).shape == (5,) and np.load(str(tmp_path / 'MPJPE-PA_samples_min_per_frame.npy')).shape == (5,)
 
 
 def test_sampling_helpers_match_reference():
@@ -306,3 +324,28 @@ def test_bench_rank_plumbing_eight_gloo_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 8 and d['rccl_ranks_seen'] == 8 and d['gathered_rank_sums'] == [4.0 * (r_ + 1) for r_ in range(8)]
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (the shape of the driver's 1-GPU command with another N) must not print
+    an n_gpus = 1 line: bench.py starts the ranks itself and the line carries n_gpus == rccl_ranks_seen == 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run-cpu'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks_seen'] == 2 and d['gathered_rank_sums'] == [4.0, 8.0]
+
+
+def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launcher():
+    """--gpus 4 under a 1-rank environment (WORLD_SIZE=1 set by a launcher) exits non-zero instead of reporting another N than asked."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1', '--dry-run-cpu'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and b'--gpus 4' in r.stderr
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
