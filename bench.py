@@ -397,14 +397,16 @@ def run_inference(args, dev, dist, world, rank):
     import humaniflow_amd as H
     from humaniflow_amd import _lib, evaluate as ev
     from humaniflow_amd.build import source_hash
-    from humaniflow_amd.synthetic import synthetic_proxy_input, init_benchmark_weights
+    from humaniflow_amd.synthetic import synthetic_proxy_input, init_benchmark_weights, calibrate_benchmark_weights
     lib = _lib.load()
     cfg = H.get_humaniflow_cfg_defaults()
     cfg.MODEL.NUM_RESNET_LAYERS = args.layers
     torch.manual_seed(0)
     model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).eval()
-    model_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
+    # metre-sized bodies from random weights: heads scaled by 1 / rms(encoder features) of one synthetic batch (same batch on every rank)
+    feat_scale = calibrate_benchmark_weights(model, synthetic_proxy_input(8, 256, seed=99).to(dev))
+    model_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model.image_encoder.gemm_terms = args.gemm_terms
     for kv in filter(None, os.environ.get('HMF_ENC_OPTS', '').split(',')):          # experiments only: e.g. HMF_ENC_OPTS=fuse_stem_pool=0,fuse_pairs=0
         k_, v_ = kv.split('=')
@@ -574,6 +576,8 @@ def run_inference(args, dev, dist, world, rank):
                                    'synthetic SMPL-shaped body model%s'
                                    % (B, N, args.layers, 'fp32' if args.blend_dtype == 'fp32' else 'fp32 with bf16 blend-shape GEMM operands',
                                       '; + T-pose bodies, target bodies, device metric-tracker update' if args.eval else ''),
+                       'weights': 'default PyTorch init (seed 0), random BatchNorm statistics; fc1 / isgc feature columns scaled by 1/rms(encoder features) = %.3e '
+                                  '(metre-sized bodies)' % feat_scale,
                        'global_batch': world * B, 'samples_per_image': N, 'parallelism': 'dp%d' % world, 'streams_per_gpu': S,
                        'distinct_input_batches': NB, 'issue': 'HIP graph replay (one captured graph per batch)' if use_graph else 'eager',
                        'exchange': 'one RCCL all_gather of per-rank metric sums per run' if world > 1 else 'none'},

@@ -41,3 +41,17 @@ def init_benchmark_weights(model, seed=0):
             elif name.endswith('running_mean'):
                 b.copy_(torch.randn(b.shape, generator=g) * 0.1)
     return model
+
+
+@torch.no_grad()
+def calibrate_benchmark_weights(model, x):
+    """Bring the random-init model into the operating range of a trained one: one encoder pass over `x` (on the device, product path), then
+    fc1 and the feature columns of fc_input_shape_glob_cam_feats are scaled by 1 / rms(features), so that the heads see O(1) inputs and emit O(1)
+    shape / camera / rotation parameters (metre-sized bodies).  Without it a default-init ResNet-50 with random BatchNorm statistics hands the
+    heads features of rms ~1e2-1e3 and the "bodies" are hundreds of metres tall -- an absolute 1e-4 m parity bar means nothing there.
+    Throughput does not depend on the weight values; returns the scale applied."""
+    f = model(x, return_input_feats_only=True)['input_feats']
+    s = float(1.0 / f.float().square().mean().sqrt().clamp_min(1e-12))
+    model.fc1.weight.mul_(s)
+    model.fc_input_shape_glob_cam_feats.weight[:, :model.input_feats_dim].mul_(s)
+    return s

@@ -430,12 +430,20 @@ def test_training_graph_guards_and_packed_weight_handle_persistence():
         b = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
     assert model._handles[('cuda', 0)].value == h0                        # same arena: re-packed in place
     assert torch.allclose(a['pose_rotmats_samples'], b['pose_rotmats_samples'], atol=1e-6)
-    # a parameter changed behind the version counters (what a graph replay of an optimiser step does): stale until mark_params_changed()
+    # re-binding .data does not bump the version counter but moves the storage: seen through the (version, address) key (round 6)
     w = next(model.fc_flow_context[0].parameters())
-    w.data = w.data * 1.5                                                 # re-binding .data does not bump the version counter
+    w.data = w.data * 1.5
     with torch.no_grad():
         c = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
-    assert torch.equal(c['pose_rotmats_samples'], b['pose_rotmats_samples'])      # stale pack (documented)
+    assert not torch.equal(c['pose_rotmats_samples'], b['pose_rotmats_samples'])
+    assert model._handles[('cuda', 0)].value == h0
+    # a parameter changed behind BOTH (what a graph replay of an optimiser step does: same storage, no counter): stale until mark_params_changed()
+    raw = torch.empty(0, device='cuda').set_(w.data.untyped_storage(), 0, w.shape, w.stride())      # an alias autograd does not know of
+    raw.mul_(1.0 / 1.5)
+    with torch.no_grad():
+        c2 = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
+    assert torch.equal(c2['pose_rotmats_samples'], c['pose_rotmats_samples'])     # stale pack (documented)
+    b = c
     model.mark_params_changed()
     with torch.no_grad():
         d = model(x, num_samples=3, noise={'shape': torch.zeros(3, 2, 10, device='cuda'), 'pose': torch.zeros(23, 2, 3, 3, device='cuda')})
