@@ -183,12 +183,16 @@ _EXPERIMENT_SIGS = {
     'hmf_debug_set_wino_nw_mode': (C.c_int, [C.c_int]),                             # tools/wino_nw_probe.py
     'hmf_conv_winograd_nw': (C.c_int, [_VP] * 5 + [C.c_int] * 6 + [_VP]),
     'hmf_debug_set_timeline': (C.c_int, [_VP]),                                     # tools/flow_timeline.py
-    'hmf_debug_set_lbs_cycles': (C.c_int, [_VP]),                                   # tools/lbs_tune.py
+    'hmf_debug_set_lbs_cycles': (C.c_int, [_VP]),
+    'hmf_debug_lbs16_phases': (C.c_int, [_VP]),                                   # tools/lbs_tune.py
     'hmf_debug_gemm_stamps': (C.c_int, [_VP, C.c_int]),
     'hmf_debug_set_wgw_target_wgs': (C.c_int, [C.c_int]),
     'hmf_debug_set_wgw_single_stage': (C.c_int, [C.c_int]),                            # tools/wgw_probe.py
     'hmf_debug_stem_stamps': (C.c_int, [_VP, C.c_int]),
     'hmf_debug_stem_wino_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/stem_probe.py
+    'hmf_debug_set_gemm_whatif': (C.c_int, [C.c_int]),                              # tools/whatif_1x1.py
+    'hmf_debug_set_pair_whatif': (C.c_int, [C.c_int]),
+    'hmf_debug_set_flow_whatif': (C.c_int, [C.c_int]),
     'hmf_debug_wino_stamps': (C.c_int, [_VP, C.c_int]),                             # tools/wino_probe.py                             # tools/gemm1x1_probe.py
 }
 

@@ -68,7 +68,10 @@ static __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_pt
 // POOL: the global average pool of models/resnet.py:214-215 rides in the epilogue of the encoder's last convolution: a 64-row tile is exactly one
 // image's 8 x 8 map, so the column means of the finished tile ARE that image's pooled features for the tile's channels -- no cross-work-group
 // reduction, a fixed summation order, and the 16.8 MB map is neither written nor re-read when the caller passes y = NULL.
-template <int BM, int BN, int S, bool DUAL, int OCC, int KS, bool POOL = false>
+// ABL (experiments build, tools/whatif_1x1.py; timing only, WRONG results): & 1 = the epilogue stores accumulator registers straight from the MFMA layout
+// (no transposition through LDS: the ceiling of any cheaper epilogue), & 2 = the activation panel is requested for the prologue chunks only (the
+// ceiling of a panel-resident form that fetches A once per work-group instead of once per n-tile).
+template <int BM, int BN, int S, bool DUAL, int OCC, int KS, bool POOL = false, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_gemm(const GemmArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;            // 32 x 32 MFMA tiles per wave (2 x 2 waves)
     constexpr int NA = BM / 32, NB = BN / 32;            // DMA instructions per wave per chunk (8 rows of 128 B each)
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (i < lo || i >= hi) continue;
+            if ((ABL & 2) && c >= S - 1) continue;
             lds_ptr_t dst = (lds_ptr_t)(st + (wave * NA + i) * 256);
             if (second) dma16(rx2, dst, voA2[i], (c - nch1) * 128);
             else dma16(rx, dst, voA[i], c * 128);
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     // ---- epilogue: wave-local transpose through LDS, then 16-byte row accesses: + bias (+ residual), ReLU ----
     __builtin_amdgcn_s_barrier();                               // every wave is done reading operand stages
     float* tw = smem + wave * (WM * WN);
+    if (!(ABL & 1))
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -261,7 +266,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         }
 #pragma unroll
         for (int s = 0; s < HALF; ++s) {
-            f32x4 v = *(const f32x4*)(tw + (row0 + (h + s) * RPI) * WN + col);
+            f32x4 v;
+            if (ABL & 1) {
+                const int q = ((h + s) * 4) % (TM * TN * 16);          // any four accumulator registers (fully unrolled: constant indices): the stores keep their count and addresses
+                const f32x16& A_ = acc[(q / 16) / TN][(q / 16) % TN];
+                v = f32x4{A_[q % 16], A_[q % 16 + 1], A_[q % 16 + 2], A_[q % 16 + 3]};
+            } else {
+                v = *(const f32x4*)(tw + (row0 + (h + s) * RPI) * WN + col);
+            }
             v = v + bv + rv[s];
             v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
             if (POOL) psum += v;
@@ -289,6 +301,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #endif
 }
 
+#ifdef HMF_EXPERIMENTS
+static int g_gemm_whatif = 0;
+#endif
+
 template <int BM, int BN, int S, int OCC, int KS = 1>
 static void launch_gemm(GemmArgs a, hipStream_t st) {
     const int MT = (a.M + BM - 1) / BM, NT = a.N / BN, T = MT * NT;
@@ -299,6 +315,24 @@ static void launch_gemm(GemmArgs a, hipStream_t st) {
         if constexpr (KS == 1 && BM == 64) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS, true>), dim3(T), dim3(256), 0, st, a);
         return;
     }
+#ifdef HMF_EXPERIMENTS
+    if constexpr (KS == 1 && BM == 64) {
+        const int wi = g_gemm_whatif;
+        if ((wi & 1) || ((wi & 2) && a.K1 + a.K2 <= 256 && a.N / BN > 1)) {
+            if ((wi & 3) == 1 || !((wi & 2) && a.K1 + a.K2 <= 256 && a.N / BN > 1)) {
+                if (a.x2) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, true, OCC, KS, false, 1>), dim3(T), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS, false, 1>), dim3(T), dim3(256), 0, st, a);
+            } else if ((wi & 3) == 2) {
+                if (a.x2) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, true, OCC, KS, false, 2>), dim3(T), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS, false, 2>), dim3(T), dim3(256), 0, st, a);
+            } else {
+                if (a.x2) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, true, OCC, KS, false, 3>), dim3(T), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS, false, 3>), dim3(T), dim3(256), 0, st, a);
+            }
+            return;
+        }
+    }
+#endif
     if (a.x2) hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, true, OCC, KS>), dim3(T), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_gemm<BM, BN, S, false, OCC, KS>), dim3(T), dim3(256), 0, st, a);
 }
@@ -308,6 +342,7 @@ static void launch_gemm(GemmArgs a, hipStream_t st) {
 using namespace hmf;
 
 #ifdef HMF_EXPERIMENTS
+extern "C" int hmf_debug_set_gemm_whatif(int mask) { g_gemm_whatif = mask; return HMF_OK; }
 extern "C" int hmf_debug_gemm_stamps(long long* out_host, int blocks) {
     if (!out_host || blocks < 1 || blocks > 4096) return fail(HMF_ERR_INVALID, "hmf_debug_gemm_stamps: bad args");
     HMF_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gemm_stamps), (size_t)blocks * 6 * sizeof(long long)));

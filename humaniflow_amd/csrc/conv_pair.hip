@@ -39,7 +39,8 @@ struct PairArgs {
 __device__ __forceinline__ int pair_swz(int r) { return ((r & 1) << 3) | ((r >> 1) & 7); }
 
 // ABL (tools/pair_probe.py, timing only; & 7 give wrong results): & 1 = y is not stored, & 2 = the residual is not loaded, & 4 = no chunk barrier,
-// & 8 = residual loads streaming (nt), & 16 = y stores NOT non-temporal.
+// & 8 = residual loads streaming (nt), & 16 = y stores NOT non-temporal, & 32 = the W3 / W1 fragments are loaded once before the chunk loop (timing only:
+// the ceiling of putting the seam's filter operands on an LDS-DMA ring -- no L2 -> VGPR stream at all).
 template <int KT, int N2, int OCC, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_conv_pair(const PairArgs a) {
     constexpr int XS = KT + 4, G3 = KT / 8, TN2 = N2 / 64, NT2 = N2 / 32, V4 = KT / 4, NX = 64 * V4 / 256;
@@ -155,8 +156,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 
     // One chunk.  Order of the memory operations: vmcnt retires in order, so everything a later MFMA phase waits for is requested BEFORE the y stores of
     // this chunk (a store is acknowledged late): W3 fragments + residual of chunk c + 1 right after phase 1, W1 fragments of c at the top.
+    if (ABL & 32) load_b1(0);
     auto chunk = [&](int c, f32x4 (&rv)[4], f32x4 (&rvn)[4]) {
-        load_b1(c);
+        if (!(ABL & 32)) load_b1(c);
         // ---- phase 1: a 32 x 32 tile of Y, K = KT ----
         f32x16 accy;
 #pragma unroll
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             for (int u = 0; u < 4; ++u) accy = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], b3[g][u], accy, 0, 0, 0);
         }
         if (c + 1 < nchunk) {
-            load_b3(c + 1);
+            if (!(ABL & 32)) load_b3(c + 1);
             load_res(c + 1, rvn);
         }
         float* yc = sY[c & 1];
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         const float* pa2 = yc + arow * 64;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (kRing1 && g + 1 < 8) load_b1g(c, g + 1, (g + 1) & 1);
+            if (kRing1 && g + 1 < 8 && !(ABL & 32)) load_b1g(c, g + 1, (g + 1) & 1);
             const f32x4 fa = *(const f32x4*)(pa2 + (((2 * g + lq) ^ aswz) << 2));
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -232,6 +234,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 }  // namespace hmf
 
 using namespace hmf;
+
+#ifdef HMF_EXPERIMENTS
+static int g_pair_whatif = 0;
+extern "C" int hmf_debug_set_pair_whatif(int mask) { g_pair_whatif = mask; return HMF_OK; }
+#endif
 
 // w3 [C][Kt] row-major (Kt = K1 + K2: the concatenated filters of conv3 and the downsample branch), w1 [N2][C] row-major ->
 //   w3p[((c * 2 + wn) * Kt/8 + g) * 64 + lane][u] = w3[64 c + 32 wn + (lane & 31)][8 g + 4 (lane >> 5) + u]
@@ -277,6 +284,14 @@ extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_p
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((M + 63) / 64);
     ProfScope ps(8, (int)M, st);               // booked with the 1x1 family (it replaces two of its launches)
+#ifdef HMF_EXPERIMENTS
+    if (variant == 0 && (g_pair_whatif & 32) && Kt == 64 && (N2 == 64 || N2 == 128)) {
+        if (N2 == 64) hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 32>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_pair<64, 128, 3, 32>), dim3(grid), dim3(256), 0, st, a);
+        HMF_LAUNCH_CHECK();
+        return HMF_OK;
+    }
+#endif
     if (variant == 0) {
         if (Kt == 64 && N2 == 64) hipLaunchKernelGGL((k_conv_pair<64, 64, 3>), dim3(grid), dim3(256), 0, st, a);
         else if (Kt == 64 && N2 == 128) hipLaunchKernelGGL((k_conv_pair<64, 128, 3>), dim3(grid), dim3(256), 0, st, a);

@@ -1057,12 +1057,16 @@ int generic_logprob(const hmf_flow* h, const float* ctx, const int* dev_ids, int
 using namespace hmf;
 
 static long long* g_timeline = nullptr;
+#ifdef HMF_EXPERIMENTS
+static int g_flow_whatif = 0;
+#endif
 
 extern "C" {
 
 #ifdef HMF_EXPERIMENTS
 /* diagnostic (tools/flow_timeline.py): device buffer of 23 x 8 int64 shader-clock stamps written by tile 0, or NULL */
 int hmf_debug_set_timeline(void* dev_ptr) { g_timeline = (long long*)dev_ptr; return HMF_OK; }
+int hmf_debug_set_flow_whatif(int mask) { g_flow_whatif = mask; return HMF_OK; }
 #endif
 
 static int n_tiles(int B, int N, int flags) { return ((B * N + ((flags & HMF_FLOW_POINT_EST) ? B : 0)) + 31) / 32; }
@@ -1156,6 +1160,10 @@ int hmf_flow_forward(const hmf_flow_t* h, const float* feats, const float* glob_
         // So: the latency form up to 1,024 rows (predict: one image x 10 samples; small evaluation batches), the 32-row form beyond;
         // HMF_FLOW_CHAIN32 / HMF_FLOW_CHAIN16 force one (cross-checks, tools/flow_timeline.py).
         const bool use32 = (flags & HMF_FLOW_CHAIN32) || (!(flags & HMF_FLOW_CHAIN16) && Mtot > 1024);
+#ifdef HMF_EXPERIMENTS
+        if (g_flow_whatif & 1) {                               // tools/whatif_1x1.py: the step WITHOUT the kinematic loop (wrong results): the ceiling of any faster chain kernel
+        } else
+#endif
         if (use32)
             hipLaunchKernelGGL(k_flow_chain, dim3(ntiles), dim3(kChainWaves * 64), 0, st, h->d, C0, ns, B, N, Mtot, rotmats_samples,
                                rotmats_point, so3_point, g_timeline);

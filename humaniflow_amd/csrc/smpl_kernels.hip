@@ -865,8 +865,26 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // 1e-4 m of the fp32 oracle -- the north-star tolerance -- at 3/16 of the fp32 MFMA time: still bound by the vertex write.
 // ABL (experiments build only, tools/lbs16_tune.py; results wrong when != 0): & 1 no skinning epilogue, & 2 no B-operand stream (the first k-group's
 // fragments serve every k-group), & 4 no MFMAs, & 8 skinning without the vertex stores.
-template <int SLOTS, bool SPLIT, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
+// Packed fp32 VALU (v_pk_fma_f32) is switched off for the library (build.py: beside fp32 MFMAs it is an anti-lever) and back ON for this kernel alone: with
+// bf16 MFMAs the matrix pipe is busy 8 k of a wave tile's ~40 k cycles and the 48 blend FMAs per (row, vertex) of the skinning epilogue pair up.  (The
+// attribute is honoured by the device pass; the host pass warns that it ignores it.)  Measured: no change (the epilogue is bound by LDS gather bandwidth).
+#define HMF_LBS16_TARGET __attribute__((target("packed-fp32-ops")))
+#ifdef HMF_EXPERIMENTS
+// tools/lbs16_tune.py: shader-clock cycles every wave spends staging + waiting at the segment barriers / between tile start and its first k-group / in the
+// main loop / in the skinning epilogue, summed over all waves (lane 0 adds at the end of the kernel), + the number of wave tiles
+__device__ unsigned long long g_lbs16_phase[8];
+#define HMF_L16_T(var) const long long var = (long long)__builtin_readcyclecounter()
+#define HMF_L16_ADD(k, v) ph[k] += (v)
+#else
+#define HMF_L16_T(var)
+#define HMF_L16_ADD(k, v)
+#endif
+// PF: k-groups of B fragments requested ahead of their use (a ring of PF + 1 register sets).  PIN: a scheduling barrier keeps every k-group's requests where
+// they are written -- left alone the scheduler SINKS them to their first use (same VGPR count for PF = 1, 2, 3), and the main loop of rounds 2-5 was 14 serial
+// L2 round trips per wave tile (26.6 k cycles for 8 k cycles of MFMA issue; pinned: 10.8 k).  LATE: the skinning offsets / weights and the template
+// (11 registers) are loaded after the main loop instead of being held through it (no scratch left: 254 VGPRs, was 256 + 56 B).
+template <int SLOTS, bool SPLIT, int ABL = 0, int PF = 1, bool LATE = true, bool PIN = true>
+__global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
                                                      const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts,
                                                      float* __restrict__ cjv) {
     constexpr int kPanelF = kRowsPerWG * kP16Stride / 2;                     // floats of one bf16 panel
@@ -881,10 +899,14 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
     int t = (int)((long long)chunk * T / wpx);
     const int t1 = (int)((long long)(chunk + 1) * T / wpx);
     const int nslots = d.skin_slots;
+#ifdef HMF_EXPERIMENTS
+    long long ph[5] = {0, 0, 0, 0, 0};
+#endif
     while (t < t1) {
         const int rg = t / kVTperX;
         const int seg_end = min(t1, (rg + 1) * kVTperX);
         const int row0 = rg * kRowsPerWG;
+        HMF_L16_T(ts0);
         {
             const f32x4* src = (const f32x4*)(panel16 + (size_t)row0 * kP16Stride);
             f32x4* dst = (f32x4*)smem;
@@ -905,20 +927,26 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
             }
         }
         __syncthreads();
+        HMF_L16_T(ts1);
+        HMF_L16_ADD(0, ts1 - ts0);
         for (int tt = t + wave; tt < seg_end; tt += 8) {
+            HMF_L16_T(tt0);
             const int vt = xr * kVTperX + (tt - rg * kVTperX);
             int off[SLOTS > 0 ? SLOTS : 1];
             float w[SLOTS > 0 ? SLOTS : 1];
-            if (SLOTS > 0) {
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    off[s] = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
-                    w[s] = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
-                }
-            }
             const int v = vt * 32 + l31;
             float tm[3] = {0.f, 0.f, 0.f};
-            if (v < kV) { tm[0] = d.tp_tmpl[v * 3]; tm[1] = d.tp_tmpl[v * 3 + 1]; tm[2] = d.tp_tmpl[v * 3 + 2]; }
+            auto load_epilogue_operands = [&]() {
+                if (SLOTS > 0) {
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        off[s] = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
+                        w[s] = d.skin_w[((size_t)vt * nslots + s) * 32 + l31];
+                    }
+                }
+                if (v < kV) { tm[0] = d.tp_tmpl[v * 3]; tm[1] = d.tp_tmpl[v * 3 + 1]; tm[2] = d.tp_tmpl[v * 3 + 2]; }
+            };
+            if (!LATE) load_epilogue_operands();
             f32x16 acc[2][3];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -930,27 +958,36 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
             const f32x4* bpl = (const f32x4*)(d.blend16_lo + (size_t)vt * kKG16 * 3 * 64 * 8) + lane;
             const unsigned short* ap = sP + l31 * kP16Stride + half * 8;
             const unsigned short* apl = ap + kRowsPerWG * kP16Stride;                  // the lo panel follows the hi panel in LDS
-            f32x4 b0 = bp[0], b1 = bp[64], b2 = bp[128];
+            constexpr int NSET = PF + 1;
+            f32x4 bs[NSET][SPLIT ? 6 : 3];
+            auto loadB = [&](int kg, int slot) {
+                bs[slot][0] = bp[kg * 192]; bs[slot][1] = bp[kg * 192 + 64]; bs[slot][2] = bp[kg * 192 + 128];
+                if (SPLIT) { bs[slot][3] = bpl[kg * 192]; bs[slot][4] = bpl[kg * 192 + 64]; bs[slot][5] = bpl[kg * 192 + 128]; }
+            };
+#pragma unroll
+            for (int p = 0; p < PF; ++p) loadB(p, p);
             f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 32 * kP16Stride);
-            f32x4 bl0 = b0, bl1 = b1, bl2 = b2, al0 = a0, al1 = a1;
+            f32x4 al0 = a0, al1 = a1;
             if (SPLIT) {
-                bl0 = bpl[0]; bl1 = bpl[64]; bl2 = bpl[128];
                 al0 = *(const f32x4*)apl; al1 = *(const f32x4*)(apl + 32 * kP16Stride);
             }
+            HMF_L16_T(tt1);
 #pragma unroll
             for (int kg = 0; kg < kKG16; ++kg) {
-                f32x4 n0 = b0, n1 = b1, n2 = b2, m0 = a0, m1 = a1;
-                f32x4 nl0 = bl0, nl1 = bl1, nl2 = bl2, ml0 = al0, ml1 = al1;
+                f32x4 m0 = a0, m1 = a1, ml0 = al0, ml1 = al1;
+                if (kg + PF < kKG16 && !(ABL & 2)) loadB(kg + PF, (kg + PF) % NSET);
+                if (PIN) __builtin_amdgcn_sched_barrier(0);        // the requests stay HERE (see PIN above)
                 if (kg + 1 < kKG16) {
-                    if (!(ABL & 2)) { n0 = bp[(kg + 1) * 192]; n1 = bp[(kg + 1) * 192 + 64]; n2 = bp[(kg + 1) * 192 + 128]; }
                     m0 = *(const f32x4*)(ap + (kg + 1) * 16);
                     m1 = *(const f32x4*)(ap + 32 * kP16Stride + (kg + 1) * 16);
                     if (SPLIT) {
-                        if (!(ABL & 2)) { nl0 = bpl[(kg + 1) * 192]; nl1 = bpl[(kg + 1) * 192 + 64]; nl2 = bpl[(kg + 1) * 192 + 128]; }
                         ml0 = *(const f32x4*)(apl + (kg + 1) * 16);
                         ml1 = *(const f32x4*)(apl + 32 * kP16Stride + (kg + 1) * 16);
                     }
                 }
+                const int cur = (ABL & 2) ? (kg < PF ? kg : 0) : kg % NSET;
+                const f32x4 b0 = bs[cur][0], b1 = bs[cur][1], b2 = bs[cur][2];
+                const f32x4 bl0 = bs[cur][SPLIT ? 3 : 0], bl1 = bs[cur][SPLIT ? 4 : 1], bl2 = bs[cur][SPLIT ? 5 : 2];
                 const bf16x8 A0 = __builtin_bit_cast(bf16x8, a0), A1 = __builtin_bit_cast(bf16x8, a1);
                 const bf16x8 B[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
                 if (ABL & 4) {
@@ -974,9 +1011,10 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
                         acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(L1, B[c], acc[1][c], 0, 0, 0);
                     }
                 }
-                b0 = n0; b1 = n1; b2 = n2; a0 = m0; a1 = m1;
-                bl0 = nl0; bl1 = nl1; bl2 = nl2; al0 = ml0; al1 = ml1;
+                a0 = m0; a1 = m1; al0 = ml0; al1 = ml1;
             }
+            HMF_L16_T(tt2);
+            if (LATE) load_epilogue_operands();
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1010,10 +1048,21 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma16(SmplDev d, int M, int nrg
 #pragma unroll
                 for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
             }
+            HMF_L16_T(tt3);
+            HMF_L16_ADD(1, tt1 - tt0); HMF_L16_ADD(2, tt2 - tt1); HMF_L16_ADD(3, tt3 - tt2); HMF_L16_ADD(4, 1);
         }
+        HMF_L16_T(ts2);
         __syncthreads();
+        HMF_L16_T(ts3);
+        HMF_L16_ADD(0, ts3 - ts2);                    // the wait at the segment's closing barrier = idle time of waves with fewer tiles: booked with staging
         t = seg_end;
     }
+#ifdef HMF_EXPERIMENTS
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) atomicAdd(&g_lbs16_phase[k], (unsigned long long)ph[k]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1327,6 +1376,14 @@ extern "C" {
 #ifdef HMF_EXPERIMENTS
 /* diagnostic (tools/lbs_tune.py): device buffer of >= 256 int64; every k_lbs_mfma block stores its shader-clock span */
 int hmf_debug_set_lbs_cycles(void* dev_ptr) { g_lbs_cycles = (long long*)dev_ptr; return HMF_OK; }
+/* reads and clears the phase counters of k_lbs_mfma16 (8 uint64: staging + barrier waits, tile start -> first k-group, main loop, epilogue, wave tiles) */
+int hmf_debug_lbs16_phases(unsigned long long* out_host) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HMF_HIP(hipDeviceSynchronize());
+    HMF_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(hmf::g_lbs16_phase), sizeof(z)));
+    HMF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hmf::g_lbs16_phase), z, sizeof(z)));
+    return HMF_OK;
+}
 #endif
 
 size_t hmf_smpl_packed_blend_floats(int) { return (size_t)kVT * kKG * 3 * 64 * 4; }
@@ -1598,6 +1655,13 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
                 case 8: HMF_LBS16A(8); break;
                 case 10: HMF_LBS16A(10); break;
                 case 12: HMF_LBS16A(12); break;
+#define HMF_LBS16V(...) hipLaunchKernelGGL((k_lbs_mfma16<__VA_ARGS__>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv)
+                case 16: HMF_LBS16V(4, true, 0, 2, true, true); break;        // round 6 (tools/lbs16_tune.py): B ring two k-groups ahead
+                case 17: HMF_LBS16V(4, true, 0, 1, false, false); break;      // the round-5 form: requests unpinned, epilogue operands held through the loop
+                case 18: HMF_LBS16V(4, true, 0, 2, false, true); break;
+                case 19: HMF_LBS16V(4, true, 0, 3, true, true); break;
+                case 21: HMF_LBS16V(4, true, 2, 1, true, true); break;        // the product form without its B stream
+#undef HMF_LBS16V
                 default: HMF_LBS16A(0); break;
             }
         } else

@@ -29,6 +29,9 @@ int hmf_debug_set_timeline(void* dev_ptr);
 /* Diagnostic: device buffer of >= 256 int64; every k_lbs_mfma block stores its shader-clock span (effective clock =
  * span / event time, tools/lbs_tune.py); NULL disables it. */
 int hmf_debug_set_lbs_cycles(void* dev_ptr);
+/* k_lbs_mfma16 (tools/lbs16_tune.py): shader-clock cycles summed over all waves since the last call -- [0] staging + waits at the segment barriers, [1] tile start ->
+ * first k-group, [2] main loop, [3] skinning epilogue, [4] number of wave tiles; [5..7] unused.  Reads and clears. */
+int hmf_debug_lbs16_phases(unsigned long long* out_host);
 
 /* Diagnostic (tools/wino_probe.py): stamps of the last k_conv_winograd launch, 8 int64 per work-group: shader clock at start, first patch in LDS,
  * main loop done, end; cycles between a slab's top and its second barrier summed over the slabs; the 100 MHz counter at start and end; unused. */
@@ -48,6 +51,14 @@ int hmf_debug_stem_wino_stamps(long long* out_host, int blocks);
 /* Diagnostic (tools/gemm1x1_probe.py --timeline): stamps of the last k_conv_gemm launch, 6 int64 per work-group: shader clock at start, first
  * chunk visible, main loop done, stores retired; the constant 100 MHz counter at start and end.  Work-groups 0 .. blocks-1 (<= 4096). */
 int hmf_debug_gemm_stamps(long long* out_host, int blocks);
+
+/* Round-6 what-if builds of the 1x1 family (tools/whatif_1x1.py; timing only, WRONG results).  hmf_debug_set_gemm_whatif: & 1 = k_conv_gemm's epilogue without
+ * its transposition through LDS, & 2 = the activation panel of the K <= 256 launches fetched for the prologue chunks only.  hmf_debug_set_pair_whatif:
+ * & 32 = the layer1 seams without their W3 / W1 operand streams. */
+int hmf_debug_set_gemm_whatif(int mask);
+int hmf_debug_set_pair_whatif(int mask);
+/* & 1 = hmf_flow_forward does not launch the kinematic-loop kernel at all (the step's ceiling for any faster k_flow_chain). */
+int hmf_debug_set_flow_whatif(int mask);
 
 #ifdef __cplusplus
 }
