@@ -14,6 +14,7 @@
 #include <utility>
 #include <cmath>
 #include "hmf_common.h"
+#include <type_traits>
 
 namespace hmf {
 
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { m0[u] = ap[((kg + 1) * 4 + u) * 128]; m1[u] = ap[((kg + 1) * 4 + u) * 128 + 32]; }
                 }
+                if (ABL & 16) __builtin_amdgcn_sched_barrier(0);      // experiments: the next k-group's requests pinned ahead of this group's MFMAs (k_lbs_mfma16's lever)
                 const float bv[12] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -873,7 +875,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // tools/lbs16_tune.py: shader-clock cycles every wave spends staging + waiting at the segment barriers / between tile start and its first k-group / in the
 // main loop / in the skinning epilogue, summed over all waves (lane 0 adds at the end of the kernel), + the number of wave tiles
 __device__ unsigned long long g_lbs16_phase[8];
-#define HMF_L16_T(var) const long long var = (long long)__builtin_readcyclecounter()
+#define HMF_L16_T(var) const long long var = (ABL & 64) ? (long long)__builtin_readcyclecounter() : 0        // a stamp drains the wave's LDS / scalar queue: only in the ABL & 64 build
 #define HMF_L16_ADD(k, v) ph[k] += (v)
 #else
 #define HMF_L16_T(var)
@@ -883,7 +885,7 @@ __device__ unsigned long long g_lbs16_phase[8];
 // they are written -- left alone the scheduler SINKS them to their first use (same VGPR count for PF = 1, 2, 3), and the main loop of rounds 2-5 was 14 serial
 // L2 round trips per wave tile (26.6 k cycles for 8 k cycles of MFMA issue; pinned: 10.8 k).  LATE: the skinning offsets / weights and the template
 // (11 registers) are loaded after the main loop instead of being held through it (no scratch left: 254 VGPRs, was 256 + 56 B).
-template <int SLOTS, bool SPLIT, int ABL = 0, int PF = 1, bool LATE = true, bool PIN = true>
+template <int SLOTS, bool SPLIT, int ABL = 0, int PF = 1, bool LATE = true, bool PIN = true, bool HALF_TILES = false, bool XT = false>
 __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
                                                      const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts,
                                                      float* __restrict__ cjv) {
@@ -929,7 +931,37 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
         __syncthreads();
         HMF_L16_T(ts1);
         HMF_L16_ADD(0, ts1 - ts0);
-        for (int tt = t + wave; tt < seg_end; tt += 8) {
+        // Work items as in k_lbs_mfma: full rounds of 8 vertex tiles, then a partial round of <= 4 tiles split by rows (two waves share a vertex tile, 32 rows
+        // each: the 27 tiles of a range cost 3.5 rounds instead of 4), the half tiles FIRST for waves 4-7 and LAST for waves 0-3 -- a SIMD's two waves are then
+        // half a tile apart, one in its main loop (matrix pipe, L2 stream) while the other skins (LDS gathers: the epilogue is bound by the CU's LDS return path).
+        const int cnt = seg_end - t, rf = cnt >> 3, rem = cnt & 7;
+        const bool splitr = HALF_TILES && rem > 0 && rem <= 4;
+        const int nB = splitr ? min(2 * rem, 4) : 0, nA = splitr ? 2 * rem - nB : 0;
+        const bool lead = wave >= 4 && (wave - 4) < nB;          // this wave starts with a half tile
+        auto item = [&](int k, int& rh_) -> int {
+            rh_ = -1;
+            if (splitr) {
+                if (lead) {
+                    if (k == 0) { rh_ = (wave - 4) & 1; return t + ((wave - 4) >> 1); }
+                    --k;
+                }
+                if (k < rf) return t + rem + k * 8 + wave;
+                if (k == rf && wave < 4 && wave < nA) { rh_ = (nB + wave) & 1; return t + ((nB + wave) >> 1); }
+                return -1;
+            }
+            if (k < rf) return t + k * 8 + wave;
+            if (k == rf && rem > 0) return wave < rem ? t + rf * 8 + wave : -1;
+            return -1;
+        };
+        int rh, kitem = 0;
+        // XT (experiments, measured slower: 322 vs 311 us, 28 B of scratch): the first k-group of the NEXT tile of this wave is requested before the skinning
+        // epilogue of the current one and waits in registers
+        f32x4 bnext[SPLIT ? 6 : 3];
+        bool have_next = false;
+        // the tile body exists twice (whole tile / half tile, compile time): a run-time `rh < 0` around the second accumulator set's MFMAs splits the k-group
+        // into basic blocks and un-pins its requests (measured: main loop 10.2 k -> 19.1 k cycles)
+        auto tile = [&](int tt, auto HALFT) {
+            constexpr bool kHalf = decltype(HALFT)::value;
             HMF_L16_T(tt0);
             const int vt = xr * kVTperX + (tt - rg * kVTperX);
             int off[SLOTS > 0 ? SLOTS : 1];
@@ -956,7 +988,7 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
                     for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
             const f32x4* bp = (const f32x4*)(d.blend16 + (size_t)vt * kKG16 * 3 * 64 * 8) + lane;
             const f32x4* bpl = (const f32x4*)(d.blend16_lo + (size_t)vt * kKG16 * 3 * 64 * 8) + lane;
-            const unsigned short* ap = sP + l31 * kP16Stride + half * 8;
+            const unsigned short* ap = sP + (l31 + (rh > 0 ? 32 : 0)) * kP16Stride + half * 8;      // half tile: this wave's 32 rows feed accumulator set 0
             const unsigned short* apl = ap + kRowsPerWG * kP16Stride;                  // the lo panel follows the hi panel in LDS
             constexpr int NSET = PF + 1;
             f32x4 bs[NSET][SPLIT ? 6 : 3];
@@ -964,8 +996,13 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
                 bs[slot][0] = bp[kg * 192]; bs[slot][1] = bp[kg * 192 + 64]; bs[slot][2] = bp[kg * 192 + 128];
                 if (SPLIT) { bs[slot][3] = bpl[kg * 192]; bs[slot][4] = bpl[kg * 192 + 64]; bs[slot][5] = bpl[kg * 192 + 128]; }
             };
+            if (XT && PF == 1 && have_next) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p) loadB(p, p);
+                for (int i = 0; i < (SPLIT ? 6 : 3); ++i) bs[0][i] = bnext[i];
+            } else {
+#pragma unroll
+                for (int p = 0; p < PF; ++p) loadB(p, p);
+            }
             f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 32 * kP16Stride);
             f32x4 al0 = a0, al1 = a1;
             if (SPLIT) {
@@ -976,6 +1013,7 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
             for (int kg = 0; kg < kKG16; ++kg) {
                 f32x4 m0 = a0, m1 = a1, ml0 = al0, ml1 = al1;
                 if (kg + PF < kKG16 && !(ABL & 2)) loadB(kg + PF, (kg + PF) % NSET);
+                if (LATE && XT && kg == kKG16 - 2) load_epilogue_operands();       // two k-groups before the epilogue: their latency under the last MFMAs
                 if (PIN) __builtin_amdgcn_sched_barrier(0);        // the requests stay HERE (see PIN above)
                 if (kg + 1 < kKG16) {
                     m0 = *(const f32x4*)(ap + (kg + 1) * 16);
@@ -997,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[c], acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[c], acc[1][c], 0, 0, 0);
+                    if (!kHalf) acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[c], acc[1][c], 0, 0, 0);
                 }
                 }
                 if (SPLIT && !(ABL & 4)) {
@@ -1006,15 +1044,30 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, BL[c], acc[0][c], 0, 0, 0);
-                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BL[c], acc[1][c], 0, 0, 0);
+                        if (!kHalf) acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BL[c], acc[1][c], 0, 0, 0);
                         acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(L0, B[c], acc[0][c], 0, 0, 0);
-                        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(L1, B[c], acc[1][c], 0, 0, 0);
+                        if (!kHalf) acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(L1, B[c], acc[1][c], 0, 0, 0);
                     }
                 }
                 a0 = m0; a1 = m1; al0 = ml0; al1 = ml1;
             }
             HMF_L16_T(tt2);
-            if (LATE) load_epilogue_operands();
+            if (LATE && !XT) load_epilogue_operands();
+            if (XT && PF == 1) {
+                int nrh;
+                const int ntt = item(kitem + 1, nrh);
+                have_next = ntt >= 0;
+                if (have_next) {
+                    const int nvt = xr * kVTperX + (ntt - rg * kVTperX);
+                    const f32x4* nbp = (const f32x4*)(d.blend16 + (size_t)nvt * kKG16 * 3 * 64 * 8) + lane;
+                    bnext[0] = nbp[0]; bnext[1] = nbp[64]; bnext[2] = nbp[128];
+                    if (SPLIT) {
+                        const f32x4* nbpl = (const f32x4*)(d.blend16_lo + (size_t)nvt * kKG16 * 3 * 64 * 8) + lane;
+                        bnext[3] = nbpl[0]; bnext[4] = nbpl[64]; bnext[5] = nbpl[128];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1024,14 +1077,15 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
             EpiCtx e;
             e.ok_v = v < kV;
             e.full_rows = row0 + kRowsPerWG <= M;
-            e.row_lim = M - row0 - 4 * half;
-            e.obase = verts + ((size_t)(row0 + 4 * half) * kV + v) * 3;
+            const int rsh = rh > 0 ? 32 : 0;                  // half tile: accumulator set 0 holds rows 32 rh .. 32 rh + 31 -> shift the row bases, run the first 16 elements
+            e.row_lim = M - row0 - 4 * half - rsh;
+            e.obase = verts + ((size_t)(row0 + 4 * half + rsh) * kV + v) * 3;
             const int jslot = cjv ? d.ju_slot[vt * 32 + l31] : -1;
             e.lane_has_ju = jslot >= 0;
             e.tile_has_ju = __builtin_amdgcn_ballot_w64(e.lane_has_ju) != 0;
             e.cj_row = d.n_ju * 3;
-            e.cj = cjv + ((size_t)(row0 + 4 * half) * d.n_ju + (jslot >= 0 ? jslot : 0)) * 3;
-            const char* lbase = (const char*)(sA + 4 * half * kAtr);
+            e.cj = cjv + ((size_t)(row0 + 4 * half + rsh) * d.n_ju + (jslot >= 0 ? jslot : 0)) * 3;
+            const char* lbase = (const char*)(sA + (4 * half + rsh) * kAtr);
             if (ABL & 1) {
                 if (e.ok_v && l31 == 0) {
                     float sacc = 0.f;
@@ -1046,10 +1100,17 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
             } else {
                 if (ABL & 8) e.ok_v = e.ok_v && (row0 < 0);          // never true, not provable: the skinning is computed, nothing stored
 #pragma unroll
-                for (int el = 0; el < 32; ++el) skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
+                for (int el = 0; el < 32; ++el) {
+                    if (el == 16 && kHalf) break;
+                    skin_element<SLOTS>(d, lbase, off, w, nslots, vt, l31, acc, el >> 4, el >> 4, el & 15, e);
+                }
             }
             HMF_L16_T(tt3);
-            HMF_L16_ADD(1, tt1 - tt0); HMF_L16_ADD(2, tt2 - tt1); HMF_L16_ADD(3, tt3 - tt2); HMF_L16_ADD(4, 1);
+            HMF_L16_ADD(1, tt1 - tt0); HMF_L16_ADD(2, tt2 - tt1); HMF_L16_ADD(3, tt3 - tt2); HMF_L16_ADD(4, kHalf ? 1 : 2);                 // counted in half tiles
+        };
+        for (int tt = item(0, rh); tt >= 0; tt = item(++kitem, rh)) {
+            if (rh < 0) tile(tt, std::false_type{});
+            else tile(tt, std::true_type{});
         }
         HMF_L16_T(ts2);
         __syncthreads();
@@ -1058,7 +1119,7 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
         t = seg_end;
     }
 #ifdef HMF_EXPERIMENTS
-    if (lane == 0) {
+    if ((ABL & 64) && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) atomicAdd(&g_lbs16_phase[k], (unsigned long long)ph[k]);
     }
@@ -1657,10 +1718,15 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
                 case 12: HMF_LBS16A(12); break;
 #define HMF_LBS16V(...) hipLaunchKernelGGL((k_lbs_mfma16<__VA_ARGS__>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv)
                 case 16: HMF_LBS16V(4, true, 0, 2, true, true); break;        // round 6 (tools/lbs16_tune.py): B ring two k-groups ahead
-                case 17: HMF_LBS16V(4, true, 0, 1, false, false); break;      // the round-5 form: requests unpinned, epilogue operands held through the loop
+                case 17: HMF_LBS16V(4, true, 0, 1, false, false, false); break; // the round-5 form: requests unpinned, epilogue operands held through the loop, whole tiles
                 case 18: HMF_LBS16V(4, true, 0, 2, false, true); break;
                 case 19: HMF_LBS16V(4, true, 0, 3, true, true); break;
                 case 21: HMF_LBS16V(4, true, 2, 1, true, true); break;        // the product form without its B stream
+                case 22: HMF_LBS16V(4, true, 0, 1, true, true, true); break;         // + the half-tile rounds of k_lbs_mfma (3.5 rounds, waves de-phased): measured no gain
+                case 23: HMF_LBS16V(4, true, 0, 1, true, true, false, true); break;   // + the next tile's first k-group requested before the epilogue: measured slower
+                case 64: HMF_LBS16V(4, true, 64, 1, true, true, false); break;      // the product form with phase stamps (hmf_debug_lbs16_phases)
+                case 65: HMF_LBS16V(4, true, 64, 1, true, true, true); break;      // ... with the half tiles
+                case 66: HMF_LBS16V(4, true, 64, 1, false, false, false); break;   // the round-5 form with phase stamps  // the product form without the half tiles (whole tiles only: 4 rounds, waves in lock step)
 #undef HMF_LBS16V
                 default: HMF_LBS16A(0); break;
             }
@@ -1698,6 +1764,7 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
                 case 1: HMF_LBS(4, 1); break;        // no skinning epilogue
                 case 3: HMF_LBS(4, 3); break;        // ... and no B-operand stream
                 case 7: HMF_LBS(4, 7); break;        // ... and no A-operand LDS reads: bare MFMA loop
+                case 16: HMF_LBS(4, 16); break;      // next k-group's operand requests pinned ahead of the MFMAs
                 case 8: case 24: HMF_LBS(4, 8); break;   // non-temporal staging loads of the panel + transforms (rejected)
                 default: HMF_LBS(4, 0); break;
             }
