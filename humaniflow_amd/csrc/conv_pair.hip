@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     if (ABL & 32) load_b1(0);
     auto chunk = [&](int c, f32x4 (&rv)[4], f32x4 (&rvn)[4]) {
         if (!(ABL & 32)) load_b1(c);
+        if (ABL & 64) __builtin_amdgcn_sched_barrier(0);          // experiments: the chunk's W1 requests pinned ahead of phase 1 (the compiler may sink them to their first use)
         // ---- phase 1: a 32 x 32 tile of Y, K = KT ----
         f32x16 accy;
 #pragma unroll
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             if (!(ABL & 32)) load_b3(c + 1);
             load_res(c + 1, rvn);
         }
+        if (ABL & 64) __builtin_amdgcn_sched_barrier(0);
         float* yc = sY[c & 1];
         {
             const float bv = a.bias3[64 * c + 32 * wn + li];
@@ -288,6 +290,12 @@ extern "C" int hmf_conv_pair(const float* x1, const float* x2, const float* w3_p
     if (variant == 0 && (g_pair_whatif & 32) && Kt == 64 && (N2 == 64 || N2 == 128)) {
         if (N2 == 64) hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 32>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_conv_pair<64, 128, 3, 32>), dim3(grid), dim3(256), 0, st, a);
+        HMF_LAUNCH_CHECK();
+        return HMF_OK;
+    }
+    if (variant == 0 && (g_pair_whatif & 64) && Kt == 64 && (N2 == 64 || N2 == 128)) {          // correct results: the operand requests pinned
+        if (N2 == 64) hipLaunchKernelGGL((k_conv_pair<64, 64, 3, 64>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_pair<64, 128, 3, 64>), dim3(grid), dim3(256), 0, st, a);
         HMF_LAUNCH_CHECK();
         return HMF_OK;
     }

@@ -5,6 +5,7 @@ method): what would each never-built item buy the headline AT MOST?
 
 variants:  base        the product kernels
            pair_nostream   layer1's two seam launches (k_conv_pair) with W3 / W1 loaded once (no L2 -> VGPR operand stream): ceiling of "seams on the LDS-DMA ring"
+           pair_pinned     the same two launches with their operand requests pinned by scheduling barriers (CORRECT results; k_lbs_mfma16's round-6 lever)
            gemm_noxpose    every k_conv_gemm epilogue without its transposition through LDS (same stores, same residual loads): ceiling of a cheaper epilogue
            gemm_a_once     K <= 256 k_conv_gemm launches with several n-tiles: the activation panel requested for the prologue chunks only: ceiling of "panel-resident"
            gemm_both       the two above together
@@ -24,7 +25,7 @@ from humaniflow_amd import _lib
 lib = _lib.use_experiments_library()
 import bench
 
-VARIANTS = [('base', 0, 0, 0), ('pair_nostream', 0, 32, 0), ('gemm_noxpose', 1, 0, 0), ('gemm_a_once', 2, 0, 0), ('gemm_both', 3, 0, 0), ('no_chain', 0, 0, 1),
+VARIANTS = [('base', 0, 0, 0), ('pair_nostream', 0, 32, 0), ('pair_pinned', 0, 64, 0), ('gemm_noxpose', 1, 0, 0), ('gemm_a_once', 2, 0, 0), ('gemm_both', 3, 0, 0), ('no_chain', 0, 0, 1),
             ('chain16', 0, 0, 16)]       # chain16: the PRODUCT 16-row kinematic loop forced at full size (correct results)
 if os.environ.get('WHATIF_ONLY'):
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ['WHATIF_ONLY'].split(',')]
