@@ -249,6 +249,12 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
     }
 }
 
+typedef __attribute__((address_space(3))) void* lbs_lds_ptr_t;
+// one LDS-DMA request: 64 lanes x 16 bytes, lane l's bytes from (rsrc base + voff + soff) land at dst + 16 l (non-template helper: see conv_gemm.hip dma16)
+static __device__ __forceinline__ void lbs_dma16(__amdgpu_buffer_rsrc_t rsrc, lbs_lds_ptr_t dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 0);
+}
+
 // Per-tile constants of the skinning epilogue of k_lbs_mfma.
 struct EpiCtx {
     float* obase;                    // verts + ((row0 + 4*half) * V + v) * 3
@@ -453,17 +459,30 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
             // of the XCD in its L2: +15 us at M = 3,232 (tools/lbs_tune.py 0 8) -- the copy sits on the critical path of every segment and the
             // non-temporal path is slower to first data; ABL & 8 keeps the variant in the experiments build)
             for (int i = 0; i < kKpad * 64 / 4 / 512; ++i) dst[tid + i * 512] = (ABL & 8) ? __builtin_nontemporal_load(src + tid + i * 512) : src[tid + i * 512];
-            const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
-            f32x4* dst2 = (f32x4*)sA;
-            const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
+            if (!(ABL & 32)) {
+                const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
+                f32x4* dst2 = (f32x4*)sA;
+                const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
 #pragma unroll
-            for (int i = 0; i < kRowsPerWG * (kAtr / 4) / 512; ++i) {
-                const int ii = tid + i * 512;
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                dst2[ii] = (ii < n4) ? ((ABL & 8) ? __builtin_nontemporal_load(src2 + ii) : src2[ii]) : z;
+                for (int i = 0; i < kRowsPerWG * (kAtr / 4) / 512; ++i) {
+                    const int ii = tid + i * 512;
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    dst2[ii] = (ii < n4) ? ((ABL & 8) ? __builtin_nontemporal_load(src2 + ii) : src2[ii]) : z;
+                }
             }
         }
         __syncthreads();
+        // ABL & 32 (round 6, k_lbs_mfma16's ADMA): the skinning transforms by LDS-DMA under the segment's first main loops, one extra barrier before the first epilogue
+        bool atr_pending = false;
+        if (ABL & 32) {
+            const int live = min(kRowsPerWG, M - row0) * kAtr * 4;
+            const __amdgpu_buffer_rsrc_t ratr = __builtin_amdgcn_make_buffer_rsrc((void*)(atr + (size_t)row0 * kAtr), 0, live, 0x00020000);
+            constexpr int kReq = kRowsPerWG * kAtr * 4 / 1024 / 8;
+#pragma unroll
+            for (int i = 0; i < kReq; ++i)
+                lbs_dma16(ratr, (lbs_lds_ptr_t)((char*)sA + (wave * kReq + i) * 1024), lane * 16, (wave * kReq + i) * 1024);
+            atr_pending = true;
+        }
         // Work items of this wave inside the segment: full rounds of 8 vertex tiles (64 rows x 32 vertices per wave), then the partial round.
         // A partial round of <= 4 tiles is split by rows: two waves share a vertex tile, 32 rows each, so the 27 tiles of a range cost
         // 3.5 rounds instead of 4 (the B operand of those tiles is fetched by both waves).
@@ -538,7 +557,9 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { m0[u] = ap[((kg + 1) * 4 + u) * 128]; m1[u] = ap[((kg + 1) * 4 + u) * 128 + 32]; }
                 }
-                if (ABL & 16) __builtin_amdgcn_sched_barrier(0);      // experiments: the next k-group's requests pinned ahead of this group's MFMAs (k_lbs_mfma16's lever)
+                // round 6: the next k-group's requests stay ahead of this group's MFMAs (k_lbs_mfma16's main lever).  Here 24 fp32 MFMAs = 1,536 cycles per
+                // k-group cover the L2 round trip either way: measured neutral (two boxes: 340 -> 328 us and 342 -> 345 us at M = 3,232; ABL & 16 = unpinned)
+                if (!(ABL & 16)) __builtin_amdgcn_sched_barrier(0);
                 const float bv[12] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -579,6 +600,11 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) asm volatile("" ::"v"(acc[a][c]));
             } else {
+                if ((ABL & 32) && atr_pending) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    atr_pending = false;
+                }
                 EpiCtx e;
                 const int v = vt * 32 + l31;
                 e.ok_v = v < kV;
@@ -606,6 +632,10 @@ __global__ __launch_bounds__(512, 2) void k_lbs_mfma(SmplDev d, int M, int nrg, 
             tt = ntt;
             rh = nrh;
             ++kitem;
+        }
+        if ((ABL & 32) && atr_pending) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
         __syncthreads();
         t = seg_end;
@@ -885,7 +915,7 @@ __device__ unsigned long long g_lbs16_phase[8];
 // they are written -- left alone the scheduler SINKS them to their first use (same VGPR count for PF = 1, 2, 3), and the main loop of rounds 2-5 was 14 serial
 // L2 round trips per wave tile (26.6 k cycles for 8 k cycles of MFMA issue; pinned: 10.8 k).  LATE: the skinning offsets / weights and the template
 // (11 registers) are loaded after the main loop instead of being held through it (no scratch left: 254 VGPRs, was 256 + 56 B).
-template <int SLOTS, bool SPLIT, int ABL = 0, int PF = 1, bool LATE = true, bool PIN = true, bool HALF_TILES = false, bool XT = false>
+template <int SLOTS, bool SPLIT, int ABL = 0, int PF = 1, bool LATE = true, bool PIN = true, bool HALF_TILES = false, bool XT = false, bool ADMA = true>
 __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
                                                      const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts,
                                                      float* __restrict__ cjv) {
@@ -918,17 +948,33 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
                 const f32x4* srcl = (const f32x4*)(panel16_lo + (size_t)row0 * kP16Stride);
                 for (int i = tid; i < n16; i += 512) dst[n16 + i] = srcl[i];
             }
-            const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
-            f32x4* dst2 = (f32x4*)sA;
-            const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
+            if (!ADMA) {
+                const f32x4* src2 = (const f32x4*)(atr + (size_t)row0 * kAtr);
+                f32x4* dst2 = (f32x4*)sA;
+                const int n4 = min(kRowsPerWG, M - row0) * (kAtr / 4);
 #pragma unroll
-            for (int i = 0; i < kRowsPerWG * (kAtr / 4) / 512; ++i) {
-                const int ii = tid + i * 512;
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                dst2[ii] = (ii < n4) ? src2[ii] : z;
+                for (int i = 0; i < kRowsPerWG * (kAtr / 4) / 512; ++i) {
+                    const int ii = tid + i * 512;
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    dst2[ii] = (ii < n4) ? src2[ii] : z;
+                }
             }
         }
         __syncthreads();
+        // ADMA: the 72 KB of skinning transforms are needed by the EPILOGUE only: they go global -> LDS by LDS-DMA (no registers, no ds_write: nine 1-KiB
+        // requests per wave, rows beyond M read as zeros through the descriptor's range) while the segment's first main loops run; every wave waits for its
+        // own requests and meets the others at one extra barrier before its first epilogue of the segment.
+        bool atr_pending = false;
+        if (ADMA) {
+            const int live = min(kRowsPerWG, M - row0) * kAtr * 4;
+            const __amdgpu_buffer_rsrc_t ratr = __builtin_amdgcn_make_buffer_rsrc((void*)(atr + (size_t)row0 * kAtr), 0, live, 0x00020000);
+            constexpr int kReq = kRowsPerWG * kAtr * 4 / 1024 / 8;               // 1-KiB requests per wave
+            static_assert(kReq * 8 * 1024 == kRowsPerWG * kAtr * 4, "transform block = whole requests");
+#pragma unroll
+            for (int i = 0; i < kReq; ++i)
+                lbs_dma16(ratr, (lbs_lds_ptr_t)((char*)sA + (wave * kReq + i) * 1024), lane * 16, (wave * kReq + i) * 1024);
+            atr_pending = true;
+        }
         HMF_L16_T(ts1);
         HMF_L16_ADD(0, ts1 - ts0);
         // Work items as in k_lbs_mfma: full rounds of 8 vertex tiles, then a partial round of <= 4 tiles split by rows (two waves share a vertex tile, 32 rows
@@ -1074,6 +1120,11 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[a][c][e] += tm[c];
+            if (ADMA && atr_pending) {                 // wave-uniform: first epilogue of the segment
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                atr_pending = false;
+            }
             EpiCtx e;
             e.ok_v = v < kV;
             e.full_rows = row0 + kRowsPerWG <= M;
@@ -1113,6 +1164,10 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
             else tile(tt, std::true_type{});
         }
         HMF_L16_T(ts2);
+        if (ADMA && atr_pending) {                     // a wave without a tile in this segment still meets the others at the transform barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         __syncthreads();
         HMF_L16_T(ts3);
         HMF_L16_ADD(0, ts3 - ts2);                    // the wait at the segment's closing barrier = idle time of waves with fewer tiles: booked with staging
@@ -1723,7 +1778,8 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
                 case 19: HMF_LBS16V(4, true, 0, 3, true, true); break;
                 case 21: HMF_LBS16V(4, true, 2, 1, true, true); break;        // the product form without its B stream
                 case 22: HMF_LBS16V(4, true, 0, 1, true, true, true); break;         // + the half-tile rounds of k_lbs_mfma (3.5 rounds, waves de-phased): measured no gain
-                case 23: HMF_LBS16V(4, true, 0, 1, true, true, false, true); break;   // + the next tile's first k-group requested before the epilogue: measured slower
+                case 23: HMF_LBS16V(4, true, 0, 1, true, true, false, true); break;
+                case 24: HMF_LBS16V(4, true, 0, 1, true, true, false, false, false); break;   // the product form with the transforms staged through registers before the first barrier   // + the next tile's first k-group requested before the epilogue: measured slower
                 case 64: HMF_LBS16V(4, true, 64, 1, true, true, false); break;      // the product form with phase stamps (hmf_debug_lbs16_phases)
                 case 65: HMF_LBS16V(4, true, 64, 1, true, true, true); break;      // ... with the half tiles
                 case 66: HMF_LBS16V(4, true, 64, 1, false, false, false); break;   // the round-5 form with phase stamps  // the product form without the half tiles (whole tiles only: 4 rounds, waves in lock step)
@@ -1764,7 +1820,9 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
                 case 1: HMF_LBS(4, 1); break;        // no skinning epilogue
                 case 3: HMF_LBS(4, 3); break;        // ... and no B-operand stream
                 case 7: HMF_LBS(4, 7); break;        // ... and no A-operand LDS reads: bare MFMA loop
-                case 16: HMF_LBS(4, 16); break;      // next k-group's operand requests pinned ahead of the MFMAs
+                case 16: HMF_LBS(4, 16); break;      // next k-group's operand requests NOT pinned (the round 1-5 form)
+                case 32: HMF_LBS(4, 32); break;      // skinning transforms by LDS-DMA under the first main loops of a segment
+                case 48: HMF_LBS(4, 48); break;
                 case 8: case 24: HMF_LBS(4, 8); break;   // non-temporal staging loads of the panel + transforms (rejected)
                 default: HMF_LBS(4, 0); break;
             }
