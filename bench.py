@@ -720,6 +720,7 @@ def run_secondary(args, dev, steps=20, warmup=6):
                 line['roofline_flow'] = {k: r['roofline_flow'].get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac')}
             if a.train:
                 line['train_images_per_s'] = r.get('train_images_per_s')
+                line['smpl_work_vs_reference_step'] = r.get('smpl_work_vs_reference_step')
         except Exception as e:                                          # a secondary flavour must not cost the headline line
             line = {'workload': what, 'error': repr(e)}
         line['wall_s'] = round(time.perf_counter() - t0, 1)
