@@ -535,3 +535,36 @@ def test_hip_graph_replay_of_the_whole_step_equals_eager_issue():
         torch.cuda.synchronize()
         diffs = [float((a - b).abs().max()) if torch.isfinite(b).all() else float('nan') for a, b in zip(ref, outs)]
         assert all(torch.equal(a, b) for a, b in zip(ref, outs)), diffs
+
+
+def test_bench_parity_block_at_small_size():
+    """bench.py's `parity` object (round 6): the cpu_baseline leg keeps its last oracle iteration, parity_block runs the product path end to end on the
+    same weights / inputs / base noise and compares -- here at 3 images x 6 samples with the benchmark's calibrated random weights (metre-sized bodies)."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module('bench')
+    from humaniflow_amd.synthetic import init_benchmark_weights, calibrate_benchmark_weights, synthetic_proxy_input as spi
+    dev = torch.device('cuda:0')
+    cfg = H.get_humaniflow_cfg_defaults()
+    cfg.MODEL.NUM_RESNET_LAYERS = 50
+    model = init_benchmark_weights(H.HumaniflowModel(torch.device('cpu'), cfg.MODEL, H.SMPL_PARENTS), seed=0).eval().to(dev)
+    scale = calibrate_benchmark_weights(model, spi(4, 256, seed=99).to(dev))
+    assert 1e-4 < scale < 1.0
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    nt = torch.get_num_threads()
+    try:
+        base, ref = bench.cpu_baseline(sd, cfg, {k: v.detach().cpu() for k, v in smpl.model_dict().items()}, 3, 6)
+    finally:
+        torch.set_num_threads(nt)
+    assert base['kind'] == 'port' and base['value'] > 0 and ref['verts_samples'].shape == (18, 6890, 3)
+    p = bench.parity_block(model, smpl, ref, 6, dev)
+    assert p['rows'] == 21 and p['logprob_rows'] == 3 * 23 and p['logprob_finite']
+    assert p['vertex_abs_max'] < 10.0                                    # metre-sized bodies: the absolute bars mean something
+    assert p['ok'] and p['vertex_linf'] <= 1e-4 and p['joint_linf'] <= 1e-4 and p['logprob_max_abs'] <= 1e-3, p
+    # the block must be able to FAIL: a perturbed product model is out of tolerance
+    with torch.no_grad():
+        model.fc_shape.bias[:10] += 0.05
+    assert not bench.parity_block(model, smpl, ref, 6, dev)['ok']
