@@ -45,6 +45,9 @@ struct SmplDev {
     float* tp_tmpl;                  // [3V]
     unsigned short* blend16;         // bf16 operand of the configs[2] variant: [kVT][kKG16][3][64 lanes][8]
     unsigned short* blend16_lo;      // bf16(x - bf16(x)) of the same operand (impl = 3: hi + lo split, three MFMAs per product)
+    // round 6, experiments build only (MEPI: measured not faster): the DENSE skinning weights W[joint][vertex] as the B operand of a matrix-pipe transform blend, bf16 hi | lo:
+    // [kVT][piece 2][ 64 lanes x 8 (joints 8 (lane >> 5) + i)  |  64 lanes x 4 (joints 16 + 4 (lane >> 5) + i) ]
+    unsigned short* skin_w16;
     // vertex-major transpose of the gathered-joint CSR (backward of joints 24..89): unique vertices and, per vertex, (output joint, weight)
     int n_ju;
     int* ju_vid;                     // [n_ju]
@@ -90,6 +93,9 @@ __host__ __device__ inline size_t blend_index(int k, int v, int c) {
 // K order as the fp32 operand (207 pose-feature rows | num_betas shape rows), no template row: v_template is added in fp32 after the GEMM
 // (a bf16 template would cost 2^-9 of ~1 m).  Lane (j = l & 31, q = l >> 5) of k-group kg holds k = 16 kg + 8 q + e, e = 0..7, for A and B alike.
 constexpr int kKG16 = kKpad / 16;                 // 14 MFMA k-groups
+constexpr int kW16PerPiece = 64 * 8 + 64 * 4;          // bf16 values of one piece of a vertex tile's dense skinning-weight operand
+constexpr int kAtr16Plane = kRowsPerWG * kJ;          // bf16 values of one (piece, element) plane of a row group's transforms: [row 64][joint 24]
+constexpr int kAtr16Group = 2 * 12 * kAtr16Plane;      // bf16 values per row group: [piece hi | lo][element 12][row][joint] = 73,728 B, as the fp32 block
 constexpr int kP16Stride = kKpad + 8;             // bf16 row stride of the row-major pose-feature panel (464 B = 29 16-byte slots: conflict-free b128 reads)
 __host__ __device__ inline unsigned short f32_to_bf16(float x) {
     unsigned int u;
@@ -126,7 +132,8 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
                                                      const float* __restrict__ body, const float* __restrict__ betas,
                                                      int Mb, int M, float* __restrict__ atr, float* __restrict__ joints,
                                                      float* __restrict__ panel, unsigned short* __restrict__ panel16,
-                                                     unsigned short* __restrict__ panel16_lo, int gN, float* __restrict__ full_pose) {
+                                                     unsigned short* __restrict__ panel16_lo, int gN, float* __restrict__ full_pose,
+                                                     unsigned short* __restrict__ atr16) {
     __shared__ float sJ[8][kJ][3];
     __shared__ float sG[8][kJ][12];
     const int j = threadIdx.x % kJ, r = threadIdx.x / kJ;
@@ -228,6 +235,27 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
         }
         __syncthreads();
     }
+    // round 6 (impl = 3): the same 3 x 4 transforms as bf16 hi | lo planes in the A-operand order of k_lbs_mfma16's transform blend,
+    // [row group][piece][element 12][row 64][joint 24]; dead rows of the last group are zeros (the grid is padded to whole groups)
+    float A12[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float t = G[i * 4 + 0] * Jc[0];
+        t = fmaf(G[i * 4 + 1], Jc[1], t);
+        t = fmaf(G[i * 4 + 2], Jc[2], t);
+        A12[i * 4 + 0] = G[i * 4 + 0]; A12[i * 4 + 1] = G[i * 4 + 1]; A12[i * 4 + 2] = G[i * 4 + 2];
+        A12[i * 4 + 3] = G[i * 4 + 3] - t;
+    }
+    if (atr16) {
+        unsigned short* g16 = atr16 + (size_t)(row >> 6) * kAtr16Group + (row & 63) * kJ + j;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const float x = live ? A12[e] : 0.f;
+            const unsigned short h = f32_to_bf16(x);
+            g16[e * kAtr16Plane] = h;
+            g16[(12 + e) * kAtr16Plane] = f32_to_bf16(x - bf16_to_f32(h));
+        }
+    }
     if (!live) return;
     if (full_pose) {                                // smplx SMPL.forward: full_pose = cat([global_orient, body_pose], dim=1)
         float* o = full_pose + ((size_t)row * kJ + j) * 9;
@@ -240,13 +268,7 @@ __global__ __launch_bounds__(192) void k_rigid_chain(SmplDev d, const float* __r
     }
     float* a = atr + ((size_t)row * kJ + j) * 12;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float t = G[i * 4 + 0] * Jc[0];
-        t = fmaf(G[i * 4 + 1], Jc[1], t);
-        t = fmaf(G[i * 4 + 2], Jc[2], t);
-        a[i * 4 + 0] = G[i * 4 + 0]; a[i * 4 + 1] = G[i * 4 + 1]; a[i * 4 + 2] = G[i * 4 + 2];
-        a[i * 4 + 3] = G[i * 4 + 3] - t;
-    }
+    for (int e = 0; e < 12; ++e) a[e] = A12[e];
 }
 
 typedef __attribute__((address_space(3))) void* lbs_lds_ptr_t;
@@ -891,6 +913,7 @@ __global__ void k_vertex_variance(const float* __restrict__ verts, int N, int V,
 //     skinning.  With 1/16 of the MFMA time the kernel is bound by the skinning epilogue (LDS gathers + VALU) and the 82,680 B/row store.
 // ---------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // SPLIT (impl = 3): both operands as bf16 hi + bf16 lo (x = hi + lo to 2^-17 relative); every product is three bf16 MFMAs
 // (hi.hi + hi.lo + lo.hi, fp32 accumulate; lo.lo ~ 2^-18 dropped), which brings the vertices from 1.5e-3 m (plain bf16 operands) to within
@@ -915,10 +938,18 @@ __device__ unsigned long long g_lbs16_phase[8];
 // they are written -- left alone the scheduler SINKS them to their first use (same VGPR count for PF = 1, 2, 3), and the main loop of rounds 2-5 was 14 serial
 // L2 round trips per wave tile (26.6 k cycles for 8 k cycles of MFMA issue; pinned: 10.8 k).  LATE: the skinning offsets / weights and the template
 // (11 registers) are loaded after the main loop instead of being held through it (no scratch left: 254 VGPRs, was 256 + 56 B).
-template <int SLOTS, bool SPLIT, int ABL = 0, int PF = 1, bool LATE = true, bool PIN = true, bool HALF_TILES = false, bool XT = false, bool ADMA = true>
+// MEPI (round 6; EXPERIMENTS BUILD ONLY -- correct, within 1.4e-5 m of the fp32 kernel, and not faster: 283-286 vs 268 us at M = 6,464, profiles/r06_lbs16_ablation.txt):
+// the skinning epilogue on the matrix pipe.  T[row][vertex] = sum_s w_s A[row][joint_s] is a dense product
+// [32 rows x 24 joints] x [24 joints x 32 vertices] per transform element once the 4-sparse weights are written densely: bf16 hi + lo operands (three MFMAs per
+// product as in the main loop; k = 16 + 8), fp32 accumulate, and it lands in the accumulator layout of the posed offsets (lane = vertex, register = row), so the
+// 3 x 4 apply is 4 FMAs per register.  Per wave tile: 144 MFMAs (4.6 k cycles), 96 LDS fragment reads and 384 FMAs replace 384 16-byte LDS gathers and ~1,900
+// FMAs (the gathers' 393 KB through the CU's LDS return path were what bounded the kernel: profiles/r06_lbs16_ablation.txt).  The transforms arrive as bf16
+// planes [piece][element][row 64][joint 24] written by k_rigid_chain (48-byte rows: the 16 lanes of a ds_read_b128 group hit 16 different 4-bank slots).
+template <int SLOTS, bool SPLIT, int ABL = 0, int PF = 1, bool LATE = true, bool PIN = true, bool HALF_TILES = false, bool XT = false, bool ADMA = true, bool MEPI = false>
 __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev d, int M, int nrg, int wpx, const unsigned short* __restrict__ panel16,
                                                      const unsigned short* __restrict__ panel16_lo, const float* __restrict__ atr, float* __restrict__ verts,
-                                                     float* __restrict__ cjv) {
+                                                     float* __restrict__ cjv, const unsigned short* __restrict__ atr16) {
+    static_assert(!MEPI || (ADMA && SPLIT && kAtr16Group * 2 == kRowsPerWG * kAtr * 4), "the matrix-pipe epilogue reads the bf16 hi + lo transform planes staged by LDS-DMA");
     constexpr int kPanelF = kRowsPerWG * kP16Stride / 2;                     // floats of one bf16 panel
     __shared__ __attribute__((aligned(16))) float smem[(SPLIT ? 2 : 1) * kPanelF + kRowsPerWG * kAtr];   // 29 (+ 29) + 72 KB
     const unsigned short* sP = (const unsigned short*)smem;
@@ -966,8 +997,9 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
         // own requests and meets the others at one extra barrier before its first epilogue of the segment.
         bool atr_pending = false;
         if (ADMA) {
-            const int live = min(kRowsPerWG, M - row0) * kAtr * 4;
-            const __amdgpu_buffer_rsrc_t ratr = __builtin_amdgcn_make_buffer_rsrc((void*)(atr + (size_t)row0 * kAtr), 0, live, 0x00020000);
+            const int live = MEPI ? kAtr16Group * 2 : min(kRowsPerWG, M - row0) * kAtr * 4;         // the bf16 planes carry their dead rows as zeros
+            const __amdgpu_buffer_rsrc_t ratr = __builtin_amdgcn_make_buffer_rsrc(
+                MEPI ? (void*)(atr16 + (size_t)rg * kAtr16Group) : (void*)(atr + (size_t)row0 * kAtr), 0, live, 0x00020000);
             constexpr int kReq = kRowsPerWG * kAtr * 4 / 1024 / 8;               // 1-KiB requests per wave
             static_assert(kReq * 8 * 1024 == kRowsPerWG * kAtr * 4, "transform block = whole requests");
 #pragma unroll
@@ -1014,8 +1046,14 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
             float w[SLOTS > 0 ? SLOTS : 1];
             const int v = vt * 32 + l31;
             float tm[3] = {0.f, 0.f, 0.f};
+            f32x4 w0h = {0.f, 0.f, 0.f, 0.f}, w0l = w0h;               // MEPI: this vertex tile's dense skinning weights, B-operand fragments (k = 16 | 8, hi | lo)
+            f32x2 w1h = {0.f, 0.f}, w1l = w1h;
             auto load_epilogue_operands = [&]() {
-                if (SLOTS > 0) {
+                if (MEPI) {
+                    const unsigned short* wb = d.skin_w16 + (size_t)vt * 2 * kW16PerPiece;
+                    w0h = ((const f32x4*)wb)[lane]; w1h = ((const f32x2*)(wb + 512))[lane];
+                    w0l = ((const f32x4*)(wb + kW16PerPiece))[lane]; w1l = ((const f32x2*)(wb + kW16PerPiece + 512))[lane];
+                } else if (SLOTS > 0) {
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
                         off[s] = d.skin_off[((size_t)vt * nslots + s) * 32 + l31];
@@ -1147,6 +1185,79 @@ __global__ __launch_bounds__(512, 2) HMF_LBS16_TARGET void k_lbs_mfma16(SmplDev 
 #pragma unroll
                             for (int q = 0; q < 16; ++q) sacc += acc[a][c][q];
                     e.obase[0] = sacc;
+                }
+            } else if (MEPI) {
+                if (ABL & 8) e.ok_v = e.ok_v && (row0 < 0);
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                const unsigned short* sT = (const unsigned short*)sA;
+                const bf16x8 W0h = __builtin_bit_cast(bf16x8, w0h), W0l = __builtin_bit_cast(bf16x8, w0l);
+                const s16x4 W1h = __builtin_bit_cast(s16x4, w1h), W1l = __builtin_bit_cast(s16x4, w1l);
+#pragma unroll
+                for (int a = 0; a < (kHalf ? 1 : 2); ++a) {
+                    const unsigned short* prow = sT + (32 * a + rsh + l31) * kJ;          // this lane's A-operand row in every (piece, element) plane
+                    float ox[16], oy[16];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        // the four elements q of transform row c in two pairs: two independent accumulator chains of six MFMAs each (a lone chain waits out every
+                        // MFMA's latency), folded into vals as they finish (v = T0 px; v = fma(T1, py, v); v = fma(T2, pz, v); v += T3: skin_element's order)
+                        float vals[16];
+#pragma unroll
+                        for (int qp = 0; qp < 2; ++qp) {
+                            bf16x8 A0h[2], A0l[2];
+                            s16x4 A1h[2], A1l[2];
+                            f32x16 T[2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const unsigned short* ph = prow + (4 * c + 2 * qp + u) * kAtr16Plane;
+                                const unsigned short* pl = ph + 12 * kAtr16Plane;
+                                A0h[u] = __builtin_bit_cast(bf16x8, *(const f32x4*)(ph + 8 * half));
+                                A1h[u] = __builtin_bit_cast(s16x4, *(const f32x2*)(ph + 16 + 4 * half));
+                                A0l[u] = __builtin_bit_cast(bf16x8, *(const f32x4*)(pl + 8 * half));
+                                A1l[u] = __builtin_bit_cast(s16x4, *(const f32x2*)(pl + 16 + 4 * half));
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) T[u][r] = 0.f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) T[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h[u], W0h, T[u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) T[u] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(A1h[u], W1h, T[u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) T[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h[u], W0l, T[u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) T[u] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(A1h[u], W1l, T[u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) T[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0l[u], W0h, T[u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) T[u] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(A1l[u], W1h, T[u], 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                if (qp == 0) vals[r] = fmaf(T[1][r], acc[a][1][r], T[0][r] * acc[a][0][r]);
+                                else vals[r] = fmaf(T[0][r], acc[a][2][r], vals[r]) + T[1][r];
+                                asm volatile("" : "+v"(vals[r]));      // the fold happens HERE: otherwise the compiler sinks it into the exec-masked store blocks and keeps (spills) every T
+                            }
+                            if (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);          // one pair at a time: left alone the scheduler hoists the fragment reads and MFMAs of all 24 (half, row, element) blocks
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float val = vals[r];
+                            if (c == 0) ox[r] = val;
+                            else if (c == 1) oy[r] = val;
+                            else {
+                                const int rc = 32 * a + (r & 3) + 8 * (r >> 2);
+                                const float x = ox[r], y = oy[r], z = val;
+                                if (e.ok_v && (e.full_rows || rc < e.row_lim)) {
+                                    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+                                    __builtin_nontemporal_store(f32x3u{x, y, z}, (f32x3u*)(e.obase + rc * (kV * 3)));
+                                }
+                                if (e.tile_has_ju) {
+                                    if (e.lane_has_ju && (e.full_rows || rc < e.row_lim)) {
+                                        float* q = e.cj + rc * e.cj_row;
+                                        q[0] = x; q[1] = y; q[2] = z;
+                                    }
+                                }
+                            }
+                        }
+                    }
                 }
             } else {
                 if (ABL & 8) e.ok_v = e.ok_v && (row0 < 0);          // never true, not provable: the skinning is computed, nothing stored
@@ -1542,6 +1653,21 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
             }
         }
     }
+    // --- the same weights, dense, as the bf16 hi | lo B operand of k_lbs_mfma16's transform blend (SmplDev::skin_w16) --------------
+    std::vector<unsigned short> w16((size_t)kVT * 2 * kW16PerPiece, 0);
+#ifdef HMF_EXPERIMENTS
+    for (int v = 0; v < kV; ++v)
+        for (int j = 0; j < kJ; ++j) {
+            const float w = m->lbs_weights_host[(size_t)v * kJ + j];
+            const unsigned short hi = f32_to_bf16(w), lo = f32_to_bf16(w - bf16_to_f32(hi));
+            // joints 0..15: k-group of 16 (lane = vertex + 32 (k >> 3), element k & 7); joints 16..23: k-group of 8 (lane = vertex + 32 ((k - 16) >> 2), element (k - 16) & 3)
+            const size_t at = j < 16 ? (size_t)(((j >> 3) * 32 + (v & 31)) * 8 + (j & 7)) : (size_t)(64 * 8 + ((((j - 16) >> 2) * 32 + (v & 31)) * 4 + ((j - 16) & 3)));
+            w16[((size_t)(v >> 5) * 2 + 0) * kW16PerPiece + at] = hi;
+            w16[((size_t)(v >> 5) * 2 + 1) * kW16PerPiece + at] = lo;
+        }
+#else
+    w16.resize(8);                                        // the product library has no consumer of the table (SmplDev::skin_w16 stays a valid pointer)
+#endif
     // --- rest joints as an affine function of beta (fp64 accumulate, rounded once) ------------------
     std::vector<float> jt(kJ * 3), jd((size_t)kJ * 3 * nb);
     for (int j = 0; j < kJ; ++j)
@@ -1633,7 +1759,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     const size_t o_tpt = place((size_t)kV * 3 * 4), o_b16 = place(blend16.size() * 2), o_b16l = place(blend16l.size() * 2);
     const size_t o_jv = place(ju_vid.size() * 4 + 4), o_jp = place(ju_ptr.size() * 4), o_jo = place(ju_out.size() * 4 + 4), o_jw = place(ju_w.size() * 4 + 4);
     const size_t o_jsl = place(ju_slot.size() * 4), o_jrs = place(jr_slot.size() * 4 + 4);
-    const size_t o_tpp = place(tpp.size() * 4), o_tpm = place(tpm.size() * 8), o_jub = place(jub.size() * 4);
+    const size_t o_tpp = place(tpp.size() * 4), o_tpm = place(tpm.size() * 8), o_jub = place(jub.size() * 4), o_w16 = place(w16.size() * 2);
     void* arena = nullptr;
     HMF_HIP(hipMalloc(&arena, off));
     char* base = (char*)arena;
@@ -1659,6 +1785,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     if (e == hipSuccess) e = up(o_tpp, tpp.data(), tpp.size() * 4);
     if (e == hipSuccess) e = up(o_tpm, tpm.data(), tpm.size() * 8);
     if (e == hipSuccess) e = up(o_jub, jub.data(), jub.size() * 4);
+    if (e == hipSuccess) e = up(o_w16, w16.data(), w16.size() * 2);
     if (e != hipSuccess) {
         (void)hipFree(arena);
         return fail(HMF_ERR_HIP, "hmf_smpl_create: upload failed: %s", hipGetErrorString(e));
@@ -1697,6 +1824,7 @@ int hmf_smpl_create(hmf_smpl_t** out, const hmf_smpl_host_t* m) {
     d.tp_mom = (double*)(base + o_tpm);
     d.tp_stride = tps;
     d.ju_blend = (float*)(base + o_jub);
+    d.skin_w16 = (unsigned short*)(base + o_w16);
     d.ju_bstride = jbs;
     *out = h;
     return HMF_OK;
@@ -1712,7 +1840,12 @@ static size_t ws_atr_bytes(int M) { return align_up((size_t)std::max(M, 1) * kAt
 static size_t ws_panel_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kKpad * 64 * sizeof(float); }
 static size_t ws_panel16_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kRowsPerWG * kP16Stride * 2; }
 static size_t ws_cj_bytes(int M) { return align_up((size_t)std::max(M, 1) * kMaxJU * 3 * sizeof(float), 256); }
+static size_t ws_atr16_bytes(int M) { return (size_t)((std::max(M, 1) + kRowsPerWG - 1) / kRowsPerWG) * kAtr16Group * 2; }
+#ifdef HMF_EXPERIMENTS
+size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + 2 * ws_panel16_bytes(M) + ws_cj_bytes(M) + ws_atr16_bytes(M); }
+#else
 size_t hmf_smpl_lbs_workspace_bytes(int M) { return ws_atr_bytes(M) + ws_panel_bytes(M) + 2 * ws_panel16_bytes(M) + ws_cj_bytes(M); }
+#endif
 
 static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg, int gN, const float* body_pose, const float* betas,
                          int Mb, int M, float* verts, float* joints, float* full_pose, void* workspace, size_t workspace_bytes, int impl,
@@ -1731,7 +1864,12 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
     float* panel = (float*)((char*)workspace + ws_atr_bytes(M));
     unsigned short* panel16 = (unsigned short*)((char*)workspace + ws_atr_bytes(M) + ws_panel_bytes(M));
     unsigned short* panel16_lo = (unsigned short*)((char*)panel16 + ws_panel16_bytes(M));
-    float* cjv = (joints && (impl & 15) != 1) ? (float*)((char*)panel16_lo + ws_panel16_bytes(M)) : nullptr;      // the scalar cross-check kernel keeps k_joints
+    float* cjv_all = (float*)((char*)panel16_lo + ws_panel16_bytes(M));
+    float* cjv = (joints && (impl & 15) != 1) ? cjv_all : nullptr;      // the scalar cross-check kernel keeps k_joints
+    unsigned short* atr16 = nullptr;
+#ifdef HMF_EXPERIMENTS
+    if ((impl & 15) == 3 && (impl >> 4) >= 25 && (impl >> 4) <= 27) atr16 = (unsigned short*)((char*)cjv_all + ws_cj_bytes(M));      // the matrix-pipe epilogue variants read bf16 transform planes
+#endif
     const bool split = (impl & 15) == 3;
     const bool bf16 = (impl & 15) == 2 || split;
     const int nrg_all = (M + kRowsPerWG - 1) / kRowsPerWG;
@@ -1739,7 +1877,7 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
         ProfScope ps(2, M, st);      // grid padded to whole row groups: dead rows zero their slice of the panel
         hipLaunchKernelGGL(k_rigid_chain, dim3(nrg_all * (kRowsPerWG / 8)), dim3(192), 0, st, h->d, global_orient, Mg, body_pose, betas,
                            Mb, M, atr, joints, bf16 ? (float*)nullptr : panel, bf16 ? panel16 : (unsigned short*)nullptr,
-                           split ? panel16_lo : (unsigned short*)nullptr, gN, full_pose);
+                           split ? panel16_lo : (unsigned short*)nullptr, gN, full_pose, atr16);
     }
     HMF_LAUNCH_CHECK();
     if ((impl & 15) == 1) {
@@ -1754,11 +1892,11 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
         const dim3 grid(8 * wpx), block(512);
 #define HMF_LBS16(S)                                                                                                                       \
     do {                                                                                                                                   \
-        if (split) hipLaunchKernelGGL((k_lbs_mfma16<S, true>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv);     \
-        else hipLaunchKernelGGL((k_lbs_mfma16<S, false>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv);          \
+        if (split) hipLaunchKernelGGL((k_lbs_mfma16<S, true>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv, atr16);     \
+        else hipLaunchKernelGGL((k_lbs_mfma16<S, false>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv, atr16);          \
     } while (0)
 #ifdef HMF_EXPERIMENTS
-#define HMF_LBS16A(A) hipLaunchKernelGGL((k_lbs_mfma16<4, true, A>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv)
+#define HMF_LBS16A(A) hipLaunchKernelGGL((k_lbs_mfma16<4, true, A>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv, atr16)
         if (h->d.skin_slots == 4 && split && (impl >> 4)) {
             switch (impl >> 4) {
                 case 1: HMF_LBS16A(1); break;
@@ -1771,18 +1909,21 @@ static int smpl_lbs_impl(const hmf_smpl_t* h, const float* global_orient, int Mg
                 case 8: HMF_LBS16A(8); break;
                 case 10: HMF_LBS16A(10); break;
                 case 12: HMF_LBS16A(12); break;
-#define HMF_LBS16V(...) hipLaunchKernelGGL((k_lbs_mfma16<__VA_ARGS__>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv)
+#define HMF_LBS16V(...) hipLaunchKernelGGL((k_lbs_mfma16<__VA_ARGS__>), grid, block, 0, st, h->d, M, nrg, wpx, panel16, panel16_lo, atr, verts, cjv, atr16)
                 case 16: HMF_LBS16V(4, true, 0, 2, true, true); break;        // round 6 (tools/lbs16_tune.py): B ring two k-groups ahead
                 case 17: HMF_LBS16V(4, true, 0, 1, false, false, false); break; // the round-5 form: requests unpinned, epilogue operands held through the loop, whole tiles
                 case 18: HMF_LBS16V(4, true, 0, 2, false, true); break;
                 case 19: HMF_LBS16V(4, true, 0, 3, true, true); break;
                 case 21: HMF_LBS16V(4, true, 2, 1, true, true); break;        // the product form without its B stream
                 case 22: HMF_LBS16V(4, true, 0, 1, true, true, true); break;         // + the half-tile rounds of k_lbs_mfma (3.5 rounds, waves de-phased): measured no gain
-                case 23: HMF_LBS16V(4, true, 0, 1, true, true, false, true); break;
-                case 24: HMF_LBS16V(4, true, 0, 1, true, true, false, false, false); break;   // the product form with the transforms staged through registers before the first barrier   // + the next tile's first k-group requested before the epilogue: measured slower
+                case 23: HMF_LBS16V(4, true, 0, 1, true, true, false, true); break;   // + the next tile's first k-group requested before the epilogue: measured slower
+                case 24: HMF_LBS16V(4, true, 0, 1, true, true, false, false, false, false); break;   // gather epilogue, transforms staged through registers before the first barrier
+                case 25: HMF_LBS16V(4, true, 0, 1, true, true, false, false, true, false); break;
+                case 26: HMF_LBS16V(4, true, 128, 1, true, true, false, false, true, true); break;   // matrix-pipe epilogue without the scheduling barrier between element pairs
+                case 27: HMF_LBS16V(4, true, 8, 1, true, true, false, false, true, true); break;     // matrix-pipe epilogue without the vertex stores    // the gather epilogue (fp32 transforms, 4 slots) instead of the matrix-pipe blend
                 case 64: HMF_LBS16V(4, true, 64, 1, true, true, false); break;      // the product form with phase stamps (hmf_debug_lbs16_phases)
                 case 65: HMF_LBS16V(4, true, 64, 1, true, true, true); break;      // ... with the half tiles
-                case 66: HMF_LBS16V(4, true, 64, 1, false, false, false); break;   // the round-5 form with phase stamps  // the product form without the half tiles (whole tiles only: 4 rounds, waves in lock step)
+                case 66: HMF_LBS16V(4, true, 64, 1, false, false, false); break;   // the round-5 form with phase stamps
 #undef HMF_LBS16V
                 default: HMF_LBS16A(0); break;
             }

@@ -18,7 +18,8 @@ betas = (torch.randn(M, 10, generator=g) * 1.25).to(dev)
 variants = [int(a) for a in sys.argv[1:]] or [0, 8, 1, 2, 3, 4, 5, 6, 7]
 names = {0: 'product', 1: 'no epilogue', 2: 'no B stream', 3: 'no epilogue, no B stream', 4: 'no MFMAs', 5: 'no MFMAs, no epilogue', 6: 'no MFMAs, no B stream',
          7: 'no MFMAs, no B stream, no epilogue (A reads + staging only)', 16: 'round 6: B ring 2 k-groups ahead (pinned) + late epilogue operands', 17: 'round 5 form: requests unpinned, epilogue operands held through the loop',
-         18: 'round 6: 2 ahead (pinned)', 19: 'round 6: 3 ahead (pinned, spills) + late', 21: 'round 6: product without the B stream', 22: 'round 6: product + half-tile rounds (3.5 rounds, waves de-phased)', 23: 'round 6: product + next tile first k-group requested before the epilogue', 24: 'round 6: product with the transforms staged through registers (no LDS-DMA overlap)', 64: 'product + phase stamps', 65: 'half tiles + phase stamps', 66: 'round-5 form + phase stamps', 8: 'skinning without vertex stores', 10: 'no B stream, no vertex stores', 12: 'no MFMAs, no vertex stores'}
+         18: 'round 6: 2 ahead (pinned)', 19: 'round 6: 3 ahead (pinned, spills) + late', 21: 'round 6: product without the B stream', 22: 'round 6: product + half-tile rounds (3.5 rounds, waves de-phased)', 23: 'round 6: product + next tile first k-group requested before the epilogue', 24: 'round 6: product with the transforms staged through registers (no LDS-DMA overlap)', 25: 'round 6: MATRIX-PIPE skinning epilogue (dense weights, bf16 hi + lo, element pairs fenced)',
+         26: 'round 6: matrix-pipe epilogue, pairs not fenced', 27: 'round 6: matrix-pipe epilogue without the vertex stores', 64: 'product + phase stamps', 65: 'half tiles + phase stamps', 66: 'round-5 form + phase stamps', 8: 'skinning without vertex stores', 10: 'no B stream, no vertex stores', 12: 'no MFMAs, no vertex stores'}
 res = {o: [] for o in variants}
 phases = {}
 import ctypes
