@@ -717,7 +717,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int t = 0; t < 4; ++t) fb[t] = xP[koff[t]];
         // (round 5, measured and rejected: the 32 k-steps fully unrolled so that every LDS operand read carries its step as an immediate -- no address
-        // VALU in the loop, but 228 instead of 80 VGPRs: 1.42 ms against 1.29-1.37 ms)
+        // VALU in the loop, but 228 instead of 80 VGPRs: 1.42 ms against 1.29-1.37 ms; round 6, measured and rejected: every wave owning all seven k-tiles of
+        // its channel half and every second pixel step -- balanced waves instead of 4 + 3 tiles, but 203 VGPRs = two work-groups per CU and 8 LDS reads per 7
+        // MFMAs: 1.67 ms, training step 12.34 vs 11.87 ms)
         for (int s = 0; s < nsteps; ++s) {
             const int sn = min(s + 1, nsteps - 1);
             const float fan = ga[sn * 128];
