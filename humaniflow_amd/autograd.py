@@ -348,18 +348,29 @@ class FlowContext(torch.autograd.Function):
         ctx.model, ctx.stash = model, stash
         ctx.save_for_backward(isgc.detach(), pose_R.detach().float().reshape(pose_R.shape[0], 23, 9), out)
         ctx.r_needs_grad = pose_R.requires_grad
+        ctx.r_dtype = pose_R.dtype
         return out
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.r_needs_grad:
-            raise NotImplementedError('humaniflow_amd: gradient w.r.t. the teacher-forced rotations (pose_R_for_loglik) is not built')
         isgc, rot, out = ctx.saved_tensors
         delta = (g * torch.where(out > 0, torch.ones_like(out), out + 1.0)).transpose(0, 1).contiguous()   # ELU', (P, B, 64)
         g_full, db, g_isgc = _context_pullback(ctx.model, delta, isgc, rot, want_weight_grads=ctx.needs_input_grad[3])
         if ctx.needs_input_grad[3]:                                   # the token: some flow parameter wants its gradient
             ctx.stash[(id(ctx), 'ctx')] = ('ctx', g_full, db)
-        return None, g_isgc, None, g.new_zeros(()), None
+        g_rot = None
+        if ctx.r_needs_grad:
+            # round 6: d L / d pose_R_for_loglik through the context layers (models/humaniflow_model.py:152-186: part j reads the rotations of its ancestors):
+            # g_R[b, a] += W_j[:, nin + 9 pos_j(a) : + 9]^T delta_j[b] for every descendant j of a.  The flow-as-prior call pattern only
+            # (optimise/optimise_humaniflow.py:96-109): 23 small products on torch operators, not a training-step path.
+            model, nin = ctx.model, isgc.shape[1]
+            g_flat = torch.zeros(rot.shape[0], model.num_bodyparts * 9, dtype=torch.float32, device=rot.device)
+            idx = _anc_index(model, rot.device)
+            for j, lin in enumerate(model.fc_flow_context):
+                if idx[j].numel():
+                    g_flat.index_add_(1, idx[j], delta[j].float() @ lin.weight.detach()[:, nin:].float())
+            g_rot = g_flat.view(rot.shape[0], model.num_bodyparts, 3, 3).to(ctx.r_dtype)
+        return None, g_isgc, g_rot, g.new_zeros(()), None
 
 
 class FlowLogProbSO3(torch.autograd.Function):

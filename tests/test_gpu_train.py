@@ -119,6 +119,46 @@ def test_teacher_forced_path_backward_through_context_and_isgc_layers():
     _check_params(model, sd64, ['pose_so3flow_transform_modules', 'fc_flow_context', 'fc_input_shape_glob_cam_feats', 'fc_cam', 'fc1'])
 
 
+def test_gradient_wrt_the_teacher_forced_inputs_matches_oracle_autograd():
+    """Round 6: the context side of the flow-as-prior call pattern (optimise/optimise_humaniflow.py:96-109): with the rotations the densities are evaluated AT
+    held fixed, d sum_j w_j log p(R_j | ctx_j) / d (pose_R_for_loglik, shape_for_loglik, glob_R_for_loglik) -- the ancestors' rotations through the 23 context
+    layers, shape and global rotation through the isgc layer -- vs float64 autograd through the oracle; with the weights frozen (the optimise case) and not."""
+    model, sd, cfg = _model(seed=9)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B = 5
+    g = torch.Generator().manual_seed(10)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    R_eval = random_rotmats(B * 23, 0.6, seed=11).view(B, 23, 3, 3)                       # where the densities are evaluated (no gradient)
+    R_anc = random_rotmats(B * 23, 0.6, seed=12).view(B, 23, 3, 3)                        # pose_R_for_loglik (gradient)
+    shape_gt, glob_gt = torch.randn(B, 10, generator=g), random_rotmats(B, 1.0, seed=13)
+    w = torch.randn(B, 23, generator=g)
+    sd64 = _sd64(sd)
+    Ra64, sh64, gl64 = (t.double().requires_grad_(True) for t in (R_anc, shape_gt, glob_gt))
+    with ot.float64_defaults():
+        out = ot.forward_grad(sd64, ocfg, input_feats=feats.double(), compute_for_loglik=True, shape_for_loglik=sh64, pose_R_for_loglik=Ra64,
+                              glob_R_for_loglik=gl64, compute_point_est=False)
+        lp_ref = ot.log_prob_SO3_grad(sd64, ocfg, out['flow_context_for_loglik'], R_eval.double())
+    (lp_ref * w.double()).sum().backward()
+    assert Ra64.grad[:, 22].abs().max() == 0 and Ra64.grad[:, 0].abs().max() > 0           # a leaf part is nobody's ancestor; the first spine joint is
+    for frozen in (True, False):
+        for p_ in model.parameters():
+            p_.requires_grad_(not frozen)
+        model.zero_grad()
+        Ra, sh, gl = (t.cuda().requires_grad_(True) for t in (R_anc, shape_gt, glob_gt))
+        o = model(None, input_feats=feats.cuda(), compute_for_loglik=True, shape_for_loglik=sh, pose_R_for_loglik=Ra, glob_R_for_loglik=gl,
+                  compute_point_est=False)
+        lp = model.log_prob_all_parts(o['flow_context_for_loglik'], R_eval.cuda())
+        assert (lp.detach().cpu() - lp_ref.detach().float()).abs().max() < 1e-3
+        (lp * w.cuda()).sum().backward()
+        _check('d pose_R_for_loglik (frozen=%s)' % frozen, Ra.grad, Ra64.grad)
+        _check('d shape_for_loglik', sh.grad, sh64.grad)
+        _check('d glob_R_for_loglik', gl.grad, gl64.grad)
+        if not frozen:
+            _check_params(model, sd64, ['pose_so3flow_transform_modules', 'fc_flow_context', 'fc_input_shape_glob_cam_feats'])
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+
+
 def test_sample_chain_backward_matches_oracle_autograd():
     """Reparameterised samples: d (sum w . R_samples) / d every flow parameter, the features and the heads, ancestors feeding descendants."""
     model, sd, cfg = _model(seed=6)
