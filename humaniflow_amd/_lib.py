@@ -101,6 +101,7 @@ _SIGS = {
     'hmf_flow_log_prob_SO3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_so3': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP]),
     'hmf_flow_log_prob_SO3_backward': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP, C.POINTER(FlowGradRecords), _VP]),
+    'hmf_flow_log_prob_so3_vjp': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     'hmf_flow_sample_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.POINTER(FlowGradRecords), _VP]),
     'hmf_flow_generic_log_prob_SO3_backward': (C.c_int, [_VP, _VP, c_int_p, C.c_int, _VP, C.c_int, _VP, _VP, C.POINTER(FlowVariantGradRecords), _VP]),
     'hmf_flow_generic_sample_backward': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.POINTER(FlowVariantGradRecords), _VP]),

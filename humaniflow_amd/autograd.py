@@ -17,6 +17,8 @@ Forward values always come from the same inference kernels as under no_grad.
 """
 import ctypes as C
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -403,6 +405,89 @@ class FlowLogProbSO3(torch.autograd.Function):
         if ctx.needs_input_grad[5]:                                   # the token
             ctx.stash[(id(ctx), 'hyper')] = ('hyperv', part0, P, rec.grads()) if variant else ('hyper', part0, P, rec.hypernet_grads())
         return None, None, None, g_ctx if ctx.needs_input_grad[3] else None, None, g.new_zeros(()), None
+
+
+class FlowLogProbAlgebra(torch.autograd.Function):
+    """log p(v | ctx) on the algebra for parts part0 .. part0+P-1, differentiable w.r.t. its ARGUMENT v (B,P,3) and the context (B,P,64); the flow's weights
+    are constants here (hmf_flow_log_prob_so3_vjp writes no weight-gradient records).  Round 6, the flow-as-prior call pattern."""
+
+    @staticmethod
+    def forward(ctx, model, part0, P, cvec, v):
+        out = model._log_prob_kernel(cvec.detach(), v.detach(), part0, P, group=False)
+        ctx.model, ctx.part0, ctx.P = model, part0, P
+        ctx.save_for_backward(cvec.detach().to(torch.float32).contiguous(), v.detach().to(torch.float32).contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cvec, v = ctx.saved_tensors
+        model, P, part0 = ctx.model, ctx.P, ctx.part0
+        B = cvec.shape[0]
+        lib = _lib.load()
+        g_ctx, g_v = torch.empty_like(cvec), torch.empty_like(v)
+        gc = g.detach().to(torch.float32).contiguous()
+        ids = (C.c_int32 * P)(*range(part0, part0 + P)) if P != model.num_bodyparts else None
+        with torch.cuda.device(cvec.device):
+            _lib.check(lib.hmf_flow_log_prob_so3_vjp(model._flow_handle(cvec.device), _lib.dptr(cvec), ids, P, _lib.dptr(v), B, _lib.dptr(gc), _lib.dptr(g_ctx),
+                                                     _lib.dptr(g_v), _lib.current_stream()), 'hmf_flow_log_prob_so3_vjp')
+        return None, None, None, g_ctx if ctx.needs_input_grad[3] else None, g_v if ctx.needs_input_grad[4] else None
+
+
+def _so3_log_vector64(R):
+    """Differentiable fp64 logarithm map R (..., 3, 3) -> v (..., 3) with the branch structure of the reference's so3_log (utils/rigid_transform_utils.py:204-279):
+    theta = acos(clamp((tr R - 1) / 2)), v = theta / sin(theta) vee((R - R^T) / 2) (series below 1e-20), and within 1e-2 of pi the components up to sign from the
+    symmetric part, sqrt(clamp(., 1e-8) / 2), with the sign triple whose exponential is closest to R (chosen without gradient, :246-262).  torch operators: this
+    runs only where a density is differentiated w.r.t. the rotation it is evaluated at, never in inference or training."""
+    from .rigid_transform_utils import so3_exp
+    Rt = R.transpose(-1, -2)
+    anti = 0.5 * (R - Rt)
+    w = torch.stack((anti[..., 2, 1], anti[..., 0, 2], anti[..., 1, 0]), dim=-1)
+    cos_t = (0.5 * (R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2] - 1.0)).clamp(-1.0, 1.0)
+    theta = torch.acos(cos_t)
+    ratio = torch.where(theta < 1e-20, 1.0 + theta ** 2 / 6.0, theta / torch.sin(theta))
+    v = ratio[..., None] * w
+    near_pi = (math.pi - theta).abs() < 1e-2
+    if bool(near_pi.any()):
+        z = (theta ** 2 / (1.0 - torch.cos(theta)))[..., None, None] * (0.5 * (R + Rt) - torch.eye(3, dtype=R.dtype, device=R.device))
+        q = torch.stack((z[..., 0, 0], z[..., 1, 1], z[..., 2, 2]), dim=-1)
+        mag = torch.sqrt((2.0 * q - q.sum(dim=-1, keepdim=True)).clamp(min=1e-8) / 2.0)                 # q_i - q_j - q_k
+        with torch.no_grad():
+            signs = torch.tensor([[a, b, c] for a in (-1.0, 1.0) for b in (-1.0, 1.0) for c in (-1.0, 1.0)], dtype=R.dtype, device=R.device)
+            cand = signs.view(8, *([1] * (mag.dim() - 1)), 3) * mag.detach()[None]
+            err = (so3_exp(cand.contiguous()) - R.detach()[None]).pow(2).sum(dim=(-1, -2))
+            pick = signs[torch.argmin(err, dim=0)]
+        v = torch.where(near_pi[..., None], pick * mag, v)
+    return v
+
+
+def _so3_exp_logdet64(x):
+    """log |det J_exp(x)| = log((2 - 2 cos |x|) / |x|^2) in fp64 (utils/rigid_transform_utils.py:298-314; 1 - |x|^2 / 12 below 1e-10), differentiable."""
+    n = x.norm(dim=-1)
+    big = n > 1e-10
+    ns = torch.where(big, n, torch.ones_like(n))
+    return torch.log(torch.where(big, (2.0 - 2.0 * torch.cos(ns)) / ns ** 2, 1.0 - ns ** 2 / 12.0))
+
+
+def log_prob_SO3_wrt_value(model, cvec, R, part0, P):
+    """log p(R_j | ctx_j) differentiable w.r.t. R (B,P,3,3) -- the rotation the density is evaluated AT -- and w.r.t. the context: the composition of
+    local_diffeo_transformed_distribution.py:84-142 (x = log R, its two 2 pi k pre-images inside the support, -log|det J_exp| + the algebra density of each,
+    log-sum-exp) with the algebra density on the library (FlowLogProbAlgebra).  The forward equals hmf_flow_log_prob_SO3 (same pre-images, fp64 exp-map terms,
+    fp32 flow) to rounding; flow weights are constants on this path.  The gradient is undefined at R = I exactly, as in the reference (x / |x|)."""
+    R64 = R.to(torch.float64)
+    x = _so3_log_vector64(R64)
+    n = x.norm(dim=-1, keepdim=True)
+    radius = float(model.model_cfg.NORM_FLOW.COMPACT_SUPPORT_RADIUS)
+    terms = []
+    for k in (0, -1, 1):
+        if k == 0:
+            xk, ok = x, None
+        else:
+            xk = x / n * (n + 2.0 * math.pi * k)
+            ok = xk.norm(dim=-1) < radius                                   # NaN at x = 0 fails the comparison, as in the reference
+            xk = torch.where(ok[..., None], xk, torch.zeros_like(xk))       # masked_fill_(0) of so3_exp_transform.py:36-41
+        t = FlowLogProbAlgebra.apply(model, part0, P, cvec, xk.to(torch.float32)) - _so3_exp_logdet64(xk).to(torch.float32)
+        terms.append(t if ok is None else torch.where(ok, t, torch.full_like(t, float('-inf'))))
+    return torch.logsumexp(torch.stack(terms), dim=0)
 
 
 class FlowSampleChain(torch.autograd.Function):

@@ -173,8 +173,12 @@ __device__ __forceinline__ float algebra_fwd(const FlowDev& d, const PartTab& pt
     return lp;
 }
 
-// g: upstream gradient of this term (wave-uniform).  Returns d L / d ctx of this lane's channel; writes the records of row `row`.
-__device__ __forceinline__ float algebra_bwd(const FlowDev& d, const PartTab& pt, int lane, float g, const AlgState& S, const GradRec& G, int p, int row) {
+// g: upstream gradient of this term (wave-uniform).  Returns d L / d ctx of this lane's channel; writes the records of row `row` (REC).
+// gx (round 6, non-null): d L / d x, the gradient w.r.t. the INPUT of the inverse couplings (x = the pre-image of v under the radial tanh): the hyper-networks'
+// scalar inputs, the splines' inputs (value and log-derivative both depend on them) and the base density, wave-uniform.
+template <bool REC = true>
+__device__ __forceinline__ float algebra_bwd(const FlowDev& d, const PartTab& pt, int lane, float g, const AlgState& S, const GradRec& G, int p, int row,
+                                             float* gx = nullptr) {
     const float r = d.radius;
     const int dim = lane & 1;
     const float var = d.base_std * d.base_std;
@@ -196,8 +200,17 @@ __device__ __forceinline__ float algebra_bwd(const FlowDev& d, const PartTab& pt
     NetDelta D1;
     float g_ctx1, g_x1_1;
     hypernet_bwd(d, pt, 1, lane, S.A1, scatter_raw_grad(S1, lane), D1, g_ctx1, g_x1_1);
-    store_net(G, p, 0, row, lane, D0, S.A0, S.u0);
-    store_net(G, p, 1, row, lane, D1, S.A1, S.x0);
+    if (REC) {
+        store_net(G, p, 0, row, lane, D0, S.A0, S.u0);
+        store_net(G, p, 1, row, lane, D1, S.A1, S.x0);
+    }
+    if (gx) {
+        // x0 enters three times: as u1 (input of dimension 0 of spline 0), as the scalar input of hyper-network 1 -- and nowhere else (it passes
+        // through coupling 1 unchanged); x1 / x2 are the inputs of dimensions 0 / 1 of spline 1
+        gx[0] = __shfl(S0.g_x, 0) + g_x1_1;
+        gx[1] = __shfl(S1.g_x, 0);
+        gx[2] = __shfl(S1.g_x, 1);
+    }
     return g_ctx0 + g_ctx1;
 }
 
@@ -256,6 +269,46 @@ __global__ __launch_bounds__(192) void k_flow_logprob_bwd(FlowDev d, const float
     s_gctx[c][lane] = algebra_bwd(d, pt, lane, g_logp[gw] * wgt, S, G, p, row);
     __syncthreads();
     if (c == 0) g_ctx[(size_t)gw * kCtx + lane] = (s_gctx[0][lane] + s_gctx[1][lane]) + s_gctx[2][lane];
+}
+
+// Round 6: d log p(v | ctx) / d v and / d ctx of the ALGEBRA density (hmf_flow_log_prob_so3's reverse sweep w.r.t. its argument): one wave per (row, part),
+// no weight-gradient records.  The flow-as-prior call pattern (optimise/optimise_humaniflow.py:96-109) differentiates the SO(3) density w.r.t. the rotation it
+// is evaluated at: host code composes this with the fp64 pull-back through so3_log / the 2 pi k pre-images / the exp map's log-determinant (autograd.py).
+// v -> x = r atanh(|v| / r) v / |v| (scaled_radial_tanh_transform.py inverse) and its log-determinant term -(2 (log |v| - log |x|) + log1p(-(|v| / r)^2)):
+//   d x / d v = (f / n)(I - e e^T) + f' e e^T,  f = r atanh(n / r), f' = 1 / (1 - (n / r)^2), e = v / n;   d lp / d n = -(2 (1 / n - f' / f) - 2 n f' / r^2)
+__global__ __launch_bounds__(256) void k_flow_logprob_so3_vjp(FlowDev d, const float* __restrict__ ctx, const int* __restrict__ part_ids, int P,
+                                                              const float* __restrict__ vin, int B, const float* __restrict__ g_logp,
+                                                              float* __restrict__ g_ctx, float* __restrict__ g_v) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= B * P) return;
+    const int p = gw % P;
+    const int j = part_ids ? part_ids[p] : p;
+    const PartTab& pt = d.tab[j];
+    const float ctx_lane = ctx[(size_t)gw * kCtx + lane];
+    const float v[3] = {vin[(size_t)gw * 3], vin[(size_t)gw * 3 + 1], vin[(size_t)gw * 3 + 2]};
+    AlgState S;
+    (void)algebra_fwd(d, pt, lane, ctx_lane, v, S);
+    const float g = g_logp[gw];
+    float gx[3];
+    GradRec none = {};
+    const float gc = algebra_bwd<false>(d, pt, lane, g, S, none, 0, 0, gx);
+    g_ctx[(size_t)gw * kCtx + lane] = gc;
+    if (lane == 0) {
+        const double r = (double)d.radius;
+        const double vd[3] = {(double)v[0], (double)v[1], (double)v[2]};
+        const double n = sqrt(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+        double out[3] = {(double)gx[0], (double)gx[1], (double)gx[2]};                  // |v| <= 1e-7: x = v, no log-determinant term (algebra_fwd)
+        if (n > 1e-7) {
+            const double e[3] = {vd[0] / n, vd[1] / n, vd[2] / n};
+            const double f = r * atanh(n / r), fp = 1.0 / (1.0 - (n / r) * (n / r));
+            const double eg = e[0] * gx[0] + e[1] * gx[1] + e[2] * gx[2];
+            const double dlp = (sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) > 1e-7f) ? -(2.0 * (1.0 / n - fp / f) - 2.0 * n * fp / (r * r)) : 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) out[i] = (f / n) * ((double)gx[i] - eg * e[i]) + fp * eg * e[i] + (double)g * dlp * e[i];
+        }
+        g_v[(size_t)gw * 3] = (float)out[0]; g_v[(size_t)gw * 3 + 1] = (float)out[1]; g_v[(size_t)gw * 3 + 2] = (float)out[2];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -446,6 +499,24 @@ int hmf_flow_log_prob_SO3_backward(const hmf_flow_t* h, const float* ctx, const 
     if (G.R != 3 * B) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_SO3_backward: records need rows == 3 * B");
     const int nw = B * P;
     hipLaunchKernelGGL(k_flow_logprob_bwd, dim3(nw), dim3(192), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, R, B, g_logp, g_ctx, G);
+    HMF_LAUNCH_CHECK();
+    return HMF_OK;
+}
+
+int hmf_flow_log_prob_so3_vjp(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const float* v, int B, const float* g_logp,
+                              float* g_ctx, float* g_v, void* stream) {
+    if (!h || !ctx || !v || !g_logp || !g_ctx || !g_v || B <= 0 || P <= 0 || P > kP) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_so3_vjp: bad args");
+    if (!part_ids_host && P != kP) return fail(HMF_ERR_INVALID, "hmf_flow_log_prob_so3_vjp: part_ids NULL requires P == 23");
+    const int* dev_ids = nullptr;
+    if (part_ids_host) {
+        for (int i = 0; i < P; ++i)
+            if (part_ids_host[i] < 0 || part_ids_host[i] >= kP || part_ids_host[i] != part_ids_host[0] + i)
+                return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_log_prob_so3_vjp: part ids must be a contiguous ascending range inside [0, 23)");
+        dev_ids = h->d_ids + part_ids_host[0];
+    }
+    if (h->g.enabled) return fail(HMF_ERR_UNSUPPORTED, "hmf_flow_log_prob_so3_vjp: built for the default flow configuration only");
+    const int nw = B * P;
+    hipLaunchKernelGGL(k_flow_logprob_so3_vjp, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->d, ctx, dev_ids, P, v, B, g_logp, g_ctx, g_v);
     HMF_LAUNCH_CHECK();
     return HMF_OK;
 }

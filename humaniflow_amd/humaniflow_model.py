@@ -604,11 +604,20 @@ class HumaniflowModel(nn.Module):
         return out
 
     def log_prob_parts(self, ctx, R, part0, P):
-        """log p(R_j | ctx_j), j = part0 .. part0+P-1; differentiable w.r.t. ctx and the hyper-network weights."""
+        """log p(R_j | ctx_j), j = part0 .. part0+P-1; differentiable w.r.t. ctx and the hyper-network weights -- or, when R requires a gradient, w.r.t. R and ctx."""
         _lib.require_cuda(R, 'value')
         if torch.is_grad_enabled() and R.requires_grad:
-            raise NotImplementedError('humaniflow_amd: gradients w.r.t. the rotation a flow density is evaluated AT are not built (the optimise driver, '
-                                      'optimise/optimise_humaniflow.py:96-109); training differentiates w.r.t. the context and the weights')
+            # round 6, the flow-as-prior call pattern (optimise/optimise_humaniflow.py:96-109): differentiable w.r.t. R and the context, weights constant
+            from .autograd import _is_variant, log_prob_SO3_wrt_value
+            if _is_variant(self):
+                raise NotImplementedError('humaniflow_amd: gradients w.r.t. the rotation a flow density is evaluated AT are built for the default flow '
+                                          '(spline coupling, fixed permutations) only')
+            if any(p.requires_grad for p in self._flow_params()) and not self.__dict__.get('_warned_value_grad'):
+                import warnings
+                warnings.warn('humaniflow_amd: log_prob(R) with R.requires_grad treats the flow weights as constants (gradients reach R and the context only); '
+                              'freeze the flow parameters to silence this')
+                self.__dict__['_warned_value_grad'] = True
+            return log_prob_SO3_wrt_value(self, ctx.to(torch.float32), R, part0, P)
         if self._needs_grad(ctx):
             from .autograd import FlowLogProbSO3, new_flow_anchor
             anchor = getattr(ctx, '_hmf_flow_anchor', None) or new_flow_anchor(self)

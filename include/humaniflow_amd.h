@@ -308,6 +308,13 @@ typedef struct {
     int rows;
 } hmf_flow_grad_records_t;
 
+/* Round 6: reverse sweep of hmf_flow_log_prob_so3 (the density on the ALGEBRA, local_diffeo_transformed_distribution.py:84-142 below the exp map) w.r.t. its
+ * ARGUMENT and the context: g_logp B x P -> g_ctx B x P x 64, g_v B x P x 3.  No weight-gradient records (the flow-as-prior call pattern of
+ * optimise/optimise_humaniflow.py:96-109 evaluates a frozen flow); the pull-back from v to the rotation R (so3_log, the 2 pi k pre-images, the exp map's
+ * log-determinant) is fp64 host-side composition (humaniflow_amd/autograd.py).  Default flow configuration only (HMF_ERR_UNSUPPORTED otherwise). */
+int hmf_flow_log_prob_so3_vjp(const hmf_flow_t* h, const float* ctx, const int32_t* part_ids_host, int P, const float* v, int B, const float* g_logp,
+                              float* g_ctx, float* g_v, void* stream);
+
 /* Reverse sweep of hmf_flow_log_prob_SO3 (losses/humaniflow_loss.py:26-31 pose NLL): g_logp B x P upstream gradients ->
  * g_ctx B x P x 64 and the records with rows = 3 B (row = pre-image term * B + b; masked pre-images contribute zeros).
  * The targets R are constants (teacher forcing).                                                                      */

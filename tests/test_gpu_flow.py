@@ -205,8 +205,8 @@ def test_full_size_B32_N100_properties():
 
 
 def test_unbuilt_gradient_paths_fail_loudly():
-    """Gradient paths that are not built raise instead of returning tensors without a graph: the rotation a density is
-    evaluated at (the optimise driver), the z = 0 point-estimate chain, the algebra density."""
+    """Gradient paths that are not built raise instead of returning tensors without a graph: the z = 0 point-estimate chain, the algebra
+    density object.  (Round 6: the rotation an SO(3) density is evaluated at IS differentiable now.)"""
     model, _, _ = _model(18)
     for p in model.parameters():
         p.requires_grad_(False)
@@ -215,8 +215,10 @@ def test_unbuilt_gradient_paths_fail_loudly():
     out = model(None, input_feats=feats, compute_for_loglik=True, shape_for_loglik=torch.zeros(2, 10).cuda(), pose_R_for_loglik=R,
                 glob_R_for_loglik=R[:, 0])
     Rg = R[:, 0].double().clone().requires_grad_(True)
+    lpg = out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(Rg)      # round 6: differentiable w.r.t. the rotation it is evaluated at (tests/test_gpu_train.py)
+    assert lpg.requires_grad
     with pytest.raises(NotImplementedError):
-        out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(Rg)
+        out['conditioned_pose_so3flow_dists_for_loglik'][0].log_prob(torch.zeros(2, 3).cuda().requires_grad_(True))      # the algebra density object stays inference-only
     with pytest.raises(NotImplementedError):
         model(None, input_feats=feats, grad_for_pose_point_est=True)
     lp = out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(R[:, 0].double())            # frozen weights, plain inputs: inference path

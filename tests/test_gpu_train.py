@@ -159,6 +159,56 @@ def test_gradient_wrt_the_teacher_forced_inputs_matches_oracle_autograd():
         p_.requires_grad_(True)
 
 
+def test_gradient_wrt_the_rotation_a_density_is_evaluated_at_matches_oracle_autograd():
+    """Round 6: `dist.log_prob(R)` with R.requires_grad -- the prior term of optimise/optimise_humaniflow.py:96-109 -- is differentiable w.r.t. R and the context.
+    Forward value = the fused kernel's; d/dR and d/d(pose_R_for_loglik, shape) vs float64 autograd through the oracle (which differentiates the reference's own op
+    chain: so3_log incl. its near-pi branch, the 2 pi k pre-images, the exp map's log-determinant, the inverse flow).  Rows with one and with two pre-images in the
+    support, and one row within 1e-3 of pi."""
+    from oracle.so3 import so3_exp
+    model, sd, cfg = _model(seed=14)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)                                         # the optimise driver's flow is frozen
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B = 6
+    g = torch.Generator().manual_seed(15)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    ax = torch.randn(B * 23, 3, generator=g, dtype=torch.float64)
+    ax = ax / ax.norm(dim=-1, keepdim=True)
+    ang = torch.rand(B * 23, 1, generator=g, dtype=torch.float64) * 2.6 + 0.2          # 0.2 .. 2.8 rad: beyond pi / 2 the -2 pi pre-image is inside the 1.5 pi support
+    ang[5] = math.pi - 1e-3                                                             # the near-pi branch of the logarithm
+    R = so3_exp(ax * ang).view(B, 23, 3, 3).float().double()             # the driver's rotations are fp32 (batch_rodrigues): both sides get the same fp32-representable matrices
+    shape_gt, glob_gt = torch.randn(B, 10, generator=g), random_rotmats(B, 1.0, seed=16)
+    w = torch.randn(B, 23, generator=g)
+    sd64 = _sd64(sd)
+    R64 = R.clone().requires_grad_(True)
+    sh64 = shape_gt.double().requires_grad_(True)
+    with ot.float64_defaults():
+        out = ot.forward_grad(sd64, ocfg, input_feats=feats.double(), compute_for_loglik=True, shape_for_loglik=sh64, pose_R_for_loglik=R64,
+                              glob_R_for_loglik=glob_gt.double(), compute_point_est=False)
+        lp_ref = ot.log_prob_SO3_grad(sd64, ocfg, out['flow_context_for_loglik'], R64)
+    (lp_ref * w.double()).sum().backward()
+    Rg = R.float().cuda().requires_grad_(True)                            # the driver's rotations are fp32 (batch_rodrigues), cast to double at the call
+    sh = shape_gt.cuda().requires_grad_(True)
+    o = model(None, input_feats=feats.cuda(), compute_for_loglik=True, shape_for_loglik=sh, pose_R_for_loglik=Rg, glob_R_for_loglik=glob_gt.cuda(),
+              compute_point_est=False)
+    dists = o['conditioned_pose_SO3flow_dists_for_loglik']
+    lp = torch.stack([dists[j].log_prob(Rg[:, j].double()) for j in range(23)], dim=1)              # the reference's loop (optimise_humaniflow.py:104-109)
+    with torch.no_grad():
+        fused = model.log_prob_all_parts(o['flow_context_for_loglik'].detach(), Rg.detach())
+    assert (lp.detach() - fused).abs().max().item() < 2e-4                                          # same value as the inference kernel
+    assert (lp.detach().cpu() - lp_ref.detach().float()).abs().max() < 1e-3
+    (lp * w.cuda()).sum().backward()
+    near = torch.zeros(B * 23, dtype=torch.bool)
+    near[5] = True
+    near = near.view(B, 23)
+    _check('d R (evaluated-at + ancestors), regular rows', Rg.grad.cpu()[~near], R64.grad[~near], rel=1e-3)
+    # within 1e-3 of pi the logarithm takes its square-root branch (d/dR ~ 1 / component): the gradient is ~1e3 larger and ill-conditioned in its input
+    _check('d R, near-pi row', Rg.grad.cpu()[near], R64.grad[near], rel=2e-2)
+    _check('d shape_for_loglik', sh.grad, sh64.grad, rel=1e-3)
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+
+
 def test_sample_chain_backward_matches_oracle_autograd():
     """Reparameterised samples: d (sum w . R_samples) / d every flow parameter, the features and the heads, ancestors feeding descendants."""
     model, sd, cfg = _model(seed=6)
