@@ -138,8 +138,11 @@ class _ConditionedFlowDist:
             out = m.log_prob_parts(self.ctx[:, None, :], value.reshape(B, 1, 3, 3), self.part, 1)[:, 0]
         else:
             if torch.is_grad_enabled() and (value.requires_grad or self.ctx.requires_grad):
-                raise NotImplementedError('humaniflow_amd: the algebra density so3flow_dists.log_prob is inference-only (the training loss uses the '
-                                          'SO(3) push-forward, losses/humaniflow_loss.py:26-31)')
+                # round 6: differentiable w.r.t. the algebra vector and the context (hmf_flow_log_prob_so3_vjp); flow weights are constants on this path
+                from .autograd import FlowLogProbAlgebra, _is_variant
+                if _is_variant(m):
+                    raise NotImplementedError('humaniflow_amd: gradients of the algebra density are built for the default flow configuration only')
+                return FlowLogProbAlgebra.apply(m, self.part, 1, self.ctx[:, None, :], value.reshape(B, 1, 3))[:, 0]
             out = m._log_prob_kernel(self.ctx[:, None, :], value.reshape(B, 1, 3), self.part, 1, group=False)[:, 0]
         if self.check_finite:
             assert torch.isnan(out).sum() == 0
@@ -637,7 +640,8 @@ class HumaniflowModel(nn.Module):
         tensors injects the base noise (exact-parity tests); otherwise it is drawn from the device generator in the reference's
         order (shape first, then the body parts).  Under autograd (training, train/train_humaniflow.py:248-256) the returned samples,
         shape samples and log-likelihood objects are differentiable; the point estimate is not, exactly as in the reference
-        (`torch.set_grad_enabled(grad_for_pose_point_est)`, :294) -- grad_for_pose_point_est=True is not built."""
+        (`torch.set_grad_enabled(grad_for_pose_point_est)`, :294) unless grad_for_pose_point_est=True (round 6: its rotations join the graph through the sample
+        chain's reverse sweep at zero base noise; `pose_axisangle_point_est` stays detached)."""
         if input_feats is None:
             _lib.require_cuda(input, 'input')
             input_feats = self.image_encoder(input)
@@ -650,8 +654,6 @@ class HumaniflowModel(nn.Module):
             assert pose_R_for_loglik is not None and pose_R_for_loglik.shape[0] == batch_size
             assert shape_for_loglik is not None and shape_for_loglik.shape[0] == batch_size
             assert glob_R_for_loglik is not None and glob_R_for_loglik.shape[0] == batch_size
-        if grad_for_pose_point_est:
-            raise NotImplementedError('humaniflow_amd: grad_for_pose_point_est=True (gradients through the z = 0 point-estimate chain) is not built')
         grad = torch.is_grad_enabled() and (input_feats.requires_grad or any(p.requires_grad for p in self.parameters()))
         isgc_feat_part = None                   # W[:, :F] . feats of the isgc layer, once per differentiable pass
         isgc_ll = None                          # the teacher-forced isgc rows when autograd.IsgcTrain produced both uses at once
@@ -747,6 +749,20 @@ class HumaniflowModel(nn.Module):
                 if packed:
                     rot_all = torch.cat([rot_s.reshape(BN, P, 3, 3), rot_p], dim=0)
                     shape_all = torch.cat([shape_samples.reshape(BN, nb), shape_mode], dim=0)
+            if grad and grad_for_pose_point_est and compute_point_est:
+                # round 6 (models/humaniflow_model.py:291-299 with grad_for_pose_point_est=True): the z = 0 point estimate is the kinematic chain at zero base noise,
+                # so its rotations join the graph through the SAME reverse sweep as the samples (one row per image, eps = 0; the exp-map derivative at the end is
+                # that of so3_exp where the forward applied smplx' batch_rodrigues: the same function up to its 1e-8 quirk).  pose_axisangle_point_est stays detached.
+                from .autograd import FlowSampleChain, new_flow_anchor
+                flow_anchor = flow_anchor or new_flow_anchor(self)
+                if isgc_feat_part is None:
+                    isgc_feat_part = self._isgc_feat_part(input_feats)
+                H_pe = self._isgc_autograd(input_feats, shape_mode, glob_R, cam, isgc_feat_part)
+                rot_p_g = FlowSampleChain.apply(self, H_pe, rot_p.view(batch_size, 1, P, 3, 3), torch.zeros(P, batch_size, 1, 3, dtype=torch.float32, device=device),
+                                                *flow_anchor).view(batch_size, P, 3, 3)
+                if packed:
+                    rot_all = torch.cat([rot_all[:BN], rot_p_g], dim=0)
+                rot_p = rot_p_g
             if packed:                # extension key (not in the reference dict): inputs of the single fused SMPL launch
                 return_dict['smpl_packed_inputs'] = {'body_pose': rot_all, 'betas': shape_all, 'num_samples': N}
             if compute_point_est:

@@ -205,8 +205,8 @@ def test_full_size_B32_N100_properties():
 
 
 def test_unbuilt_gradient_paths_fail_loudly():
-    """Gradient paths that are not built raise instead of returning tensors without a graph: the z = 0 point-estimate chain, the algebra
-    density object.  (Round 6: the rotation an SO(3) density is evaluated at IS differentiable now.)"""
+    """Gradient paths that are not built raise instead of returning tensors without a graph.  Round 6 built the flow's: the rotation an SO(3)
+    density is evaluated at, the algebra density, the z = 0 point-estimate chain (tests/test_gpu_train.py); what still raises is the SMPL vertex gradient."""
     model, _, _ = _model(18)
     for p in model.parameters():
         p.requires_grad_(False)
@@ -217,10 +217,15 @@ def test_unbuilt_gradient_paths_fail_loudly():
     Rg = R[:, 0].double().clone().requires_grad_(True)
     lpg = out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(Rg)      # round 6: differentiable w.r.t. the rotation it is evaluated at (tests/test_gpu_train.py)
     assert lpg.requires_grad
-    with pytest.raises(NotImplementedError):
-        out['conditioned_pose_so3flow_dists_for_loglik'][0].log_prob(torch.zeros(2, 3).cuda().requires_grad_(True))      # the algebra density object stays inference-only
-    with pytest.raises(NotImplementedError):
-        model(None, input_feats=feats, grad_for_pose_point_est=True)
+    lpa = out['conditioned_pose_so3flow_dists_for_loglik'][0].log_prob((torch.ones(2, 3) * 0.1).cuda().requires_grad_(True))      # ... and so is the algebra density
+    assert lpa.requires_grad
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
+    # SMPL: the joints carry the graph, the vertices are returned WITHOUT one (vertex gradients are not built: the training loss reads joints) -- a backward
+    # through them fails loudly in autograd instead of yielding silent zeros
+    o = smpl(body_pose=R.clone().requires_grad_(True), global_orient=R[:, :1].contiguous(), betas=torch.zeros(2, 10).cuda(), pose2rot=False)
+    assert o.joints.requires_grad and not o.vertices.requires_grad
+    with pytest.raises(RuntimeError):
+        o.vertices.sum().backward()
     lp = out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(R[:, 0].double())            # frozen weights, plain inputs: inference path
     assert lp.shape == (2,) and not lp.requires_grad
 

@@ -209,6 +209,58 @@ def test_gradient_wrt_the_rotation_a_density_is_evaluated_at_matches_oracle_auto
         p_.requires_grad_(True)
 
 
+def test_point_estimate_gradients_and_algebra_density_gradients_match_oracle_autograd():
+    """Round 6: (i) grad_for_pose_point_est=True (models/humaniflow_model.py:198,291): the z = 0 point-estimate rotations are differentiable w.r.t. the features and
+    the flow / heads weights through the sample chain's reverse sweep at zero noise; (ii) the algebra-density objects (conditioned_pose_so3flow_dists_for_loglik)
+    are differentiable w.r.t. their argument and the context.  Both vs float64 autograd through the oracle."""
+    model, sd, cfg = _model(seed=17)
+    ocfg = oracle_cfg_from(cfg.MODEL)
+    B = 4
+    g = torch.Generator().manual_seed(18)
+    feats = torch.randn(B, 512, generator=g) * 0.5
+    w = torch.randn(B, 23, 3, 3, generator=g)
+    sd64 = _sd64(sd)
+    f64 = feats.double().requires_grad_(True)
+    with ot.float64_defaults():
+        out = ot.forward_grad(sd64, ocfg, input_feats=f64, num_samples=0)
+    (out['pose_rotmats_point_est'] * w.double()).sum().backward()
+    fg = feats.cuda().requires_grad_(True)
+    model.zero_grad()
+    o = model(None, input_feats=fg, grad_for_pose_point_est=True)
+    assert o['pose_rotmats_point_est'].requires_grad and (o['pose_rotmats_point_est'].detach().cpu() - out['pose_rotmats_point_est'].detach().float()).abs().max() < 5e-5
+    (o['pose_rotmats_point_est'] * w.cuda()).sum().backward()
+    _check('d input_feats (point estimate)', fg.grad, f64.grad, rel=1e-3)
+    _check_params(model, sd64, ['pose_so3flow_transform_modules', 'fc_flow_context', 'fc_input_shape_glob_cam_feats', 'fc_shape', 'fc1'], rel=1e-3)
+    with torch.no_grad():                                                  # default: no graph on the point estimate, exactly as the reference
+        assert not model(None, input_feats=feats.cuda())['pose_rotmats_point_est'].requires_grad
+    assert not model(None, input_feats=feats.cuda().requires_grad_(True))['pose_rotmats_point_est'].requires_grad
+    # (ii) algebra density objects
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    R_gt = random_rotmats(B * 23, 0.6, seed=19).view(B, 23, 3, 3)
+    shape_gt, glob_gt = torch.randn(B, 10, generator=g), random_rotmats(B, 1.0, seed=20)
+    v = torch.randn(B, 23, 3, generator=g) * 0.8
+    wv = torch.randn(B, 23, generator=g)
+    sd64b = _sd64(sd)
+    v64 = v.double().requires_grad_(True)
+    sh64 = shape_gt.double().requires_grad_(True)
+    with ot.float64_defaults():
+        ol = ot.forward_grad(sd64b, ocfg, input_feats=feats.double(), compute_for_loglik=True, shape_for_loglik=sh64, pose_R_for_loglik=R_gt.double(),
+                             glob_R_for_loglik=glob_gt.double(), compute_point_est=False)
+        lp_ref = omodel.log_prob_so3.__wrapped__(sd64b, ocfg, ol['flow_context_for_loglik'], v64)
+    (lp_ref * wv.double()).sum().backward()
+    vg, sh = v.cuda().requires_grad_(True), shape_gt.cuda().requires_grad_(True)
+    ol2 = model(None, input_feats=feats.cuda(), compute_for_loglik=True, shape_for_loglik=sh, pose_R_for_loglik=R_gt.cuda(), glob_R_for_loglik=glob_gt.cuda(),
+                compute_point_est=False)
+    lp = torch.stack([ol2['conditioned_pose_so3flow_dists_for_loglik'][j].log_prob(vg[:, j]) for j in range(23)], dim=1)
+    assert (lp.detach().cpu() - lp_ref.detach().float()).abs().max() < 1e-3
+    (lp * wv.cuda()).sum().backward()
+    _check('d v (algebra density)', vg.grad, v64.grad, rel=1e-3)
+    _check('d shape_for_loglik (through the context)', sh.grad, sh64.grad, rel=1e-3)
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+
+
 def test_sample_chain_backward_matches_oracle_autograd():
     """Reparameterised samples: d (sum w . R_samples) / d every flow parameter, the features and the heads, ancestors feeding descendants."""
     model, sd, cfg = _model(seed=6)
