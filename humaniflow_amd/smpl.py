@@ -89,6 +89,17 @@ def load_smpl_pkl(model_path, gender='neutral', num_betas=10):
             'parents': parents, 'faces': np.asarray(d['f']).astype(np.int64) if 'f' in d else None}
 
 
+def _rodrigues_torch(rot_vecs):
+    """smplx==0.1.26 lbs.batch_rodrigues in torch operators, quirk included (angle = |v + 1e-8|, added per component): the differentiable form of
+    hmf_batch_rodrigues for the axis-angle inputs of a SMPL call under autograd.  (N, 3) -> (N, 3, 3)."""
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    ax = rot_vecs / angle
+    c, s_ = torch.cos(angle)[:, :, None], torch.sin(angle)[:, :, None]
+    z = torch.zeros_like(angle[:, 0])
+    K = torch.stack([z, -ax[:, 2], ax[:, 1], ax[:, 2], z, -ax[:, 0], -ax[:, 1], ax[:, 0], z], dim=1).view(-1, 3, 3)
+    return torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None] + s_ * K + (1.0 - c) * torch.bmm(K, K)
+
+
 class SMPL(nn.Module):
     NUM_JOINTS = 23
     NUM_BODY_JOINTS = 23
@@ -241,8 +252,8 @@ class SMPL(nn.Module):
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, impl=None, joints_only=False, **kwargs):
         """models/smpl.py:27-41 over smplx SMPL.forward.  `get_skin`/`return_verts` kwargs are accepted and ignored
         (vertices are always produced, as the reference forces) -- except with the extension keyword joints_only=True under autograd (the training
-        loss reads joints only: hmf_smpl_joints poses just the <= 320 vertices the joint tables touch; `.vertices` is then None).  With rotation-matrix inputs (pose2rot=False) under autograd the JOINTS
-        are differentiable w.r.t. global_orient / body_pose / betas (the training step's 2D reprojection loss); vertices are not."""
+        loss reads joints only: hmf_smpl_joints poses just the <= 320 vertices the joint tables touch; `.vertices` is then None).  Under autograd the JOINTS are differentiable w.r.t. global_orient / body_pose / betas (the training step's 2D reprojection loss; rotation matrices or,
+        since round 6, axis-angle vectors with pose2rot=True); the vertices come back without a graph."""
         global_orient = self.global_orient if global_orient is None else global_orient
         body_pose = self.body_pose if body_pose is None else body_pose
         betas = self.betas if betas is None else betas
@@ -257,8 +268,10 @@ class SMPL(nn.Module):
         with torch.cuda.device(dev):
             if wants_grad:
                 if pose2rot:
-                    raise NotImplementedError('humaniflow_amd: SMPL gradients are built for rotation-matrix inputs (pose2rot=False), as the training '
-                                              'step uses them (train/train_humaniflow.py:283-307)')
+                    # round 6 (the optimise driver's call, optimise/optimise_humaniflow.py:74-80): axis-angle inputs under autograd go through smplx'
+                    # batch_rodrigues as torch operators (24 small rotations per body, differentiable), then through the rotation-matrix path below
+                    global_orient = _rodrigues_torch(global_orient.reshape(-1, 3)).reshape(global_orient.shape[0], 1, 3, 3)
+                    body_pose = _rodrigues_torch(body_pose.reshape(-1, 3)).reshape(body_pose.shape[0], 23, 3, 3)
                 if global_orient.shape[0] != M or betas.shape[0] != M or body_pose.shape[0] != M:
                     raise ValueError('SMPL.forward under autograd: expand global_orient / betas to the pose batch (M = %d) first' % M)
                 from .autograd import SmplJoints

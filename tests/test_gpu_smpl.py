@@ -310,3 +310,30 @@ def test_joints_only_forward_equals_the_joints_of_the_full_lbs(M):
         grads.append((body.grad, glob.grad, be.grad))
     for a, b in zip(*grads):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+
+
+def test_axis_angle_inputs_under_autograd_give_the_joint_gradients_of_the_oracle():
+    """Round 6 (the optimise driver's SMPL call, optimise/optimise_humaniflow.py:74-80: axis-angle pose, pose2rot=True, gradients w.r.t. pose / shape through the
+    joints): same joints as the inference path, gradients vs float64 autograd through the oracle."""
+    from oracle import train as ot
+    data = H.synthetic_smpl_model(seed=0)
+    smpl = H.SMPL(model_data=data, create_transl=False).to('cuda:0')
+    g = torch.Generator().manual_seed(21)
+    M = 5
+    pose = torch.randn(M, 72, generator=g) * 0.4
+    betas = torch.randn(M, 10, generator=g)
+    w = torch.randn(M, 90, 3, generator=g)
+    om = {k: (v.double() if v.is_floating_point() else v) for k, v in smpl_oracle_model(smpl.model_dict()).items()}
+    p64, b64 = pose.double().requires_grad_(True), betas.double().requires_grad_(True)
+    with ot.float64_defaults():
+        _, j_ref = osmpl.smpl_forward(om, b64, p64[:, 3:], p64[:, :3], pose2rot=True)
+    (j_ref * w.double()).sum().backward()
+    pg, bg = pose.cuda().requires_grad_(True), betas.cuda().requires_grad_(True)
+    out = smpl(body_pose=pg[:, 3:], global_orient=pg[:, :3], betas=bg)
+    with torch.no_grad():
+        plain = smpl(body_pose=pose[:, 3:].cuda(), global_orient=pose[:, :3].cuda(), betas=betas.cuda())
+    assert (out.joints.detach() - plain.joints).abs().max().item() < 2e-6 and (out.joints.detach().cpu() - j_ref.detach().float()).abs().max() < 1e-4
+    (out.joints * w.cuda()).sum().backward()
+    for name, got, ref in (('d pose', pg.grad, p64.grad), ('d betas', bg.grad, b64.grad)):
+        scale = ref.abs().max().item()
+        assert (got.double().cpu() - ref).abs().max().item() <= 1e-3 * scale, name
