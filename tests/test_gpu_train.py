@@ -783,3 +783,51 @@ def test_isgc_layer_under_autograd_runs_on_the_library_and_matches_float64_autog
     for name, got, ref in (('d feats', f_.grad, f6.grad), ('d glob_R', R_.grad, R6.grad), ('d cam', cam_.grad, c6.grad), ('d shape_samples', ss_.grad, s6.grad),
                            ('d weight', lin.weight.grad, W6.grad), ('d bias', lin.bias.grad, b6.grad)):
         _check(name, got, ref)
+
+
+def test_the_optimise_objective_is_differentiable_end_to_end_and_sgd_lowers_it():
+    """Round 6 capstone: the objective of optimise/optimise_humaniflow.py:70-115 -- 2-D joints through SMPL joints of axis-angle pose / shape (pose2rot=True), minus
+    the flow's pose prior evaluated AT the optimised rotations (which are also the ancestors the prior is conditioned on), minus the shape prior -- runs through the
+    boundary objects with the reference's call pattern, every optimisation variable receives a finite gradient, and a few SGD steps lower the objective."""
+    from humaniflow_amd import evaluate as ev
+    from humaniflow_amd.rigid_transform_utils import batch_rodrigues
+    from humaniflow_amd.smpl import _rodrigues_torch
+    model, sd, cfg = _model(seed=22)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    dev = torch.device('cuda:0')
+    smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to(dev)
+    B, S = 3, 256
+    g = torch.Generator().manual_seed(23)
+    feats = (torch.randn(B, 512, generator=g) * 0.5).to(dev)
+    with torch.no_grad():
+        init = model(None, input_feats=feats)                                # the driver starts from the network's point estimate
+    pose = init['pose_axisangle_point_est'].reshape(B, 69).clone().requires_grad_(True)
+    glob = (torch.randn(B, 3, generator=g) * 0.2).to(dev).requires_grad_(True)
+    shape = init['shape_mode'].clone().requires_grad_(True)
+    cam = init['cam_wp'].clone().requires_grad_(True)
+    target2d = (torch.rand(B, 17, 2, generator=g) * S).to(dev)
+    opt = torch.optim.SGD([pose, glob, shape, cam], lr=1e-3)
+    hist = []
+    for it in range(6):
+        o = smpl(body_pose=pose, global_orient=glob, betas=shape, pose2rot=True)
+        j2d = ev.undo_keypoint_normalisation(ev.orthographic_project_torch(ev.flip_about_x(ev.select_joints(o.joints, 'coco')), cam), S)
+        loss_j2d = ((j2d - target2d) ** 2).mean()
+        R = _rodrigues_torch(pose.reshape(-1, 3)).view(B, 23, 3, 3)           # batch_rodrigues of the driver (:96), differentiable
+        Rg = _rodrigues_torch(glob)
+        d = model(None, input_feats=feats, compute_point_est=False, num_samples=0, compute_for_loglik=True, shape_for_loglik=shape,
+                  pose_R_for_loglik=R, glob_R_for_loglik=Rg)
+        lp = sum(d['conditioned_pose_SO3flow_dists_for_loglik'][j].log_prob(R[:, j].double()).sum() for j in range(23)) / B
+        ls = d['shape_dist_for_loglik'].log_prob(shape).sum() / B
+        loss = 1e-4 * loss_j2d - 0.02 * lp - 0.02 * ls
+        opt.zero_grad()
+        loss.backward()
+        for name, t in (('pose', pose), ('glob', glob), ('shape', shape), ('cam', cam)):
+            assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().max() > 0, name
+        opt.step()
+        hist.append(float(loss.detach()))
+    assert hist[-1] < hist[0], hist
+    with torch.no_grad():                                                    # the kernel Rodrigues and its torch-operator form agree
+        assert (batch_rodrigues(pose.detach().reshape(-1, 3)) - _rodrigues_torch(pose.detach().reshape(-1, 3))).abs().max().item() < 2e-6
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
