@@ -524,40 +524,70 @@ class FlowSampleChain(torch.autograd.Function):
         return None, g_H, None, None, g_rot.new_zeros(()), None
 
 
+def _lbs_vertices_torch(smpl, glob9, body207, betas):
+    """The posed vertices as a differentiable composition of torch operators on the module's buffers (smplx lbs: shape blend, rest joints, pose blend, the 24-joint
+    chain, 4-sparse skinning written densely).  Used ONLY to pull a VERTEX gradient back (round 6: LOSS.APPLY_POINT_EST_LOSS, vertex terms of an optimisation) -- the
+    forward vertices always come from hmf_smpl_lbs; this restatement never produces an output, it is differentiated at the saved inputs."""
+    M = betas.shape[0]
+    R = torch.cat([glob9.view(M, 1, 3, 3), body207.view(M, 23, 3, 3)], dim=1)
+    v_shaped = smpl.v_template[None] + torch.einsum('vck,mk->mvc', smpl.shapedirs, betas)
+    J = torch.einsum('jv,mvc->mjc', smpl.J_regressor, v_shaped)
+    feat = (R[:, 1:] - torch.eye(3, dtype=R.dtype, device=R.device)).reshape(M, 207)
+    v_posed = v_shaped + (feat @ smpl.posedirs).view(M, -1, 3)
+    parents = smpl.parents.tolist()
+    GR, Gt = [R[:, 0]], [J[:, 0]]
+    for i in range(1, 24):
+        p = parents[i]
+        GR.append(GR[p] @ R[:, i])
+        Gt.append((GR[p] @ (J[:, i] - J[:, p])[..., None])[..., 0] + Gt[p])
+    GR, Gt = torch.stack(GR, dim=1), torch.stack(Gt, dim=1)                              # (M,24,3,3), (M,24,3)
+    At = Gt - (GR @ J[..., None])[..., 0]                                                # A_i = [G_R | G_t - G_R J_i]
+    TR = torch.einsum('vj,mjab->mvab', smpl.lbs_weights, GR)
+    Tt = torch.einsum('vj,mja->mva', smpl.lbs_weights, At)
+    return (TR @ v_posed[..., None])[..., 0] + Tt
+
+
 class SmplJoints(torch.autograd.Function):
-    """hmf_smpl_lbs with a backward for the JOINTS output (vertex gradients are not built).  The backward (hmf_smpl_joints_backward) re-derives
-    the joints from the fp32 blend operand whatever `impl` the forward ran with: with impl = 2 (bf16 blend-shape operands, BASELINE configs[2])
-    the gradient is that of the fp32 function at the same inputs -- the two forwards differ by <= 1.5e-3 m, the Jacobians to the same relative
-    order; training (configs[4]) runs impl = 0."""
+    """hmf_smpl_lbs under autograd.  JOINTS: the backward is hmf_smpl_joints_backward (re-derives the joints from the fp32 blend operand whatever `impl` the
+    forward ran with: with impl = 2 (bf16 blend-shape operands, BASELINE configs[2]) the gradient is that of the fp32 function at the same inputs -- the two forwards
+    differ by <= 1.5e-3 m, the Jacobians to the same relative order; training (configs[4]) runs impl = 0).  VERTICES (round 6): when a vertex gradient arrives --
+    the opt-in LOSS.APPLY_POINT_EST_LOSS of the reference, vertex terms of an optimisation; never the default training step -- it is pulled back through
+    `_lbs_vertices_torch` on torch operators and added to the joints' gradients."""
 
     @staticmethod
     def forward(ctx, smpl, glob9, body207, betas, impl):
         if impl == -1:                                                # joints only (hmf_smpl_joints): the training loss never reads the vertices
             joints = smpl._joints_kernel(glob9.detach(), body207.detach(), betas.detach())
             verts = joints.new_empty(0)
+            ctx.mark_non_differentiable(verts)
         else:
             verts, joints = smpl._lbs_kernel(glob9.detach(), body207.detach(), betas.detach(), impl)
         ctx.smpl = smpl
         ctx.save_for_backward(glob9.detach(), body207.detach(), betas.detach())
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(verts)
         return verts, joints
 
     @staticmethod
     def backward(ctx, g_verts, g_joints):
-        if g_verts is not None:
-            raise NotImplementedError('humaniflow_amd: SMPL vertex gradients are not built (LOSS.APPLY_POINT_EST_LOSS); only the joints backward is')
-        if g_joints is None:
+        if g_verts is None and g_joints is None:
             return None, None, None, None, None
         glob9, body207, betas = ctx.saved_tensors
         M = body207.shape[0]
-        lib = _lib.load()
-        gj = g_joints.detach().to(torch.float32).contiguous()
-        gg, gb, gbe = torch.empty_like(glob9), torch.empty_like(body207), torch.empty_like(betas)
-        with torch.cuda.device(gj.device):
-            _lib.check(lib.hmf_smpl_joints_backward(ctx.smpl._handle(gj.device), _lib.dptr(glob9), _lib.dptr(body207), _lib.dptr(betas), M,
-                                                    _lib.dptr(gj), _lib.dptr(gg), _lib.dptr(gb), _lib.dptr(gbe), _lib.current_stream()),
-                       'hmf_smpl_joints_backward')
+        gg = gb = gbe = None
+        if g_joints is not None:
+            lib = _lib.load()
+            gj = g_joints.detach().to(torch.float32).contiguous()
+            gg, gb, gbe = torch.empty_like(glob9), torch.empty_like(body207), torch.empty_like(betas)
+            with torch.cuda.device(gj.device):
+                _lib.check(lib.hmf_smpl_joints_backward(ctx.smpl._handle(gj.device), _lib.dptr(glob9), _lib.dptr(body207), _lib.dptr(betas), M,
+                                                        _lib.dptr(gj), _lib.dptr(gg), _lib.dptr(gb), _lib.dptr(gbe), _lib.current_stream()),
+                           'hmf_smpl_joints_backward')
+        if g_verts is not None:
+            with torch.enable_grad():
+                ins = [t.detach().clone().requires_grad_(True) for t in (glob9, body207, betas)]
+                v = _lbs_vertices_torch(ctx.smpl, *ins)
+                vg = torch.autograd.grad(v, ins, g_verts.detach().to(v.dtype))
+            gg, gb, gbe = (a if b is None else b + a for a, b in zip(vg, (gg, gb, gbe)))
         return None, gg, gb, gbe, None
 
 

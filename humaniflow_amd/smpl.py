@@ -253,7 +253,8 @@ class SMPL(nn.Module):
         """models/smpl.py:27-41 over smplx SMPL.forward.  `get_skin`/`return_verts` kwargs are accepted and ignored
         (vertices are always produced, as the reference forces) -- except with the extension keyword joints_only=True under autograd (the training
         loss reads joints only: hmf_smpl_joints poses just the <= 320 vertices the joint tables touch; `.vertices` is then None).  Under autograd the JOINTS are differentiable w.r.t. global_orient / body_pose / betas (the training step's 2D reprojection loss; rotation matrices or,
-        since round 6, axis-angle vectors with pose2rot=True); the vertices come back without a graph."""
+        since round 6, axis-angle vectors with pose2rot=True).  The VERTICES are differentiable too (round 6): their gradient, when one arrives, is pulled back through a
+        torch-operator restatement of the LBS (autograd._lbs_vertices_torch) -- the opt-in vertex loss of the reference, not a training-step path."""
         global_orient = self.global_orient if global_orient is None else global_orient
         body_pose = self.body_pose if body_pose is None else body_pose
         betas = self.betas if betas is None else betas

@@ -206,7 +206,8 @@ def test_full_size_B32_N100_properties():
 
 def test_unbuilt_gradient_paths_fail_loudly():
     """Gradient paths that are not built raise instead of returning tensors without a graph.  Round 6 built the flow's: the rotation an SO(3)
-    density is evaluated at, the algebra density, the z = 0 point-estimate chain (tests/test_gpu_train.py); what still raises is the SMPL vertex gradient."""
+    density is evaluated at, the algebra density, the z = 0 point-estimate chain, SMPL vertices (tests/test_gpu_train.py, test_gpu_smpl.py); what still raises are
+    the value-gradient paths of the non-default flow variants."""
     model, _, _ = _model(18)
     for p in model.parameters():
         p.requires_grad_(False)
@@ -220,12 +221,19 @@ def test_unbuilt_gradient_paths_fail_loudly():
     lpa = out['conditioned_pose_so3flow_dists_for_loglik'][0].log_prob((torch.ones(2, 3) * 0.1).cuda().requires_grad_(True))      # ... and so is the algebra density
     assert lpa.requires_grad
     smpl = H.SMPL(model_data=H.synthetic_smpl_model(seed=0), create_transl=False).to('cuda:0')
-    # SMPL: the joints carry the graph, the vertices are returned WITHOUT one (vertex gradients are not built: the training loss reads joints) -- a backward
-    # through them fails loudly in autograd instead of yielding silent zeros
+    # SMPL: joints AND (round 6) vertices carry the graph; the joints-only form has no vertices at all
     o = smpl(body_pose=R.clone().requires_grad_(True), global_orient=R[:, :1].contiguous(), betas=torch.zeros(2, 10).cuda(), pose2rot=False)
-    assert o.joints.requires_grad and not o.vertices.requires_grad
-    with pytest.raises(RuntimeError):
-        o.vertices.sum().backward()
+    assert o.joints.requires_grad and o.vertices.requires_grad
+    oj = smpl(body_pose=R.clone().requires_grad_(True), global_orient=R[:, :1].contiguous(), betas=torch.zeros(2, 10).cuda(), pose2rot=False, joints_only=True)
+    assert oj.vertices is None and oj.joints.requires_grad
+    c3 = H.get_humaniflow_cfg_defaults()
+    c3.MODEL.NORM_FLOW.PERMUTE_TYPE = 'linear_plu'
+    mv = init_model_for_tests(H.HumaniflowModel(torch.device('cpu'), c3.MODEL, H.SMPL_PARENTS), seed=1).eval().cuda()
+    for p in mv.parameters():
+        p.requires_grad_(False)
+    ov = mv(None, input_feats=feats, compute_for_loglik=True, shape_for_loglik=torch.zeros(2, 10).cuda(), pose_R_for_loglik=R, glob_R_for_loglik=R[:, 0])
+    with pytest.raises(NotImplementedError):                                   # what still raises: the value-gradient paths of the NON-DEFAULT flow variants
+        ov['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(R[:, 0].double().clone().requires_grad_(True))
     lp = out['conditioned_pose_SO3flow_dists_for_loglik'][0].log_prob(R[:, 0].double())            # frozen weights, plain inputs: inference path
     assert lp.shape == (2,) and not lp.requires_grad
 

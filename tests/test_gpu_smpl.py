@@ -337,3 +337,41 @@ def test_axis_angle_inputs_under_autograd_give_the_joint_gradients_of_the_oracle
     for name, got, ref in (('d pose', pg.grad, p64.grad), ('d betas', bg.grad, b64.grad)):
         scale = ref.abs().max().item()
         assert (got.double().cpu() - ref).abs().max().item() <= 1e-3 * scale, name
+
+
+@pytest.mark.parametrize('pose2rot', [False, True])
+def test_vertex_gradients_match_oracle_autograd(pose2rot):
+    """Round 6: a gradient arriving at the VERTICES of a differentiable SMPL call (the reference's opt-in LOSS.APPLY_POINT_EST_LOSS, vertex terms of an optimisation)
+    is pulled back to pose and shape, and adds to the joints' gradient when both are used -- vs float64 autograd through the oracle."""
+    from oracle import train as ot
+    from oracle.so3 import so3_exp
+    data = H.synthetic_smpl_model(seed=0)
+    smpl = H.SMPL(model_data=data, create_transl=False).to('cuda:0')
+    g = torch.Generator().manual_seed(31)
+    M = 4
+    aa = torch.randn(M, 72, generator=g) * 0.4
+    betas = torch.randn(M, 10, generator=g)
+    wv = torch.randn(M, 6890, 3, generator=g) * 0.01
+    wj = torch.randn(M, 90, 3, generator=g)
+    om = {k: (v.double() if v.is_floating_point() else v) for k, v in smpl_oracle_model(smpl.model_dict()).items()}
+    b64 = betas.double().requires_grad_(True)
+    if pose2rot:
+        p64 = aa.double().requires_grad_(True)
+        with ot.float64_defaults():
+            v_ref, j_ref = osmpl.smpl_forward(om, b64, p64[:, 3:], p64[:, :3], pose2rot=True)
+        pg = aa.cuda().requires_grad_(True)
+        kw = dict(body_pose=pg[:, 3:], global_orient=pg[:, :3])
+    else:
+        p64 = so3_exp(aa.double().view(-1, 3)).view(M, 24, 3, 3).float().double().requires_grad_(True)
+        with ot.float64_defaults():
+            v_ref, j_ref = osmpl.smpl_forward(om, b64, p64[:, 1:], p64[:, :1], pose2rot=False)
+        pg = p64.detach().float().cuda().requires_grad_(True)
+        kw = dict(body_pose=pg[:, 1:], global_orient=pg[:, :1], pose2rot=False)
+    ((v_ref * wv.double()).sum() + (j_ref * wj.double()).sum()).backward()
+    bg = betas.cuda().requires_grad_(True)
+    out = smpl(betas=bg, **kw)
+    assert (out.vertices.detach().cpu() - v_ref.detach().float()).abs().max() < 1e-4
+    ((out.vertices * wv.cuda()).sum() + (out.joints * wj.cuda()).sum()).backward()
+    for name, got, ref in (('d pose', pg.grad, p64.grad), ('d betas', bg.grad, b64.grad)):
+        scale = ref.abs().max().item()
+        assert (got.double().cpu() - ref).abs().max().item() <= 1e-3 * scale, name
